@@ -1,0 +1,226 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per entry point).
+
+All tensors must live on a HIP device; every call is enqueued on PyTorch's current stream for that
+device.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+def _f32c(t: Tensor) -> Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class RaysArg:
+    """fnr_rays view of RayBundle tensors (keeps the converted tensors alive)."""
+
+    def __init__(self, origins: Tensor, directions: Tensor, nears: Optional[Tensor], fars: Optional[Tensor],
+                 camera_indices: Optional[Tensor] = None):
+        L.require_gpu_tensor(origins, "ray origins")
+        self.device = origins.device
+        self.origins = _f32c(origins.reshape(-1, 3))
+        self.directions = _f32c(directions.reshape(-1, 3))
+        self.n = self.origins.shape[0]
+        self.nears = None if nears is None else _f32c(nears.reshape(-1))
+        self.fars = None if fars is None else _f32c(fars.reshape(-1))
+        self.cam = None
+        if camera_indices is not None:
+            self.cam = camera_indices.reshape(-1).to(torch.int32).contiguous()
+        self.c = L.fnr_rays(self.n, L.ptr(self.origins), L.ptr(self.directions), L.ptr(self.nears), L.ptr(self.fars),
+                            L.ptr(self.cam))
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+
+def make_warp(mode: int, aabb: Tensor) -> L.fnr_warp:
+    w = L.fnr_warp()
+    w.mode = mode
+    a = aabb.detach().to("cpu", torch.float32).reshape(-1).tolist()
+    for i in range(6):
+        w.aabb[i] = a[i]
+    return w
+
+
+def make_grid(table: Tensor, n_levels: int, log2_hashmap_size: int, scalings: Sequence[int]) -> L.fnr_grid:
+    g = L.fnr_grid()
+    g.n_levels = n_levels
+    g.log2_hashmap_size = log2_hashmap_size
+    for i, s in enumerate(scalings):
+        g.scalings[i] = int(s)
+    g.table = L.ptr(table)
+    return g
+
+
+def hash_scalings(num_levels: int, min_res: int, max_res: int) -> list:
+    """floor(min_res * growth**levels) in float32, exactly as nerfstudio HashEncoding.__init__
+    (reference call sites fruit_field.py:124-131, fruit_nerf.py:111-127)."""
+    levels = torch.arange(num_levels)
+    growth = np.exp((np.log(max_res) - np.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1
+    return [int(v) for v in torch.floor(min_res * growth ** levels).tolist()]
+
+
+_host_linspace_cache = {}
+
+
+def host_linspace(start: float, end: float, steps: int, device) -> Tensor:
+    """torch.linspace evaluated on the CPU (ATen's rounding), cached on the device."""
+    key = (float(start), float(end), int(steps), str(device))
+    t = _host_linspace_cache.get(key)
+    if t is None:
+        t = torch.linspace(start, end, steps, dtype=torch.float32).to(device)
+        _host_linspace_cache[key] = t
+    return t
+
+
+# ---- samplers ---------------------------------------------------------------------------------------
+
+
+def sample_spaced(rays: RaysArg, spacing_kind: int, S: int, t_rand: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    lib = L.load()
+    dev = rays.device
+    base = host_linspace(0.0, 1.0, S + 1, dev)
+    spacing = torch.empty(rays.n, S + 1, device=dev)
+    euclid = torch.empty(rays.n, S + 1, device=dev)
+    tr = None if t_rand is None else _f32c(t_rand.reshape(-1))
+    L.check(lib.fnr_sample_spaced(rays.ref, spacing_kind, S, L.ptr(base), L.ptr(tr), L.ptr(spacing), L.ptr(euclid),
+                                  L.stream_ptr(dev)), "sample_spaced")
+    return spacing, euclid
+
+
+def weights_pdf(rays: RaysArg, spacing_kind: int, S_prev: int, S_new: int, density: Tensor, spacing_prev: Tensor,
+                euclid_prev: Tensor, anneal: float, rand: Optional[Tensor], want_depth: bool = True):
+    lib = L.load()
+    dev = rays.device
+    weights = torch.empty(rays.n, S_prev, device=dev)
+    depth = torch.empty(rays.n, device=dev) if want_depth else None
+    spacing_new = euclid_new = u_base = None
+    if S_new > 0:
+        nb = S_new + 1
+        u_base = host_linspace(0.0, 1.0 - (1.0 / nb), nb, dev)
+        spacing_new = torch.empty(rays.n, nb, device=dev)
+        euclid_new = torch.empty(rays.n, nb, device=dev)
+    rd = None if rand is None else _f32c(rand.reshape(-1))
+    L.check(lib.fnr_weights_pdf(rays.ref, spacing_kind, S_prev, S_new, L.ptr(density), L.ptr(spacing_prev),
+                                L.ptr(euclid_prev), float(anneal), L.ptr(u_base), L.ptr(rd), L.ptr(weights),
+                                L.ptr(depth), L.ptr(spacing_new), L.ptr(euclid_new), L.stream_ptr(dev)),
+            "weights_pdf")
+    return weights, depth, spacing_new, euclid_new
+
+
+# ---- networks ----------------------------------------------------------------------------------------
+
+
+def prop_density_fwd(net: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
+                     save_feats: bool = False):
+    lib = L.load()
+    dev = rays.device
+    density = torch.empty(rays.n, S, device=dev)
+    feats = torch.empty(net.grid.n_levels, rays.n * S, 2, device=dev) if save_feats else None
+    L.check(lib.fnr_prop_density_fwd(C.byref(net), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(density),
+                                     L.ptr(feats), L.stream_ptr(dev)), "prop_density_fwd")
+    return density, feats
+
+
+def hash_encode_fwd(grid: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int):
+    lib = L.load()
+    dev = rays.device
+    N = rays.n * S
+    feats = torch.empty(grid.n_levels, N, 2, device=dev)
+    selector = torch.empty(N, dtype=torch.uint8, device=dev)
+    L.check(lib.fnr_hash_encode_fwd(C.byref(grid), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(feats),
+                                    L.ptr(selector), L.stream_ptr(dev)), "hash_encode_fwd")
+    return feats, selector
+
+
+class LatticeArg:
+    def __init__(self, xs: Tensor, ys: Tensor, zs: Tensor):
+        self.xs, self.ys, self.zs = _f32c(xs), _f32c(ys), _f32c(zs)
+        self.device = self.xs.device
+        self.c = L.fnr_lattice(self.xs.numel(), self.ys.numel(), self.zs.numel(), L.ptr(self.xs), L.ptr(self.ys),
+                               L.ptr(self.zs))
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+
+def hash_encode_lattice(grid: L.fnr_grid, warp: L.fnr_warp, lat: LatticeArg, ray_begin: int, n_rays: int):
+    lib = L.load()
+    dev = lat.device
+    N = n_rays * lat.c.n_z
+    feats = torch.empty(grid.n_levels, N, 2, device=dev)
+    selector = torch.empty(N, dtype=torch.uint8, device=dev)
+    L.check(lib.fnr_hash_encode_lattice(C.byref(grid), C.byref(warp), lat.ref, ray_begin, n_rays, L.ptr(feats),
+                                        L.ptr(selector), L.stream_ptr(dev)), "hash_encode_lattice")
+    return feats, selector
+
+
+def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, selector: Optional[Tensor],
+                  mean_embedding: Optional[Tensor], want_geo: bool = False):
+    lib = L.load()
+    dev = rays.device
+    N = rays.n * S
+    density = torch.empty(N, device=dev)
+    rgb = torch.empty(N, 3, device=dev)
+    logit = torch.empty(N, device=dev)
+    geo = torch.empty(N, net.geo_feat_dim, device=dev) if want_geo else None
+    L.check(lib.fnr_field_mlp_fwd(C.byref(net), rays.ref, S, L.ptr(feats), L.ptr(selector), L.ptr(mean_embedding),
+                                  L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.stream_ptr(dev)),
+            "field_mlp_fwd")
+    return density, rgb, logit, geo
+
+
+def embedding_mean(embedding: Tensor) -> Tensor:
+    lib = L.load()
+    out = torch.empty(embedding.shape[1], device=embedding.device)
+    L.check(lib.fnr_embedding_mean(L.ptr(embedding), embedding.shape[0], embedding.shape[1], L.ptr(out),
+                                   L.stream_ptr(embedding.device)), "embedding_mean")
+    return out
+
+
+def composite_fwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, logit: Tensor, training: bool):
+    lib = L.load()
+    dev = rays.device
+    weights = torch.empty(rays.n, S, device=dev)
+    out_rgb = torch.empty(rays.n, 3, device=dev)
+    acc = torch.empty(rays.n, device=dev)
+    depth = torch.empty(rays.n, device=dev)
+    sem = torch.empty(rays.n, device=dev)
+    L.check(lib.fnr_composite_fwd(rays.ref, S, L.ptr(euclid), L.ptr(density), L.ptr(rgb), L.ptr(logit),
+                                  1 if training else 0, L.ptr(weights), L.ptr(out_rgb), L.ptr(acc), L.ptr(depth),
+                                  L.ptr(sem), L.stream_ptr(dev)), "composite_fwd")
+    return weights, out_rgb, acc, depth, sem
+
+
+# ---- export -------------------------------------------------------------------------------------------
+
+
+def export_compact(lat: Optional[LatticeArg], ray_begin: int, n_rays: int, positions: Optional[Tensor],
+                   density: Tensor, rgb: Tensor, logit: Tensor, points: Sequence[Tensor], colors: Sequence[Tensor],
+                   counts: Tensor) -> None:
+    """Appends this batch's selected samples to the three point/colour streams (order-preserving); `counts`
+    (uint64 x3, stored as int64 on the device) holds the running totals.  Positions: lattice or explicit."""
+    lib = L.load()
+    dev = density.device
+    N = density.numel()
+    ws = torch.empty(lib.fnr_export_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    cap = points[0].shape[0]
+    assert all(p.shape[0] == cap for p in points) and all(c.shape[0] == cap for c in colors)
+    parr = (C.c_void_p * 3)(*[L.ptr(p) for p in points])
+    carr = (C.c_void_p * 3)(*[L.ptr(c) for c in colors])
+    pos = None if positions is None else _f32c(positions.reshape(-1, 3))
+    L.check(lib.fnr_export_compact(None if lat is None else lat.ref, ray_begin, n_rays, L.ptr(pos), N,
+                                   L.ptr(density), L.ptr(rgb), L.ptr(logit), parr, carr, cap, L.ptr(counts),
+                                   L.ptr(ws), L.stream_ptr(dev)), "export_compact")

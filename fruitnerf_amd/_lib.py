@@ -1,0 +1,137 @@
+"""ctypes binding of include/fruitnerf_hip.h (libfruitnerf_hip.so, gfx950).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, a RuntimeError carrying
+`fnr_last_error()` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfruitnerf_hip.so")
+
+FNR_MAX_LEVELS = 16
+FNR_MAX_SEM_LAYERS = 4
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class fnr_grid(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("log2_hashmap_size", C.c_int32),
+                ("scalings", C.c_int32 * FNR_MAX_LEVELS), ("table", C.c_void_p)]
+
+
+class fnr_rays(C.Structure):
+    _fields_ = [("n_rays", C.c_int64), ("origins", C.c_void_p), ("directions", C.c_void_p),
+                ("nears", C.c_void_p), ("fars", C.c_void_p), ("camera_indices", C.c_void_p)]
+
+
+class fnr_warp(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("aabb", C.c_float * 6)]
+
+
+class fnr_prop_net(C.Structure):
+    _fields_ = [("grid", fnr_grid), ("hidden_dim", C.c_int32), ("w0", C.c_void_p), ("b0", C.c_void_p),
+                ("w1", C.c_void_p), ("b1", C.c_void_p)]
+
+
+class fnr_field_net(C.Structure):
+    _fields_ = [("grid", fnr_grid), ("geo_feat_dim", C.c_int32), ("hidden_dim", C.c_int32),
+                ("hidden_dim_color", C.c_int32), ("hidden_dim_semantics", C.c_int32),
+                ("num_layers_semantic", C.c_int32), ("semantic_out_dim", C.c_int32),
+                ("appearance_dim", C.c_int32), ("n_images", C.c_int32),
+                ("base_w0", C.c_void_p), ("base_b0", C.c_void_p), ("base_w1", C.c_void_p), ("base_b1", C.c_void_p),
+                ("sem_w", C.c_void_p * FNR_MAX_SEM_LAYERS), ("sem_b", C.c_void_p * FNR_MAX_SEM_LAYERS),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p),
+                ("col_w", C.c_void_p * 3), ("col_b", C.c_void_p * 3), ("embedding", C.c_void_p)]
+
+
+class fnr_lattice(C.Structure):
+    _fields_ = [("n_x", C.c_int32), ("n_y", C.c_int32), ("n_z", C.c_int32),
+                ("xs", C.c_void_p), ("ys", C.c_void_p), ("zs", C.c_void_p)]
+
+
+P = C.POINTER
+_vp = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_f = C.c_float
+
+# name -> (restype, argtypes); every symbol include/fruitnerf_hip.h declares
+SIGNATURES = {
+    "fnr_abi_version": (_i, []),
+    "fnr_last_error": (C.c_char_p, []),
+    "fnr_device_check": (_i, [P(C.c_int), C.c_char_p, _i]),
+    "fnr_sample_spaced": (_i, [P(fnr_rays), _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_weights_pdf": (_i, [P(fnr_rays), _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_prop_density_fwd": (_i, [P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
+    "fnr_hash_encode_fwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
+    "fnr_hash_encode_lattice": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_lattice), _i64, _i64, _vp, _vp, _vp]),
+    "fnr_field_mlp_fwd": (_i, [P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_embedding_mean": (_i, [_vp, _i, _i, _vp, _vp]),
+    "fnr_composite_fwd": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_export_workspace_bytes": (C.c_size_t, [_i64]),
+    "fnr_export_compact": (_i, [P(fnr_lattice), _i64, _i64, _vp, _i64, _vp, _vp, _vp, P(_vp), P(_vp), _i64, _vp, _vp,
+                                _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libfruitnerf_hip.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). fruitnerf_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> loud failure on a stale library
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fnr_abi_version() != 1:
+        raise RuntimeError(f"libfruitnerf_hip.so ABI {lib.fnr_abi_version()} != 1; rebuild")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().fnr_last_error().decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"fruitnerf_hip {what} failed (rc={rc}): {last_error()}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "fruitnerf_hip needs contiguous tensors"
+    return t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> Optional[int]:
+    """The HIP stream PyTorch currently enqueues on for `device`."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def device_check() -> dict:
+    lib = load()
+    n = C.c_int(0)
+    buf = C.create_string_buffer(64)
+    check(lib.fnr_device_check(C.byref(n), buf, 64), "device_check")
+    return {"arch": buf.value.decode(), "cus": n.value}
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}; fruitnerf_amd runs only on a HIP device (no CPU path)")

@@ -1,0 +1,49 @@
+"""UniformSamplerWithNoise — mirror of /root/reference/fruit_nerf/components/ray_samplers.py:31-104.
+
+Export-time sampler: `num_samples` uniform bins in [near, far] (spacing fn = identity); stratified jitter
+only when `self.training` (never true during export).  Bins are produced by fnr_sample_spaced.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import _kernels as K
+from ..rays import RayBundle, RaySamples
+
+
+class UniformSamplerWithNoise(nn.Module):
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
+        super().__init__()
+        self.num_samples = num_samples
+        self.train_stratified = train_stratified
+        self.single_jitter = single_jitter
+
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, num_samples: Optional[int] = None,
+                             t_rand: Optional[torch.Tensor] = None) -> RaySamples:
+        assert ray_bundle is not None
+        assert ray_bundle.nears is not None
+        assert ray_bundle.fars is not None
+        num_samples = num_samples or self.num_samples
+        assert num_samples is not None
+        rays = K.RaysArg(ray_bundle.origins, ray_bundle.directions, ray_bundle.nears, ray_bundle.fars,
+                         ray_bundle.camera_indices)
+        if self.train_stratified and self.training:
+            if not self.single_jitter:
+                raise NotImplementedError("per-bin jitter (single_jitter=False) in training mode is not built; "
+                                          "the reference only uses this sampler in eval mode (fruit_nerf.py:182)")
+            if t_rand is None:
+                t_rand = torch.rand(rays.n, device=rays.device)
+        else:
+            t_rand = None
+        spacing, euclid = K.sample_spaced(rays, 0, num_samples, t_rand)
+        samples = ray_bundle.get_ray_samples(
+            bin_starts=euclid[..., :-1, None], bin_ends=euclid[..., 1:, None],
+            spacing_starts=spacing[..., :-1, None], spacing_ends=spacing[..., 1:, None])
+        samples._structured = (rays, euclid, num_samples)
+        return samples
+
+    def forward(self, *args, **kwargs) -> RaySamples:
+        return self.generate_ray_samples(*args, **kwargs)

@@ -1,0 +1,222 @@
+// common.hpp — shared device/host helpers for the gfx950 FruitNeRF kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/fruitnerf_hip.h"
+
+namespace fnr {
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define FNR_CHECK_ARG(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::fnr::set_error(__VA_ARGS__);      \
+      return FNR_ERR_INVALID;             \
+    }                                     \
+  } while (0)
+
+#define FNR_UNSUPPORTED(cond, ...)        \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::fnr::set_error(__VA_ARGS__);      \
+      return FNR_ERR_UNSUPPORTED;         \
+    }                                     \
+  } while (0)
+
+#define FNR_HIP(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      ::fnr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return FNR_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+#define FNR_LAUNCH_CHECK() FNR_HIP(hipGetLastError())
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// number of CUs of the current device (cached)
+int device_cu_count();
+
+// ---- exact (non-contracted) fp32 arithmetic -----------------------------------------------------
+// The oracle (PyTorch CPU eager) rounds after every elementwise op.  Wherever a discrete decision
+// depends on the value (selector mask, floor/ceil cell, searchsorted) we use these so the HIP path
+// produces the same bits.
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+
+// torch.nan_to_num defaults: nan->0, +inf->FLT_MAX, -inf->-FLT_MAX
+__device__ __forceinline__ float nan_to_num(float x) {
+  if (x != x) return 0.0f;
+  if (x == __builtin_inff()) return 3.4028234663852886e38f;
+  if (x == -__builtin_inff()) return -3.4028234663852886e38f;
+  return x;
+}
+
+// ---- wave (64-lane) primitives -------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    float t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_bcast(float v, int src) { return __shfl(v, src, 64); }
+
+// ---- position warp (fruit_field.py:168-179) -------------------------------------------------------
+struct Warp {
+  int mode;
+  float lo[3];
+  float len[3];
+};
+static inline Warp make_warp(const fnr_warp* w) {
+  Warp r;
+  r.mode = w->mode;
+  for (int i = 0; i < 3; ++i) {
+    r.lo[i] = w->aabb[i];
+    r.len[i] = w->aabb[3 + i] - w->aabb[i];  // fp32, like aabb[1] - aabb[0]
+  }
+  return r;
+}
+
+// world position -> masked unit-cube position; returns selector
+__device__ __forceinline__ bool warp_position(const Warp& w, float px, float py, float pz, float (&x)[3]) {
+  if (w.mode == 0) {
+    float mag = fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
+    if (!(mag < 1.0f)) {
+      float s = fsub(2.0f, fdiv(1.0f, mag));
+      px = fmul(s, fdiv(px, mag));
+      py = fmul(s, fdiv(py, mag));
+      pz = fmul(s, fdiv(pz, mag));
+    }
+    x[0] = fdiv(fadd(px, 2.0f), 4.0f);
+    x[1] = fdiv(fadd(py, 2.0f), 4.0f);
+    x[2] = fdiv(fadd(pz, 2.0f), 4.0f);
+  } else {
+    x[0] = fdiv(fsub(px, w.lo[0]), w.len[0]);
+    x[1] = fdiv(fsub(py, w.lo[1]), w.len[1]);
+    x[2] = fdiv(fsub(pz, w.lo[2]), w.len[2]);
+  }
+  bool sel = (x[0] > 0.0f) && (x[0] < 1.0f) && (x[1] > 0.0f) && (x[1] < 1.0f) && (x[2] > 0.0f) && (x[2] < 1.0f);
+  if (!sel) {
+    x[0] = 0.0f;
+    x[1] = 0.0f;
+    x[2] = 0.0f;
+  }
+  return sel;
+}
+
+// Frustums.get_positions(): origins + directions * (starts + ends) / 2
+__device__ __forceinline__ void ray_position(const float* __restrict__ o, const float* __restrict__ d, float t0,
+                                             float t1, float& px, float& py, float& pz) {
+  float s = fadd(t0, t1);
+  px = fadd(o[0], fdiv(fmul(d[0], s), 2.0f));
+  py = fadd(o[1], fdiv(fmul(d[1], s), 2.0f));
+  pz = fadd(o[2], fdiv(fmul(d[2], s), 2.0f));
+}
+
+// ---- hash grid (HashEncoding torch path) -------------------------------------
+struct GridLevel {
+  uint32_t c[3], f[3];
+  float o[3];
+};
+__device__ __forceinline__ GridLevel grid_cell(const float (&x)[3], int scaling) {
+  GridLevel g;
+  const float s = (float)scaling;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float sc = fmul(x[a], s);
+    float fl = floorf(sc);
+    g.c[a] = (uint32_t)(int)ceilf(sc);
+    g.f[a] = (uint32_t)(int)fl;
+    g.o[a] = fsub(sc, fl);
+  }
+  return g;
+}
+__device__ __forceinline__ uint32_t grid_hash(uint32_t x, uint32_t y, uint32_t z, uint32_t mask) {
+  return (x ^ (y * 2654435761u) ^ (z * 805459861u)) & mask;
+}
+// the 8 corner rows in the oracle's order h0..h7
+__device__ __forceinline__ void grid_corners(const GridLevel& g, uint32_t mask, uint32_t (&h)[8]) {
+  h[0] = grid_hash(g.c[0], g.c[1], g.c[2], mask);
+  h[1] = grid_hash(g.c[0], g.f[1], g.c[2], mask);
+  h[2] = grid_hash(g.f[0], g.f[1], g.c[2], mask);
+  h[3] = grid_hash(g.f[0], g.c[1], g.c[2], mask);
+  h[4] = grid_hash(g.c[0], g.c[1], g.f[2], mask);
+  h[5] = grid_hash(g.c[0], g.f[1], g.f[2], mask);
+  h[6] = grid_hash(g.f[0], g.f[1], g.f[2], mask);
+  h[7] = grid_hash(g.f[0], g.c[1], g.f[2], mask);
+}
+// trilinear blend in the oracle's op order (mul, mul, add — no fma)
+__device__ __forceinline__ float lerp_nf(float a, float b, float o, float om) { return fadd(fmul(a, o), fmul(b, om)); }
+__device__ __forceinline__ float2 grid_interp(const float2 (&v)[8], const float (&o)[3]) {
+  const float omx = fsub(1.0f, o[0]), omy = fsub(1.0f, o[1]), omz = fsub(1.0f, o[2]);
+  float2 r;
+  {
+    float f03 = lerp_nf(v[0].x, v[3].x, o[0], omx), f12 = lerp_nf(v[1].x, v[2].x, o[0], omx);
+    float f56 = lerp_nf(v[5].x, v[6].x, o[0], omx), f47 = lerp_nf(v[4].x, v[7].x, o[0], omx);
+    float f0312 = lerp_nf(f03, f12, o[1], omy), f4756 = lerp_nf(f47, f56, o[1], omy);
+    r.x = lerp_nf(f0312, f4756, o[2], omz);
+  }
+  {
+    float f03 = lerp_nf(v[0].y, v[3].y, o[0], omx), f12 = lerp_nf(v[1].y, v[2].y, o[0], omx);
+    float f56 = lerp_nf(v[5].y, v[6].y, o[0], omx), f47 = lerp_nf(v[4].y, v[7].y, o[0], omx);
+    float f0312 = lerp_nf(f03, f12, o[1], omy), f4756 = lerp_nf(f47, f56, o[1], omy);
+    r.y = lerp_nf(f0312, f4756, o[2], omz);
+  }
+  return r;
+}
+// one level: gather 8 corners and blend
+__device__ __forceinline__ float2 grid_lookup(const float2* __restrict__ level_table, const float (&x)[3], int scaling,
+                                              uint32_t mask) {
+  GridLevel g = grid_cell(x, scaling);
+  uint32_t h[8];
+  grid_corners(g, mask, h);
+  float2 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = level_table[h[k]];
+  return grid_interp(v, g.o);
+}
+
+struct GridDev {
+  int n_levels;
+  int log2_T;
+  int scalings[FNR_MAX_LEVELS];
+  float2* table;
+};
+static inline GridDev make_grid(const fnr_grid* g) {
+  GridDev d;
+  d.n_levels = g->n_levels;
+  d.log2_T = g->log2_hashmap_size;
+  for (int i = 0; i < FNR_MAX_LEVELS; ++i) d.scalings[i] = g->scalings[i];
+  d.table = reinterpret_cast<float2*>(g->table);
+  return d;
+}
+
+struct RaysDev {
+  long long n_rays;
+  const float* origins;
+  const float* directions;
+  const float* nears;
+  const float* fars;
+  const int32_t* cam;
+};
+static inline RaysDev make_rays(const fnr_rays* r) {
+  RaysDev d{r->n_rays, r->origins, r->directions, r->nears, r->fars, r->camera_indices};
+  return d;
+}
+
+}  // namespace fnr

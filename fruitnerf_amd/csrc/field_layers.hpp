@@ -1,0 +1,175 @@
+// field_layers.hpp — MFMA fragment layout of FruitField's tiny MLPs (fruit_field.py:132-166) on gfx950.
+//
+// Formulation (per 16-sample tile, one wave): every layer is computed TRANSPOSED,
+//     Y^T[out][sample] = W[out][in] * X^T[in][sample]
+// with v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain):  A = W fragment, B = X^T fragment.
+//   A[i][k]: lane l supplies i = l&15, k = l>>4        B[k][j]: lane l supplies k = l>>4, j = l&15
+//   D[row][col]: lane l holds col = l&15, rows 4*(l>>4)+r, r = 0..3
+// With samples on j = l&15 the accumulator of layer n (lane holds features 16*ob + 4g + r of sample j)
+// is *directly* the B operand of layer n+1 if K-step (ib, r) is defined to cover the four features
+// {16*ib + 4g + r : g = 0..3}: activations never leave registers between layers, and the sum over k
+// is only re-ordered (fp32 rounding differences ~1e-7 vs the oracle).
+//
+// LDS image ("P"): for layer l, block (ob, ib) is 64 slots x 4 floats; lane (i = l&15, g = l>>4)
+// reads slot (i ^ g) + 16 g as one ds_read_b128 = {W[16 ob + i][kmap(ib, g, r)] : r = 0..3}.
+// The XOR swizzle keeps that read conflict-free AND makes the transposed-weight read of the backward
+// pass (lane wants W[16 ob + 4 kg + r][16 ib + i']) conflict-free as a broadcast b128 + select.
+#pragma once
+#include "common.hpp"
+
+namespace fnr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+enum KMap : int { KM_LINEAR = 0, KM_HASH = 1, KM_GEO = 2, KM_COLOR = 3 };
+
+// base configuration `fruit_nerf`: L=16,F=2 -> 32; hidden 64; geo 15; semantic 15->64->64 + head;
+// colour 63->64->64->3.
+struct FieldCfgBase {
+  static constexpr int GEO = 15;
+  static constexpr int NLAYERS = 8;
+  // layer ids:                 base0 base1 sem0 sem1 head col0 col1 col2
+  static constexpr int nob(int l) { constexpr int a[NLAYERS] = {4, 1, 4, 4, 1, 4, 4, 1}; return a[l]; }
+  static constexpr int nib(int l) { constexpr int a[NLAYERS] = {2, 4, 1, 4, 4, 4, 4, 4}; return a[l]; }
+  static constexpr int out_dim(int l) { constexpr int a[NLAYERS] = {64, 16, 64, 64, 1, 64, 64, 3}; return a[l]; }
+  static constexpr int in_dim(int l) { constexpr int a[NLAYERS] = {32, 64, 15, 64, 64, 63, 64, 64}; return a[l]; }
+  static constexpr int km(int l) {
+    constexpr int a[NLAYERS] = {KM_HASH, KM_LINEAR, KM_GEO, KM_LINEAR, KM_LINEAR, KM_COLOR, KM_LINEAR, KM_LINEAR};
+    return a[l];
+  }
+  static constexpr int woff(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += nob(i) * nib(i) * 256;
+    return o;
+  }
+  static constexpr int boff(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += nob(i) * 16;
+    return o;
+  }
+  static constexpr int W_TOTAL = 18432;  // = woff(NLAYERS), floats
+  static constexpr int B_TOTAL = 368;    // = boff(NLAYERS)
+  static constexpr int LDS_FLOATS = W_TOTAL + B_TOTAL;
+};
+static_assert(FieldCfgBase::woff(FieldCfgBase::NLAYERS) == FieldCfgBase::W_TOTAL, "W_TOTAL");
+static_assert(FieldCfgBase::boff(FieldCfgBase::NLAYERS) == FieldCfgBase::B_TOTAL, "B_TOTAL");
+
+struct FieldPtrs {
+  const float* w[8];
+  const float* b[8];
+};
+
+// input column of nn.Linear weight for K-slot (ib, g, r); -1 -> structural zero
+template <class Cfg>
+__device__ __forceinline__ int kmap(int kind, int ib, int g, int r, int in_dim) {
+  const int k = 4 * g + r;
+  int col;
+  switch (kind) {
+    case KM_HASH: {  // hash features: slot s = 4 ib + r covers level 4 (s >> 1) + g, feature s & 1
+      const int s = 4 * ib + r;
+      col = 2 * (4 * (s >> 1) + g) + (s & 1);
+      break;
+    }
+    case KM_GEO:  // input block = base-MLP output h (h[0] = density logit is not an input)
+      col = k - 1;
+      break;
+    case KM_COLOR:  // [h | SH16 | emb32] -> nn.Linear columns [SH16, geo, emb]
+      if (ib == 0) col = (k == 0) ? -1 : 16 + (k - 1);
+      else if (ib == 1) col = k;
+      else col = 16 + Cfg::GEO + 16 * (ib - 2) + k;
+      break;
+    default:
+      col = 16 * ib + k;
+  }
+  return (col >= 0 && col < in_dim) ? col : -1;
+}
+
+__device__ __forceinline__ int swz_slot(int i, int g) { return (i ^ g) + 16 * g; }
+
+// global nn.Linear weights -> LDS fragment image (pack-on-load; weights change every optimiser step)
+template <class Cfg>
+__device__ void stage_field_weights(float* __restrict__ lds, const FieldPtrs& p) {
+  for (int idx = threadIdx.x; idx < Cfg::W_TOTAL; idx += blockDim.x) {
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < Cfg::NLAYERS; ++q)
+      if (idx >= Cfg::woff(q)) l = q;
+    const int local = idx - Cfg::woff(l);
+    const int r = local & 3, slot = (local >> 2) & 63, blk = local >> 8;
+    const int nib = Cfg::nib(l);
+    const int ib = blk % nib, ob = blk / nib;
+    const int g = slot >> 4, i = (slot & 15) ^ g;
+    const int out = 16 * ob + i;
+    const int col = kmap<Cfg>(Cfg::km(l), ib, g, r, Cfg::in_dim(l));
+    float v = 0.0f;
+    if (out < Cfg::out_dim(l) && col >= 0) v = p.w[l][out * Cfg::in_dim(l) + col];
+    lds[idx] = v;
+  }
+  for (int idx = threadIdx.x; idx < Cfg::B_TOTAL; idx += blockDim.x) {
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < Cfg::NLAYERS; ++q)
+      if (idx >= Cfg::boff(q)) l = q;
+    const int o = idx - Cfg::boff(l);
+    lds[Cfg::W_TOTAL + idx] = (o < Cfg::out_dim(l)) ? p.b[l][o] : 0.0f;
+  }
+}
+
+// one layer: out^T[16 NOB][16] = W * in^T + b ; `in`/`out` are C-layout accumulators
+template <int NOB, int NIB>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ P, const float* __restrict__ B,
+                                          const f32x4 (&in)[NIB], f32x4 (&out)[NOB], int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int slot = swz_slot(i, g);
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(B + 16 * ob + 4 * g);
+#pragma unroll
+  for (int ib = 0; ib < NIB; ++ib) {
+    f32x4 w[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) w[ob] = *reinterpret_cast<const f32x4*>(P + ((ob * NIB + ib) * 64 + slot) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob)
+        out[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ob][r], in[ib][r], out[ob], 0, 0, 0);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void relu_(f32x4 (&a)[N]) {
+#pragma unroll
+  for (int b = 0; b < N; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[b][r] = fmaxf(a[b][r], 0.0f);
+}
+
+// SHEncoding(levels=4) torch path on the shifted direction d' = (d+1)/2 (fruit_field.py:208-210,243-245);
+// returns the 4 components 4g..4g+3 this lane feeds as B operand.
+__device__ __forceinline__ f32x4 sh16_fragment(const float* __restrict__ dir, int g) {
+  const float x = (dir[0] + 1.0f) / 2.0f, y = (dir[1] + 1.0f) / 2.0f, z = (dir[2] + 1.0f) / 2.0f;
+  const float xx = x * x, yy = y * y, zz = z * z;
+  float c[16];
+  c[0] = 0.28209479177387814f;
+  c[1] = 0.4886025119029199f * y;
+  c[2] = 0.4886025119029199f * z;
+  c[3] = 0.4886025119029199f * x;
+  c[4] = 1.0925484305920792f * x * y;
+  c[5] = 1.0925484305920792f * y * z;
+  c[6] = 0.9461746957575601f * zz - 0.31539156525251999f;
+  c[7] = 1.0925484305920792f * x * z;
+  c[8] = 0.5462742152960396f * (xx - yy);
+  c[9] = 0.5900435899266435f * y * (3.0f * xx - yy);
+  c[10] = 2.890611442640554f * x * y * z;
+  c[11] = 0.4570457994644658f * y * (5.0f * zz - 1.0f);
+  c[12] = 0.3731763325901154f * z * (5.0f * zz - 3.0f);
+  c[13] = 0.4570457994644658f * x * (5.0f * zz - 1.0f);
+  c[14] = 1.445305721320277f * z * (xx - yy);
+  c[15] = 0.5900435899266435f * x * (xx - 3.0f * yy);
+  f32x4 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r[q] = (g == 0) ? c[q] : (g == 1) ? c[4 + q] : (g == 2) ? c[8 + q] : c[12 + q];
+  return r;
+}
+
+}  // namespace fnr

@@ -1,0 +1,190 @@
+// hashgrid.hip — multiresolution hash-grid encode (HashEncoding torch semantics) and the fused
+// proposal-network density kernel, for gfx950.
+//
+// Roofline: HBM/L2-bound random 8-byte gathers (8 corners x L levels per sample, 64 B/level
+// algorithmic).  Layout decisions:
+//   * features are written level-major [L][N] float2 so a wave's store is one contiguous 512 B run;
+//   * the main-field encode launches one workgroup per (256 samples, level) and maps workgroup b to
+//     XCD b%8 (observed dispatch order) so each XCD's private 4 MiB L2 only ever sees the table
+//     slices of the two levels {x, L-1-x} it owns (one coarse = cache-friendly, one fine = 4 MiB);
+//     a different placement changes speed only, never results.
+#include "common.hpp"
+
+namespace fnr {
+
+// ------------------------------------------------------------------------------------------------
+// position sources
+// ------------------------------------------------------------------------------------------------
+struct RaySource {
+  RaysDev rays;
+  const float* euclid;  // [R, S+1]
+  int S;
+  __device__ __forceinline__ void position(long long n, float& px, float& py, float& pz) const {
+    long long r = n / S;
+    int k = (int)(n - r * S);
+    const float* b = euclid + r * (S + 1) + k;
+    ray_position(rays.origins + 3 * r, rays.directions + 3 * r, b[0], b[1], px, py, pz);
+  }
+};
+struct LatticeSource {
+  const float* xs;
+  const float* ys;
+  const float* zs;
+  int n_y, n_z;
+  long long ray_begin;
+  __device__ __forceinline__ void position(long long n, float& px, float& py, float& pz) const {
+    long long r = n / n_z;
+    int k = (int)(n - r * n_z);
+    r += ray_begin;
+    long long ix = r / n_y;
+    int iy = (int)(r - ix * n_y);
+    px = xs[ix];
+    py = ys[iy];
+    pz = zs[k];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// main-field encode: one thread per (sample, level)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void decode_block(int b, int L, long long nsb, int& level, long long& sb) {
+  if ((L & 7) == 0) {
+    // XCD-aware: xcd = b % 8 owns L/8 levels, coarse levels paired with fine ones
+    const int lpx = L >> 3;
+    const int xcd = b & 7;
+    const long long q = b >> 3;
+    const int li = (int)(q % lpx);
+    sb = q / lpx;
+    const int base = (li >> 1) * 8 + xcd;  // li even -> ascending from the coarse end
+    level = (li & 1) ? (L - 1 - base) : base;
+  } else {
+    level = b % L;
+    sb = b / L;
+  }
+}
+
+template <class Source>
+__global__ __launch_bounds__(256) void k_hash_encode(GridDev grid, Warp warp, Source src, long long N,
+                                                     float2* __restrict__ feats, uint8_t* __restrict__ selector) {
+  const long long nsb = (N + 255) / 256;
+  int level;
+  long long sb;
+  decode_block(blockIdx.x, grid.n_levels, nsb, level, sb);
+  const long long n = sb * 256 + threadIdx.x;
+  if (n >= N) return;
+  float px, py, pz, x[3];
+  src.position(n, px, py, pz);
+  const bool sel = warp_position(warp, px, py, pz, x);
+  const uint32_t mask = (1u << grid.log2_T) - 1u;
+  const float2* lt = grid.table + ((size_t)level << grid.log2_T);
+  float2 f = grid_lookup(lt, x, grid.scalings[level], mask);
+  feats[(size_t)level * N + n] = f;
+  if (level == 0 && selector) selector[n] = sel ? 1 : 0;
+}
+
+template <class Source>
+static int launch_encode(const fnr_grid* grid, const fnr_warp* warp, const Source& src, long long N, float* feats,
+                         uint8_t* selector, void* stream) {
+  FNR_CHECK_ARG(grid && warp && feats, "hash_encode: null argument");
+  FNR_CHECK_ARG(grid->n_levels >= 1 && grid->n_levels <= FNR_MAX_LEVELS, "hash_encode: n_levels %d out of range",
+                grid->n_levels);
+  FNR_CHECK_ARG(grid->log2_hashmap_size >= 1 && grid->log2_hashmap_size <= 28, "hash_encode: log2_hashmap_size");
+  if (N == 0) return FNR_OK;
+  const long long nsb = (N + 255) / 256;
+  const long long nblk = nsb * grid->n_levels;
+  FNR_CHECK_ARG(nblk < (1ll << 31), "hash_encode: too many samples for one launch (%lld)", N);
+  hipLaunchKernelGGL((k_hash_encode<Source>), dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), make_grid(grid),
+                     make_warp(warp), src, N, reinterpret_cast<float2*>(feats), selector);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// proposal network: hash(L levels) -> Linear(2L,H) ReLU Linear(H,1) -> trunc_exp * selector,
+// one thread per sample, weights through scalar loads (uniform addresses), fp32 VALU.
+// ------------------------------------------------------------------------------------------------
+template <int L, int H>
+__global__ __launch_bounds__(256) void k_prop_density(GridDev grid, Warp warp, RaySource src, long long N,
+                                                      const float* __restrict__ w0, const float* __restrict__ b0,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      float* __restrict__ density, float2* __restrict__ feat_save) {
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float px, py, pz, x[3];
+  src.position(n, px, py, pz);
+  const bool sel = warp_position(warp, px, py, pz, x);
+  const uint32_t mask = (1u << grid.log2_T) - 1u;
+  float f[2 * L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    float2 v = grid_lookup(grid.table + ((size_t)l << grid.log2_T), x, grid.scalings[l], mask);
+    f[2 * l] = v.x;
+    f[2 * l + 1] = v.y;
+    if (feat_save) feat_save[(size_t)l * N + n] = v;
+  }
+  float out = b1[0];
+#pragma unroll
+  for (int o = 0; o < H; ++o) {
+    float a = b0[o];
+#pragma unroll
+    for (int k = 0; k < 2 * L; ++k) a = fmaf(w0[o * 2 * L + k], f[k], a);
+    a = fmaxf(a, 0.0f);
+    out = fmaf(w1[o], a, out);
+  }
+  density[n] = sel ? expf(out) : 0.0f;
+}
+
+}  // namespace fnr
+
+using namespace fnr;
+
+extern "C" int fnr_hash_encode_fwd(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays,
+                                   const float* euclid_bins, int S, float* feats, uint8_t* selector, void* stream) {
+  FNR_CHECK_ARG(rays && euclid_bins && S > 0, "hash_encode_fwd: null rays/bins or S<=0");
+  RaySource src{make_rays(rays), euclid_bins, S};
+  return launch_encode(grid, warp, src, rays->n_rays * (long long)S, feats, selector, stream);
+}
+
+extern "C" int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fnr_lattice* lat,
+                                       int64_t ray_begin, int64_t n_rays, float* feats, uint8_t* selector,
+                                       void* stream) {
+  FNR_CHECK_ARG(lat && lat->xs && lat->ys && lat->zs, "hash_encode_lattice: null lattice");
+  FNR_CHECK_ARG(ray_begin >= 0 && n_rays >= 0 && ray_begin + n_rays <= (int64_t)lat->n_x * lat->n_y,
+                "hash_encode_lattice: ray range [%lld,+%lld) outside %d x %d lattice", (long long)ray_begin,
+                (long long)n_rays, lat->n_x, lat->n_y);
+  LatticeSource src{lat->xs, lat->ys, lat->zs, lat->n_y, lat->n_z, ray_begin};
+  return launch_encode(grid, warp, src, n_rays * (long long)lat->n_z, feats, selector, stream);
+}
+
+extern "C" int fnr_prop_density_fwd(const fnr_prop_net* net, const fnr_warp* warp, const fnr_rays* rays,
+                                    const float* euclid_bins, int S, float* density, float* feat_save, void* stream) {
+  FNR_CHECK_ARG(net && warp && rays && euclid_bins && density && S > 0, "prop_density_fwd: null argument");
+  FNR_UNSUPPORTED(net->hidden_dim == 16, "prop_density_fwd: hidden_dim %d not built (16 only)", net->hidden_dim);
+  const long long N = rays->n_rays * (long long)S;
+  if (N == 0) return FNR_OK;
+  RaySource src{make_rays(rays), euclid_bins, S};
+  const unsigned nblk = (unsigned)((N + 255) / 256);
+  GridDev g = make_grid(&net->grid);
+  Warp w = make_warp(warp);
+  float2* fs = reinterpret_cast<float2*>(feat_save);
+#define FNR_PROP_CASE(LL)                                                                                      \
+  case LL:                                                                                                     \
+    hipLaunchKernelGGL((k_prop_density<LL, 16>), dim3(nblk), dim3(256), 0, as_stream(stream), g, w, src, N,    \
+                       net->w0, net->b0, net->w1, net->b1, density, fs);                                       \
+    break;
+  switch (net->grid.n_levels) {
+    FNR_PROP_CASE(1)
+    FNR_PROP_CASE(2)
+    FNR_PROP_CASE(3)
+    FNR_PROP_CASE(4)
+    FNR_PROP_CASE(5)
+    FNR_PROP_CASE(6)
+    FNR_PROP_CASE(7)
+    FNR_PROP_CASE(8)
+    default:
+      FNR_UNSUPPORTED(false, "prop_density_fwd: n_levels %d not built (1..8)", net->grid.n_levels);
+  }
+#undef FNR_PROP_CASE
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}

@@ -1,0 +1,89 @@
+"""sample_volume — MI355X-native mirror of /root/reference/fruit_nerf/export/exporter_utils.py:47-258.
+
+Export loop: per batch of orthographic rays run the model in 'export' mode, threshold (density >= 70,
+logit >= 3, sigmoid(logit) > 0.9), gather the three point sets, rescale.  The per-sample field queries and
+the order-preserving three-stream compaction run in libfruitnerf_hip.so; Open3D object creation and PLY
+writing are out of scope here — the function returns the point / colour arrays the
+reference would hand to Open3D (float64, same order).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, Optional
+
+import torch
+
+from .. import _kernels as K
+
+SET_NAMES = ("semantic_colormap", "semantic", "density")
+
+
+def _compact_batch(lat, ray_begin, n_rays, positions, density, rgb, logit, state):
+    dev = density.device
+    while True:
+        cap = state["cap"]
+        if state.get("buf_cap") != cap:
+            state["points"] = [torch.empty(cap, 3, device=dev) for _ in range(3)]
+            state["colors"] = [torch.empty(cap, 4, device=dev) for _ in range(3)]
+            state["buf_cap"] = cap
+        counts = torch.zeros(3, dtype=torch.int64, device=dev)
+        K.export_compact(lat, ray_begin, n_rays, positions, density, rgb, logit, state["points"], state["colors"],
+                         counts)
+        c = counts.cpu().tolist()  # the reference also synchronises per batch (.cpu(), exporter_utils.py:126-153)
+        if max(c) <= cap:
+            return c
+        while state["cap"] < max(c):
+            state["cap"] *= 2
+
+
+def sample_volume(pipeline, num_points: int, output_dir: Optional[Path] = None, config=None,
+                  transform_json: Optional[dict] = None) -> Dict[str, dict]:
+    """`pipeline` needs `.model` (FruitModel in test_mode='export' after setup_inference) and
+    `.datamanager` (setup_inference done; `next_sample_volume`).  `num_points` = number of rays, as in the
+    reference (exporter_utils.py:94,172)."""
+    model = pipeline.model
+    dm = pipeline.datamanager
+    pts = {k: [] for k in SET_NAMES}
+    cols = {k: [] for k in SET_NAMES}
+    state = {"cap": 1 << 20}
+    lattice = getattr(dm, "export_lattice", None)
+    lat = None
+    if lattice is not None and lattice["n_samples"] == getattr(model, "num_inference_samples", None):
+        lat = K.LatticeArg(lattice["xs"], lattice["ys"], lattice["zs"])
+    done = 0
+    while done < num_points:
+        if lat is not None:
+            # fused path: same batches as OrthographicRayGenerator (ray_generators.py:52-58), positions implicit
+            dm.train_count += 1
+            start, end = dm.orthographic_ray_generator.batch_range(dm.train_count)
+            n_rays = end - start
+            density, rgb, logit = model.export_lattice_batch(lat, lattice["direction"], start, n_rays)
+            c = _compact_batch(lat, start, n_rays, None, density, rgb, logit, state)
+        else:
+            with torch.no_grad():
+                ray_bundle, _ = dm.next_sample_volume(0)
+                outputs = model(ray_bundle)
+            n_rays = outputs["point_location"].shape[0]
+            c = _compact_batch(None, 0, 0, outputs["point_location"].reshape(-1, 3),
+                               outputs["density"].reshape(-1).contiguous(),
+                               outputs["rgb"].reshape(-1, 3).contiguous(),
+                               outputs["semantics"].reshape(-1).contiguous(), state)
+        for s, name in enumerate(SET_NAMES):
+            pts[name].append(state["points"][s][:c[s]].cpu())
+            cols[name].append(state["colors"][s][:c[s]].cpu())
+        done += n_rays
+
+    scale = 1.0 if transform_json is None else float(transform_json["scale"])
+    pcd_list = {}
+    for name in SET_NAMES:
+        p = torch.cat(pts[name], dim=0)
+        c = torch.cat(cols[name], dim=0)
+        if name != "semantic_colormap" and c.shape[0] != 0:
+            c = c / c.max()  # exporter_utils.py:202-203,227-228
+        # pcd.scale(1/scale) then pcd.scale(2) about the origin (exporter_utils.py:190-191,216-217,241-242)
+        p = p.double() * (1.0 / scale) * 2.0
+        path = None
+        if output_dir is not None and config is not None:
+            path = str(Path(output_dir) / config.load_dir.parts[-3] / f"{name}.ply")
+        pcd_list[name] = {"points": p.numpy(), "colors": c.double().numpy()[:, :3], "path": path}
+    return pcd_list

@@ -1,0 +1,447 @@
+"""FruitModel — MI355X-native mirror of /root/reference/fruit_nerf/fruit_nerf.py:50-458.
+
+Same config fields, constructor kwargs, method names, output keys and loss names as the reference
+Nerfstudio model.  The hot path (collider -> proposal sampling -> proposal nets -> field -> weights ->
+renderers -> losses, and the export field queries) runs in libfruitnerf_hip.so; this file only sequences
+kernel launches on PyTorch's current HIP stream.  There is no PyTorch fallback for any of it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import defaultdict
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple, Type, Union
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import _kernels as K
+from . import _lib as L
+from .components.ray_samplers import UniformSamplerWithNoise
+from .fruit_field import FieldHeadNames, FruitField, SceneContraction
+from .params import HashEncoding, MLP, ParamArena
+from .rays import RayBundle, RaySamples
+
+
+@dataclass
+class FruitNerfModelConfig:
+    """FruitNerfModelConfig(NerfactoModelConfig) — fruit_nerf.py:50-59 plus the inherited Nerfacto 0.3.2
+    defaults the hot path reads."""
+    _target: Type = field(default_factory=lambda: FruitModel)
+    near_plane: float = 0.05
+    far_plane: float = 1000.0
+    background_color: str = "last_sample"
+    hidden_dim: int = 64            # ignored by FruitField construction (fruit_nerf.py:88-103)
+    hidden_dim_color: int = 64      # ignored
+    appearance_embed_dim: int = 32  # ignored
+    num_levels: int = 16
+    base_res: int = 16              # ignored
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    features_per_level: int = 2     # ignored
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_nerf_samples_per_ray: int = 48
+    proposal_update_every: int = 5
+    proposal_warmup: int = 5000
+    num_proposal_iterations: int = 2
+    use_same_proposal_network: bool = False
+    proposal_net_args_list: List[Dict] = field(default_factory=lambda: [
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 128, "use_linear": False},
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256, "use_linear": False},
+    ])
+    proposal_initial_sampler: str = "piecewise"
+    interlevel_loss_mult: float = 1.0
+    distortion_loss_mult: float = 0.002
+    use_proposal_weight_anneal: bool = True
+    use_average_appearance_embedding: bool = True
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    use_single_jitter: bool = True
+    disable_scene_contraction: bool = False
+    use_gradient_scaling: bool = False
+    eval_num_rays_per_chunk: int = 1 << 15
+    # FruitNerfModelConfig proper
+    semantic_loss_weight: float = 1.0
+    pass_semantic_gradients: bool = False
+    num_layers_semantic: int = 2
+    hidden_dim_semantics: int = 64
+    geo_feat_dim: int = 15
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+class HashMLPDensityField(nn.Module):
+    """Parameter holder for nerfstudio HashMLPDensityField (fruit_nerf.py:104-129); evaluated by
+    fnr_prop_density_fwd."""
+
+    def __init__(self, aabb: Tensor, num_layers: int = 2, hidden_dim: int = 64, spatial_distortion=None,
+                 use_linear: bool = False, num_levels: int = 8, max_res: int = 1024, base_res: int = 16,
+                 log2_hashmap_size: int = 18, features_per_level: int = 2, implementation: str = "hip"):
+        super().__init__()
+        if use_linear or num_layers != 2:
+            raise NotImplementedError("proposal nets are built as hash -> Linear -> ReLU -> Linear (use_linear=False)")
+        self.register_buffer("aabb", aabb.clone().float())
+        self.spatial_distortion = spatial_distortion
+        self.hidden_dim = hidden_dim
+        self.encoding = HashEncoding(num_levels=num_levels, min_res=base_res, max_res=max_res,
+                                     log2_hashmap_size=log2_hashmap_size, features_per_level=features_per_level)
+        network = MLP(in_dim=self.encoding.get_out_dim(), num_layers=num_layers, layer_width=hidden_dim, out_dim=1)
+        self.mlp_base = nn.Sequential(self.encoding, network)
+
+    def prop_struct(self, grads: bool = False) -> L.fnr_prop_net:
+        def P(p):
+            return (p.grad if grads else p.data).data_ptr()
+
+        e = self.encoding
+        net = L.fnr_prop_net()
+        net.grid = K.make_grid(e.hash_table.grad if grads else e.hash_table.data, e.num_levels, e.log2_hashmap_size,
+                               e.scalings)
+        net.hidden_dim = self.hidden_dim
+        lyr = self.mlp_base[1].layers
+        net.w0, net.b0, net.w1, net.b1 = P(lyr[0].weight), P(lyr[0].bias), P(lyr[1].weight), P(lyr[1].bias)
+        return net
+
+    def warp_struct(self) -> L.fnr_warp:
+        return K.make_warp(0 if self.spatial_distortion is not None else 1, self.aabb)
+
+    @torch.no_grad()
+    def density_fn(self, positions: Tensor) -> Tensor:
+        """Field.density_fn (positions [...,3] -> density [...,1]); zero-length frustums."""
+        shape = positions.shape[:-1]
+        pos = positions.reshape(-1, 3).float()
+        rays = K.RaysArg(pos, torch.ones_like(pos), None, None)
+        euclid = torch.zeros(rays.n, 2, device=pos.device)
+        density, _ = K.prop_density_fwd(self.prop_struct(), self.warp_struct(), rays, euclid, 1)
+        return density.view(*shape, 1)
+
+
+class ProposalNetworkSampler(nn.Module):
+    """State of nerfstudio's ProposalNetworkSampler (fruit_nerf.py:151-158): anneal, update schedule."""
+
+    def __init__(self, num_proposal_samples_per_ray=(64,), num_nerf_samples_per_ray=32,
+                 num_proposal_network_iterations=2, single_jitter=False, update_sched: Callable = lambda x: 1,
+                 initial_sampler=None):
+        super().__init__()
+        if initial_sampler is not None:
+            raise NotImplementedError("only the default piecewise initial sampler is built (fruit_nerf.py:140,157)")
+        if not single_jitter:
+            raise NotImplementedError("use_single_jitter=False is not built (Nerfacto default is True)")
+        self.num_proposal_samples_per_ray = tuple(num_proposal_samples_per_ray)
+        self.num_nerf_samples_per_ray = num_nerf_samples_per_ray
+        self.num_proposal_network_iterations = num_proposal_network_iterations
+        self.update_sched = update_sched
+        self._anneal = 1.0
+        self._steps_since_update = 0
+        self._step = 0
+
+    def set_anneal(self, anneal: float) -> None:
+        self._anneal = anneal
+
+    def step_cb(self, step):
+        self._step = step
+        self._steps_since_update += 1
+
+    def updated_now(self) -> bool:
+        return bool(self._steps_since_update > self.update_sched(self._step) or self._step < 10)
+
+
+@dataclass
+class RenderContext:
+    """Everything one forward pass produced (kept for the backward pass in training)."""
+    rays: K.RaysArg
+    levels: List[dict]          # per sampling level: S, spacing, euclid, density, weights, feats
+    updated: bool
+    training: bool
+    field_feats: Optional[Tensor] = None
+    field_selector: Optional[Tensor] = None
+    sample_rgb: Optional[Tensor] = None
+    sample_logit: Optional[Tensor] = None
+    sample_density: Optional[Tensor] = None
+    weights: Optional[Tensor] = None
+
+
+class FruitModel(nn.Module):
+    config: FruitNerfModelConfig
+
+    def __init__(self, config: FruitNerfModelConfig, metadata: Optional[Dict] = None, scene_box=None,
+                 num_train_data: int = 1, device: Union[str, torch.device] = "cuda", grad_scaler=None,
+                 test_mode: Optional[str] = None, render_rgb_inference: bool = True, **kwargs) -> None:
+        super().__init__()
+        # fruit_nerf.py:71-76
+        self.semantics = None if metadata is None else metadata.get("semantics")
+        self.test_mode = test_mode
+        self.config = config
+        self.num_train_data = num_train_data
+        self.kwargs = kwargs
+        if scene_box is None:
+            aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])  # fruitnerf_dataparser.py:218-223
+        else:
+            aabb = scene_box.aabb if hasattr(scene_box, "aabb") else torch.as_tensor(scene_box)
+        self.scene_aabb = aabb.float()
+        self._device = torch.device(device)
+        colors = getattr(self.semantics, "colors", None)
+        self.colormap = (colors.clone().detach() if colors is not None else torch.tensor([0.0, 1.0]))
+        self._arena: Optional[ParamArena] = None
+        self.populate_modules()
+        if self._device.type == "cuda":
+            self.to(self._device)
+
+    # ---- construction (fruit_nerf.py:78-177) -------------------------------------------------------------
+    def populate_modules(self):
+        cfg = self.config
+        scene_contraction = None if cfg.disable_scene_contraction else SceneContraction(order=float("inf"))
+        # fruit_nerf.py:88-103 — only these config fields reach the field
+        self.field = FruitField(self.scene_aabb, num_levels=cfg.num_levels, max_res=cfg.max_res,
+                                num_layers_semantic=cfg.num_layers_semantic,
+                                hidden_dim_semantics=cfg.hidden_dim_semantics,
+                                log2_hashmap_size=cfg.log2_hashmap_size, spatial_distortion=scene_contraction,
+                                num_images=self.num_train_data, geo_feat_dim=cfg.geo_feat_dim,
+                                use_average_appearance_embedding=cfg.use_average_appearance_embedding,
+                                use_semantics=True, test_mode=self.test_mode, num_semantic_classes=1,
+                                pass_semantic_gradients=cfg.pass_semantic_gradients)
+        self.density_fns = []
+        num_prop_nets = cfg.num_proposal_iterations
+        self.proposal_networks = nn.ModuleList()
+        if cfg.use_same_proposal_network:
+            assert len(cfg.proposal_net_args_list) == 1, "Only one proposal network is allowed."
+            network = HashMLPDensityField(self.scene_aabb, spatial_distortion=scene_contraction,
+                                          **cfg.proposal_net_args_list[0])
+            self.proposal_networks.append(network)
+            self.density_fns.extend([network.density_fn for _ in range(num_prop_nets)])
+        else:
+            for i in range(num_prop_nets):
+                args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
+                self.proposal_networks.append(
+                    HashMLPDensityField(self.scene_aabb, spatial_distortion=scene_contraction, **args))
+            self.density_fns.extend([network.density_fn for network in self.proposal_networks])
+
+        def update_schedule(step):  # fruit_nerf.py:131-136
+            return np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]),
+                           1, cfg.proposal_update_every)
+
+        if cfg.proposal_initial_sampler == "uniform":
+            # the reference leaves self.proposal_sampler undefined on this branch (fruit_nerf.py:145-149)
+            raise NotImplementedError('proposal_initial_sampler="uniform" is broken in the reference; use "piecewise"')
+        self.proposal_sampler = ProposalNetworkSampler(
+            num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray,
+            num_proposal_samples_per_ray=cfg.num_proposal_samples_per_ray,
+            num_proposal_network_iterations=cfg.num_proposal_iterations,
+            single_jitter=cfg.use_single_jitter, update_sched=update_schedule, initial_sampler=None)
+        if cfg.background_color != "last_sample":
+            raise NotImplementedError("only background_color='last_sample' (Nerfacto default) is built")
+        if cfg.use_gradient_scaling:
+            raise NotImplementedError("use_gradient_scaling=True is not built (Nerfacto default False)")
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._arena = None
+        return out
+
+    @property
+    def device(self):
+        return self.field.aabb.device
+
+    def arena(self) -> ParamArena:
+        """One flat fp32 arena for proposal networks + field (stable pointers, single all-reduce)."""
+        if self._arena is None:
+            dev = self.field.aabb.device
+            if dev.type != "cuda":
+                raise RuntimeError("FruitModel is on %s; move it to a HIP device (no CPU path)" % dev)
+            self._arena = ParamArena([("proposal_networks", list(self.proposal_networks.parameters())),
+                                      ("fields", list(self.field.parameters()))], dev)
+            self.field.adopt_arena(self._arena)
+        return self._arena
+
+    # ---- reference API -------------------------------------------------------------------------------------
+    def setup_inference(self, render_rgb, num_inference_samples):  # fruit_nerf.py:179-183
+        self.render_rgb = render_rgb
+        self.num_inference_samples = num_inference_samples
+        self.proposal_sampler = UniformSamplerWithNoise(num_samples=self.num_inference_samples, single_jitter=False)
+        self.proposal_sampler.train(self.training)
+        self.field.spatial_distortion = None
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:  # fruit_nerf.py:185-189
+        return {"proposal_networks": list(self.proposal_networks.parameters()),
+                "fields": list(self.field.parameters())}
+
+    def set_anneal(self, step: int) -> None:  # the BEFORE_TRAIN_ITERATION callback, fruit_nerf.py:199-207
+        N = self.config.proposal_weights_anneal_max_num_iters
+        train_frac = np.clip(step / N, 0, 1)
+
+        def bias(x, b):
+            return b * x / ((b - 1) * x + 1)
+
+        self.proposal_sampler.set_anneal(bias(train_frac, self.config.proposal_weights_anneal_slope))
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> List[Tuple[str, Callable]]:
+        """fruit_nerf.py:191-223 as (location, fn(step)) pairs (nerfstudio's TrainingCallback is not importable)."""
+        callbacks = []
+        if self.config.use_proposal_weight_anneal:
+            callbacks.append(("BEFORE_TRAIN_ITERATION", self.set_anneal))
+            callbacks.append(("AFTER_TRAIN_ITERATION", self.proposal_sampler.step_cb))
+        return callbacks
+
+    def _collide(self, ray_bundle: RayBundle) -> RayBundle:  # NearFarCollider, fruit_nerf.py:161,382-383
+        if ray_bundle.nears is not None and ray_bundle.fars is not None:
+            return ray_bundle
+        ones = torch.ones_like(ray_bundle.origins[..., 0:1])
+        near_plane = self.config.near_plane if self.training else 0
+        ray_bundle.nears = ones * near_plane
+        ray_bundle.fars = ones * self.config.far_plane
+        return ray_bundle
+
+    # ---- the hot path ----------------------------------------------------------------------------------------
+    def _render(self, ray_bundle: RayBundle, jitter: Optional[List[Tensor]] = None) -> Tuple[Dict, RenderContext]:
+        """ProposalNetworkSampler.generate_ray_samples + field + weights + renderers (fruit_nerf.py:316-357)."""
+        self.arena()
+        cfg = self.config
+        sampler = self.proposal_sampler
+        training = self.training
+        rays = K.RaysArg(ray_bundle.origins, ray_bundle.directions, ray_bundle.nears, ray_bundle.fars,
+                         ray_bundle.camera_indices)
+        dev = rays.device
+        n_prop = sampler.num_proposal_network_iterations
+        updated = sampler.updated_now()
+        jit = list(jitter) if jitter is not None else [None] * (n_prop + 1)
+        if training:
+            jit = [j if j is not None else torch.rand(rays.n, device=dev) for j in jit]
+        else:
+            jit = [None] * (n_prop + 1)
+        levels: List[dict] = []
+        S0 = sampler.num_proposal_samples_per_ray[0]
+        spacing, euclid = K.sample_spaced(rays, 1, S0, jit[0])
+        S = S0
+        for i in range(n_prop):
+            net = self.proposal_networks[0 if cfg.use_same_proposal_network else i]
+            save = training and updated
+            density, feats = K.prop_density_fwd(net.prop_struct(), net.warp_struct(), rays, euclid, S,
+                                                save_feats=save)
+            S_next = sampler.num_proposal_samples_per_ray[i + 1] if i + 1 < n_prop else sampler.num_nerf_samples_per_ray
+            weights, depth, spacing_n, euclid_n = K.weights_pdf(rays, 1, S, S_next, density, spacing, euclid,
+                                                                sampler._anneal, jit[i + 1])
+            levels.append(dict(S=S, spacing=spacing, euclid=euclid, density=density, weights=weights, depth=depth,
+                               feats=feats))
+            spacing, euclid, S = spacing_n, euclid_n, S_next
+        if updated:
+            sampler._steps_since_update = 0
+
+        fld = self.field
+        net = fld.net_struct()
+        feats, selector = K.hash_encode_fwd(net.grid, fld.warp_struct(), rays, euclid, S)
+        mean_emb = fld._mean_embedding() if fld._uses_mean_embedding() else None
+        if mean_emb is None and rays.cam is None:
+            raise AttributeError("Camera indices are not provided.")
+        density, rgb, logit, _ = K.field_mlp_fwd(net, rays, S, feats, selector, mean_emb)
+        weights, out_rgb, acc, depth, sem = K.composite_fwd(rays, S, euclid, density, rgb, logit, training)
+        levels.append(dict(S=S, spacing=spacing, euclid=euclid, density=density.view(rays.n, S), weights=weights,
+                           depth=depth, feats=None))
+        ctx = RenderContext(rays=rays, levels=levels, updated=updated, training=training, field_feats=feats,
+                            field_selector=selector, sample_rgb=rgb, sample_logit=logit, sample_density=density,
+                            weights=weights)
+        outputs = {"rgb": out_rgb, "accumulation": acc[:, None], "depth": depth[:, None],
+                   "semantics": sem[:, None]}
+        for i in range(n_prop):
+            outputs[f"prop_depth_{i}"] = levels[i]["depth"][:, None]
+        return outputs, ctx
+
+    def _samples_lists(self, ray_bundle: RayBundle, ctx: RenderContext):
+        weights_list, ray_samples_list = [], []
+        for lv in ctx.levels:
+            weights_list.append(lv["weights"][..., None])
+            e, s = lv["euclid"], lv["spacing"]
+            rs = ray_bundle.get_ray_samples(bin_starts=e[..., :-1, None], bin_ends=e[..., 1:, None],
+                                            spacing_starts=s[..., :-1, None], spacing_ends=s[..., 1:, None])
+            rs._structured = (ctx.rays, e, lv["S"])
+            ray_samples_list.append(rs)
+        return weights_list, ray_samples_list
+
+    def _finish_outputs(self, ray_bundle, outputs, ctx, repeat_colormap: bool):
+        weights_list, ray_samples_list = self._samples_lists(ray_bundle, ctx)
+        outputs["weights_list"] = weights_list
+        outputs["ray_samples_list"] = ray_samples_list
+        # semantics colormap (fruit_nerf.py:309-312, 351-355): heaviside(sigmoid(sem) - 0.9, 0) -> colormap lookup
+        semantic_labels = torch.sigmoid(outputs["semantics"].detach())
+        semantic_labels = torch.heaviside(semantic_labels - 0.9, torch.tensor(0.0, device=semantic_labels.device)
+                                          ).to(torch.long)
+        cm = self.colormap.to(semantic_labels.device)[semantic_labels]
+        outputs["semantics_colormap"] = cm.repeat(1, 3) if repeat_colormap else cm
+        outputs["_ctx"] = ctx
+        return outputs
+
+    @torch.no_grad()
+    def get_inference_outputs(self, ray_bundle: RayBundle):  # fruit_nerf.py:272-314
+        outputs, ctx = self._render(ray_bundle)
+        return self._finish_outputs(ray_bundle, outputs, ctx, repeat_colormap=True)
+
+    def get_outputs(self, ray_bundle: RayBundle, jitter: Optional[List[Tensor]] = None):  # fruit_nerf.py:316-357
+        if self.training and torch.is_grad_enabled():
+            from .training import render_with_grad  # differentiable path (custom autograd.Function)
+            outputs, ctx = render_with_grad(self, ray_bundle, jitter)
+        else:
+            with torch.no_grad():
+                outputs, ctx = self._render(ray_bundle, jitter)
+        return self._finish_outputs(ray_bundle, outputs, ctx, repeat_colormap=False)
+
+    @torch.no_grad()
+    def get_export_outputs(self, ray_bundle: RayBundle):  # fruit_nerf.py:251-269
+        outputs = {}
+        ray_samples = self.proposal_sampler(ray_bundle)
+        field_outputs = self.field.forward(ray_samples)
+        outputs["rgb"] = field_outputs[FieldHeadNames.RGB]
+        outputs["point_location"] = ray_samples.frustums.get_positions()
+        outputs["semantics"] = field_outputs[FieldHeadNames.SEMANTICS][..., 0]
+        outputs["density"] = field_outputs[FieldHeadNames.DENSITY][..., 0]
+        semantic_labels = torch.sigmoid(outputs["semantics"])
+        threshold = 0.9
+        semantic_labels = torch.heaviside(semantic_labels - threshold,
+                                          torch.tensor(0.0, device=semantic_labels.device)).to(torch.long)
+        outputs["semantics_colormap"] = semantic_labels
+        return outputs
+
+    @torch.no_grad()
+    def export_lattice_batch(self, lat: "K.LatticeArg", direction: Tensor, ray_begin: int, n_rays: int):
+        """Fused get_export_outputs for lattice rays [ray_begin, ray_begin+n_rays): per-sample density, rgb,
+        logit without materialising positions / labels (they are re-derived inside fnr_export_compact)."""
+        self.arena()
+        fld = self.field
+        net = fld.net_struct()
+        feats, selector = K.hash_encode_lattice(net.grid, fld.warp_struct(), lat, ray_begin, n_rays)
+        dirs = direction.reshape(1, 3).expand(n_rays, 3).contiguous()
+        rays = K.RaysArg(dirs, dirs, None, None)  # the MLP stage only reads directions
+        density, rgb, logit, _ = K.field_mlp_fwd(net, rays, lat.c.n_z, feats, selector, fld._mean_embedding())
+        return density, rgb, logit
+
+    def forward(self, ray_bundle: RayBundle, jitter: Optional[List[Tensor]] = None):  # fruit_nerf.py:374-394
+        ray_bundle = self._collide(ray_bundle)
+        if self.test_mode == "inference":
+            return self.get_inference_outputs(ray_bundle)
+        elif self.test_mode == "export":
+            return self.get_export_outputs(ray_bundle)
+        return self.get_outputs(ray_bundle, jitter=jitter)
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """fruit_nerf.py:225-249: chunked full-image evaluation, outputs moved to the CPU per chunk."""
+        num_rays_per_chunk = self.config.eval_num_rays_per_chunk
+        image_height, image_width = camera_ray_bundle.origins.shape[:2]
+        num_rays = len(camera_ray_bundle)
+        outputs_lists = defaultdict(list)
+        for i in range(0, num_rays, num_rays_per_chunk):
+            ray_bundle = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + num_rays_per_chunk)
+            outputs = self.forward(ray_bundle=ray_bundle)
+            for output_name, output in outputs.items():
+                if not torch.is_tensor(output):
+                    continue
+                outputs_lists[output_name].append(output.cpu())
+        return {k: torch.cat(v).view(image_height, image_width, -1) for k, v in outputs_lists.items()}
+
+    # ---- losses / metrics ----------------------------------------------------------------------------------------
+    def get_loss_dict(self, outputs, batch, metrics_dict=None):  # fruit_nerf.py:359-372
+        from .training import fused_losses
+        return fused_losses(self, outputs, batch)
+
+    def get_metrics_dict(self, outputs, batch):  # fruit_nerf.py:396-401
+        from .training import metrics
+        return metrics(self, outputs, batch)

@@ -1,0 +1,193 @@
+/*
+ * fruitnerf_hip.h — C ABI of the MI355X-native (gfx950) FruitNeRF ray-marching hot path.
+ *
+ * The reference (meyerls/FruitNeRF) has no FFI: its hot path is the Nerfstudio Python plugin API
+ * (fruit_nerf/fruit_field.py FruitField, fruit_nerf/fruit_nerf.py FruitModel) and the arithmetic
+ * runs in nerfstudio==0.3.2 / tiny-cuda-nn.  This header is the C boundary our Python mirror of
+ * that API (fruitnerf_amd/) binds with ctypes; every entry point cites the reference interface
+ * (file:line relative to /root/reference) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * reference-side binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless a name ends in _host;
+ *   - the caller owns every buffer (parameters, gradients, workspace, outputs);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *     no entry point synchronises unless documented;
+ *   - return value 0 = ok, negative = error (fnr_last_error() gives the message); no exceptions
+ *     cross the ABI; nothing falls back to the CPU.
+ *   - tensors are dense row-major fp32 unless stated; N = n_rays * S samples, sample n = ray*S + k.
+ */
+#ifndef FRUITNERF_HIP_H
+#define FRUITNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FNR_ABI_VERSION 1
+#define FNR_MAX_LEVELS 16
+#define FNR_MAX_SEM_LAYERS 4
+
+enum {
+  FNR_OK = 0,
+  FNR_ERR_INVALID = -1,     /* bad argument */
+  FNR_ERR_UNSUPPORTED = -2, /* configuration not built into this library */
+  FNR_ERR_HIP = -3,         /* HIP runtime error (message in fnr_last_error) */
+};
+
+/* Multiresolution hash grid, nerfstudio-0.3.2 torch layout: HashEncoding (constructed at
+ * fruit_field.py:124-131 and fruit_nerf.py:111-127).  Every level owns T = 2^log2_hashmap_size rows
+ * of 2 floats; `scalings` are the integers floor(min_res * growth**level) computed on the HOST in
+ * float32 exactly as HashEncoding.__init__ does. */
+typedef struct fnr_grid {
+  int32_t n_levels;
+  int32_t log2_hashmap_size;
+  int32_t scalings[FNR_MAX_LEVELS];
+  float* table; /* [n_levels << log2_hashmap_size, 2] */
+} fnr_grid;
+
+/* RayBundle (nerfstudio.cameras.rays; built at data/fruit_datamanager.py:188-197 and
+ * components/ray_generators.py:52-64), after the collider (fruit_nerf.py:161,382-383). */
+typedef struct fnr_rays {
+  int64_t n_rays;
+  const float* origins;          /* [R,3] */
+  const float* directions;       /* [R,3] */
+  const float* nears;            /* [R]   */
+  const float* fars;             /* [R]   */
+  const int32_t* camera_indices; /* [R] or NULL */
+} fnr_rays;
+
+/* World position -> unit cube (fruit_field.py:168-179).
+ * mode 0: SceneContraction(order=inf) then (x+2)/4     (training / rendering)
+ * mode 1: SceneBox.get_normalized_positions(x, aabb)   (export: spatial_distortion=None, fruit_nerf.py:183) */
+typedef struct fnr_warp {
+  int32_t mode;
+  float aabb[6]; /* min xyz, max xyz */
+} fnr_warp;
+
+/* HashMLPDensityField (fruit_nerf.py:104-129): hash grid -> Linear(2L,H) ReLU Linear(H,1) -> trunc_exp. */
+typedef struct fnr_prop_net {
+  fnr_grid grid;
+  int32_t hidden_dim; /* 16 */
+  float* w0;          /* [H, 2L] */
+  float* b0;          /* [H] */
+  float* w1;          /* [1, H] */
+  float* b1;          /* [1] */
+} fnr_prop_net;
+
+/* FruitField (fruit_field.py:43-301).  Linear weights are nn.Linear layout [out, in].
+ * A second instance of this struct with pointers into the gradient arena describes the gradients. */
+typedef struct fnr_field_net {
+  fnr_grid grid;
+  int32_t geo_feat_dim;         /* 15 */
+  int32_t hidden_dim;           /* 64 (base MLP width)  */
+  int32_t hidden_dim_color;     /* 64 */
+  int32_t hidden_dim_semantics; /* 64 */
+  int32_t num_layers_semantic;  /* 2  */
+  int32_t semantic_out_dim;     /* 64 (hidden_dim_transient, fruit_field.py:150) */
+  int32_t appearance_dim;       /* 32 */
+  int32_t n_images;
+  float* base_w0; float* base_b0;           /* [64, 2L], [64] */
+  float* base_w1; float* base_b1;           /* [1+geo, 64], [1+geo] */
+  float* sem_w[FNR_MAX_SEM_LAYERS];         /* mlp_semantics layers */
+  float* sem_b[FNR_MAX_SEM_LAYERS];
+  float* head_w; float* head_b;             /* SemanticFieldHead: [1, 64], [1] (components/field_heads.py:29-40) */
+  float* col_w[3]; float* col_b[3];         /* mlp_head: [64,16+geo+32],[64,64],[3,64] */
+  float* embedding;                         /* embedding_appearance [n_images, 32] */
+} fnr_field_net;
+
+/* ---- library / device ----------------------------------------------------------------------- */
+int fnr_abi_version(void);
+const char* fnr_last_error(void);
+/* Queries the current HIP device; fails loudly when no gfx950 device is present. */
+int fnr_device_check(int* cu_count_out, char* name_out, int name_len);
+
+/* ---- samplers ------------------------------------------------------------------------------- */
+/* SpacedSampler.generate_ray_samples (components/ray_samplers.py:54-104; nerfstudio
+ * UniformLinDispPiecewiseSampler for the proposal level 0, fruit_nerf.py:151-158).
+ * spacing_kind 0: identity (UniformSamplerWithNoise, export); 1: lin/disparity piecewise.
+ * base_bins: [S+1] = torch.linspace(0, 1, S+1) evaluated on the HOST (ray_samplers.py:76), so the bins
+ *            carry ATen's exact linspace rounding.
+ * t_rand: [R] single-jitter random numbers (training) or NULL (eval: no jitter).
+ * Outputs: spacing bins [R,S+1] and euclidean bins [R,S+1]. */
+int fnr_sample_spaced(const fnr_rays* rays, int spacing_kind, int S, const float* base_bins, const float* t_rand,
+                      float* spacing_bins, float* euclid_bins, void* stream);
+
+/* RaySamples.get_weights on the previous level + PDFSampler (nerfstudio; driven from
+ * ProposalNetworkSampler, fruit_nerf.py:151-158,318): weights of the S_prev samples, annealed
+ * (w^anneal), histogram padding 0.01, inverse-CDF resampling to S_new+1 bins.
+ * u_base: [S_new+1] = torch.linspace(0, 1 - 1/(S_new+1), S_new+1) evaluated on the HOST.
+ * rand: [R] single-jitter numbers (training) or NULL (eval: centred u).
+ * S_new = 0: weights (and median depth) only.
+ * median_depth (optional, [R]): DepthRenderer("median") of the S_prev samples (fruit_nerf.py:299-300). */
+int fnr_weights_pdf(const fnr_rays* rays, int spacing_kind, int S_prev, int S_new, const float* density,
+                    const float* spacing_prev, const float* euclid_prev, float anneal, const float* u_base,
+                    const float* rand, float* weights, float* median_depth, float* spacing_new, float* euclid_new, void* stream);
+
+/* ---- proposal networks ---------------------------------------------------------------------- */
+/* HashMLPDensityField.density_fn at the S bin midpoints of every ray (fruit_nerf.py:111-129).
+ * feat_save: optional [L][N][2] encoded features kept for fnr_prop_density_bwd. */
+int fnr_prop_density_fwd(const fnr_prop_net* net, const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins,
+                         int S, float* density, float* feat_save, void* stream);
+
+/* ---- main field ----------------------------------------------------------------------------- */
+/* HashEncoding forward of FruitField.get_density (fruit_field.py:168-186) at the bin midpoints.
+ * feats: [L][N][2] (level-major), selector: [N] bytes (the 0<x<1 mask, fruit_field.py:178). */
+int fnr_hash_encode_fwd(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins,
+                        int S, float* feats, uint8_t* selector, void* stream);
+
+/* Same on the orthographic export lattice (data/fruit_datamanager.py:71-121,157-172;
+ * components/ray_generators.py:46-66; components/ray_samplers.py:76-94): sample n of the batch is
+ * ray (ray_begin + n / n_z), depth index n % n_z, at (xs[ray / n_y], ys[ray % n_y], zs[n % n_z]). */
+typedef struct fnr_lattice {
+  int32_t n_x, n_y, n_z;
+  const float* xs; /* [n_x] torch.linspace values */
+  const float* ys; /* [n_y] */
+  const float* zs; /* [n_z] sample-midpoint z coordinates */
+} fnr_lattice;
+int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fnr_lattice* lat, int64_t ray_begin,
+                            int64_t n_rays, float* feats, uint8_t* selector, void* stream);
+
+/* mlp_base_mlp + trunc_exp, mlp_semantics + SemanticFieldHead, SHEncoding + mlp_head
+ * (fruit_field.py:187-193, 195-232, 234-281) on MFMA.
+ * mean_embedding: [32] -> eval/export path (fruit_field.py:217-219,253-256); NULL -> training path,
+ * per-ray Embedding[camera_indices] (fruit_field.py:251).
+ * Outputs per sample: density [N], rgb [N,3], logit [N]; geo_out (optional) [N, geo_feat_dim] = the
+ * density embedding `base_mlp_out` returned by get_density (fruit_field.py:187-193). */
+int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays, int S, const float* feats,
+                      const uint8_t* selector, const float* mean_embedding, float* density, float* rgb, float* logit,
+                      float* geo_out, void* stream);
+
+/* embedding_appearance.mean(dim=0) (fruit_field.py:219,256): out [appearance_dim]. */
+int fnr_embedding_mean(const float* embedding, int n_images, int dim, float* out, void* stream);
+
+/* ---- compositing ---------------------------------------------------------------------------- */
+/* RaySamples.get_weights + RGBRenderer("last_sample") + AccumulationRenderer + DepthRenderer("median")
+ * + SemanticRenderer (fruit_nerf.py:325-348).  training=0 additionally applies nan_to_num / clamp. */
+int fnr_composite_fwd(const fnr_rays* rays, int S, const float* euclid_bins, const float* density, const float* rgb,
+                      const float* logit, int training, float* weights, float* out_rgb, float* out_accumulation,
+                      float* out_depth, float* out_semantics, void* stream);
+
+/* ---- export --------------------------------------------------------------------------------- */
+/* sample_volume's masks + gathers (export/exporter_utils.py:111-153) as an order-preserving stream
+ * compaction.  Sets: 0 = semantic_colormap (sigmoid(logit) > 0.9 and density >= 70),
+ * 1 = semantic (logit >= 3 and density >= 70), 2 = density (density >= 70).
+ * points[s]: [capacity,3] world positions (fruit_nerf.py:259), colors[s]: [capacity,4] = rgb || sigmoid(x)
+ * with x = logit (sets 0,1) or density (set 2).  counts: uint64[3] running totals (device), advanced by
+ * this call; entries beyond `capacity` are counted but not written.
+ * Sample positions come either from the lattice (lat != NULL: rays [ray_begin, ray_begin+n_rays) x n_z) or
+ * from an explicit array positions[n_positions,3] (lat == NULL; outputs['point_location'], fruit_nerf.py:259).
+ * workspace: >= fnr_export_workspace_bytes(n_samples) bytes. */
+size_t fnr_export_workspace_bytes(int64_t n_samples);
+int fnr_export_compact(const fnr_lattice* lat, int64_t ray_begin, int64_t n_rays, const float* positions,
+                       int64_t n_positions, const float* density,
+                       const float* rgb, const float* logit, float* const points[3], float* const colors[3],
+                       int64_t capacity, uint64_t* counts, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRUITNERF_HIP_H */

@@ -90,6 +90,12 @@ class RayBundle:
         )
         if camera_indices is not None:
             camera_indices = camera_indices.expand(-1, S, -1)
+        # nerfstudio's RaySamples is a TensorDataclass: every field is broadcast to the batch shape [R, S]
+        # (eval-mode spacing bins start life as [1, S+1])
+        R = self.origins.shape[0]
+        if spacing_starts is not None:
+            spacing_starts = spacing_starts.expand(R, S, 1)
+            spacing_ends = spacing_ends.expand(R, S, 1)
         return RaySamples(frustums, camera_indices, deltas, spacing_starts, spacing_ends, spacing_to_euclidean_fn)
 
 
