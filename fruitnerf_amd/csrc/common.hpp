@@ -6,6 +6,12 @@
 
 #include "../../include/fruitnerf_hip.h"
 
+// hipcc defaults to -ffp-contract=fast and HIP's __fmul_rn/__fadd_rn are plain operators, so a*b+c (and
+// x*s - floor(x*s)!) would be fused into FMAs.  The oracle (PyTorch CPU eager) rounds after every op and
+// discrete decisions (cell index vs. offset, selector, thresholds) depend on those roundings: contraction
+// is off for every translation unit; FMAs are written explicitly (fmaf / MFMA) where they are wanted.
+#pragma clang fp contract(off)
+
 namespace fnr {
 
 // ---- error plumbing ---------------------------------------------------------------------------

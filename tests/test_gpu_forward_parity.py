@@ -192,6 +192,9 @@ def test_export_counts_and_points_identical(dev):
     cfg = util.small_config(log2=15)
     om = util.make_oracle(cfg, seed=4, test_mode="export")
     util.randomize_(om, 9, density_boost=3.0)
+    with torch.no_grad():  # make the logit >= 3 and sigmoid > 0.9 sets non-trivial
+        om.field.field_head_semantics.net.weight.mul_(8.0)
+        om.field.field_head_semantics.net.bias.add_(1.5)
     om.field.test_mode = "export"
     om.eval()
     hm = util.make_hip_like(om, dev, test_mode="export")
