@@ -224,3 +224,101 @@ def export_compact(lat: Optional[LatticeArg], ray_begin: int, n_rays: int, posit
     L.check(lib.fnr_export_compact(None if lat is None else lat.ref, ray_begin, n_rays, L.ptr(pos), N,
                                    L.ptr(density), L.ptr(rgb), L.ptr(logit), parr, carr, cap, L.ptr(counts),
                                    L.ptr(ws), L.stream_ptr(dev)), "export_compact")
+
+
+# ---- training ---------------------------------------------------------------------------------------
+
+
+def losses_fwd(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tensor, semantic_loss_weight: float):
+    lib = L.load()
+    dev = rgb.device
+    R = rgb.shape[0]
+    losses = torch.empty(2, device=dev)
+    d_rgb = torch.empty(R, 3, device=dev)
+    d_sem = torch.empty(R, device=dev)
+    L.check(lib.fnr_losses_fwd(R, L.ptr(_f32c(rgb)), L.ptr(_f32c(image.reshape(R, 3))),
+                               L.ptr(_f32c(semantics.reshape(R))), L.ptr(_f32c(fruit_mask.reshape(R))),
+                               float(semantic_loss_weight), L.ptr(losses), L.ptr(d_rgb), L.ptr(d_sem),
+                               L.stream_ptr(dev)), "losses_fwd")
+    return losses, d_rgb, d_sem
+
+
+def interlevel_fwd(S_f: int, spacing_f: Tensor, weights_f: Tensor, S_p: int, spacing_p: Tensor, weights_p: Tensor,
+                   mult: float, loss_acc: Tensor) -> Tensor:
+    lib = L.load()
+    dev = spacing_f.device
+    R = spacing_f.shape[0]
+    d_wp = torch.empty(R, S_p, device=dev)
+    L.check(lib.fnr_interlevel_fwd(R, S_f, L.ptr(spacing_f), L.ptr(weights_f), S_p, L.ptr(spacing_p), L.ptr(weights_p),
+                                   float(mult), L.ptr(loss_acc), L.ptr(d_wp), L.stream_ptr(dev)), "interlevel_fwd")
+    return d_wp
+
+
+def distortion(S: int, spacing: Tensor, weights: Tensor) -> Tensor:
+    lib = L.load()
+    dev = spacing.device
+    out = torch.zeros(1, device=dev)
+    L.check(lib.fnr_distortion(spacing.shape[0], S, L.ptr(spacing), L.ptr(weights), L.ptr(out), L.stream_ptr(dev)),
+            "distortion")
+    return out[0]
+
+
+def composite_bwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, weights: Tensor, g_rgb: Tensor,
+                  g_sem: Tensor):
+    lib = L.load()
+    dev = rays.device
+    N = rays.n * S
+    d_density = torch.empty(N, device=dev)
+    d_rgb = torch.empty(N, 3, device=dev)
+    d_logit = torch.empty(N, device=dev)
+    L.check(lib.fnr_composite_bwd(rays.ref, S, L.ptr(euclid), L.ptr(density), L.ptr(rgb), L.ptr(weights),
+                                  L.ptr(_f32c(g_rgb)), L.ptr(_f32c(g_sem.reshape(-1))), L.ptr(d_density),
+                                  L.ptr(d_rgb), L.ptr(d_logit), L.stream_ptr(dev)), "composite_bwd")
+    return d_density, d_rgb, d_logit
+
+
+def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weights: Tensor,
+                upstream: Optional[Tensor]) -> Tensor:
+    lib = L.load()
+    dev = euclid.device
+    R = euclid.shape[0]
+    d_density = torch.empty(R, S, device=dev)
+    L.check(lib.fnr_weights_bwd(R, S, L.ptr(euclid), L.ptr(density), L.ptr(weights), L.ptr(d_weights),
+                                L.ptr(upstream), L.ptr(d_density), L.stream_ptr(dev)), "weights_bwd")
+    return d_density
+
+
+def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor,
+                  selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor) -> Tensor:
+    lib = L.load()
+    dev = rays.device
+    N = rays.n * S
+    d_feats = torch.empty_like(feats)
+    nbytes = lib.fnr_field_mlp_bwd_workspace_bytes(N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    L.check(lib.fnr_field_mlp_bwd(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(selector),
+                                  L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(ws), nbytes,
+                                  L.stream_ptr(dev)), "field_mlp_bwd")
+    return d_feats
+
+
+def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
+                    d_feats: Tensor) -> None:
+    lib = L.load()
+    L.check(lib.fnr_hash_encode_bwd(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
+                                    L.stream_ptr(rays.device)), "hash_encode_bwd")
+
+
+def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor,
+                     S: int, feats: Tensor, d_density: Tensor) -> None:
+    lib = L.load()
+    L.check(lib.fnr_prop_density_bwd(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
+                                     L.ptr(feats), L.ptr(d_density), L.stream_ptr(rays.device)), "prop_density_bwd")
+
+
+def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float,
+              beta2: float, eps: float, step: int, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
+    lib = L.load()
+    L.check(lib.fnr_adam_step(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(),
+                              float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
+                              1 if zero_grad else 0, L.stream_ptr(params.device)), "adam_step")

@@ -8,7 +8,7 @@
 
 namespace fnr {
 
-static int field_ptrs(const fnr_field_net* net, FieldPtrs& p) {
+int field_ptrs(const fnr_field_net* net, FieldPtrs& p) {
   FNR_UNSUPPORTED(net->grid.n_levels == 16, "field_mlp: num_levels %d not built (16 only)", net->grid.n_levels);
   FNR_UNSUPPORTED(net->geo_feat_dim == 15 && net->hidden_dim == 64 && net->hidden_dim_color == 64 &&
                       net->hidden_dim_semantics == 64 && net->num_layers_semantic == 2 &&

@@ -1,0 +1,359 @@
+// train.hip — losses, their gradients, compositing backward and the fused Adam step for gfx950.
+//   get_loss_dict (fruit_nerf.py:359-372): MSELoss, BCEWithLogitsLoss, interlevel_loss
+//   get_metrics_dict (fruit_nerf.py:396-401): distortion_loss (metric only)
+//   backward of RaySamples.get_weights + renderers (fruit_nerf.py:325-348)
+//   optimiser: torch.optim.Adam semantics (fruit_nerf_config.py:47-56)
+// One wave per ray for the per-ray scans; everything here is bandwidth-trivial next to the field kernels.
+#include "common.hpp"
+
+namespace fnr {
+
+// ---------------------------------------------------------------------------------------------------
+// rgb MSE + semantic BCE-with-logits: values and unit gradients
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_losses(long long R, const float* __restrict__ rgb,
+                                                const float* __restrict__ image, const float* __restrict__ sem,
+                                                const float* __restrict__ mask, float sem_weight,
+                                                float* __restrict__ losses, float* __restrict__ d_rgb,
+                                                float* __restrict__ d_sem) {
+  float l_rgb = 0.0f, l_sem = 0.0f;
+  const float inv3r = 1.0f / (float)(3 * R), invr = 1.0f / (float)R;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long long)gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = rgb[3 * r + c] - image[3 * r + c];
+      l_rgb += d * d;
+      d_rgb[3 * r + c] = 2.0f * d * inv3r;
+    }
+    const float x = sem[r], y = mask[r];
+    // BCEWithLogits: max(x,0) - x*y + log1p(exp(-|x|))
+    l_sem += fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
+    const float s = 1.0f / (1.0f + expf(-x));
+    d_sem[r] = sem_weight * (s - y) * invr;
+  }
+  l_rgb = wave_sum(l_rgb);
+  l_sem = wave_sum(l_sem);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&losses[0], l_rgb * inv3r);
+    atomicAdd(&losses[1], sem_weight * l_sem * invr);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// interlevel loss of one proposal level against the final level (nerfstudio losses.interlevel_loss):
+// value (accumulated) + unit gradient w.r.t. the proposal weights.
+// ---------------------------------------------------------------------------------------------------
+constexpr int IL_MAX_P = 512;
+
+__device__ __forceinline__ int searchsorted_right(const float* a, int n, float v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const float* __restrict__ spacing_f,
+                                                    const float* __restrict__ w_f, int S_p,
+                                                    const float* __restrict__ spacing_p,
+                                                    const float* __restrict__ w_p, float mult,
+                                                    float* __restrict__ loss, float* __restrict__ d_wp) {
+  __shared__ float s_cp[4][IL_MAX_P + 1];
+  __shared__ float s_cy[4][IL_MAX_P + 1];
+  __shared__ float s_d[4][IL_MAX_P + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float* cp = s_cp[wave];
+  float* cy = s_cy[wave];
+  float* dd = s_d[wave];
+  const float* sp = spacing_p + r * (S_p + 1);
+  const float* wp = w_p + r * S_p;
+  // cy1 = [0, cumsum(wp)] : lane-chunked scan
+  const int E = (S_p + 63) >> 6;
+  float local = 0.0f;
+  for (int e = 0; e < E; ++e) {
+    const int k = lane * E + e;
+    if (k < S_p) local += wp[k];
+  }
+  float run = wave_incl_scan(local, lane) - local;
+  if (lane == 0) cy[0] = 0.0f;
+  for (int e = 0; e < E; ++e) {
+    const int k = lane * E + e;
+    if (k < S_p) {
+      run += wp[k];
+      cy[k + 1] = run;
+    }
+  }
+  for (int k = lane; k <= S_p; k += 64) cp[k] = sp[k];
+  for (int k = lane; k <= S_p + 1; k += 64) dd[k] = 0.0f;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+
+  const float* c = spacing_f + r * (S_f + 1);
+  const float* w = w_f + r * S_f;
+  const float scale = mult / (float)(R * (long long)S_f);
+  float lsum = 0.0f;
+  for (int i = lane; i < S_f; i += 64) {
+    int lo = searchsorted_right(cp, S_p, c[i]) - 1;          // t1_starts = cp[:-1]
+    lo = min(max(lo, 0), S_p - 1);
+    int hi = searchsorted_right(cp + 1, S_p, c[i + 1]);      // t1_ends = cp[1:]
+    hi = min(max(hi, 0), S_p - 1);
+    const float w_outer = cy[hi + 1] - cy[lo];
+    const float wi = w[i];
+    const float diff = fmaxf(wi - w_outer, 0.0f);
+    const float den = wi + 1.0e-7f;
+    lsum += diff * diff / den;
+    const float g = -2.0f * diff / den * scale;  // d loss / d w_outer
+    if (g != 0.0f) {
+      atomicAdd(&dd[lo], g);
+      atomicAdd(&dd[hi + 1], -g);
+    }
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) atomicAdd(loss, lsum * scale);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  // d_wp = inclusive scan of the difference array
+  float l2 = 0.0f;
+  for (int e = 0; e < E; ++e) {
+    const int k = lane * E + e;
+    if (k < S_p) l2 += dd[k];
+  }
+  float run2 = wave_incl_scan(l2, lane) - l2;
+  for (int e = 0; e < E; ++e) {
+    const int k = lane * E + e;
+    if (k < S_p) {
+      run2 += dd[k];
+      d_wp[r * S_p + k] = run2;
+    }
+  }
+}
+
+// distortion_loss (metric, fruit_nerf.py:400): mean over rays of sum_ij w_i w_j |m_i - m_j| + sum_i w_i^2 ds_i / 3
+__global__ __launch_bounds__(256) void k_distortion(long long R, int S, const float* __restrict__ spacing,
+                                                    const float* __restrict__ weights, float* __restrict__ out) {
+  __shared__ float s_m[4][512];
+  __shared__ float s_w[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const float* t = spacing + r * (S + 1);
+  const float* w = weights + r * S;
+  for (int k = lane; k < S; k += 64) {
+    s_m[wave][k] = (t[k + 1] + t[k]) / 2.0f;
+    s_w[wave][k] = w[k];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  float acc = 0.0f;
+  for (int i = lane; i < S; i += 64) {
+    const float mi = s_m[wave][i], wi = s_w[wave][i];
+    float inner = 0.0f;
+    for (int j = 0; j < S; ++j) inner += s_w[wave][j] * fabsf(mi - s_m[wave][j]);
+    acc += wi * inner + wi * wi * (t[i + 1] - t[i]) / 3.0f;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) atomicAdd(out, acc / (float)R);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward of w_i = (1 - exp(-d_i s_i)) exp(-sum_{j<i} d_j s_j):
+//   dL/ds_k = d_k [ g_k T_{k+1} - sum_{i>k} g_i w_i ],  T_{k+1} = exp(-sum_{j<=k} d_j s_j)
+// ---------------------------------------------------------------------------------------------------
+constexpr int WB_MAXE = 8;
+
+template <bool COMPOSITE>
+__global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const float* __restrict__ euclid,
+                                                     const float* __restrict__ density,
+                                                     const float* __restrict__ weights,
+                                                     const float* __restrict__ d_w_in,    // !COMPOSITE: [R,S]
+                                                     const float* __restrict__ upstream,  // optional device scalar
+                                                     const float* __restrict__ rgb,       // COMPOSITE: samples [N,3]
+                                                     const float* __restrict__ g_rgb,     // COMPOSITE: [R,3]
+                                                     const float* __restrict__ g_sem,     // COMPOSITE: [R]
+                                                     float* __restrict__ d_density, float* __restrict__ d_rgb,
+                                                     float* __restrict__ d_logit) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int E = (S + 63) >> 6;
+  const float* eb = euclid + r * (S + 1);
+  const float* dn = density + r * S;
+  const float* w = weights + r * S;
+  const float up = upstream ? upstream[0] : 1.0f;
+  float gr = 0.0f, gg = 0.0f, gb = 0.0f, gs = 0.0f, l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, bgw = 0.0f;
+  if (COMPOSITE) {
+    gr = g_rgb[3 * r];
+    gg = g_rgb[3 * r + 1];
+    gb = g_rgb[3 * r + 2];
+    gs = g_sem[r];
+    const float* cl = rgb + (r * S + (S - 1)) * 3;
+    l0 = cl[0];
+    l1 = cl[1];
+    l2 = cl[2];
+  }
+  float delta[WB_MAXE], gw[WB_MAXE], wk[WB_MAXE];
+  float dd_local = 0.0f, gww_local = 0.0f, wsum_local = 0.0f;
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    delta[e] = 0.0f;
+    gw[e] = 0.0f;
+    wk[e] = 0.0f;
+    if (e < E && k < S) {
+      delta[e] = eb[k + 1] - eb[k];
+      wk[e] = w[k];
+      if (COMPOSITE) {
+        const float* c = rgb + (r * S + k) * 3;
+        gw[e] = gr * (c[0] - l0) + gg * (c[1] - l1) + gb * (c[2] - l2);  // semantic weights are detached
+      } else {
+        gw[e] = d_w_in[r * S + k] * up;
+      }
+      dd_local += delta[e] * dn[k];
+      gww_local += gw[e] * wk[e];
+      wsum_local += wk[e];
+    }
+  }
+  float cum_dd = wave_incl_scan(dd_local, lane) - dd_local;     // sum_{j<first k of lane}
+  float cum_gww = wave_incl_scan(gww_local, lane) - gww_local;
+  const float total_gww = wave_sum(gww_local);
+  if (COMPOSITE) bgw = 1.0f - wave_sum(wsum_local);
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    if (e < E && k < S) {
+      cum_dd += delta[e] * dn[k];   // inclusive of k
+      cum_gww += gw[e] * wk[e];     // inclusive of k
+      const float T_next = expf(-cum_dd);
+      const float suffix = total_gww - cum_gww;  // sum_{i>k} g_i w_i
+      d_density[r * S + k] = delta[e] * (gw[e] * T_next - suffix);
+      if (COMPOSITE) {
+        float f = wk[e];
+        if (k == S - 1) f += bgw;  // background = last sample's colour (RGBRenderer "last_sample")
+        float* o = d_rgb + (r * S + k) * 3;
+        o[0] = gr * f;
+        o[1] = gg * f;
+        o[2] = gb * f;
+        d_logit[r * S + k] = gs * wk[e];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, no weight decay / amsgrad), whole arena in one launch; optionally zeroes grads
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                              float4* __restrict__ v, long long n4, float lr, float b1, float b2,
+                                              float eps, float bc1, float bc2_sqrt, float grad_scale, int zero_grad) {
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 P = p[i], G = g[i], M = m[i], V = v[i];
+    float* pp = reinterpret_cast<float*>(&P);
+    float* gp = reinterpret_cast<float*>(&G);
+    float* mp = reinterpret_cast<float*>(&M);
+    float* vp = reinterpret_cast<float*>(&V);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float gr = gp[c] * grad_scale;
+      mp[c] = mp[c] + (gr - mp[c]) * (1.0f - b1);           // exp_avg.lerp_(grad, 1 - beta1)
+      vp[c] = vp[c] * b2 + (1.0f - b2) * gr * gr;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float denom = sqrtf(vp[c]) / bc2_sqrt + eps;    // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+      pp[c] = pp[c] - step_size * (mp[c] / denom);          // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+    p[i] = P;
+    m[i] = M;
+    v[i] = V;
+    if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+}  // namespace fnr
+
+using namespace fnr;
+
+extern "C" int fnr_losses_fwd(int64_t n_rays, const float* rgb, const float* image, const float* semantics,
+                              const float* fruit_mask, float semantic_loss_weight, float* losses, float* d_rgb,
+                              float* d_semantics, void* stream) {
+  FNR_CHECK_ARG(rgb && image && semantics && fruit_mask && losses && d_rgb && d_semantics && n_rays > 0,
+                "losses_fwd: null argument");
+  FNR_HIP(hipMemsetAsync(losses, 0, 2 * sizeof(float), as_stream(stream)));
+  long long blocks = (n_rays + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_losses, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (long long)n_rays, rgb, image,
+                     semantics, fruit_mask, semantic_loss_weight, losses, d_rgb, d_semantics);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_interlevel_fwd(int64_t n_rays, int S_f, const float* spacing_f, const float* weights_f, int S_p,
+                                  const float* spacing_p, const float* weights_p, float mult, float* loss,
+                                  float* d_weights_p, void* stream) {
+  FNR_CHECK_ARG(spacing_f && weights_f && spacing_p && weights_p && loss && d_weights_p, "interlevel_fwd: null argument");
+  FNR_CHECK_ARG(S_f > 0 && S_p > 0 && S_p <= IL_MAX_P, "interlevel_fwd: S_p %d out of range", S_p);
+  if (n_rays == 0) return FNR_OK;
+  hipLaunchKernelGGL(k_interlevel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     (long long)n_rays, S_f, spacing_f, weights_f, S_p, spacing_p, weights_p, mult, loss, d_weights_p);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_distortion(int64_t n_rays, int S, const float* spacing, const float* weights, float* out,
+                              void* stream) {
+  FNR_CHECK_ARG(spacing && weights && out && S > 0 && S <= 512, "distortion: bad argument");
+  if (n_rays == 0) return FNR_OK;
+  hipLaunchKernelGGL(k_distortion, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     (long long)n_rays, S, spacing, weights, out);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_composite_bwd(const fnr_rays* rays, int S, const float* euclid_bins, const float* density,
+                                 const float* rgb, const float* weights, const float* g_rgb, const float* g_semantics,
+                                 float* d_density, float* d_rgb, float* d_logit, void* stream) {
+  FNR_CHECK_ARG(rays && euclid_bins && density && rgb && weights && g_rgb && g_semantics && d_density && d_rgb &&
+                    d_logit,
+                "composite_bwd: null argument");
+  FNR_CHECK_ARG(S > 0 && S <= 64 * WB_MAXE, "composite_bwd: S %d out of range", S);
+  if (rays->n_rays == 0) return FNR_OK;
+  hipLaunchKernelGGL((k_weights_bwd<true>), dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     (long long)rays->n_rays, S, euclid_bins, density, weights, (const float*)nullptr,
+                     (const float*)nullptr, rgb, g_rgb, g_semantics, d_density, d_rgb, d_logit);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, const float* density,
+                               const float* weights, const float* d_weights, const float* upstream,
+                               float* d_density, void* stream) {
+  FNR_CHECK_ARG(euclid_bins && density && weights && d_weights && d_density, "weights_bwd: null argument");
+  FNR_CHECK_ARG(S > 0 && S <= 64 * WB_MAXE, "weights_bwd: S %d out of range", S);
+  if (n_rays == 0) return FNR_OK;
+  hipLaunchKernelGGL((k_weights_bwd<false>), dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     (long long)n_rays, S, euclid_bins, density, weights, d_weights, upstream, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, d_density, (float*)nullptr, (float*)nullptr);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
+                             void* stream) {
+  FNR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "adam_step: null argument");
+  FNR_CHECK_ARG(n % 4 == 0 && step >= 1, "adam_step: n must be a multiple of 4 (arena is padded) and step >= 1");
+  if (n == 0) return FNR_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long long n4 = n / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<float4*>(params), reinterpret_cast<float4*>(grads),
+                     reinterpret_cast<float4*>(exp_avg), reinterpret_cast<float4*>(exp_avg_sq), n4, lr, beta1, beta2,
+                     eps, (float)bc1, (float)sqrt(bc2), grad_scale, zero_grad);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}

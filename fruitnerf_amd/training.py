@@ -1,0 +1,261 @@
+"""Differentiable training path of FruitModel on the HIP kernels.
+
+Mirrors what Nerfstudio's Trainer does around the reference model:
+    set_anneal(step) -> model(ray_bundle) -> get_loss_dict -> sum -> backward -> optimizer step -> step_cb
+with the reference's semantics:
+  * rgb loss reaches the field through rgb samples AND compositing weights (density);
+  * the semantic loss only trains mlp_semantics + the head (detached geo features and detached weights,
+    fruit_field.py:263-265, fruit_nerf.py:343-345);
+  * proposal networks are trained by the interlevel loss only, and only on "updated" steps
+    (ProposalNetworkSampler, fruit_nerf.py:131-158);
+  * data parallelism = DistributedDataParallel's gradient all-reduce(mean) (fruit_pipeline.py:116-118):
+    here ONE RCCL all-reduce over the flat gradient arena, then the fused Adam step scales by 1/world.
+
+Gradients are written by the HIP backward kernels straight into the model's flat gradient arena
+(`param.grad` are views of it); the autograd Functions below only carry the dependency structure.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _kernels as K
+
+
+def _anchor(model) -> Tensor:
+    a = getattr(model, "_grad_anchor", None)
+    if a is None or a.device != model.device:
+        a = torch.zeros(1, device=model.device, requires_grad=True)
+        model._grad_anchor = a
+    return a
+
+
+class _RenderFn(torch.autograd.Function):
+    """rays -> (rgb, semantics, accumulation, depth, prop depths); backward runs compositing-bwd,
+    field-MLP-bwd (MFMA) and the hash-grid scatter."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, ray_bundle, jitter):
+        outputs, rctx = model._render(ray_bundle, jitter)
+        ctx.model = model
+        ctx.rctx = rctx
+        n_prop = len(rctx.levels) - 1
+        outs = [outputs["rgb"], outputs["semantics"], outputs["accumulation"], outputs["depth"]]
+        outs += [outputs[f"prop_depth_{i}"] for i in range(n_prop)]
+        ctx.mark_non_differentiable(*outs[2:])
+        ctx.rctx_holder = rctx
+        model._last_render_ctx = rctx
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sem, *_):
+        model, rctx = ctx.model, ctx.rctx
+        arena = model.arena()
+        arena.reattach_grads()
+        rays = rctx.rays
+        lv = rctx.levels[-1]
+        S = lv["S"]
+        dev = rays.device
+        if g_rgb is None:
+            g_rgb = torch.zeros(rays.n, 3, device=dev)
+        if g_sem is None:
+            g_sem = torch.zeros(rays.n, 1, device=dev)
+        d_density, d_rgb, d_logit = K.composite_bwd(rays, S, lv["euclid"], rctx.sample_density, rctx.sample_rgb,
+                                                    rctx.weights, g_rgb.contiguous(), g_sem.contiguous())
+        fld = model.field
+        net, gnet = fld.net_struct(), fld.net_struct(grads=True)
+        d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_selector, d_density, d_rgb,
+                                  d_logit)
+        K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, lv["euclid"], S, d_feats)
+        return None, None, None, None
+
+
+class _InterlevelFn(torch.autograd.Function):
+    """interlevel_loss(weights_list, ray_samples_list) (fruit_nerf.py:368-370); backward trains the
+    proposal networks (only when this step 'updated' them)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, rctx, mult):
+        fin = rctx.levels[-1]
+        dev = rctx.rays.device
+        loss = torch.zeros(1, device=dev)
+        d_wps = []
+        for lv in rctx.levels[:-1]:
+            d_wps.append(K.interlevel_fwd(fin["S"], fin["spacing"], fin["weights"], lv["S"], lv["spacing"],
+                                          lv["weights"], mult, loss))
+        ctx.model, ctx.rctx, ctx.d_wps = model, rctx, d_wps
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        model, rctx = ctx.model, ctx.rctx
+        if not (rctx.training and rctx.updated):
+            return None, None, None, None  # proposal densities were computed under no_grad
+        arena = model.arena()
+        arena.reattach_grads()
+        rays = rctx.rays
+        up = g.reshape(1).float().contiguous()
+        cfg = model.config
+        for i, (lv, d_wp) in enumerate(zip(rctx.levels[:-1], ctx.d_wps)):
+            d_density = K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, up)
+            net = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
+            K.prop_density_bwd(net.prop_struct(), net.prop_struct(grads=True), net.warp_struct(), rays,
+                               lv["euclid"], lv["S"], lv["feats"], d_density)
+        return None, None, None, None
+
+
+class _LossFn(torch.autograd.Function):
+    """rgb_loss + semantics_loss in one launch; unit gradients are produced in the forward."""
+
+    @staticmethod
+    def forward(ctx, rgb, semantics, image, fruit_mask, weight):
+        losses, d_rgb, d_sem = K.losses_fwd(rgb, image, semantics, fruit_mask, weight)
+        ctx.save_for_backward(d_rgb, d_sem)
+        ctx.sem_shape = semantics.shape
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        d_rgb, d_sem = ctx.saved_tensors
+        return d_rgb * g0, (d_sem * g1).view(ctx.sem_shape), None, None, None
+
+
+def render_with_grad(model, ray_bundle, jitter=None):
+    outs = _RenderFn.apply(_anchor(model), model, ray_bundle, jitter)
+    rctx = model._last_render_ctx
+    n_prop = len(rctx.levels) - 1
+    outputs = {"rgb": outs[0], "semantics": outs[1], "accumulation": outs[2], "depth": outs[3]}
+    for i in range(n_prop):
+        outputs[f"prop_depth_{i}"] = outs[4 + i]
+    return outputs, rctx
+
+
+def fused_losses(model, outputs, batch) -> Dict[str, Tensor]:
+    """get_loss_dict (fruit_nerf.py:359-372)."""
+    dev = outputs["rgb"].device
+    image = batch["image"].to(dev)
+    mask = batch["fruit_mask"].to(dev)
+    rgb_loss, sem_loss = _LossFn.apply(outputs["rgb"], outputs["semantics"], image, mask,
+                                       model.config.semantic_loss_weight)
+    loss_dict = {"rgb_loss": rgb_loss, "semantics_loss": sem_loss}
+    if model.training:
+        rctx = outputs["_ctx"]
+        loss_dict["interlevel_loss"] = _InterlevelFn.apply(_anchor(model), model, rctx,
+                                                           model.config.interlevel_loss_mult)
+    return loss_dict
+
+
+def metrics(model, outputs, batch) -> Dict[str, Tensor]:
+    """get_metrics_dict (fruit_nerf.py:396-401): PSNR(data_range=1) + distortion (metric only)."""
+    dev = outputs["rgb"].device
+    with torch.no_grad():
+        image = batch["image"].to(dev)
+        losses, _, _ = K.losses_fwd(outputs["rgb"].detach(), image, outputs["semantics"].detach(),
+                                    batch["fruit_mask"].to(dev), 1.0)
+        psnr = -10.0 * torch.log10(losses[0])
+        fin = outputs["_ctx"].levels[-1]
+        dist = K.distortion(fin["S"], fin["spacing"], fin["weights"])
+    return {"psnr": psnr, "distortion": dist}
+
+
+# ---- optimiser ----------------------------------------------------------------------------------------------
+
+
+def exponential_decay_lr(step: int, lr_init: float, lr_final: float, max_steps: int) -> float:
+    """nerfstudio ExponentialDecayScheduler without warm-up (fruit_nerf_config.py:49,53)."""
+    t = float(np.clip(step / max_steps, 0, 1))
+    return float(np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics for both parameter groups of the `fruit_nerf` method
+    (AdamOptimizerConfig(lr=1e-2, eps=1e-15) + ExponentialDecay to 1e-4 over 200k steps,
+    fruit_nerf_config.py:47-56) as one launch per group over the flat arena, fused with the 1/world
+    scaling of the all-reduced gradient and with zero_grad."""
+
+    def __init__(self, model, lr: float = 1e-2, eps: float = 1e-15, betas=(0.9, 0.999), lr_final: float = 1e-4,
+                 max_steps: int = 200000, group_lr: Optional[Dict[str, dict]] = None):
+        self.model = model
+        self.arena = model.arena()
+        self.betas, self.eps = betas, eps
+        self.exp_avg = torch.zeros_like(self.arena.params)
+        self.exp_avg_sq = torch.zeros_like(self.arena.params)
+        self.groups = group_lr or {name: dict(lr=lr, lr_final=lr_final, max_steps=max_steps)
+                                   for name in self.arena.group_ranges}
+        self.step_count = 0
+
+    def current_lr(self, name: str) -> float:
+        g = self.groups[name]
+        if g.get("lr_final") is None:
+            return g["lr"]
+        return exponential_decay_lr(self.step_count, g["lr"], g["lr_final"], g["max_steps"])
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.step_count += 1
+        lrs = {name: self.current_lr(name) if self.step_count > 1 else self.groups[name]["lr"]
+               for name in self.groups}
+        # scheduler.step() runs after optimizer.step(): update k uses lr(k-1)
+        lrs = {name: (exponential_decay_lr(self.step_count - 1, g["lr"], g["lr_final"], g["max_steps"])
+                      if g.get("lr_final") is not None else g["lr"]) for name, g in self.groups.items()}
+        same = len(set(lrs.values())) == 1
+        spans = [("all", (0, self.arena.numel))] if same else list(self.arena.group_ranges.items())
+        for name, (a, b) in spans:
+            lr = next(iter(lrs.values())) if same else lrs[name]
+            K.adam_step(self.arena.params[a:b], self.arena.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr,
+                        self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, True)
+
+
+def sync_gradients(arena, world_size: int) -> float:
+    """DDP's gradient exchange (fruit_pipeline.py:116-118) as ONE all-reduce(SUM) over the flat gradient
+    arena (RCCL over xGMI on GPUs; gloo in the CPU tests).  Returns the scale (1/world) the optimiser must
+    apply — folding the mean into the Adam kernel saves a pass over the 78 MB buffer."""
+    if world_size <= 1:
+        return 1.0
+    import torch.distributed as dist
+    dist.all_reduce(arena.grads, op=dist.ReduceOp.SUM)
+    return 1.0 / world_size
+
+
+def train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, world_size: int = 1,
+                    jitter: Optional[List[Tensor]] = None, want_metrics: bool = True):
+    """One Trainer.train_iteration for the hot path."""
+    model.set_anneal(step)                                     # BEFORE_TRAIN_ITERATION callback
+    outputs = model(ray_bundle, jitter=jitter)
+    metrics_dict = model.get_metrics_dict(outputs, batch) if want_metrics else {}
+    loss_dict = model.get_loss_dict(outputs, batch, metrics_dict)
+    loss = sum(loss_dict.values())                             # functools.reduce(torch.add, loss_dict.values())
+    loss.backward()
+    scale = sync_gradients(model.arena(), world_size)
+    optimizer.step(grad_scale=scale)
+    model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
+    return loss_dict, metrics_dict
+
+
+def smoke_train_step(oracle_model, hip_model, dev) -> None:
+    """Used by __graft_entry__.smoke(): one training step on 64 rays, HIP vs oracle loss values."""
+    from tests import util
+    from oracle import ns_torch as ns
+    from .rays import RayBundle
+    oracle_model.train()
+    hip_model.train()
+    R = 64
+    o, d, pa, cam = util.random_rays(R, oracle_model.field.num_images, seed=2)
+    jit = [torch.rand(R, 1) for _ in range(3)]
+    g = torch.Generator().manual_seed(5)
+    batch = {"image": torch.rand(R, 3, generator=g), "fruit_mask": (torch.rand(R, 1, generator=g) > 0.5).float()}
+    ref_out = oracle_model(ns.RayBundle(o, d, pa, camera_indices=cam), jitter=jit)
+    ref_ld = oracle_model.get_loss_dict(ref_out, batch)
+    sum(ref_ld.values()).backward()
+    opt = FusedAdam(hip_model)
+    rb = RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev))
+    ld, md = train_iteration(hip_model, opt, rb, {k: v.to(dev) for k, v in batch.items()}, 0,
+                             jitter=[j.to(dev) for j in jit])
+    torch.cuda.synchronize()
+    for k in ref_ld:
+        a, b = float(ld[k]), float(ref_ld[k])
+        print(f"smoke.{k}: hip {a:.6e} oracle {b:.6e}")
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), k

@@ -171,6 +171,57 @@ int fnr_composite_fwd(const fnr_rays* rays, int S, const float* euclid_bins, con
                       const float* logit, int training, float* weights, float* out_rgb, float* out_accumulation,
                       float* out_depth, float* out_semantics, void* stream);
 
+/* ---- training: losses, backward, optimiser --------------------------------------------------- */
+/* get_loss_dict's rgb_loss = MSELoss(image, rgb) and semantics_loss = w * BCEWithLogitsLoss(semantics,
+ * fruit_mask) (fruit_nerf.py:171-172,362-366).  losses[0..1] are overwritten with the two scalars;
+ * d_rgb [R,3] / d_semantics [R] receive dloss/drgb and dloss/dsemantics (unit upstream). */
+int fnr_losses_fwd(int64_t n_rays, const float* rgb, const float* image, const float* semantics,
+                   const float* fruit_mask, float semantic_loss_weight, float* losses, float* d_rgb,
+                   float* d_semantics, void* stream);
+
+/* nerfstudio interlevel_loss (fruit_nerf.py:368-370) of ONE proposal level against the final level:
+ * *loss += mult * mean(clip(w - outer(c, cp, wp), 0)^2 / (w + 1e-7)); d_weights_p [R,S_p] = d/d wp. */
+int fnr_interlevel_fwd(int64_t n_rays, int S_f, const float* spacing_f, const float* weights_f, int S_p,
+                       const float* spacing_p, const float* weights_p, float mult, float* loss, float* d_weights_p,
+                       void* stream);
+
+/* nerfstudio distortion_loss on the final level — a metric only (fruit_nerf.py:400): *out += value. */
+int fnr_distortion(int64_t n_rays, int S, const float* spacing, const float* weights, float* out, void* stream);
+
+/* Backward of fnr_composite_fwd (training): g_rgb [R,3], g_semantics [R] -> per-sample d_density [N],
+ * d_rgb [N,3], d_logit [N].  Semantic compositing weights are detached (fruit_nerf.py:343-345). */
+int fnr_composite_bwd(const fnr_rays* rays, int S, const float* euclid_bins, const float* density, const float* rgb,
+                      const float* weights, const float* g_rgb, const float* g_semantics, float* d_density,
+                      float* d_rgb, float* d_logit, void* stream);
+
+/* Backward of RaySamples.get_weights for a proposal level: d_weights [R,S] (x *upstream if non-NULL, a
+ * device scalar) -> d_density [R,S]. */
+int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, const float* density, const float* weights,
+                    const float* d_weights, const float* upstream, float* d_density, void* stream);
+
+/* Backward of fnr_field_mlp_fwd (training path): accumulates (+=) the Linear weight/bias/embedding gradients
+ * into `grads` and writes dL/dfeatures d_feats [L][N][2] for fnr_hash_encode_bwd.
+ * workspace: >= fnr_field_mlp_bwd_workspace_bytes(N) bytes. */
+size_t fnr_field_mlp_bwd_workspace_bytes(int64_t n_samples);
+int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
+                      const float* feats, const uint8_t* selector, const float* d_density, const float* d_rgb,
+                      const float* d_logit, float* d_feats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of fnr_hash_encode_fwd: scatter-adds d_feats [L][N][2] into grid_grad->table (+=, fp32 atomics). */
+int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
+                        const float* euclid_bins, int S, const float* d_feats, void* stream);
+
+/* Backward of fnr_prop_density_fwd: d_density [R,S] -> += into grads (table, w0, b0, w1, b1). */
+int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
+                         const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
+                         const float* d_density, void* stream);
+
+/* torch.optim.Adam step (no weight decay, no amsgrad; fruit_nerf_config.py:47-56) over a flat arena of n
+ * floats (n % 4 == 0); the gradient is multiplied by grad_scale first (1/world_size after an all-reduce(SUM))
+ * and zeroed afterwards when zero_grad != 0.  `step` is the 1-based step count for the bias corrections. */
+int fnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int64_t step, float grad_scale, int zero_grad, void* stream);
+
 /* ---- export --------------------------------------------------------------------------------- */
 /* sample_volume's masks + gathers (export/exporter_utils.py:111-153) as an order-preserving stream
  * compaction.  Sets: 0 = semantic_colormap (sigmoid(logit) > 0.9 and density >= 70),
