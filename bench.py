@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py — train rays/s of the `fruit_nerf` method on the synthetic apple scene (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training iteration of the reference's hot loop on every rank:
+pixel sampling + ray generation on the device, set_anneal, FruitModel.forward (proposal sampling 256/96/48,
+two proposal nets, main field), get_metrics_dict (PSNR + distortion), get_loss_dict (MSE + BCE + interlevel),
+backward, gradient all-reduce over RCCL (N > 1), fused Adam over all 19.4 M parameters, step_cb.
+Every rank draws its own 4096 rays (reference DDP semantics, fruit_pipeline.py:116-118) => weak scaling;
+`value` = N * K * 4096 / max-over-ranks wall time, inputs resident in HBM.
+
+Extra objects in the JSON line:  roofline (dominant kernel, HIP events on the launch stream, live in the
+timed region), cpu_baseline (the oracle's train step on the host cores, rank 0, bounded sample),
+breakdown_ms (per entry point, from a short instrumented pass after the timed region), quality (PSNR / IoU on
+held-out views after --quality-steps more steps).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+RAYS_PER_BATCH = 4096          # fruit_nerf_config.py:37
+N_CAMERAS = 100
+TRAIN_SPLIT = 0.9              # fruitnerf_dataparser.py:62
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3
+
+# algorithmic bytes / flops per unit: hash-table reads (fwd) or gradient RMW (bwd, 2x) per sample
+ALG = {
+    "hash_encode_fwd": ("hbm", 1024.0 + 128.0),          # 16 lvl x 8 corners x 8 B + 128 B features written
+    "hash_encode_bwd": ("hbm", 2 * 1024.0 + 128.0),      # gradient read-modify-write + d_feats read
+    "prop_density_fwd": ("hbm", 320.0 + 4.0),            # 5 lvl x 8 corners x 8 B + density
+    "prop_density_bwd": ("hbm", 2 * 320.0 + 40.0 + 4.0),
+    "field_mlp_fwd": ("mfma", 33024.0),                  # useful FLOP / sample
+    "field_mlp_bwd": ("mfma", 2 * 33024.0 + 33024.0),    # recompute + dX + dW ~ 3x forward
+    "adam_step": ("hbm", 28.0),                          # p,g,m,v read + p,m,v,g written per parameter (32 B w/ zero)
+}
+
+
+def split_indices(n: int, frac: float):
+    """Nerfstudio-style 'fraction' split (fruitnerf_dataparser.py:171-186): evenly spaced train images."""
+    num_train = int(np.ceil(n * frac))
+    i_all = np.arange(n)
+    i_train = np.linspace(0, n - 1, num_train, dtype=int)
+    i_eval = np.setdiff1d(i_all, i_train)
+    return i_train, i_eval
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--quality-steps", type=int, default=1500, help="extra training steps before the PSNR/IoU eval")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-quality", action="store_true")
+    ap.add_argument("--image-size", type=int, default=800)
+    ap.add_argument("--roofline-op", default="auto")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+
+    from fruitnerf_amd import _lib as L
+    from fruitnerf_amd.data import synthetic_apple as sa
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.rays import RayBundle
+    from fruitnerf_amd.training import FusedAdam, train_iteration
+
+    info = L.device_check()
+    HW = args.image_size
+    focal = 1111.0 * HW / 800.0
+
+    # ---- synthetic dataset (identical on every rank), resident in HBM ------------------------------------
+    t_setup = time.time()
+    scene = sa.make_scene(seed=0, device=dev)
+    c2w = sa.make_cameras(N_CAMERAS, seed=0, device=dev)
+    data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
+    i_train, i_eval = split_indices(N_CAMERAS, TRAIN_SPLIT)
+    train_ids = torch.as_tensor(i_train, device=dev)
+    batcher = sa.PixelBatcher(data, train_ids, seed=1234 + rank)   # each rank draws its own rays (seed + rank)
+    torch.manual_seed(0)                                           # identical initial weights on every rank
+    model = FruitModel(FruitNerfModelConfig(), num_train_data=len(i_train), device=dev)
+    model.train()
+    opt = FusedAdam(model)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t_setup
+
+    step_idx = [0]
+
+    def one_step(want_metrics=True):
+        o, d, cam, batch = batcher.sample(RAYS_PER_BATCH)
+        rb = RayBundle(o, d, None, cam)
+        out = train_iteration(model, opt, rb, batch, step_idx[0], world_size=world, want_metrics=want_metrics)
+        step_idx[0] += 1
+        return out
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+
+    # pick the dominant entry point from a short instrumented run (not timed)
+    roof_op = args.roofline_op
+    if roof_op == "auto":
+        L.profile_enable(True)
+        for _ in range(4):
+            one_step()
+        torch.cuda.synchronize()
+        recs = L.profile_collect()
+        L.profile_enable(False)
+        tot = {}
+        for op, units, ms in recs:
+            if op in ALG:
+                tot[(op, units)] = tot.get((op, units), 0.0) + ms
+        roof_op, roof_units = max(tot, key=tot.get) if tot else ("hash_encode_fwd", RAYS_PER_BATCH * 48)
+    else:
+        roof_units = None
+
+    # ---- timed region: exactly K steps -------------------------------------------------------------------
+    L.profile_enable(True, ops=[roof_op])   # two events per launch of ONE entry point, on its own stream
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ld, md = one_step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    recs = L.profile_collect()
+    L.profile_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rays_per_s = world * args.steps * RAYS_PER_BATCH / dt
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel ------------------------------------------------------------------
+    sel = [(u, ms) for op, u, ms in recs if op == roof_op and (roof_units is None or u == roof_units)]
+    roofline = None
+    if sel:
+        units = sel[0][0]
+        avg_ms = float(np.mean([ms for _, ms in sel]))
+        bound, per_unit = ALG[roof_op]
+        if bound == "hbm":
+            achieved = per_unit * units / (avg_ms * 1e-3) / 1e9
+            roofline = {"kernel": roof_op, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 5), "launches": len(sel), "units_per_launch": int(units),
+                        "alg_bytes_per_unit": per_unit}
+        else:
+            achieved = per_unit * units / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": roof_op, "bound": "mfma", "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 5), "launches": len(sel), "units_per_launch": int(units),
+                        "alg_flop_per_unit": per_unit}
+
+    # ---- per-entry-point breakdown (short instrumented pass, outside the timed region; N = 1 only: the
+    # other ranks have left, so no collective may run here) ------------------------------------------------
+    nb = 12 if world == 1 else 0
+    L.profile_enable(True)
+    for _ in range(nb):
+        one_step()
+    torch.cuda.synchronize()
+    recs = L.profile_collect() if nb else []
+    L.profile_enable(False)
+    breakdown = {}
+    for op, units, ms in recs:
+        key = f"{op}[{units}]"
+        breakdown[key] = breakdown.get(key, 0.0) + ms / nb
+    breakdown = {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])}
+
+    # ---- quality: keep training, then PSNR / IoU on held-out views ---------------------------------------------
+    quality = None
+    if not args.no_quality and world == 1:
+        for _ in range(args.quality_steps):
+            one_step(want_metrics=False)
+        model.eval()
+        psnrs, inter, union = [], 0.0, 0.0
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        with torch.no_grad():
+            for img in i_eval[:5]:
+                n = 65536
+                y = torch.randint(0, HW, (n,), device=dev, generator=g)
+                x = torch.randint(0, HW, (n,), device=dev, generator=g)
+                ci = torch.full((n,), int(img), device=dev)
+                o, d = sa.pixel_rays(c2w, ci, y, x, focal, focal, HW / 2.0, HW / 2.0)
+                tgt = data["images"][ci, y, x].float() / 255.0
+                msk = data["masks"][ci, y, x].float()
+                for s in range(0, n, 32768):  # eval_num_rays_per_chunk
+                    out = model(RayBundle(o[s:s + 32768], d[s:s + 32768], None, None))
+                    mse = torch.mean((out["rgb"] - tgt[s:s + 32768]) ** 2)
+                    psnrs.append(float(-10.0 * torch.log10(mse)))
+                    pred = (torch.sigmoid(out["semantics"][:, 0]) > 0.5).float()
+                    inter += float((pred * msk[s:s + 32768]).sum())
+                    union += float(((pred + msk[s:s + 32768]) > 0).float().sum())
+        model.train()
+        quality = {"train_steps": step_idx[0], "psnr_heldout": round(float(np.mean(psnrs)), 3),
+                   "semantic_iou_heldout": round(inter / max(union, 1.0), 4),
+                   "final_train_losses": {k: round(float(v), 6) for k, v in ld.items()}}
+
+    # ---- CPU baseline: the oracle's training step on the host cores -------------------------------------------------
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import fruit_oracle as fo
+        from oracle import ns_torch as ns
+        # bounded sample (~20 s of CPU work): CPU_RAYS-ray steps of the SAME model / sample counts; eager
+        # PyTorch does not scale past a few dozen threads (256 threads on the GPU box: 124 s per 4096-ray step)
+        ncores = min(os.cpu_count() or 1, 32)
+        CPU_RAYS = 512
+        torch.set_num_threads(ncores)
+        torch.manual_seed(0)
+        om = fo.FruitModel(fo.FruitNerfModelConfig(), num_train_data=len(i_train))
+        om.train()
+        groups = om.get_param_groups()
+        oopts = [torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15),
+                 torch.optim.Adam(groups["fields"], lr=1e-2, eps=1e-15)]
+        cb = sa.PixelBatcher({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()},
+                             train_ids.cpu(), seed=99)
+        times = []
+        n_cpu = 2
+        for i in range(n_cpu + 1):
+            o, d, cam, batch = cb.sample(CPU_RAYS)
+            t1 = time.perf_counter()
+            om.set_anneal(i)
+            for op_ in oopts:
+                op_.zero_grad()
+            out = om(ns.RayBundle(o, d, torch.ones(CPU_RAYS, 1), camera_indices=cam))
+            om.get_metrics_dict(out, batch)
+            sum(om.get_loss_dict(out, batch).values()).backward()
+            for op_ in oopts:
+                op_.step()
+            om.proposal_sampler.step_cb(i)
+            if i > 0:  # first iteration = warm-up
+                times.append(time.perf_counter() - t1)
+        med = float(np.median(times))
+        cpu = {"value": round(CPU_RAYS / med, 1), "unit": "rays/s", "cores": ncores, "kind": "port",
+               "sample": f"{n_cpu} full fruit_nerf training steps (fwd+bwd+Adam over all 19.4 M parameters) of "
+                         f"{CPU_RAYS} rays each after 1 warm-up, oracle/ PyTorch-CPU fp32, {ncores} threads, "
+                         f"median {med:.2f} s/step"}
+
+    result = {
+        "metric": "train rays/sec, fruit_nerf on synthetic apple 800x800",
+        "value": round(rays_per_s, 1),
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"fruit_nerf synthetic apple {HW}x{HW}, {N_CAMERAS} cameras ({len(i_train)} train), "
+                               f"{RAYS_PER_BATCH} rays/rank/step, samples 256/96/48, hash 16x2^19x2 + 2x(5x2^17x2), "
+                               "semantic head, fwd+bwd+Adam, proposal-net update schedule from step 0",
+                   "rays_per_rank": RAYS_PER_BATCH, "parallelism": f"dp{world}", "device": info["arch"],
+                   "setup_s": round(setup_s, 1)},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "breakdown_ms": breakdown,
+        "quality": quality,
+    }
+    if cpu:
+        result["speedup_vs_cpu_baseline"] = round(rays_per_s / cpu["value"], 1)
+    print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

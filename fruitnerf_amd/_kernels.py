@@ -44,7 +44,23 @@ class RaysArg:
         return C.byref(self.c)
 
 
+_warp_cache = {}
+
+
 def make_warp(mode: int, aabb: Tensor) -> L.fnr_warp:
+    # reading the aabb back is a device->host copy (a full stream sync): do it once per buffer version
+    key = (mode, aabb.data_ptr(), aabb._version, str(aabb.device))
+    cached = _warp_cache.get(key)
+    if cached is not None:
+        return cached
+    w = _make_warp_uncached(mode, aabb)
+    if len(_warp_cache) > 64:
+        _warp_cache.clear()
+    _warp_cache[key] = w
+    return w
+
+
+def _make_warp_uncached(mode: int, aabb: Tensor) -> L.fnr_warp:
     w = L.fnr_warp()
     w.mode = mode
     a = aabb.detach().to("cpu", torch.float32).reshape(-1).tolist()
@@ -305,15 +321,20 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
 def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
                     d_feats: Tensor) -> None:
     lib = L.load()
+    nbytes = lib.fnr_hash_scatter_workspace_bytes(rays.n * S, grid_grad.n_levels, grid_grad.log2_hashmap_size)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=rays.device)
     L.check(lib.fnr_hash_encode_bwd(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
-                                    L.stream_ptr(rays.device)), "hash_encode_bwd")
+                                    L.ptr(ws), nbytes, L.stream_ptr(rays.device)), "hash_encode_bwd")
 
 
 def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor,
                      S: int, feats: Tensor, d_density: Tensor) -> None:
     lib = L.load()
+    nbytes = lib.fnr_prop_density_bwd_workspace_bytes(rays.n * S, net.grid.n_levels, net.grid.log2_hashmap_size)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=rays.device)
     L.check(lib.fnr_prop_density_bwd(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
-                                     L.ptr(feats), L.ptr(d_density), L.stream_ptr(rays.device)), "prop_density_bwd")
+                                     L.ptr(feats), L.ptr(d_density), L.ptr(ws), nbytes, L.stream_ptr(rays.device)),
+            "prop_density_bwd")
 
 
 def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float,

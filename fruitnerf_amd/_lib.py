@@ -66,7 +66,9 @@ SIGNATURES = {
     "fnr_abi_version": (_i, []),
     "fnr_last_error": (C.c_char_p, []),
     "fnr_device_check": (_i, [P(C.c_int), C.c_char_p, _i]),
-    "fnr_sample_spaced": (_i, [P(fnr_rays), _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_profile_enable": (_i, [_i, C.c_uint64]),
+    "fnr_profile_collect": (_i64, [P(C.c_int32), P(C.c_int64), P(C.c_float), _i64]),
+    "fnr_sample_spaced":(_i, [P(fnr_rays), _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "fnr_weights_pdf": (_i, [P(fnr_rays), _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_prop_density_fwd": (_i, [P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
     "fnr_hash_encode_fwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
@@ -82,8 +84,11 @@ SIGNATURES = {
     "fnr_field_mlp_bwd_workspace_bytes": (C.c_size_t, [_i64]),
     "fnr_field_mlp_bwd": (_i, [P(fnr_field_net), P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.c_size_t, _vp]),
-    "fnr_hash_encode_bwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp]),
-    "fnr_prop_density_bwd": (_i, [P(fnr_prop_net), P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
+    "fnr_hash_scatter_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
+    "fnr_hash_encode_bwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, C.c_size_t, _vp]),
+    "fnr_prop_density_bwd_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
+    "fnr_prop_density_bwd": (_i, [P(fnr_prop_net), P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp,
+                                  C.c_size_t, _vp]),
     "fnr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _i, _vp]),
     "fnr_export_workspace_bytes": (C.c_size_t, [_i64]),
     "fnr_export_compact": (_i, [P(fnr_lattice), _i64, _i64, _vp, _i64, _vp, _vp, _vp, P(_vp), P(_vp), _i64, _vp, _vp,
@@ -146,3 +151,22 @@ def device_check() -> dict:
 def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{name} is on {t.device}; fruitnerf_amd runs only on a HIP device (no CPU path)")
+
+
+PROFILE_OPS = ["sample_spaced", "weights_pdf", "prop_density_fwd", "hash_encode_fwd", "hash_encode_lattice",
+               "field_mlp_fwd", "composite_fwd", "losses_fwd", "interlevel_fwd", "distortion", "composite_bwd",
+               "weights_bwd", "field_mlp_bwd", "hash_encode_bwd", "prop_density_bwd", "adam_step", "export_compact"]
+
+
+def profile_enable(on: bool, ops=None) -> None:
+    mask = (1 << 64) - 1 if ops is None else sum(1 << PROFILE_OPS.index(o) for o in ops)
+    check(load().fnr_profile_enable(1 if on else 0, mask), "profile_enable")
+
+
+def profile_collect(capacity: int = 1 << 20):
+    """-> list of (op name, units, milliseconds) for every profiled entry-point call since enable()."""
+    ops = (C.c_int32 * capacity)()
+    units = (C.c_int64 * capacity)()
+    ms = (C.c_float * capacity)()
+    n = load().fnr_profile_collect(ops, units, ms, capacity)
+    return [(PROFILE_OPS[ops[i]], units[i], ms[i]) for i in range(n)]

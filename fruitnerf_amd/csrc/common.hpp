@@ -49,6 +49,21 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 // number of CUs of the current device (cached)
 int device_cu_count();
 
+// ---- optional per-entry-point HIP-event timing (fnr_profile_enable / fnr_profile_collect) -------
+// Brackets everything an entry point enqueues with two events on the SAME stream the kernels run on.
+enum ProfOp : int {
+  OP_SAMPLE_SPACED = 0, OP_WEIGHTS_PDF, OP_PROP_FWD, OP_ENCODE_FWD, OP_ENCODE_LATTICE, OP_MLP_FWD, OP_COMPOSITE_FWD,
+  OP_LOSSES, OP_INTERLEVEL, OP_DISTORTION, OP_COMPOSITE_BWD, OP_WEIGHTS_BWD, OP_MLP_BWD, OP_ENCODE_BWD, OP_PROP_BWD,
+  OP_ADAM, OP_EXPORT_COMPACT, OP_COUNT
+};
+struct ProfScope {
+  ProfScope(int op, long long units, void* stream);
+  ~ProfScope();
+  int slot;
+  hipStream_t st;
+};
+#define FNR_PROF(op, units) ::fnr::ProfScope prof_scope__((op), (long long)(units), stream)
+
 // ---- exact (non-contracted) fp32 arithmetic -----------------------------------------------------
 // The oracle (PyTorch CPU eager) rounds after every elementwise op.  Wherever a discrete decision
 // depends on the value (selector mask, floor/ceil cell, searchsorted) we use these so the HIP path

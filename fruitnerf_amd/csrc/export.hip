@@ -205,6 +205,7 @@ extern "C" int fnr_export_compact(const fnr_lattice* lat, int64_t ray_begin, int
   }
   unsigned long long* bc = reinterpret_cast<unsigned long long*>(workspace);
   hipStream_t st = as_stream(stream);
+  FNR_PROF(OP_EXPORT_COMPACT, N);
   hipLaunchKernelGGL(k_export_count, dim3((unsigned)nblocks), dim3(EXP_BLOCK), 0, st, N, density, logit, bc, nblocks);
   FNR_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_export_scan, dim3(3), dim3(1024), 0, st, bc, nblocks,

@@ -137,6 +137,7 @@ extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays,
   long long blocks = (n_tiles + 7) / 8;
   const long long max_blocks = 2ll * device_cu_count();
   if (blocks > max_blocks) blocks = max_blocks;
+  FNR_PROF(OP_MLP_FWD, N);
   hipLaunchKernelGGL((k_field_mlp_fwd<FieldCfgBase>), dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), p,
                      make_rays(rays), S, N, reinterpret_cast<const float2*>(feats), selector, net->embedding,
                      mean_embedding, density, rgb, logit, geo_out);

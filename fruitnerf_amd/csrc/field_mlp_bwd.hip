@@ -397,6 +397,7 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
   const RaysDev rd = make_rays(rays);
   const float2* f2 = reinterpret_cast<const float2*>(feats);
   float2* df2 = reinterpret_cast<float2*>(d_feats);
+  FNR_PROF(OP_MLP_BWD, N);
   hipLaunchKernelGGL((k_field_mlp_bwd<FieldCfgBase, BR_COLOR>), dim3((unsigned)blocks), dim3(64 * BWD_WAVES), 0, st, p,
                      rd, S, N, f2, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,
                      partials);

@@ -1,0 +1,431 @@
+// hash_scatter.hip — backward of the hash-grid lookup (autograd of HashEncoding's 8-corner blend) and of the
+// proposal networks, for gfx950.
+//
+// Measured on MI355X: global fp32 atomic adds run at ~21 G atomics/s for the whole chip, independent of table
+// size, scope or XCD locality.  A straight atomicAdd scatter (8 corners x 2 features per sample and level) needs
+// 165 M atomics per 4096-ray training step = ~8 ms, 20x the whole forward pass.  So the scatter is BINNED:
+//   1. emit       every contribution (row, w*gx, w*gy) is appended to the queue of the bin that owns its table
+//                 row (a bin = E consecutive rows of one level, E*8 B <= 64 KiB); a workgroup counts its
+//                 contributions per bin in LDS, reserves queue space with ONE global atomic per non-empty bin,
+//                 then writes 16-byte records;
+//   2. accumulate one workgroup per bin sums its queue into LDS (ds_add_f32 runs at LDS speed) and adds the
+//                 dense E-row tile to the gradient table with plain coalesced read-modify-writes (it is the
+//                 only writer of those rows).
+// Queue overflow (a pathologically hot bin) falls back to global atomics in step 1, so results never depend on
+// the capacity heuristic.  HBM-bound: 16 B written + read per contribution instead of two serialized atomics.
+#include "hash_sources.hpp"
+
+namespace fnr {
+
+constexpr int SC_MAX_ROWS = 8192;       // rows per bin (64 KiB of float2 in LDS)
+constexpr int SC_MIN_BINS = 64;         // bins per level at least
+constexpr int SC_MAX_BINS = 1024;       // per level (LDS histogram size)
+constexpr int SC_CHUNK = 512;           // samples per emit workgroup (512 x 8 records x 16 B = 64 KiB of LDS)
+constexpr int SC_PER_THREAD = SC_CHUNK / 256;
+
+struct ScatterPlan {
+  int log2_rows;         // log2(E)
+  int bins_per_level;    // T / E
+  long long cap;         // queue capacity per bin (records)
+  size_t count_bytes, queue_bytes;
+};
+
+static ScatterPlan scatter_plan(long long N, int n_levels, int log2_T) {
+  ScatterPlan p;
+  int log2_rows = log2_T - 6;  // 64 bins per level ...
+  if (log2_rows > 13) log2_rows = 13;  // ... but at most 8192 rows per bin
+  if (log2_rows < 0) log2_rows = 0;
+  p.log2_rows = log2_rows;
+  p.bins_per_level = 1 << (log2_T - log2_rows);
+  const long long avg = (N * 8 + p.bins_per_level - 1) / p.bins_per_level;
+  p.cap = (3 * avg + 1023) / 1024 * 1024;
+  if (p.cap < 1024) p.cap = 1024;
+  const size_t nbins = (size_t)n_levels * p.bins_per_level;
+  p.count_bytes = (nbins * sizeof(unsigned) + 255) / 256 * 256;
+  p.queue_bytes = nbins * (size_t)p.cap * sizeof(float4);
+  return p;
+}
+
+// the 8 (row, weight) pairs of one sample at one level, in the oracle's corner order
+__device__ __forceinline__ void corner_weights(const float (&x)[3], int scaling, uint32_t mask, uint32_t (&h)[8],
+                                               float (&wgt)[8]) {
+  GridLevel g = grid_cell(x, scaling);
+  grid_corners(g, mask, h);
+  const float ox = g.o[0], oy = g.o[1], oz = g.o[2];
+  const float mx = 1.0f - ox, my = 1.0f - oy, mz = 1.0f - oz;
+  wgt[0] = ox * oy * oz;
+  wgt[1] = ox * my * oz;
+  wgt[2] = mx * my * oz;
+  wgt[3] = mx * oy * oz;
+  wgt[4] = ox * oy * mz;
+  wgt[5] = ox * my * mz;
+  wgt[6] = mx * my * mz;
+  wgt[7] = mx * oy * mz;
+}
+
+// segmented (by equal key in adjacent lanes) inclusive sum of (vx, vy); the LAST lane of a run holds its total
+__device__ __forceinline__ void run_combine(uint32_t key, float& vx, float& vy, bool& is_tail, int lane) {
+  const uint32_t prev = __shfl_up(key, 1, 64);
+  int head = (lane == 0) || (prev != key);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float ux = __shfl_up(vx, d, 64), uy = __shfl_up(vy, d, 64);
+    const int uh = __shfl_up(head, d, 64);
+    if (lane >= d && !head) {
+      vx += ux;
+      vy += uy;
+      head = uh;
+    }
+  }
+  const uint32_t next = __shfl_down(key, 1, 64);
+  is_tail = (lane == 63) || (next != key);
+}
+
+template <class Source>
+__global__ __launch_bounds__(256) void k_scatter_emit(GridDev grid, Warp warp, Source src, long long N,
+                                                      const float2* __restrict__ d_feats, float4* __restrict__ queue,
+                                                      unsigned* __restrict__ qcount, long long cap, int log2_rows) {
+  // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs
+  __shared__ float4 s_rec[SC_CHUNK * 8];
+  __shared__ unsigned s_cnt[SC_MAX_BINS];   // per-bin count, then running cursor
+  __shared__ unsigned s_off[SC_MAX_BINS];   // per-bin start inside s_rec
+  __shared__ unsigned s_base[SC_MAX_BINS];  // per-bin start inside the global queue
+  __shared__ unsigned s_wsum[4];
+  const int level = blockIdx.y;
+  const int bins = 1 << (grid.log2_T - log2_rows);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < bins; i += 256) s_cnt[i] = 0;
+  __syncthreads();
+  const uint32_t mask = (1u << grid.log2_T) - 1u;
+  const uint32_t row_mask = (1u << log2_rows) - 1u;
+  const int scaling = grid.scalings[level];
+  const long long n0 = (long long)blockIdx.x * SC_CHUNK;
+  const float2* gl = d_feats + (size_t)level * N;
+
+  // contributions of this thread's samples; equal rows in adjacent lanes (consecutive samples of a ray share
+  // cells at coarse levels) are pre-summed so only the last lane of a run emits a record
+  uint32_t hk[SC_PER_THREAD][8];
+  float vxk[SC_PER_THREAD][8], vyk[SC_PER_THREAD][8];
+  unsigned emit_mask[SC_PER_THREAD];
+#pragma unroll
+  for (int q = 0; q < SC_PER_THREAD; ++q) {
+    const long long n = n0 + q * 256 + threadIdx.x;
+    float2 gf = make_float2(0.f, 0.f);
+    float x[3] = {0.f, 0.f, 0.f};
+    if (n < N) {
+      gf = gl[n];
+      float px, py, pz;
+      src.position(n, px, py, pz);
+      warp_position(warp, px, py, pz, x);
+    }
+    float wgt[8];
+    corner_weights(x, scaling, mask, hk[q], wgt);
+    emit_mask[q] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool live = (n < N) && (wgt[k] != 0.0f) && (gf.x != 0.0f || gf.y != 0.0f);
+      vxk[q][k] = live ? wgt[k] * gf.x : 0.0f;
+      vyk[q][k] = live ? wgt[k] * gf.y : 0.0f;
+      // dead contributions get a key that never matches a neighbour
+      const uint32_t key = live ? hk[q][k] : (0x80000000u | (uint32_t)lane);
+      bool tail;
+      run_combine(key, vxk[q][k], vyk[q][k], tail, lane);
+      if (live && tail) {
+        emit_mask[q] |= 1u << k;
+        atomicAdd(&s_cnt[hk[q][k] >> log2_rows], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the per-bin counts (bins <= 1024 = 4 per thread) + one global reservation per non-empty bin
+  unsigned c4[4], tsum = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = threadIdx.x * 4 + t;
+    c4[t] = (i < bins) ? s_cnt[i] : 0u;
+    tsum += c4[t];
+  }
+  unsigned incl = tsum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned u = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += u;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  unsigned woff = 0;
+  for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+  const unsigned total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  unsigned run = woff + incl - tsum;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = threadIdx.x * 4 + t;
+    if (i < bins) {
+      s_off[i] = run;
+      s_base[i] = c4[t] ? atomicAdd(&qcount[level * bins + i], c4[t]) : 0u;
+      s_cnt[i] = 0;
+      run += c4[t];
+    }
+  }
+  __syncthreads();
+  // place the records bin by bin in LDS
+#pragma unroll
+  for (int q = 0; q < SC_PER_THREAD; ++q) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if ((emit_mask[q] >> k) & 1u) {
+        const int bin = hk[q][k] >> log2_rows;
+        const unsigned pos = s_off[bin] + atomicAdd(&s_cnt[bin], 1u);
+        s_rec[pos] = make_float4(__uint_as_float(hk[q][k] & row_mask), vxk[q][k], vyk[q][k], __uint_as_float((unsigned)bin));
+      }
+    }
+  }
+  __syncthreads();
+  // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 16-byte stores)
+  float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
+  for (unsigned i = threadIdx.x; i < total; i += 256) {
+    const float4 r = s_rec[i];
+    const unsigned bin = __float_as_uint(r.w);
+    const unsigned slot = s_base[bin] + (i - s_off[bin]);
+    if ((long long)slot < cap) {
+      queue[((size_t)level * bins + bin) * cap + slot] = r;
+    } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
+      const size_t row = ((size_t)bin << log2_rows) + __float_as_uint(r.x);
+      atomicAdd(table + 2 * row, r.y);
+      atomicAdd(table + 2 * row + 1, r.z);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float4* __restrict__ queue,
+                                                             const unsigned* __restrict__ qcount, long long cap,
+                                                             int log2_rows) {
+  extern __shared__ float s_acc[];  // [rows][2]
+  const int rows = 1 << log2_rows;
+  const int bins = 1 << (grid.log2_T - log2_rows);
+  const int gbin = blockIdx.x;  // level * bins + bin
+  const int level = gbin / bins, bin = gbin - level * bins;
+  long long n = qcount[gbin];
+  if (n == 0) return;
+  if (n > cap) n = cap;
+  for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0.0f;
+  __syncthreads();
+  const float4* qb = queue + (size_t)gbin * cap;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float4 r = qb[i];
+    const unsigned row = __float_as_uint(r.x);
+    atomicAdd(&s_acc[2 * row], r.y);
+    atomicAdd(&s_acc[2 * row + 1], r.z);
+  }
+  __syncthreads();
+  float2* dst = grid.table + ((size_t)level << grid.log2_T) + (size_t)bin * rows;
+  for (int e = threadIdx.x; e < rows; e += blockDim.x) {
+    const float ax = s_acc[2 * e], ay = s_acc[2 * e + 1];
+    if (ax != 0.0f || ay != 0.0f) {
+      float2 t = dst[e];
+      t.x += ax;
+      t.y += ay;
+      dst[e] = t;
+    }
+  }
+}
+
+template <class Source>
+static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Source& src, long long N,
+                          const float2* d_feats, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const ScatterPlan p = scatter_plan(N, grid_grad->n_levels, grid_grad->log2_hashmap_size);
+  FNR_CHECK_ARG(p.bins_per_level <= SC_MAX_BINS, "hash scatter: log2_hashmap_size %d too large for the bin histogram",
+                grid_grad->log2_hashmap_size);
+  FNR_CHECK_ARG(workspace && workspace_bytes >= p.count_bytes + p.queue_bytes, "hash scatter: workspace too small");
+  unsigned* qcount = reinterpret_cast<unsigned*>(workspace);
+  float4* queue = reinterpret_cast<float4*>(reinterpret_cast<char*>(workspace) + p.count_bytes);
+  FNR_HIP(hipMemsetAsync(qcount, 0, p.count_bytes, st));
+  const long long chunks = (N + SC_CHUNK - 1) / SC_CHUNK;
+  FNR_CHECK_ARG(chunks < (1ll << 31), "hash scatter: too many samples");
+  const GridDev gd = make_grid(grid_grad);
+  hipLaunchKernelGGL((k_scatter_emit<Source>), dim3((unsigned)chunks, (unsigned)grid_grad->n_levels), dim3(256), 0, st,
+                     gd, warp, src, N, d_feats, queue, qcount, p.cap, p.log2_rows);
+  FNR_LAUNCH_CHECK();
+  const unsigned nbins = (unsigned)(grid_grad->n_levels * p.bins_per_level);
+  hipLaunchKernelGGL(k_scatter_accumulate, dim3(nbins), dim3(1024), (size_t)(2u << p.log2_rows) * sizeof(float), st, gd,
+                     queue, qcount, p.cap, p.log2_rows);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// proposal network backward.  Persistent workgroups; per iteration 256 samples:
+//   phase 1 (thread = sample): recompute the MLP from the saved features, d_out = d_sigma * trunc_exp'(out),
+//            hidden gradients -> LDS, feature gradients -> d_feats [L][N][2] (scattered by binned_scatter);
+//   phase 2 (thread = weight): accumulate dW0[o][k], db0[o], dW1[o], db1 over the 256 samples from LDS.
+// Weight gradients leave the workgroup once, at the end (one atomicAdd per weight per workgroup).
+// ------------------------------------------------------------------------------------------------
+template <int L, int H>
+__global__ __launch_bounds__(256) void k_prop_bwd(Warp warp, RaySource src, long long N, const float* __restrict__ w0,
+                                                  const float* __restrict__ b0, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1, const float2* __restrict__ feat_save,
+                                                  const float* __restrict__ d_density, float2* __restrict__ d_feats,
+                                                  float* __restrict__ g_w0, float* __restrict__ g_b0,
+                                                  float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  constexpr int K = 2 * L;
+  __shared__ float s_dh[256][H + 1];   // d hidden (pre-activation)
+  __shared__ float s_ha[256][H + 1];   // relu(hidden) * d_out  (for dW1)
+  __shared__ float s_f[256][K + 1];    // input features
+  __shared__ float s_do[256];          // d_out
+  const int tid = threadIdx.x;
+  constexpr int NW = H * K + H + H + 1;  // dW0, db0, dW1, db1
+  float acc[2] = {0.0f, 0.0f};           // this thread's weight-gradient accumulators (tid, tid + 256)
+  const long long n_iter = (N + 255) / 256;
+  for (long long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const long long n = it * 256 + tid;
+    float f[K], dout = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) f[k] = 0.0f;
+    bool sel = false;
+    if (n < N) {
+      float px, py, pz, x[3];
+      src.position(n, px, py, pz);
+      sel = warp_position(warp, px, py, pz, x);
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const float2 v = feat_save[(size_t)l * N + n];
+        f[2 * l] = v.x;
+        f[2 * l + 1] = v.y;
+      }
+    }
+    float a[H];
+    float out = b1[0];
+#pragma unroll
+    for (int o = 0; o < H; ++o) {
+      float t = b0[o];
+#pragma unroll
+      for (int k = 0; k < K; ++k) t = fmaf(w0[o * K + k], f[k], t);
+      a[o] = t;
+      out = fmaf(w1[o], fmaxf(t, 0.0f), out);
+    }
+    if (n < N && sel) dout = d_density[n] * expf(fminf(fmaxf(out, -15.0f), 15.0f));  // trunc_exp backward
+    float df[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) df[k] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < H; ++o) {
+      const float dh = (a[o] > 0.0f) ? dout * w1[o] : 0.0f;
+      s_dh[tid][o] = dh;
+      s_ha[tid][o] = fmaxf(a[o], 0.0f) * dout;
+#pragma unroll
+      for (int k = 0; k < K; ++k) df[k] = fmaf(dh, w0[o * K + k], df[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) s_f[tid][k] = f[k];
+    s_do[tid] = dout;
+    if (n < N) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) d_feats[(size_t)l * N + n] = make_float2(df[2 * l], df[2 * l + 1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int widx = tid + 256 * half;
+      if (widx < NW) {
+        float s = 0.0f;
+        if (widx < H * K) {
+          const int o = widx / K, k = widx - o * K;
+          for (int q = 0; q < 256; ++q) s = fmaf(s_dh[q][o], s_f[q][k], s);
+        } else if (widx < H * K + H) {
+          const int o = widx - H * K;
+          for (int q = 0; q < 256; ++q) s += s_dh[q][o];
+        } else if (widx < H * K + 2 * H) {
+          const int o = widx - H * K - H;
+          for (int q = 0; q < 256; ++q) s += s_ha[q][o];
+        } else {
+          for (int q = 0; q < 256; ++q) s += s_do[q];
+        }
+        acc[half] += s;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int widx = tid + 256 * half;
+    if (widx < NW && acc[half] != 0.0f) {
+      if (widx < H * K) atomicAdd(&g_w0[widx], acc[half]);
+      else if (widx < H * K + H) atomicAdd(&g_b0[widx - H * K], acc[half]);
+      else if (widx < H * K + 2 * H) atomicAdd(&g_w1[widx - H * K - H], acc[half]);
+      else atomicAdd(&g_b1[0], acc[half]);
+    }
+  }
+}
+
+}  // namespace fnr
+
+using namespace fnr;
+
+extern "C" size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
+  const ScatterPlan p = scatter_plan(n_samples, n_levels, log2_hashmap_size);
+  return p.count_bytes + p.queue_bytes;
+}
+
+extern "C" int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
+                                   const float* euclid_bins, int S, const float* d_feats, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  FNR_CHECK_ARG(grid_grad && warp && rays && euclid_bins && d_feats && S > 0, "hash_encode_bwd: null argument");
+  FNR_CHECK_ARG(grid_grad->n_levels >= 1 && grid_grad->n_levels <= FNR_MAX_LEVELS, "hash_encode_bwd: n_levels");
+  const long long N = rays->n_rays * (long long)S;
+  if (N == 0) return FNR_OK;
+  RaySource src{make_rays(rays), euclid_bins, S};
+  FNR_PROF(OP_ENCODE_BWD, N);
+  return binned_scatter(grid_grad, make_warp(warp), src, N, reinterpret_cast<const float2*>(d_feats), workspace,
+                        workspace_bytes, as_stream(stream));
+}
+
+extern "C" size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
+  const size_t dfeat = ((size_t)n_levels * (size_t)n_samples * sizeof(float2) + 255) / 256 * 256;
+  return dfeat + fnr_hash_scatter_workspace_bytes(n_samples, n_levels, log2_hashmap_size);
+}
+
+extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
+                                    const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
+                                    const float* d_density, void* workspace, size_t workspace_bytes, void* stream) {
+  FNR_CHECK_ARG(net && grads && warp && rays && euclid_bins && feat_save && d_density && workspace && S > 0,
+                "prop_density_bwd: null argument");
+  FNR_UNSUPPORTED(net->hidden_dim == 16, "prop_density_bwd: hidden_dim %d not built (16 only)", net->hidden_dim);
+  FNR_CHECK_ARG(grads->grid.table && grads->w0 && grads->b0 && grads->w1 && grads->b1,
+                "prop_density_bwd: null gradient pointer");
+  const long long N = rays->n_rays * (long long)S;
+  if (N == 0) return FNR_OK;
+  const int L = net->grid.n_levels;
+  FNR_CHECK_ARG(workspace_bytes >= fnr_prop_density_bwd_workspace_bytes(N, L, net->grid.log2_hashmap_size),
+                "prop_density_bwd: workspace too small");
+  RaySource src{make_rays(rays), euclid_bins, S};
+  long long blocks = (N + 255) / 256;
+  const long long max_blocks = 8ll * device_cu_count();
+  if (blocks > max_blocks) blocks = max_blocks;
+  Warp w = make_warp(warp);
+  const float2* fs = reinterpret_cast<const float2*>(feat_save);
+  float2* d_feats = reinterpret_cast<float2*>(workspace);
+  const size_t dfeat_bytes = ((size_t)L * (size_t)N * sizeof(float2) + 255) / 256 * 256;
+  FNR_PROF(OP_PROP_BWD, N);
+#define FNR_PROPB_CASE(LL)                                                                                          \
+  case LL:                                                                                                          \
+    hipLaunchKernelGGL((k_prop_bwd<LL, 16>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), w, src, N,    \
+                       net->w0, net->b0, net->w1, net->b1, fs, d_density, d_feats, grads->w0, grads->b0, grads->w1, \
+                       grads->b1);                                                                                  \
+    break;
+  switch (L) {
+    FNR_PROPB_CASE(1)
+    FNR_PROPB_CASE(2)
+    FNR_PROPB_CASE(3)
+    FNR_PROPB_CASE(4)
+    FNR_PROPB_CASE(5)
+    FNR_PROPB_CASE(6)
+    FNR_PROPB_CASE(7)
+    FNR_PROPB_CASE(8)
+    default:
+      FNR_UNSUPPORTED(false, "prop_density_bwd: n_levels %d not built (1..8)", L);
+  }
+#undef FNR_PROPB_CASE
+  FNR_LAUNCH_CHECK();
+  return binned_scatter(&grads->grid, w, src, N, d_feats, reinterpret_cast<char*>(workspace) + dfeat_bytes,
+                        workspace_bytes - dfeat_bytes, as_stream(stream));
+}

@@ -111,6 +111,7 @@ extern "C" int fnr_composite_fwd(const fnr_rays* rays, int S, const float* eucli
                 "composite_fwd: null argument");
   FNR_CHECK_ARG(S > 0 && S <= 64 * CMP_MAXE, "composite_fwd: S %d out of range", S);
   if (rays->n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_COMPOSITE_FWD, rays->n_rays * (long long)S);
   hipLaunchKernelGGL(k_composite_fwd, dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      make_rays(rays), S, euclid_bins, density, rgb, logit, training, weights, out_rgb,
                      out_accumulation, out_depth, out_semantics);

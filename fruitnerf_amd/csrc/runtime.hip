@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.hpp"
 
 namespace fnr {
@@ -30,7 +32,61 @@ int device_cu_count() {
   return cached_cus;
 }
 
+// ---- event timing ---------------------------------------------------------------------------------
+struct ProfRec {
+  hipEvent_t a, b;
+  int op;
+  long long units;
+};
+static bool g_prof_on = false;
+static unsigned long long g_prof_mask = ~0ull;
+static std::vector<ProfRec> g_prof;
+
+ProfScope::ProfScope(int op, long long units, void* stream) : slot(-1), st(as_stream(stream)) {
+  if (!g_prof_on || !((g_prof_mask >> op) & 1ull) || g_prof.size() >= (1u << 20)) return;
+  ProfRec r;
+  r.op = op;
+  r.units = units;
+  if (hipEventCreate(&r.a) != hipSuccess) return;
+  if (hipEventCreate(&r.b) != hipSuccess) {
+    (void)hipEventDestroy(r.a);
+    return;
+  }
+  (void)hipEventRecord(r.a, st);
+  slot = (int)g_prof.size();
+  g_prof.push_back(r);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
+
 }  // namespace fnr
+
+extern "C" int fnr_profile_enable(int on, uint64_t op_mask) {
+  for (auto& r : fnr::g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  fnr::g_prof.clear();
+  fnr::g_prof_on = on != 0;
+  fnr::g_prof_mask = op_mask;
+  return FNR_OK;
+}
+
+extern "C" int64_t fnr_profile_collect(int32_t* ops, int64_t* units, float* ms, int64_t capacity) {
+  int64_t n = 0;
+  for (auto& r : fnr::g_prof) {
+    if (n >= capacity) break;
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ops[n] = r.op;
+    units[n] = r.units;
+    ms[n] = t;
+    ++n;
+  }
+  return n;
+}
 
 extern "C" int fnr_abi_version(void) { return FNR_ABI_VERSION; }
 

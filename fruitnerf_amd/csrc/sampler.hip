@@ -181,6 +181,7 @@ extern "C" int fnr_sample_spaced(const fnr_rays* rays, int spacing_kind, int S, 
   FNR_CHECK_ARG(spacing_kind == 0 || spacing_kind == 1, "sample_spaced: spacing_kind %d", spacing_kind);
   const long long total = rays->n_rays * (long long)(S + 1);
   if (total == 0) return FNR_OK;
+  FNR_PROF(OP_SAMPLE_SPACED, total);
   hipLaunchKernelGGL(k_sample_spaced, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                      make_rays(rays), spacing_kind, S, base_bins, t_rand, spacing_bins, euclid_bins);
   FNR_LAUNCH_CHECK();
@@ -198,6 +199,7 @@ extern "C" int fnr_weights_pdf(const fnr_rays* rays, int spacing_kind, int S_pre
                 "weights_pdf: resampling needs spacing_prev/u_base/outputs");
   FNR_CHECK_ARG(spacing_kind == 0 || spacing_kind == 1, "weights_pdf: spacing_kind %d", spacing_kind);
   if (rays->n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_WEIGHTS_PDF, rays->n_rays * (long long)S_prev);
   hipLaunchKernelGGL(k_weights_pdf, dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      make_rays(rays), spacing_kind, S_prev, S_new, density, spacing_prev, euclid_prev, anneal, u_base,
                      rand, weights, median_depth, spacing_new, euclid_new);

@@ -283,6 +283,7 @@ extern "C" int fnr_losses_fwd(int64_t n_rays, const float* rgb, const float* ima
   FNR_HIP(hipMemsetAsync(losses, 0, 2 * sizeof(float), as_stream(stream)));
   long long blocks = (n_rays + 255) / 256;
   if (blocks > 1024) blocks = 1024;
+  FNR_PROF(OP_LOSSES, n_rays);
   hipLaunchKernelGGL(k_losses, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (long long)n_rays, rgb, image,
                      semantics, fruit_mask, semantic_loss_weight, losses, d_rgb, d_semantics);
   FNR_LAUNCH_CHECK();
@@ -295,6 +296,7 @@ extern "C" int fnr_interlevel_fwd(int64_t n_rays, int S_f, const float* spacing_
   FNR_CHECK_ARG(spacing_f && weights_f && spacing_p && weights_p && loss && d_weights_p, "interlevel_fwd: null argument");
   FNR_CHECK_ARG(S_f > 0 && S_p > 0 && S_p <= IL_MAX_P, "interlevel_fwd: S_p %d out of range", S_p);
   if (n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_INTERLEVEL, n_rays * (long long)S_p);
   hipLaunchKernelGGL(k_interlevel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      (long long)n_rays, S_f, spacing_f, weights_f, S_p, spacing_p, weights_p, mult, loss, d_weights_p);
   FNR_LAUNCH_CHECK();
@@ -305,6 +307,7 @@ extern "C" int fnr_distortion(int64_t n_rays, int S, const float* spacing, const
                               void* stream) {
   FNR_CHECK_ARG(spacing && weights && out && S > 0 && S <= 512, "distortion: bad argument");
   if (n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_DISTORTION, n_rays * (long long)S);
   hipLaunchKernelGGL(k_distortion, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      (long long)n_rays, S, spacing, weights, out);
   FNR_LAUNCH_CHECK();
@@ -319,6 +322,7 @@ extern "C" int fnr_composite_bwd(const fnr_rays* rays, int S, const float* eucli
                 "composite_bwd: null argument");
   FNR_CHECK_ARG(S > 0 && S <= 64 * WB_MAXE, "composite_bwd: S %d out of range", S);
   if (rays->n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_COMPOSITE_BWD, rays->n_rays * (long long)S);
   hipLaunchKernelGGL((k_weights_bwd<true>), dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      (long long)rays->n_rays, S, euclid_bins, density, weights, (const float*)nullptr,
                      (const float*)nullptr, rgb, g_rgb, g_semantics, d_density, d_rgb, d_logit);
@@ -332,6 +336,7 @@ extern "C" int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, 
   FNR_CHECK_ARG(euclid_bins && density && weights && d_weights && d_density, "weights_bwd: null argument");
   FNR_CHECK_ARG(S > 0 && S <= 64 * WB_MAXE, "weights_bwd: S %d out of range", S);
   if (n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_WEIGHTS_BWD, n_rays * (long long)S);
   hipLaunchKernelGGL((k_weights_bwd<false>), dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      (long long)n_rays, S, euclid_bins, density, weights, d_weights, upstream, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, d_density, (float*)nullptr, (float*)nullptr);
@@ -350,6 +355,7 @@ extern "C" int fnr_adam_step(float* params, float* grads, float* exp_avg, float*
   long long n4 = n / 4;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  FNR_PROF(OP_ADAM, n);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<float4*>(params), reinterpret_cast<float4*>(grads),
                      reinterpret_cast<float4*>(exp_avg), reinterpret_cast<float4*>(exp_avg_sq), n4, lr, beta1, beta2,

@@ -122,12 +122,14 @@ class FruitField(nn.Module):
     def net_struct(self, grads: bool = False) -> L.fnr_field_net:
         """fnr_field_net over the parameters (or, grads=True, over the arena's gradient views)."""
         self._ensure_arena()
-        key = self.mlp_base_grid.hash_table.data_ptr()
-        if not grads and self._net_c is not None and self._net_ptr_key == key:
-            return self._net_c
-
         def P(p: nn.Parameter):
             return (p.grad if grads else p.data).data_ptr()
+
+        key = (P(self.mlp_base_grid.hash_table), P(self.mlp_head.layers[2].bias))
+        cache = self.__dict__.setdefault("_struct_cache", {})
+        hit = cache.get(grads)
+        if hit is not None and hit[0] == key and self._net_c is not None:
+            return hit[1]
 
         g = self.mlp_base_grid
         net = L.fnr_field_net()
@@ -151,8 +153,8 @@ class FruitField(nn.Module):
         for i, lyr in enumerate(self.mlp_head.layers):
             net.col_w[i], net.col_b[i] = P(lyr.weight), P(lyr.bias)
         net.embedding = P(self.embedding_appearance.embedding.weight)
-        if not grads:
-            self._net_c, self._net_ptr_key = net, key
+        cache[grads] = (key, net)
+        self._net_c = net  # non-None marks the cache valid (reset by _apply / adopt_arena)
         return net
 
     def warp_struct(self) -> L.fnr_warp:

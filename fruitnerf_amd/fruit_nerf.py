@@ -95,7 +95,13 @@ class HashMLPDensityField(nn.Module):
             return (p.grad if grads else p.data).data_ptr()
 
         e = self.encoding
+        key = (grads, P(e.hash_table), P(self.mlp_base[1].layers[0].weight))
+        cache = self.__dict__.setdefault("_struct_cache", {})
+        hit = cache.get(grads)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         net = L.fnr_prop_net()
+        cache[grads] = (key, net)
         net.grid = K.make_grid(e.hash_table.grad if grads else e.hash_table.data, e.num_levels, e.log2_hashmap_size,
                                e.scalings)
         net.hidden_dim = self.hidden_dim
@@ -363,9 +369,10 @@ class FruitModel(nn.Module):
         outputs["ray_samples_list"] = ray_samples_list
         # semantics colormap (fruit_nerf.py:309-312, 351-355): heaviside(sigmoid(sem) - 0.9, 0) -> colormap lookup
         semantic_labels = torch.sigmoid(outputs["semantics"].detach())
-        semantic_labels = torch.heaviside(semantic_labels - 0.9, torch.tensor(0.0, device=semantic_labels.device)
-                                          ).to(torch.long)
-        cm = self.colormap.to(semantic_labels.device)[semantic_labels]
+        semantic_labels = ((semantic_labels - 0.9) > 0).to(torch.long)  # == heaviside(x - 0.9, 0); no H2D scalar
+        if self.colormap.device != semantic_labels.device:
+            self.colormap = self.colormap.to(semantic_labels.device)  # once, not per call (H2D copies synchronise)
+        cm = self.colormap[semantic_labels]
         outputs["semantics_colormap"] = cm.repeat(1, 3) if repeat_colormap else cm
         outputs["_ctx"] = ctx
         return outputs

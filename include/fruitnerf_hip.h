@@ -105,6 +105,16 @@ const char* fnr_last_error(void);
 /* Queries the current HIP device; fails loudly when no gfx950 device is present. */
 int fnr_device_check(int* cu_count_out, char* name_out, int name_len);
 
+/* Optional HIP-event timing of the entry points (bench.py's roofline leg).  While enabled, every entry
+ * point whose op id is set in op_mask brackets what it enqueues with two events recorded on the caller's
+ * stream.  fnr_profile_collect synchronises those events and returns up to `capacity` records
+ * (op id, units = samples/rays/params the call processed, milliseconds); enable(…) clears old records.
+ * Op ids: 0 sample_spaced, 1 weights_pdf, 2 prop_density_fwd, 3 hash_encode_fwd, 4 hash_encode_lattice,
+ * 5 field_mlp_fwd, 6 composite_fwd, 7 losses_fwd, 8 interlevel_fwd, 9 distortion, 10 composite_bwd,
+ * 11 weights_bwd, 12 field_mlp_bwd, 13 hash_encode_bwd, 14 prop_density_bwd, 15 adam_step, 16 export_compact. */
+int fnr_profile_enable(int on, uint64_t op_mask);
+int64_t fnr_profile_collect(int32_t* ops_host, int64_t* units_host, float* ms_host, int64_t capacity);
+
 /* ---- samplers ------------------------------------------------------------------------------- */
 /* SpacedSampler.generate_ray_samples (components/ray_samplers.py:54-104; nerfstudio
  * UniformLinDispPiecewiseSampler for the proposal level 0, fruit_nerf.py:151-158).
@@ -207,14 +217,20 @@ int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, cons
                       const float* feats, const uint8_t* selector, const float* d_density, const float* d_rgb,
                       const float* d_logit, float* d_feats, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Backward of fnr_hash_encode_fwd: scatter-adds d_feats [L][N][2] into grid_grad->table (+=, fp32 atomics). */
+/* Backward of fnr_hash_encode_fwd: adds (+=) the trilinear scatter of d_feats [L][N][2] into
+ * grid_grad->table.  Binned through per-bin queues in `workspace` (>= fnr_hash_scatter_workspace_bytes)
+ * because global fp32 atomics top out at ~21 G/s on MI355X (hash_scatter.hip). */
+size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size);
 int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
-                        const float* euclid_bins, int S, const float* d_feats, void* stream);
+                        const float* euclid_bins, int S, const float* d_feats, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
-/* Backward of fnr_prop_density_fwd: d_density [R,S] -> += into grads (table, w0, b0, w1, b1). */
+/* Backward of fnr_prop_density_fwd: d_density [R,S] -> += into grads (table, w0, b0, w1, b1).
+ * workspace >= fnr_prop_density_bwd_workspace_bytes(N, L, log2_hashmap_size). */
+size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size);
 int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
                          const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
-                         const float* d_density, void* stream);
+                         const float* d_density, void* workspace, size_t workspace_bytes, void* stream);
 
 /* torch.optim.Adam step (no weight decay, no amsgrad; fruit_nerf_config.py:47-56) over a flat arena of n
  * floats (n % 4 == 0); the gradient is multiplied by grad_scale first (1/world_size after an all-reduce(SUM))
