@@ -21,7 +21,9 @@ constexpr int SC_MAX_ROWS = 8192;       // rows per bin (64 KiB of float2 in LDS
 constexpr int SC_MIN_BINS = 64;         // bins per level at least
 constexpr int SC_MAX_BINS = 1024;       // per level (LDS histogram size)
 constexpr int SC_CHUNK = 512;           // samples per emit workgroup (512 x 8 records x 16 B = 64 KiB of LDS)
-constexpr int SC_PER_THREAD = SC_CHUNK / 256;
+constexpr int SC_EMIT_THREADS = 512;    // 8 waves, one sample per thread
+constexpr int SC_PER_THREAD = SC_CHUNK / SC_EMIT_THREADS;
+constexpr int SC_BINS_PER_THREAD = SC_MAX_BINS / SC_EMIT_THREADS;
 
 struct ScatterPlan {
   int log2_rows;         // log2(E)
@@ -82,7 +84,7 @@ __device__ __forceinline__ void run_combine(uint32_t key, float& vx, float& vy, 
 }
 
 template <class Source>
-__global__ __launch_bounds__(256) void k_scatter_emit(GridDev grid, Warp warp, Source src, long long N,
+__global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, Warp warp, Source src, long long N,
                                                       const float2* __restrict__ d_feats, float4* __restrict__ queue,
                                                       unsigned* __restrict__ qcount, long long cap, int log2_rows) {
   // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs
@@ -90,11 +92,11 @@ __global__ __launch_bounds__(256) void k_scatter_emit(GridDev grid, Warp warp, S
   __shared__ unsigned s_cnt[SC_MAX_BINS];   // per-bin count, then running cursor
   __shared__ unsigned s_off[SC_MAX_BINS];   // per-bin start inside s_rec
   __shared__ unsigned s_base[SC_MAX_BINS];  // per-bin start inside the global queue
-  __shared__ unsigned s_wsum[4];
+  __shared__ unsigned s_wsum[SC_EMIT_THREADS / 64];
   const int level = blockIdx.y;
   const int bins = 1 << (grid.log2_T - log2_rows);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < bins; i += 256) s_cnt[i] = 0;
+  for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) s_cnt[i] = 0;
   __syncthreads();
   const uint32_t mask = (1u << grid.log2_T) - 1u;
   const uint32_t row_mask = (1u << log2_rows) - 1u;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void k_scatter_emit(GridDev grid, Warp warp, S
   unsigned emit_mask[SC_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < SC_PER_THREAD; ++q) {
-    const long long n = n0 + q * 256 + threadIdx.x;
+    const long long n = n0 + q * SC_EMIT_THREADS + threadIdx.x;
     float2 gf = make_float2(0.f, 0.f);
     float x[3] = {0.f, 0.f, 0.f};
     if (n < N) {
@@ -138,10 +140,10 @@ __global__ __launch_bounds__(256) void k_scatter_emit(GridDev grid, Warp warp, S
   }
   __syncthreads();
   // exclusive scan of the per-bin counts (bins <= 1024 = 4 per thread) + one global reservation per non-empty bin
-  unsigned c4[4], tsum = 0;
+  unsigned c4[SC_BINS_PER_THREAD], tsum = 0;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = threadIdx.x * 4 + t;
+  for (int t = 0; t < SC_BINS_PER_THREAD; ++t) {
+    const int i = threadIdx.x * SC_BINS_PER_THREAD + t;
     c4[t] = (i < bins) ? s_cnt[i] : 0u;
     tsum += c4[t];
   }
@@ -155,11 +157,13 @@ __global__ __launch_bounds__(256) void k_scatter_emit(GridDev grid, Warp warp, S
   __syncthreads();
   unsigned woff = 0;
   for (int w = 0; w < wave; ++w) woff += s_wsum[w];
-  const unsigned total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  unsigned total = 0;
+#pragma unroll
+  for (int w = 0; w < SC_EMIT_THREADS / 64; ++w) total += s_wsum[w];
   unsigned run = woff + incl - tsum;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = threadIdx.x * 4 + t;
+  for (int t = 0; t < SC_BINS_PER_THREAD; ++t) {
+    const int i = threadIdx.x * SC_BINS_PER_THREAD + t;
     if (i < bins) {
       s_off[i] = run;
       s_base[i] = c4[t] ? atomicAdd(&qcount[level * bins + i], c4[t]) : 0u;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void k_scatter_emit(GridDev grid, Warp warp, S
   __syncthreads();
   // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 16-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
-  for (unsigned i = threadIdx.x; i < total; i += 256) {
+  for (unsigned i = threadIdx.x; i < total; i += SC_EMIT_THREADS) {
     const float4 r = s_rec[i];
     const unsigned bin = __float_as_uint(r.w);
     const unsigned slot = s_base[bin] + (i - s_off[bin]);
@@ -211,7 +215,19 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0.0f;
   __syncthreads();
   const float4* qb = queue + (size_t)gbin * cap;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+  long long i = threadIdx.x;
+  for (; i + 3 * (long long)blockDim.x < n; i += 4 * (long long)blockDim.x) {  // 4 loads in flight per thread
+    float4 r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = qb[i + u * (long long)blockDim.x];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned row = __float_as_uint(r[u].x);
+      atomicAdd(&s_acc[2 * row], r[u].y);
+      atomicAdd(&s_acc[2 * row + 1], r[u].z);
+    }
+  }
+  for (; i < n; i += blockDim.x) {
     const float4 r = qb[i];
     const unsigned row = __float_as_uint(r.x);
     atomicAdd(&s_acc[2 * row], r.y);
@@ -243,7 +259,7 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
   const long long chunks = (N + SC_CHUNK - 1) / SC_CHUNK;
   FNR_CHECK_ARG(chunks < (1ll << 31), "hash scatter: too many samples");
   const GridDev gd = make_grid(grid_grad);
-  hipLaunchKernelGGL((k_scatter_emit<Source>), dim3((unsigned)chunks, (unsigned)grid_grad->n_levels), dim3(256), 0, st,
+  hipLaunchKernelGGL((k_scatter_emit<Source>), dim3((unsigned)chunks, (unsigned)grid_grad->n_levels), dim3(SC_EMIT_THREADS), 0, st,
                      gd, warp, src, N, d_feats, queue, qcount, p.cap, p.log2_rows);
   FNR_LAUNCH_CHECK();
   const unsigned nbins = (unsigned)(grid_grad->n_levels * p.bins_per_level);

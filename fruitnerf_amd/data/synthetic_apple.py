@@ -78,7 +78,8 @@ def pixel_rays(c2w: Tensor, cam_idx: Tensor, y: Tensor, x: Tensor, fx: float, fy
     """Nerfstudio RayGenerator convention for pinhole cameras: pixel centre (x+0.5, y+0.5), camera -z forward."""
     dirs_cam = torch.stack([(x.float() + 0.5 - cx) / fx, -(y.float() + 0.5 - cy) / fy, -torch.ones_like(x).float()], -1)
     R = c2w[cam_idx, :, :3]
-    d = torch.einsum("nij,nj->ni", R, dirs_cam)
+    # (a batched-GEMM einsum here costs a 58 us hipBLASLt launch per step; three fused multiply-adds do not)
+    d = R[:, :, 0] * dirs_cam[:, 0:1] + R[:, :, 1] * dirs_cam[:, 1:2] + R[:, :, 2] * dirs_cam[:, 2:3]
     d = torch.nn.functional.normalize(d, dim=-1)
     o = c2w[cam_idx, :, 3]
     return o, d
