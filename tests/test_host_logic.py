@@ -1,0 +1,168 @@
+"""CPU: host-side logic of the Python mirror (no kernel launches): checkpoint contract, export lattice,
+ray batches, proposal update schedule / anneal, flat parameter arena, learning-rate schedule."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fruit_oracle as fo
+from tests import util
+
+
+def _models(cfg=None):
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    cfg = cfg or util.small_config(log2=8, prop_log2=6)
+    om = util.make_oracle(cfg, num_images=5, seed=0, randomize=False)
+    hc = FruitNerfModelConfig()
+    for k, v in vars(cfg).items():
+        if hasattr(hc, k):
+            setattr(hc, k, v)
+    hm = FruitModel(hc, num_train_data=5, device="cpu")
+    return om, hm
+
+
+def test_state_dict_keys_and_shapes_match_the_torch_layout():
+    om, hm = _models()
+    so, sh = om.state_dict(), hm.state_dict()
+    assert list(so.keys()) == list(sh.keys())  # SURVEY Appendix C incl. the mlp_base.0 / mlp_base.1 aliases
+    for k in so:
+        assert tuple(so[k].shape) == tuple(sh[k].shape), k
+    hm.load_state_dict(so, strict=True)  # fruit_pipeline.py:240
+    assert set(hm.get_param_groups()) == {"proposal_networks", "fields"}  # fruit_nerf.py:185-189
+    n_o = sum(p.numel() for p in om.parameters())
+    n_h = sum(p.numel() for p in hm.parameters())
+    assert n_o == n_h
+
+
+def test_full_config_parameter_count():
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    hm = FruitModel(FruitNerfModelConfig(), num_train_data=90, device="cpu")
+    n = sum(p.numel() for p in hm.parameters())
+    assert n == 16 * 2 ** 19 * 2 + 2 * (5 * 2 ** 17 * 2 + 16 * 10 + 16 + 16 + 1) + (64 * 32 + 64 + 16 * 64 + 16) \
+        + (64 * 15 + 64 + 64 * 64 + 64 + 64 + 1) + (64 * 63 + 64 + 64 * 64 + 64 + 3 * 64 + 3) + 90 * 32
+    assert hm.field.mlp_base_grid.scalings == [16, 22, 30, 42, 58, 80, 111, 153, 212, 294, 406, 561, 776, 1072, 1482,
+                                               2047]
+    assert hm.proposal_networks[0].encoding.scalings == [16, 26, 45, 76, 128]
+    assert hm.proposal_networks[1].encoding.scalings == [16, 32, 64, 128, 256]
+
+
+def test_ignored_config_fields_do_not_reach_the_field():
+    """hidden_dim / hidden_dim_color / appearance_embed_dim of fruit_nerf_big are silently ignored."""
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    cfg = FruitNerfModelConfig(log2_hashmap_size=6, hidden_dim=128, hidden_dim_color=128, appearance_embed_dim=128)
+    cfg.proposal_net_args_list = util.small_config(prop_log2=5).proposal_net_args_list
+    hm = FruitModel(cfg, num_train_data=3, device="cpu")
+    assert hm.field.mlp_base_mlp.layers[0].weight.shape == (64, 32)
+    assert hm.field.mlp_head.layers[0].weight.shape == (64, 16 + 15 + 32)
+    assert hm.field.embedding_appearance.embedding.weight.shape == (3, 32)
+
+
+@pytest.mark.parametrize("aabb,n", [(((-1, -1, -1), (1, 1, 1)), 50), (((-1.0, -0.6, -1.0), (1.0, 0.6, 1.0)), 40),
+                                    (((-0.5, -0.25, -1.0), (0.5, 0.25, 0.5)), 33)])
+def test_export_lattice_matches_the_oracle(aabb, n):
+    from fruitnerf_amd.data.fruit_datamanager import ExportDataManager, get_corners_of_aabb, sample_surface_points
+    pts_o, vec_o = fo.sample_surface_points(fo.get_corners_of_aabb(aabb), n)
+    pts_h, vec_h = sample_surface_points(get_corners_of_aabb(aabb), n)
+    assert torch.equal(pts_o, pts_h) and torch.equal(vec_o, vec_h)
+    dm = ExportDataManager("cpu", eval_num_rays_per_batch=97)
+    num = dm.setup_inference(aabb=aabb, num_points=n)
+    assert num == pts_o.shape[0]
+    lat = dm.export_lattice
+    assert lat["xs"].numel() * lat["ys"].numel() == num and lat["zs"].numel() == n
+    # fused-path lattice == positions of the generic path (origins + dir * (t0 + t1) / 2)
+    gen_o = fo.OrthographicRayGenerator(pts_o, vec_o, 97)
+    total = 0
+    for count in range(1, (num + 96) // 97 + 1):
+        rb_o = gen_o(count)
+        rb_h, _ = dm.next_sample_volume(0)
+        assert torch.equal(rb_o.origins, rb_h.origins) and torch.equal(rb_o.fars, rb_h.fars)
+        assert torch.equal(rb_o.directions, rb_h.directions)
+        total += rb_h.origins.shape[0]
+    assert total == num
+    s = fo.UniformSamplerWithNoise(num_samples=n)
+    s.eval()
+    rs = s(gen_o(1))
+    pos = rs.frustums.get_positions()
+    n_y = lat["ys"].numel()
+    ray = torch.arange(pos.shape[0])
+    assert torch.equal(pos[0, :, 2], lat["zs"])
+    assert torch.equal(pos[:, 0, 0], lat["xs"][ray // n_y]) and torch.equal(pos[:, 0, 1], lat["ys"][ray % n_y])
+
+
+def test_proposal_update_schedule_and_anneal_match_the_oracle():
+    om, hm = _models()
+    for step in list(range(0, 40)) + [999, 1000, 2500, 5000, 7000]:
+        om.set_anneal(step)
+        hm.set_anneal(step)
+        assert om.proposal_sampler._anneal == pytest.approx(hm.proposal_sampler._anneal, abs=0)
+    upd_o, upd_h = [], []
+    for step in range(60):
+        so, sh = om.proposal_sampler, hm.proposal_sampler
+        uo = so._steps_since_update > so.update_sched(so._step) or so._step < 10
+        uh = sh.updated_now()
+        upd_o.append(bool(uo))
+        upd_h.append(uh)
+        if uo:
+            so._steps_since_update = 0
+        if uh:
+            sh._steps_since_update = 0
+        so.step_cb(step)
+        sh.step_cb(step)
+    assert upd_o == upd_h
+    assert all(upd_h[:10]) and not all(upd_h[10:])
+
+
+def test_param_arena_views_and_groups():
+    from fruitnerf_amd.params import ParamArena
+    om, hm = _models()
+    arena = ParamArena([("proposal_networks", list(hm.proposal_networks.parameters())),
+                        ("fields", list(hm.field.parameters()))], "cpu")
+    assert arena.numel % 4 == 0 and arena.numel >= sum(p.numel() for p in hm.parameters())
+    a, b = arena.group_ranges["proposal_networks"]
+    c, d = arena.group_ranges["fields"]
+    assert a == 0 and b == c and d == arena.numel
+    p = hm.field.mlp_head.layers[2].bias
+    assert p.data_ptr() >= arena.params.data_ptr() and p.grad.data_ptr() >= arena.grads.data_ptr()
+    arena.grads.fill_(3.0)
+    assert float(p.grad.sum()) == 9.0
+    arena.params.zero_()
+    assert float(hm.field.mlp_base_grid.hash_table.abs().sum()) == 0.0
+    p.grad = None
+    arena.reattach_grads()
+    assert p.grad is not None and p.grad.data_ptr() >= arena.grads.data_ptr()
+
+
+def test_exponential_decay_schedule():
+    from fruitnerf_amd.training import exponential_decay_lr
+    assert exponential_decay_lr(0, 1e-2, 1e-4, 200000) == pytest.approx(1e-2)
+    assert exponential_decay_lr(200000, 1e-2, 1e-4, 200000) == pytest.approx(1e-4)
+    assert exponential_decay_lr(100000, 1e-2, 1e-4, 200000) == pytest.approx(1e-3)
+    assert exponential_decay_lr(300000, 1e-2, 1e-4, 200000) == pytest.approx(1e-4)
+
+
+def test_unsupported_configurations_fail_loudly():
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    with pytest.raises(NotImplementedError):
+        FruitModel(FruitNerfModelConfig(log2_hashmap_size=4, proposal_initial_sampler="uniform"), num_train_data=1,
+                   device="cpu")
+    with pytest.raises(NotImplementedError):
+        FruitModel(FruitNerfModelConfig(log2_hashmap_size=4, pass_semantic_gradients=True), num_train_data=1,
+                   device="cpu")
+    hm = FruitModel(FruitNerfModelConfig(log2_hashmap_size=4), num_train_data=1, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        hm.arena()
+
+
+def test_synthetic_scene_is_seeded_and_sane():
+    from fruitnerf_amd.data import synthetic_apple as sa
+    s1, s2 = sa.make_scene(seed=0), sa.make_scene(seed=0)
+    assert torch.equal(s1.centers, s2.centers) and s1.n_fruits == 32 and int(s1.is_fruit.sum()) == 32
+    c2w = sa.make_cameras(8, seed=0)
+    assert torch.allclose(c2w[:, :, 3].norm(dim=-1), torch.ones(8), atol=1e-5)
+    data = sa.render_dataset(s1, c2w, H=40, W=40, fx=55.0, fy=55.0)
+    assert data["images"].shape == (8, 40, 40, 3) and data["masks"].max() == 1
+    frac = data["masks"].float().mean().item()
+    assert 0.001 < frac < 0.3
+    b = sa.PixelBatcher(data, torch.arange(8), seed=3)
+    o, d, cam, batch = b.sample(64)
+    assert o.shape == (64, 3) and torch.allclose(d.norm(dim=-1), torch.ones(64), atol=1e-5)
+    assert batch["image"].shape == (64, 3) and batch["fruit_mask"].shape == (64, 1) and cam.max() < 8
