@@ -16,6 +16,8 @@
 //     workgroup -> k_reduce_dw sums the partials deterministically and un-permutes into nn.Linear layout.
 // The three branches (colour, semantic, base) are separate instantiations so that the dW accumulators
 // (144 / 96 / 48 registers) fit next to the recomputed activations.
+#include <stdlib.h>
+
 #include "field_layers.hpp"
 
 namespace fnr {
@@ -126,15 +128,15 @@ __device__ __forceinline__ void flush_dw(float* __restrict__ lds_acc, int l, con
       }
 }
 
-template <class Cfg, int BRANCH>
-__global__ __launch_bounds__(64 * BWD_WAVES, 2) void k_field_mlp_bwd(
+template <class Cfg, int BRANCH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd(
     FieldPtrs ptrs, RaysDev rays, int S, long long N, const float2* __restrict__ feats,
     const uint8_t* __restrict__ selector, const float* __restrict__ embedding, const float* __restrict__ d_density,
     const float* __restrict__ d_rgb, const float* __restrict__ d_logit, float* __restrict__ d_h,
     float2* __restrict__ d_feats, float* __restrict__ g_embedding, float* __restrict__ partials) {
-  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS + BWD_WAVES * SCR_FLOATS + Cfg::B_TOTAL];
+  __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS + WAVES * SCR_FLOATS + Cfg::B_TOTAL];
   float* scr_all = lds + Cfg::LDS_FLOATS;
-  float* lds_bias = scr_all + BWD_WAVES * SCR_FLOATS;  // bias-gradient accumulators (whole workgroup)
+  float* lds_bias = scr_all + WAVES * SCR_FLOATS;  // bias-gradient accumulators (whole workgroup)
   stage_field_weights<Cfg>(lds, ptrs);
   for (int i = threadIdx.x; i < Cfg::B_TOTAL; i += blockDim.x) lds_bias[i] = 0.0f;
   __syncthreads();
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES, 2) void k_field_mlp_bwd(
     for (auto& v : row) v = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const long long n_tiles = (N + 15) / 16;
-  for (long long tile = (long long)blockIdx.x * BWD_WAVES + wave; tile < n_tiles;
-       tile += (long long)gridDim.x * BWD_WAVES) {
+  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles;
+       tile += (long long)gridDim.x * WAVES) {
     asm volatile("" ::: "memory");  // keep the LDS weight reads inside the loop (see field_mlp.hip)
     const long long n = tile * 16 + j;
     const bool valid = n < N;
@@ -387,9 +389,7 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
   if (N == 0) return FNR_OK;
   FNR_CHECK_ARG(workspace_bytes >= fnr_field_mlp_bwd_workspace_bytes(N), "field_mlp_bwd: workspace too small");
   const long long n_tiles = (N + 15) / 16;
-  long long blocks = (n_tiles + BWD_WAVES - 1) / BWD_WAVES;
   const long long max_blocks = device_cu_count();
-  if (blocks > max_blocks) blocks = max_blocks;
   float* partials = reinterpret_cast<float*>(workspace);
   float* d_h = partials + (size_t)max_blocks * (FieldCfgBase::W_TOTAL + FieldCfgBase::B_TOTAL);
   d_h = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(d_h) + 63) & ~(uintptr_t)63);
@@ -397,19 +397,27 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
   const RaysDev rd = make_rays(rays);
   const float2* f2 = reinterpret_cast<const float2*>(feats);
   float2* df2 = reinterpret_cast<float2*>(d_feats);
+  static const int color_waves = [] {
+    const char* e = getenv("FNR_COLOR_WAVES");
+    return (e && atoi(e) == 4) ? 4 : 8;
+  }();
   FNR_PROF(OP_MLP_BWD, N);
-  hipLaunchKernelGGL((k_field_mlp_bwd<FieldCfgBase, BR_COLOR>), dim3((unsigned)blocks), dim3(64 * BWD_WAVES), 0, st, p,
-                     rd, S, N, f2, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,
-                     partials);
+  // every branch uses the same number of workgroups so that they share one partial-image buffer
+  long long blocks = (n_tiles + 3) / 4;
+  if (blocks > max_blocks) blocks = max_blocks;
+#define FNR_BWD_LAUNCH(BR, WV)                                                                                       \
+  hipLaunchKernelGGL((k_field_mlp_bwd<FieldCfgBase, BR, WV>), dim3((unsigned)blocks), dim3(64 * WV), 0, st, p, rd, S, \
+                     N, f2, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,          \
+                     partials);                                                                                       \
   FNR_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_field_mlp_bwd<FieldCfgBase, BR_SEM>), dim3((unsigned)blocks), dim3(64 * BWD_WAVES), 0, st, p,
-                     rd, S, N, f2, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,
-                     partials);
-  FNR_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_field_mlp_bwd<FieldCfgBase, BR_BASE>), dim3((unsigned)blocks), dim3(64 * BWD_WAVES), 0, st, p,
-                     rd, S, N, f2, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,
-                     partials);
-  FNR_LAUNCH_CHECK();
+  if (color_waves == 4) {
+    FNR_BWD_LAUNCH(BR_COLOR, 4)
+  } else {
+    FNR_BWD_LAUNCH(BR_COLOR, 8)
+  }
+  FNR_BWD_LAUNCH(BR_SEM, 8)
+  FNR_BWD_LAUNCH(BR_BASE, 8)
+#undef FNR_BWD_LAUNCH
   constexpr int TOT = FieldCfgBase::W_TOTAL + FieldCfgBase::B_TOTAL;
   hipLaunchKernelGGL((k_reduce_dw<FieldCfgBase>), dim3((TOT + 255) / 256), dim3(256), 0, st, partials, (int)blocks, gp);
   FNR_LAUNCH_CHECK();
