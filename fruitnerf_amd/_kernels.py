@@ -184,7 +184,7 @@ def hash_encode_lattice(grid: L.fnr_grid, warp: L.fnr_warp, lat: LatticeArg, ray
 
 
 def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, selector: Optional[Tensor],
-                  mean_embedding: Optional[Tensor], want_geo: bool = False):
+                  mean_embedding: Optional[Tensor], want_geo: bool = False, want_h: bool = False):
     lib = L.load()
     dev = rays.device
     N = rays.n * S
@@ -192,9 +192,12 @@ def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, se
     rgb = torch.empty(N, 3, device=dev)
     logit = torch.empty(N, device=dev)
     geo = torch.empty(N, net.geo_feat_dim, device=dev) if want_geo else None
+    h = torch.empty(N, 16, device=dev) if want_h else None
     L.check(lib.fnr_field_mlp_fwd(C.byref(net), rays.ref, S, L.ptr(feats), L.ptr(selector), L.ptr(mean_embedding),
-                                  L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.stream_ptr(dev)),
+                                  L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.ptr(h), L.stream_ptr(dev)),
             "field_mlp_fwd")
+    if want_h:
+        return density, rgb, logit, geo, h
     return density, rgb, logit, geo
 
 
@@ -304,7 +307,7 @@ def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weig
     return d_density
 
 
-def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor,
+def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, h_saved: Tensor,
                   selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor) -> Tensor:
     lib = L.load()
     dev = rays.device
@@ -312,8 +315,8 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
     d_feats = torch.empty_like(feats)
     nbytes = lib.fnr_field_mlp_bwd_workspace_bytes(N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    L.check(lib.fnr_field_mlp_bwd(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(selector),
-                                  L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(ws), nbytes,
+    L.check(lib.fnr_field_mlp_bwd(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
+                                  L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(ws), nbytes,
                                   L.stream_ptr(dev)), "field_mlp_bwd")
     return d_feats
 

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(512, 4) void k_field_mlp_fwd(FieldPtrs ptrs, RaysDe
                                                           const float* __restrict__ embedding,
                                                           const float* __restrict__ mean_embedding,
                                                           float* __restrict__ density, float* __restrict__ rgb,
-                                                          float* __restrict__ logit, float* __restrict__ geo_out) {
+                                                          float* __restrict__ logit, float* __restrict__ geo_out,
+                                                          float* __restrict__ h_save) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
   stage_field_weights<Cfg>(lds, ptrs);
   __syncthreads();
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(512, 4) void k_field_mlp_fwd(FieldPtrs ptrs, RaysDe
     relu_(c2);
     mlp_layer<1, 4>(lds + Cfg::woff(7), Bv + Cfg::boff(7), c2, c3, lane);
 
+    if (h_save && valid) *reinterpret_cast<f32x4*>(h_save + (size_t)n * 16 + 4 * g) = h[0];
     if (geo_out && valid) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -122,7 +124,7 @@ using namespace fnr;
 
 extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays, int S, const float* feats,
                                  const uint8_t* selector, const float* mean_embedding, float* density, float* rgb,
-                                 float* logit, float* geo_out, void* stream) {
+                                 float* logit, float* geo_out, float* h_save, void* stream) {
   FNR_CHECK_ARG(net && rays && feats && density && rgb && logit && S > 0, "field_mlp_fwd: null argument");
   FNR_CHECK_ARG(rays->directions, "field_mlp_fwd: rays.directions is null");
   FNR_CHECK_ARG(mean_embedding || (rays->camera_indices && net->embedding),
@@ -140,7 +142,7 @@ extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays,
   FNR_PROF(OP_MLP_FWD, N);
   hipLaunchKernelGGL((k_field_mlp_fwd<FieldCfgBase>), dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), p,
                      make_rays(rays), S, N, reinterpret_cast<const float2*>(feats), selector, net->embedding,
-                     mean_embedding, density, rgb, logit, geo_out);
+                     mean_embedding, density, rgb, logit, geo_out, h_save);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -131,7 +131,7 @@ __device__ __forceinline__ void flush_dw(float* __restrict__ lds_acc, int l, con
 template <class Cfg, int BRANCH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd(
     FieldPtrs ptrs, RaysDev rays, int S, long long N, const float2* __restrict__ feats,
-    const uint8_t* __restrict__ selector, const float* __restrict__ embedding, const float* __restrict__ d_density,
+    const float* __restrict__ h_saved, const uint8_t* __restrict__ selector, const float* __restrict__ embedding, const float* __restrict__ d_density,
     const float* __restrict__ d_rgb, const float* __restrict__ d_logit, float* __restrict__ d_h,
     float2* __restrict__ d_feats, float* __restrict__ g_embedding, float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS + WAVES * SCR_FLOATS + Cfg::B_TOTAL];
@@ -173,18 +173,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd(
     const long long nn = valid ? n : N - 1;
     const long long ray = nn / S;
 
-    // ---- recompute the base MLP (every branch needs h) ----
-    f32x4 x0[2];
+    // ---- h = base MLP output: COLOR / SEM read the copy the forward pass saved (64 B/sample); BASE needs the
+    // hidden layer too and recomputes it from the hash features ----
+    f32x4 x0[2], a1[4], h[1];
+    if constexpr (BRANCH == BR_BASE) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float2 v = feats[(size_t)(4 * m + g) * N + nn];
-      x0[m >> 1][2 * (m & 1)] = v.x;
-      x0[m >> 1][2 * (m & 1) + 1] = v.y;
+      for (int m = 0; m < 4; ++m) {
+        const float2 v = feats[(size_t)(4 * m + g) * N + nn];
+        x0[m >> 1][2 * (m & 1)] = v.x;
+        x0[m >> 1][2 * (m & 1) + 1] = v.y;
+      }
+      mlp_layer<4, 2>(lds + Cfg::woff(0), Bv + Cfg::boff(0), x0, a1, lane);
+      relu_(a1);
+      mlp_layer<1, 4>(lds + Cfg::woff(1), Bv + Cfg::boff(1), a1, h, lane);
+    } else {
+      h[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * 16 + 4 * g);
     }
-    f32x4 a1[4], h[1];
-    mlp_layer<4, 2>(lds + Cfg::woff(0), Bv + Cfg::boff(0), x0, a1, lane);
-    relu_(a1);
-    mlp_layer<1, 4>(lds + Cfg::woff(1), Bv + Cfg::boff(1), a1, h, lane);
 
     if constexpr (BRANCH == BR_COLOR) {
       f32x4 cin[4], c1[4], c2[4], c3[1];
@@ -373,10 +377,10 @@ extern "C" size_t fnr_field_mlp_bwd_workspace_bytes(int64_t n_samples) {
 }
 
 extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
-                                 const float* feats, const uint8_t* selector, const float* d_density,
-                                 const float* d_rgb, const float* d_logit, float* d_feats, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-  FNR_CHECK_ARG(net && grads && rays && feats && d_density && d_rgb && d_logit && d_feats && workspace && S > 0,
+                                 const float* feats, const float* h_saved, const uint8_t* selector,
+                                 const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  FNR_CHECK_ARG(net && grads && rays && feats && h_saved && d_density && d_rgb && d_logit && d_feats && workspace && S > 0,
                 "field_mlp_bwd: null argument");
   FNR_CHECK_ARG(rays->directions && rays->camera_indices && net->embedding && grads->embedding,
                 "field_mlp_bwd: training path needs directions, camera indices and the embedding (+ its gradient)");
@@ -407,7 +411,7 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
   if (blocks > max_blocks) blocks = max_blocks;
 #define FNR_BWD_LAUNCH(BR, WV)                                                                                       \
   hipLaunchKernelGGL((k_field_mlp_bwd<FieldCfgBase, BR, WV>), dim3((unsigned)blocks), dim3(64 * WV), 0, st, p, rd, S, \
-                     N, f2, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,          \
+                     N, f2, h_saved, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,          \
                      partials);                                                                                       \
   FNR_LAUNCH_CHECK();
   if (color_waves == 4) {

@@ -162,6 +162,7 @@ class RenderContext:
     training: bool
     field_feats: Optional[Tensor] = None
     field_selector: Optional[Tensor] = None
+    field_h: Optional[Tensor] = None
     sample_rgb: Optional[Tensor] = None
     sample_logit: Optional[Tensor] = None
     sample_density: Optional[Tensor] = None
@@ -339,12 +340,12 @@ class FruitModel(nn.Module):
         mean_emb = fld._mean_embedding() if fld._uses_mean_embedding() else None
         if mean_emb is None and rays.cam is None:
             raise AttributeError("Camera indices are not provided.")
-        density, rgb, logit, _ = K.field_mlp_fwd(net, rays, S, feats, selector, mean_emb)
+        density, rgb, logit, _, h_saved = K.field_mlp_fwd(net, rays, S, feats, selector, mean_emb, want_h=True)
         weights, out_rgb, acc, depth, sem = K.composite_fwd(rays, S, euclid, density, rgb, logit, training)
         levels.append(dict(S=S, spacing=spacing, euclid=euclid, density=density.view(rays.n, S), weights=weights,
                            depth=depth, feats=None))
         ctx = RenderContext(rays=rays, levels=levels, updated=updated, training=training, field_feats=feats,
-                            field_selector=selector, sample_rgb=rgb, sample_logit=logit, sample_density=density,
+                            field_selector=selector, field_h=h_saved, sample_rgb=rgb, sample_logit=logit, sample_density=density,
                             weights=weights)
         outputs = {"rgb": out_rgb, "accumulation": acc[:, None], "depth": depth[:, None],
                    "semantics": sem[:, None]}

@@ -68,7 +68,7 @@ class _RenderFn(torch.autograd.Function):
                                                     rctx.weights, g_rgb.contiguous(), g_sem.contiguous())
         fld = model.field
         net, gnet = fld.net_struct(), fld.net_struct(grads=True)
-        d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_selector, d_density, d_rgb,
+        d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density, d_rgb,
                                   d_logit)
         K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, lv["euclid"], S, d_feats)
         return None, None, None, None
