@@ -276,10 +276,10 @@ def interlevel_fwd(S_f: int, spacing_f: Tensor, weights_f: Tensor, S_p: int, spa
 def distortion(S: int, spacing: Tensor, weights: Tensor) -> Tensor:
     lib = L.load()
     dev = spacing.device
-    out = torch.zeros(1, device=dev)
+    out = torch.zeros(L.FNR_LOSS_SLOTS, device=dev)
     L.check(lib.fnr_distortion(spacing.shape[0], S, L.ptr(spacing), L.ptr(weights), L.ptr(out), L.stream_ptr(dev)),
             "distortion")
-    return out[0]
+    return out.sum()
 
 
 def composite_bwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, weights: Tensor, g_rgb: Tensor,

@@ -331,7 +331,15 @@ __global__ __launch_bounds__(256) void k_reduce_dw(const float* __restrict__ par
   constexpr int TOT = Cfg::W_TOTAL + Cfg::B_TOTAL;
   if (idx >= TOT) return;
   float s = 0.0f;
-  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * TOT + idx];
+  int b = 0;
+  for (; b + 8 <= nblocks; b += 8) {  // 8 independent loads in flight (the plain loop is one HBM latency per row)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u) * TOT + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < nblocks; ++b) s += partials[(size_t)b * TOT + idx];
   if (idx < Cfg::W_TOTAL) {
     int l = 0;
 #pragma unroll

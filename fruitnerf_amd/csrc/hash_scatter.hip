@@ -440,7 +440,7 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
                 "prop_density_bwd: workspace too small");
   RaySource src{make_rays(rays), euclid_bins, S};
   long long blocks = (N + 255) / 256;
-  const long long max_blocks = 8ll * device_cu_count();
+  const long long max_blocks = 3ll * device_cu_count();  // 3 x 46 KiB LDS per CU; fewer workgroups = fewer dW atomics
   if (blocks > max_blocks) blocks = max_blocks;
   Warp w = make_warp(warp);
   const float2* fs = reinterpret_cast<const float2*>(feat_save);

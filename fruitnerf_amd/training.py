@@ -82,13 +82,14 @@ class _InterlevelFn(torch.autograd.Function):
     def forward(ctx, anchor, model, rctx, mult):
         fin = rctx.levels[-1]
         dev = rctx.rays.device
-        loss = torch.zeros(1, device=dev)
+        from . import _lib as L
+        loss = torch.zeros(L.FNR_LOSS_SLOTS, device=dev)
         d_wps = []
         for lv in rctx.levels[:-1]:
             d_wps.append(K.interlevel_fwd(fin["S"], fin["spacing"], fin["weights"], lv["S"], lv["spacing"],
                                           lv["weights"], mult, loss))
         ctx.model, ctx.rctx, ctx.d_wps = model, rctx, d_wps
-        return loss[0]
+        return loss.sum()
 
     @staticmethod
     def backward(ctx, g):

@@ -30,6 +30,7 @@ extern "C" {
 #define FNR_ABI_VERSION 1
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
+#define FNR_LOSS_SLOTS 32 /* per-ray loss partials are spread over this many accumulators (see fnr_interlevel_fwd) */
 
 enum {
   FNR_OK = 0,
@@ -191,12 +192,14 @@ int fnr_losses_fwd(int64_t n_rays, const float* rgb, const float* image, const f
                    float* d_semantics, void* stream);
 
 /* nerfstudio interlevel_loss (fruit_nerf.py:368-370) of ONE proposal level against the final level:
- * *loss += mult * mean(clip(w - outer(c, cp, wp), 0)^2 / (w + 1e-7)); d_weights_p [R,S_p] = d/d wp. */
+ * sum(loss[0..FNR_LOSS_SLOTS)) += mult * mean(clip(w - outer(c, cp, wp), 0)^2 / (w + 1e-7)) — the caller adds the
+ * slots up (same-address global atomics serialise at ~12 ns each on MI355X); d_weights_p [R,S_p] = d/d wp. */
 int fnr_interlevel_fwd(int64_t n_rays, int S_f, const float* spacing_f, const float* weights_f, int S_p,
                        const float* spacing_p, const float* weights_p, float mult, float* loss, float* d_weights_p,
                        void* stream);
 
-/* nerfstudio distortion_loss on the final level — a metric only (fruit_nerf.py:400): *out += value. */
+/* nerfstudio distortion_loss on the final level — a metric only (fruit_nerf.py:400):
+ * sum(out[0..FNR_LOSS_SLOTS)) += value. */
 int fnr_distortion(int64_t n_rays, int S, const float* spacing, const float* weights, float* out, void* stream);
 
 /* Backward of fnr_composite_fwd (training): g_rgb [R,3], g_semantics [R] -> per-sample d_density [N],
