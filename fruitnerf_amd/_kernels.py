@@ -217,10 +217,11 @@ def composite_fwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: T
     acc = torch.empty(rays.n, device=dev)
     depth = torch.empty(rays.n, device=dev)
     sem = torch.empty(rays.n, device=dev)
+    label = torch.empty(rays.n, dtype=torch.int64, device=dev)
     L.check(lib.fnr_composite_fwd(rays.ref, S, L.ptr(euclid), L.ptr(density), L.ptr(rgb), L.ptr(logit),
                                   1 if training else 0, L.ptr(weights), L.ptr(out_rgb), L.ptr(acc), L.ptr(depth),
-                                  L.ptr(sem), L.stream_ptr(dev)), "composite_fwd")
-    return weights, out_rgb, acc, depth, sem
+                                  L.ptr(sem), L.ptr(label), L.stream_ptr(dev)), "composite_fwd")
+    return weights, out_rgb, acc, depth, sem, label
 
 
 # ---- export -------------------------------------------------------------------------------------------
@@ -346,3 +347,34 @@ def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
     L.check(lib.fnr_adam_step(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(),
                               float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
                               1 if zero_grad else 0, L.stream_ptr(params.device)), "adam_step")
+
+
+# ---- caller side -------------------------------------------------------------------------------------
+
+
+class ImageSetArg:
+    """fnr_image_set over the on-device image batch (uint8 images [M,H,W,3], uint8 masks [M,H,W], c2w [M,3,4])."""
+
+    def __init__(self, images: Tensor, masks: Tensor, c2w: Tensor, fx: float, fy: float, cx: float, cy: float):
+        L.require_gpu_tensor(images, "images")
+        assert images.dtype == torch.uint8 and masks.dtype == torch.uint8
+        self.images, self.masks, self.c2w = images.contiguous(), masks.contiguous(), _f32c(c2w)
+        M, H, W, _ = images.shape
+        self.c = L.fnr_image_set(M, H, W, L.ptr(self.images), L.ptr(self.masks), L.ptr(self.c2w), float(fx), float(fy),
+                                 float(cx), float(cy))
+
+
+def sample_pixels(image_set: ImageSetArg, train_ids: Tensor, u: Tensor):
+    lib = L.load()
+    dev = u.device
+    R = u.shape[0]
+    ids = train_ids.to(torch.int64).contiguous()
+    origins = torch.empty(R, 3, device=dev)
+    directions = torch.empty(R, 3, device=dev)
+    cam = torch.empty(R, dtype=torch.int32, device=dev)
+    image = torch.empty(R, 3, device=dev)
+    mask = torch.empty(R, device=dev)
+    L.check(lib.fnr_sample_pixels(C.byref(image_set.c), L.ptr(ids), ids.numel(), R, L.ptr(_f32c(u)), L.ptr(origins),
+                                  L.ptr(directions), L.ptr(cam), L.ptr(image), L.ptr(mask), L.stream_ptr(dev)),
+            "sample_pixels")
+    return origins, directions, cam, image, mask

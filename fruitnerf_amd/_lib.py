@@ -56,6 +56,12 @@ class fnr_lattice(C.Structure):
                 ("xs", C.c_void_p), ("ys", C.c_void_p), ("zs", C.c_void_p)]
 
 
+class fnr_image_set(C.Structure):
+    _fields_ = [("n_images", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("images", C.c_void_p),
+                ("masks", C.c_void_p), ("c2w", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float)]
+
+
 P = C.POINTER
 _vp = C.c_void_p
 _i = C.c_int
@@ -69,6 +75,7 @@ SIGNATURES = {
     "fnr_device_check": (_i, [P(C.c_int), C.c_char_p, _i]),
     "fnr_profile_enable": (_i, [_i, C.c_uint64]),
     "fnr_profile_collect": (_i64, [P(C.c_int32), P(C.c_int64), P(C.c_float), _i64]),
+    "fnr_sample_pixels": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_sample_spaced":(_i, [P(fnr_rays), _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "fnr_weights_pdf": (_i, [P(fnr_rays), _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_prop_density_fwd": (_i, [P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
@@ -76,7 +83,7 @@ SIGNATURES = {
     "fnr_hash_encode_lattice": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_lattice), _i64, _i64, _vp, _vp, _vp]),
     "fnr_field_mlp_fwd": (_i, [P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_embedding_mean": (_i, [_vp, _i, _i, _vp, _vp]),
-    "fnr_composite_fwd": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_composite_fwd": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_losses_fwd": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "fnr_interlevel_fwd": (_i, [_i64, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "fnr_distortion": (_i, [_i64, _i, _vp, _vp, _vp, _vp]),

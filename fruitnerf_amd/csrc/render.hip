@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(RaysDev rays, int S, cons
                                                        const float* __restrict__ rgb, const float* __restrict__ logit,
                                                        int training, float* __restrict__ weights,
                                                        float* __restrict__ out_rgb, float* __restrict__ out_acc,
-                                                       float* __restrict__ out_depth, float* __restrict__ out_sem) {
+                                                       float* __restrict__ out_depth, float* __restrict__ out_sem,
+                                                       long long* __restrict__ out_label) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r = (long long)blockIdx.x * 4 + wave;
   if (r >= rays.n_rays) return;
@@ -95,6 +96,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(RaysDev rays, int S, cons
     out_rgb[3 * r + 2] = o2;
     out_acc[r] = acc;
     out_sem[r] = sm;
+    // heaviside(sigmoid(semantics) - 0.9, 0) (fruit_nerf.py:309-311, 351-353)
+    if (out_label) out_label[r] = (fsub(1.0f / (1.0f + expf(-sm)), 0.9f) > 0.0f) ? 1 : 0;
     out_depth[r] = fdiv(fadd(eb[first], eb[first + 1]), 2.0f);
   }
 }
@@ -105,7 +108,8 @@ using namespace fnr;
 
 extern "C" int fnr_composite_fwd(const fnr_rays* rays, int S, const float* euclid_bins, const float* density,
                                  const float* rgb, const float* logit, int training, float* weights, float* out_rgb,
-                                 float* out_accumulation, float* out_depth, float* out_semantics, void* stream) {
+                                 float* out_accumulation, float* out_depth, float* out_semantics,
+                                 int64_t* out_label, void* stream) {
   FNR_CHECK_ARG(rays && euclid_bins && density && rgb && logit && weights && out_rgb && out_accumulation &&
                     out_depth && out_semantics,
                 "composite_fwd: null argument");
@@ -114,7 +118,7 @@ extern "C" int fnr_composite_fwd(const fnr_rays* rays, int S, const float* eucli
   FNR_PROF(OP_COMPOSITE_FWD, rays->n_rays * (long long)S);
   hipLaunchKernelGGL(k_composite_fwd, dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      make_rays(rays), S, euclid_bins, density, rgb, logit, training, weights, out_rgb,
-                     out_accumulation, out_depth, out_semantics);
+                     out_accumulation, out_depth, out_semantics, reinterpret_cast<long long*>(out_label));
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -137,11 +137,25 @@ class PixelBatcher:
         self.image_ids = image_ids          # dataset indices used for training (camera_indices = position here)
         self.gen = torch.Generator(device=data["images"].device)
         self.gen.manual_seed(seed)
+        self._set = None
 
     def sample(self, n_rays: int):
+        """On a HIP device: one fused kernel (fnr_sample_pixels).  On the CPU (oracle baseline, host tests):
+        the equivalent torch ops below — this is data preparation for the oracle, not a fallback of the hot path."""
         d = self.data
         dev = d["images"].device
         u = torch.rand(n_rays, 3, device=dev, generator=self.gen)
+        if dev.type == "cuda":
+            from .. import _kernels as K
+            if self._set is None:
+                self._set = K.ImageSetArg(d["images"], d["masks"], d["c2w"], d["fx"], d["fy"], d["cx"], d["cy"])
+            o, dirs, cam, image, mask = K.sample_pixels(self._set, self.image_ids, u)
+            return o, dirs, cam[:, None], {"image": image, "fruit_mask": mask[:, None]}
+        return self.sample_torch(u)
+
+    def sample_torch(self, u: Tensor):
+        d = self.data
+        n_rays = u.shape[0]
         k = (u[:, 0] * self.image_ids.numel()).long().clamp_max(self.image_ids.numel() - 1)
         y = (u[:, 1] * d["H"]).long().clamp_max(d["H"] - 1)
         x = (u[:, 2] * d["W"]).long().clamp_max(d["W"] - 1)

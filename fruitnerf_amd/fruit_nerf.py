@@ -163,6 +163,7 @@ class RenderContext:
     field_feats: Optional[Tensor] = None
     field_selector: Optional[Tensor] = None
     field_h: Optional[Tensor] = None
+    labels: Optional[Tensor] = None
     sample_rgb: Optional[Tensor] = None
     sample_logit: Optional[Tensor] = None
     sample_density: Optional[Tensor] = None
@@ -293,10 +294,16 @@ class FruitModel(nn.Module):
     def _collide(self, ray_bundle: RayBundle) -> RayBundle:  # NearFarCollider, fruit_nerf.py:161,382-383
         if ray_bundle.nears is not None and ray_bundle.fars is not None:
             return ray_bundle
-        ones = torch.ones_like(ray_bundle.origins[..., 0:1])
         near_plane = self.config.near_plane if self.training else 0
-        ray_bundle.nears = ones * near_plane
-        ray_bundle.fars = ones * self.config.far_plane
+        # constant per (shape, mode): built once instead of 4 launches per call; the hot path only reads them
+        key = (tuple(ray_bundle.origins.shape[:-1]), float(near_plane), str(ray_bundle.origins.device))
+        cache = self.__dict__.setdefault("_collider_cache", {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            ones = torch.ones_like(ray_bundle.origins[..., 0:1])
+            cache[key] = (ones * near_plane, ones * self.config.far_plane)
+        ray_bundle.nears, ray_bundle.fars = cache[key]
         return ray_bundle
 
     # ---- the hot path ----------------------------------------------------------------------------------------
@@ -313,7 +320,9 @@ class FruitModel(nn.Module):
         updated = sampler.updated_now()
         jit = list(jitter) if jitter is not None else [None] * (n_prop + 1)
         if training:
-            jit = [j if j is not None else torch.rand(rays.n, device=dev) for j in jit]
+            if any(j is None for j in jit):
+                fresh = torch.rand(n_prop + 1, rays.n, device=dev)  # one launch for all sampling levels
+                jit = [j if j is not None else fresh[i] for i, j in enumerate(jit)]
         else:
             jit = [None] * (n_prop + 1)
         levels: List[dict] = []
@@ -341,12 +350,13 @@ class FruitModel(nn.Module):
         if mean_emb is None and rays.cam is None:
             raise AttributeError("Camera indices are not provided.")
         density, rgb, logit, _, h_saved = K.field_mlp_fwd(net, rays, S, feats, selector, mean_emb, want_h=True)
-        weights, out_rgb, acc, depth, sem = K.composite_fwd(rays, S, euclid, density, rgb, logit, training)
+        weights, out_rgb, acc, depth, sem, label = K.composite_fwd(rays, S, euclid, density, rgb, logit, training)
         levels.append(dict(S=S, spacing=spacing, euclid=euclid, density=density.view(rays.n, S), weights=weights,
                            depth=depth, feats=None))
         ctx = RenderContext(rays=rays, levels=levels, updated=updated, training=training, field_feats=feats,
                             field_selector=selector, field_h=h_saved, sample_rgb=rgb, sample_logit=logit, sample_density=density,
                             weights=weights)
+        ctx.labels = label[:, None]
         outputs = {"rgb": out_rgb, "accumulation": acc[:, None], "depth": depth[:, None],
                    "semantics": sem[:, None]}
         for i in range(n_prop):
@@ -369,8 +379,7 @@ class FruitModel(nn.Module):
         outputs["weights_list"] = weights_list
         outputs["ray_samples_list"] = ray_samples_list
         # semantics colormap (fruit_nerf.py:309-312, 351-355): heaviside(sigmoid(sem) - 0.9, 0) -> colormap lookup
-        semantic_labels = torch.sigmoid(outputs["semantics"].detach())
-        semantic_labels = ((semantic_labels - 0.9) > 0).to(torch.long)  # == heaviside(x - 0.9, 0); no H2D scalar
+        semantic_labels = ctx.labels  # heaviside(sigmoid(sem) - 0.9, 0), produced by the compositing kernel
         if self.colormap.device != semantic_labels.device:
             self.colormap = self.colormap.to(semantic_labels.device)  # once, not per call (H2D copies synchronise)
         cm = self.colormap[semantic_labels]

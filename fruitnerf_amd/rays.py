@@ -14,6 +14,9 @@ import torch
 from torch import Tensor
 
 
+_zero_cols = {}
+
+
 @dataclass
 class Frustums:
     origins: Tensor  # [..., 3]
@@ -70,8 +73,14 @@ class RayBundle:
                         spacing_to_euclidean_fn=None) -> RaySamples:
         S = bin_starts.shape[-2]
         exp = lambda t: None if t is None else t[:, None, :].expand(-1, S, -1)  # noqa: E731
-        frustums = Frustums(exp(self.origins), exp(self.directions), bin_starts, bin_ends,
-                            exp(self.pixel_area if self.pixel_area is not None
-                                else torch.zeros_like(self.origins[:, :1])))
+        pixel_area = self.pixel_area
+        if pixel_area is None:  # not read by the hot path; one cached zero column instead of a fill per call
+            key = (self.origins.shape[0], str(self.origins.device))
+            pixel_area = _zero_cols.get(key)
+            if pixel_area is None:
+                if len(_zero_cols) > 16:
+                    _zero_cols.clear()
+                pixel_area = _zero_cols[key] = torch.zeros_like(self.origins[:, :1])
+        frustums = Frustums(exp(self.origins), exp(self.directions), bin_starts, bin_ends, exp(pixel_area))
         return RaySamples(frustums, exp(self.camera_indices), bin_ends - bin_starts, spacing_starts, spacing_ends,
                           spacing_to_euclidean_fn)

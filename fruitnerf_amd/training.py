@@ -113,8 +113,11 @@ class _LossFn(torch.autograd.Function):
     """rgb_loss + semantics_loss in one launch; unit gradients are produced in the forward."""
 
     @staticmethod
-    def forward(ctx, rgb, semantics, image, fruit_mask, weight):
-        losses, d_rgb, d_sem = K.losses_fwd(rgb, image, semantics, fruit_mask, weight)
+    def forward(ctx, rgb, semantics, image, fruit_mask, weight, cached):
+        # get_metrics_dict runs just before get_loss_dict on the same outputs/batch (fruit_pipeline.py:131,144)
+        # and needs the same MSE: it leaves its launch's results here instead of launching twice
+        losses, d_rgb, d_sem = cached if cached is not None else K.losses_fwd(rgb, image, semantics, fruit_mask,
+                                                                              weight)
         ctx.save_for_backward(d_rgb, d_sem)
         ctx.sem_shape = semantics.shape
         return losses[0], losses[1]
@@ -122,7 +125,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g0, g1):
         d_rgb, d_sem = ctx.saved_tensors
-        return d_rgb * g0, (d_sem * g1).view(ctx.sem_shape), None, None, None
+        return d_rgb * g0, (d_sem * g1).view(ctx.sem_shape), None, None, None, None
 
 
 def render_with_grad(model, ray_bundle, jitter=None):
@@ -140,8 +143,11 @@ def fused_losses(model, outputs, batch) -> Dict[str, Tensor]:
     dev = outputs["rgb"].device
     image = batch["image"].to(dev)
     mask = batch["fruit_mask"].to(dev)
+    cached = outputs.pop("_loss_cache", None)
+    if cached is not None and (cached[3] is not batch or cached[4] != model.config.semantic_loss_weight):
+        cached = None
     rgb_loss, sem_loss = _LossFn.apply(outputs["rgb"], outputs["semantics"], image, mask,
-                                       model.config.semantic_loss_weight)
+                                       model.config.semantic_loss_weight, None if cached is None else cached[:3])
     loss_dict = {"rgb_loss": rgb_loss, "semantics_loss": sem_loss}
     if model.training:
         rctx = outputs["_ctx"]
@@ -155,8 +161,10 @@ def metrics(model, outputs, batch) -> Dict[str, Tensor]:
     dev = outputs["rgb"].device
     with torch.no_grad():
         image = batch["image"].to(dev)
-        losses, _, _ = K.losses_fwd(outputs["rgb"].detach(), image, outputs["semantics"].detach(),
-                                    batch["fruit_mask"].to(dev), 1.0)
+        w = model.config.semantic_loss_weight
+        losses, d_rgb, d_sem = K.losses_fwd(outputs["rgb"].detach(), image, outputs["semantics"].detach(),
+                                            batch["fruit_mask"].to(dev), w)
+        outputs["_loss_cache"] = (losses, d_rgb, d_sem, batch, w)
         psnr = -10.0 * torch.log10(losses[0])
         fin = outputs["_ctx"].levels[-1]
         dist = K.distortion(fin["S"], fin["spacing"], fin["weights"])

@@ -116,6 +116,25 @@ int fnr_device_check(int* cu_count_out, char* name_out, int name_len);
 int fnr_profile_enable(int on, uint64_t op_mask);
 int64_t fnr_profile_collect(int32_t* ops_host, int64_t* units_host, float* ms_host, int64_t capacity);
 
+/* ---- caller side: pixel sampling + ray generation --------------------------------------------- */
+/* The on-device image batch of a datamanager: uint8 images [M,H,W,3], uint8 fruit masks [M,H,W] (1 = fruit),
+ * pinhole cameras (camera-to-world [M,3,4]; fx, fy, cx, cy shared). */
+typedef struct fnr_image_set {
+  int32_t n_images, H, W;
+  const uint8_t* images;
+  const uint8_t* masks;
+  const float* c2w;
+  float fx, fy, cx, cy;
+} fnr_image_set;
+
+/* FruitDataManager.next_train (data/fruit_datamanager.py:188-197): PixelSampler (uniform (image, y, x) from
+ * u [R,3] in [0,1)) + RayGenerator (pixel centre +0.5, -z forward, unit directions).  train_ids [n_train] maps
+ * training slot -> dataset image; camera_indices receives the slot (the appearance-embedding row).
+ * Outputs: origins/directions [R,3], camera_indices [R], image [R,3] in [0,1], fruit_mask [R] in {0,1}. */
+int fnr_sample_pixels(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays, const float* u,
+                      float* origins, float* directions, int32_t* camera_indices, float* image, float* fruit_mask,
+                      void* stream);
+
 /* ---- samplers ------------------------------------------------------------------------------- */
 /* SpacedSampler.generate_ray_samples (components/ray_samplers.py:54-104; nerfstudio
  * UniformLinDispPiecewiseSampler for the proposal level 0, fruit_nerf.py:151-158).
@@ -181,7 +200,7 @@ int fnr_embedding_mean(const float* embedding, int n_images, int dim, float* out
  * + SemanticRenderer (fruit_nerf.py:325-348).  training=0 additionally applies nan_to_num / clamp. */
 int fnr_composite_fwd(const fnr_rays* rays, int S, const float* euclid_bins, const float* density, const float* rgb,
                       const float* logit, int training, float* weights, float* out_rgb, float* out_accumulation,
-                      float* out_depth, float* out_semantics, void* stream);
+                      float* out_depth, float* out_semantics, int64_t* out_label, void* stream);
 
 /* ---- training: losses, backward, optimiser --------------------------------------------------- */
 /* get_loss_dict's rgb_loss = MSELoss(image, rgb) and semantics_loss = w * BCEWithLogitsLoss(semantics,

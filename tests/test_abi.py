@@ -43,7 +43,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     rays = L.fnr_rays(0, None, None, None, None, None)
     rc = lib.fnr_sample_spaced(C.byref(rays), 1, 16, None, None, None, None, None)
     assert rc == -1 and b"null" in lib.fnr_last_error()
-    rc = lib.fnr_composite_fwd(C.byref(rays), 0, None, None, None, None, 0, None, None, None, None, None, None)
+    rc = lib.fnr_composite_fwd(C.byref(rays), 0, None, None, None, None, 0, None, None, None, None, None, None, None)
     assert rc == -1
     net = L.fnr_field_net()
     net.grid.n_levels = 8  # not the built configuration

@@ -185,6 +185,30 @@ def test_model_forward_end_to_end(dev, training):
     assert torch.equal(got["semantics_colormap"].cpu().float().view(-1), ref["semantics_colormap"].float().view(-1))
 
 
+def test_pixel_sampler_matches_torch_mirror(dev):
+    """fnr_sample_pixels (PixelSampler + RayGenerator) vs the torch ops the CPU baseline uses."""
+    from fruitnerf_amd.data import synthetic_apple as sa
+    scene = sa.make_scene(seed=0)
+    c2w = sa.make_cameras(6, seed=0)
+    data = sa.render_dataset(scene, c2w, H=48, W=40, fx=61.0, fy=59.0)
+    ids = torch.tensor([0, 2, 3, 5])
+    cpu = sa.PixelBatcher(data, ids, seed=1)
+    gdata = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
+    gpu = sa.PixelBatcher(gdata, ids.to(dev), seed=1)
+    u = torch.rand(5000, 3)
+    u[0] = torch.tensor([0.999999, 0.999999, 0.999999])
+    u[1] = 0.0
+    o, d, cam, batch = cpu.sample_torch(u)
+    from fruitnerf_amd import _kernels as K
+    st = K.ImageSetArg(gdata["images"], gdata["masks"], gdata["c2w"], data["fx"], data["fy"], data["cx"], data["cy"])
+    go, gd, gcam, gimg, gmask = K.sample_pixels(st, ids.to(dev), u.to(dev))
+    assert torch.equal(gcam.cpu().long(), cam[:, 0])
+    assert torch.equal(go.cpu(), o)
+    a, _ = util.report("pixel_sampler.directions", gd, d)
+    assert a <= 2e-7
+    assert torch.equal(gimg.cpu(), batch["image"]) and torch.equal(gmask.cpu(), batch["fruit_mask"][:, 0])
+
+
 def test_export_counts_and_points_identical(dev):
     """Volume export: identical point counts and identical ordered point lists for the three sets."""
     from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
