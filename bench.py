@@ -76,12 +76,20 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # FNR_BENCH_BACKEND=gloo + FNR_BENCH_ONE_DEVICE=1: self-test of the multi-rank control flow on a 1-GPU box
+    # (RCCL refuses two ranks on one device); the driver's runs use the defaults (nccl = RCCL, one GPU per rank)
+    backend = os.environ.get("FNR_BENCH_BACKEND", "nccl")
+    if os.environ.get("FNR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fruitnerf_amd import _lib as L
     from fruitnerf_amd.data import synthetic_apple as sa

@@ -35,6 +35,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // out (C-layout blocks IB0..IB0+NIBO-1 of the layer INPUT) = W^T * G^T
+// LDS reads are issued in batches of 4*NIBO (one output block of the layer) ahead of their MFMAs: with one
+// ds_read_b32 per MFMA the un-batched loop exposed one LDS round trip (~100 clk) per 4 MFMAs (128 clk).
 template <int NOB, int NIB_TOTAL, int IB0, int NIBO>
 __device__ __forceinline__ void mlp_layer_T(const float* __restrict__ P, const f32x4 (&G)[NOB], f32x4 (&out)[NIBO],
                                             int lane) {
@@ -42,17 +44,24 @@ __device__ __forceinline__ void mlp_layer_T(const float* __restrict__ P, const f
   const int a = ip >> 2, b = ip & 3;
 #pragma unroll
   for (int q = 0; q < NIBO; ++q) out[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) {
+  float w[2][4][NIBO];
+  auto load_ob = [&](int ob, float (&dst)[4][NIBO]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int slot = ((4 * kg + r) ^ a) + 16 * a;
 #pragma unroll
-      for (int q = 0; q < NIBO; ++q) {
-        const float w = P[((ob * NIB_TOTAL + (IB0 + q)) * 64 + slot) * 4 + b];
-        out[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, G[ob][r], out[q], 0, 0, 0);
-      }
+      for (int q = 0; q < NIBO; ++q) dst[r][q] = P[((ob * NIB_TOTAL + (IB0 + q)) * 64 + slot) * 4 + b];
     }
+  };
+  load_ob(0, w[0]);
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    if (ob + 1 < NOB) load_ob(ob + 1, w[(ob + 1) & 1]);  // next block's weights in flight during these MFMAs
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < NIBO; ++q)
+        out[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ob & 1][r][q], G[ob][r], out[q], 0, 0, 0);
   }
 }
 
@@ -72,20 +81,34 @@ __device__ __forceinline__ void dw_accumulate(float* __restrict__ scr, const f32
 #pragma unroll
     for (int r = 0; r < 4; ++r) sX[(16 * ib + 4 * g + r) * SCR_LD + j] = X[ib][r];
   wave_lds_fence();
+  // all 4*(NOB+NIB) fragment reads first, then the 4*NOB*NIB MFMAs: one LDS round trip per layer, not per k-step
+  float av[4][NOB], bv[4][NIB];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    float av[NOB], bv[NIB];
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) av[ob] = sG[(16 * ob + j) * SCR_LD + 4 * ks + g];
+    for (int ob = 0; ob < NOB; ++ob) av[ks][ob] = sG[(16 * ob + j) * SCR_LD + 4 * ks + g];
 #pragma unroll
-    for (int ib = 0; ib < NIB; ++ib) bv[ib] = sX[(16 * ib + j) * SCR_LD + 4 * ks + g];
+    for (int ib = 0; ib < NIB; ++ib) bv[ks][ib] = sX[(16 * ib + j) * SCR_LD + 4 * ks + g];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
       for (int ib = 0; ib < NIB; ++ib)
-        acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ob], bv[ib], acc[ob][ib], 0, 0, 0);
-  }
+        acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][ob], bv[ks][ib], acc[ob][ib], 0, 0, 0);
   wave_lds_fence();
+}
+
+// sum over the 16 lanes of a DPP row (= the 16 samples of the tile) without touching the LDS crossbar:
+// quad xor 1, quad xor 2, row_half_mirror, row_mirror — every lane ends up with the row total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v;
 }
 
 // bias gradient of one layer for this tile: row-reduce over the 16 samples, one LDS atomic per feature
@@ -96,11 +119,7 @@ __device__ __forceinline__ void db_accumulate(float* __restrict__ lds_bias, cons
   for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = G[ob][r];
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 1, 64);
+      const float v = row16_sum(G[ob][r]);
       if (j == 0) atomicAdd(&lds_bias[16 * ob + 4 * g + r], v);
     }
 }
@@ -113,7 +132,9 @@ __device__ __forceinline__ void relu_mask_(f32x4 (&G)[N], const f32x4 (&act)[N])
     for (int r = 0; r < 4; ++r) G[b][r] = (act[b][r] > 0.0f) ? G[b][r] : 0.0f;
 }
 
-// add this wave's dW accumulators of layer `l` into the workgroup's LDS image (same index space as "P")
+// add this wave's dW accumulators of layer `l` into the workgroup's LDS image (same index space as "P").
+// Plain read-add-write: the caller serialises the waves (ds_add_f32 retires ~1 lane per 3 clocks on gfx950 —
+// 74k float atomics per workgroup cost 92 us here; 8 barrier-separated rounds cost ~4 us).
 template <class Cfg, int NOB, int NIB>
 __device__ __forceinline__ void flush_dw(float* __restrict__ lds_acc, int l, const f32x4 (&acc)[NOB][NIB], int lane) {
   const int jn = lane & 15, g = lane >> 4;
@@ -124,7 +145,7 @@ __device__ __forceinline__ void flush_dw(float* __restrict__ lds_acc, int l, con
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int slot = swz_slot(4 * g + r, jn >> 2);
-        atomicAdd(&lds_acc[Cfg::woff(l) + ((ob * NIB + ib) * 64 + slot) * 4 + (jn & 3)], acc[ob][ib][r]);
+        lds_acc[Cfg::woff(l) + ((ob * NIB + ib) * 64 + slot) * 4 + (jn & 3)] += acc[ob][ib][r];
       }
 }
 
@@ -305,19 +326,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd(
   constexpr int L1 = (BRANCH == BR_COLOR) ? 8 : (BRANCH == BR_SEM) ? 5 : 2;
   for (int i = Cfg::woff(L0) + threadIdx.x; i < Cfg::woff(L1); i += blockDim.x) lds[i] = 0.0f;
   __syncthreads();
-  if constexpr (BRANCH == BR_COLOR) {
-    flush_dw<Cfg, 4, 4>(lds, 5, accA, lane);
-    flush_dw<Cfg, 4, 4>(lds, 6, accB, lane);
-    flush_dw<Cfg, 1, 4>(lds, 7, accC, lane);
-  } else if constexpr (BRANCH == BR_SEM) {
-    flush_dw<Cfg, 4, 1>(lds, 2, accA, lane);
-    flush_dw<Cfg, 4, 4>(lds, 3, accB, lane);
-    flush_dw<Cfg, 1, 4>(lds, 4, accC, lane);
-  } else {
-    flush_dw<Cfg, 4, 2>(lds, 0, accA, lane);
-    flush_dw<Cfg, 1, 4>(lds, 1, accB, lane);
+  for (int turn = 0; turn < WAVES; ++turn) {
+    if (wave == turn) {
+      if constexpr (BRANCH == BR_COLOR) {
+        flush_dw<Cfg, 4, 4>(lds, 5, accA, lane);
+        flush_dw<Cfg, 4, 4>(lds, 6, accB, lane);
+        flush_dw<Cfg, 1, 4>(lds, 7, accC, lane);
+      } else if constexpr (BRANCH == BR_SEM) {
+        flush_dw<Cfg, 4, 1>(lds, 2, accA, lane);
+        flush_dw<Cfg, 4, 4>(lds, 3, accB, lane);
+        flush_dw<Cfg, 1, 4>(lds, 4, accC, lane);
+      } else {
+        flush_dw<Cfg, 4, 2>(lds, 0, accA, lane);
+        flush_dw<Cfg, 1, 4>(lds, 1, accB, lane);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
   for (int i = Cfg::woff(L0) + threadIdx.x; i < Cfg::woff(L1); i += blockDim.x) part[i] = lds[i];
   for (int i = Cfg::boff(L0) + threadIdx.x; i < Cfg::boff(L1); i += blockDim.x)
