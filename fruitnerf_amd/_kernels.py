@@ -183,6 +183,19 @@ def hash_encode_lattice(grid: L.fnr_grid, warp: L.fnr_warp, lat: LatticeArg, ray
     return feats, selector
 
 
+_MLP_FWD_WS = {}
+
+
+def _mlp_fwd_workspace(dev) -> Tensor:
+    """Per-device scratch for the packed fragment image (reused: calls are ordered on the device's stream)."""
+    key = (dev.type, dev.index)
+    ws = _MLP_FWD_WS.get(key)
+    if ws is None:
+        ws = torch.empty(L.load().fnr_field_mlp_fwd_workspace_bytes(), dtype=torch.uint8, device=dev)
+        _MLP_FWD_WS[key] = ws
+    return ws
+
+
 def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, selector: Optional[Tensor],
                   mean_embedding: Optional[Tensor], want_geo: bool = False, want_h: bool = False):
     lib = L.load()
@@ -193,8 +206,10 @@ def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, se
     logit = torch.empty(N, device=dev)
     geo = torch.empty(N, net.geo_feat_dim, device=dev) if want_geo else None
     h = torch.empty(N, 16, device=dev) if want_h else None
+    ws = _mlp_fwd_workspace(dev)
     L.check(lib.fnr_field_mlp_fwd(C.byref(net), rays.ref, S, L.ptr(feats), L.ptr(selector), L.ptr(mean_embedding),
-                                  L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.ptr(h), L.stream_ptr(dev)),
+                                  L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.ptr(h), L.ptr(ws),
+                                  ws.numel(), L.stream_ptr(dev)),
             "field_mlp_fwd")
     if want_h:
         return density, rgb, logit, geo, h

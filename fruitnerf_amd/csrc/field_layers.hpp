@@ -86,10 +86,10 @@ __device__ __forceinline__ int kmap(int kind, int ib, int g, int r, int in_dim) 
 
 __device__ __forceinline__ int swz_slot(int i, int g) { return (i ^ g) + 16 * g; }
 
-// global nn.Linear weights -> LDS fragment image (pack-on-load; weights change every optimiser step)
+// value of element `idx` of the fragment image (weights then biases) taken from the nn.Linear tensors
 template <class Cfg>
-__device__ void stage_field_weights(float* __restrict__ lds, const FieldPtrs& p) {
-  for (int idx = threadIdx.x; idx < Cfg::W_TOTAL; idx += blockDim.x) {
+__device__ __forceinline__ float packed_value(int idx, const FieldPtrs& p) {
+  if (idx < Cfg::W_TOTAL) {
     int l = 0;
 #pragma unroll
     for (int q = 1; q < Cfg::NLAYERS; ++q)
@@ -101,18 +101,33 @@ __device__ void stage_field_weights(float* __restrict__ lds, const FieldPtrs& p)
     const int g = slot >> 4, i = (slot & 15) ^ g;
     const int out = 16 * ob + i;
     const int col = kmap<Cfg>(Cfg::km(l), ib, g, r, Cfg::in_dim(l));
-    float v = 0.0f;
-    if (out < Cfg::out_dim(l) && col >= 0) v = p.w[l][out * Cfg::in_dim(l) + col];
-    lds[idx] = v;
+    return (out < Cfg::out_dim(l) && col >= 0) ? p.w[l][out * Cfg::in_dim(l) + col] : 0.0f;
   }
-  for (int idx = threadIdx.x; idx < Cfg::B_TOTAL; idx += blockDim.x) {
-    int l = 0;
+  const int bi = idx - Cfg::W_TOTAL;
+  int l = 0;
 #pragma unroll
-    for (int q = 1; q < Cfg::NLAYERS; ++q)
-      if (idx >= Cfg::boff(q)) l = q;
-    const int o = idx - Cfg::boff(l);
-    lds[Cfg::W_TOTAL + idx] = (o < Cfg::out_dim(l)) ? p.b[l][o] : 0.0f;
-  }
+  for (int q = 1; q < Cfg::NLAYERS; ++q)
+    if (bi >= Cfg::boff(q)) l = q;
+  const int o = bi - Cfg::boff(l);
+  return (o < Cfg::out_dim(l)) ? p.b[l][o] : 0.0f;
+}
+
+// nn.Linear weights -> fragment image in global memory, once per call (weights change every optimiser step).
+// Packing inside every workgroup's prologue cost ~40 us per launch (18.8k scattered 4-byte loads + index math
+// per workgroup); a 74-workgroup pack launch + linear float4 copies cost ~3 us.
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_pack_field_weights(FieldPtrs p, float* __restrict__ packed) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < Cfg::LDS_FLOATS) packed[idx] = packed_value<Cfg>(idx, p);
+}
+
+// fragment image (global, 16-byte aligned) -> LDS
+template <class Cfg>
+__device__ __forceinline__ void stage_field_weights(float* __restrict__ lds, const float* __restrict__ packed) {
+  static_assert(Cfg::LDS_FLOATS % 4 == 0, "image must be float4-copyable");
+  const f32x4* src = reinterpret_cast<const f32x4*>(packed);
+  f32x4* dst = reinterpret_cast<f32x4*>(lds);
+  for (int i = threadIdx.x; i < Cfg::LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
 }
 
 // one layer: out^T[16 NOB][16] = W * in^T + b ; `in`/`out` are C-layout accumulators

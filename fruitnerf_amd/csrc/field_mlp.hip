@@ -30,7 +30,7 @@ int field_ptrs(const fnr_field_net* net, FieldPtrs& p) {
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(512, 4) void k_field_mlp_fwd(FieldPtrs ptrs, RaysDev rays, int S, long long N,
+__global__ __launch_bounds__(512, 4) void k_field_mlp_fwd(const float* __restrict__ packed, RaysDev rays, int S, long long N,
                                                           const float2* __restrict__ feats,
                                                           const uint8_t* __restrict__ selector,
                                                           const float* __restrict__ embedding,
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512, 4) void k_field_mlp_fwd(FieldPtrs ptrs, RaysDe
                                                           float* __restrict__ logit, float* __restrict__ geo_out,
                                                           float* __restrict__ h_save) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-  stage_field_weights<Cfg>(lds, ptrs);
+  stage_field_weights<Cfg>(lds, packed);
   __syncthreads();
   const float* Bv = lds + Cfg::W_TOTAL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,9 +122,12 @@ __global__ void k_embedding_mean(const float* __restrict__ emb, int n, int dim, 
 
 using namespace fnr;
 
+extern "C" size_t fnr_field_mlp_fwd_workspace_bytes(void) { return FieldCfgBase::LDS_FLOATS * sizeof(float) + 256; }
+
 extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays, int S, const float* feats,
                                  const uint8_t* selector, const float* mean_embedding, float* density, float* rgb,
-                                 float* logit, float* geo_out, float* h_save, void* stream) {
+                                 float* logit, float* geo_out, float* h_save, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   FNR_CHECK_ARG(net && rays && feats && density && rgb && logit && S > 0, "field_mlp_fwd: null argument");
   FNR_CHECK_ARG(rays->directions, "field_mlp_fwd: rays.directions is null");
   FNR_CHECK_ARG(mean_embedding || (rays->camera_indices && net->embedding),
@@ -139,8 +142,13 @@ extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays,
   long long blocks = (n_tiles + 7) / 8;
   const long long max_blocks = 2ll * device_cu_count();
   if (blocks > max_blocks) blocks = max_blocks;
+  FNR_CHECK_ARG(workspace && workspace_bytes >= fnr_field_mlp_fwd_workspace_bytes(), "field_mlp_fwd: workspace too small");
+  float* packed = reinterpret_cast<float*>(workspace);
   FNR_PROF(OP_MLP_FWD, N);
-  hipLaunchKernelGGL((k_field_mlp_fwd<FieldCfgBase>), dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), p,
+  hipLaunchKernelGGL((k_pack_field_weights<FieldCfgBase>), dim3((FieldCfgBase::LDS_FLOATS + 255) / 256), dim3(256), 0,
+                     as_stream(stream), p, packed);
+  FNR_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_field_mlp_fwd<FieldCfgBase>), dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), packed,
                      make_rays(rays), S, N, reinterpret_cast<const float2*>(feats), selector, net->embedding,
                      mean_embedding, density, rgb, logit, geo_out, h_save);
   FNR_LAUNCH_CHECK();

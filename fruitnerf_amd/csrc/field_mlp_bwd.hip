@@ -151,14 +151,14 @@ __device__ __forceinline__ void flush_dw(float* __restrict__ lds_acc, int l, con
 
 template <class Cfg, int BRANCH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd(
-    FieldPtrs ptrs, RaysDev rays, int S, long long N, const float2* __restrict__ feats,
+    const float* __restrict__ packed, RaysDev rays, int S, long long N, const float2* __restrict__ feats,
     const float* __restrict__ h_saved, const uint8_t* __restrict__ selector, const float* __restrict__ embedding, const float* __restrict__ d_density,
     const float* __restrict__ d_rgb, const float* __restrict__ d_logit, float* __restrict__ d_h,
     float2* __restrict__ d_feats, float* __restrict__ g_embedding, float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS + WAVES * SCR_FLOATS + Cfg::B_TOTAL];
   float* scr_all = lds + Cfg::LDS_FLOATS;
   float* lds_bias = scr_all + WAVES * SCR_FLOATS;  // bias-gradient accumulators (whole workgroup)
-  stage_field_weights<Cfg>(lds, ptrs);
+  stage_field_weights<Cfg>(lds, packed);
   for (int i = threadIdx.x; i < Cfg::B_TOTAL; i += blockDim.x) lds_bias[i] = 0.0f;
   __syncthreads();
   const float* Bv = lds + Cfg::W_TOTAL;
@@ -406,7 +406,8 @@ extern "C" size_t fnr_field_mlp_bwd_workspace_bytes(int64_t n_samples) {
   // per-workgroup partial weight-gradient images (<= one workgroup per CU) + dL/dh [N,16]
   const size_t blocks = (size_t)device_cu_count();
   return blocks * (FieldCfgBase::W_TOTAL + FieldCfgBase::B_TOTAL) * sizeof(float) +
-         (size_t)(n_samples > 0 ? n_samples : 0) * 16 * sizeof(float) + 256;
+         (size_t)(n_samples > 0 ? n_samples : 0) * 16 * sizeof(float) + 256 + FieldCfgBase::LDS_FLOATS * sizeof(float) +
+         256;
 }
 
 extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
@@ -430,6 +431,8 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
   float* partials = reinterpret_cast<float*>(workspace);
   float* d_h = partials + (size_t)max_blocks * (FieldCfgBase::W_TOTAL + FieldCfgBase::B_TOTAL);
   d_h = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(d_h) + 63) & ~(uintptr_t)63);
+  float* packed = d_h + (size_t)N * 16;
+  packed = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(packed) + 63) & ~(uintptr_t)63);
   hipStream_t st = as_stream(stream);
   const RaysDev rd = make_rays(rays);
   const float2* f2 = reinterpret_cast<const float2*>(feats);
@@ -439,12 +442,15 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
     return (e && atoi(e) == 4) ? 4 : 8;
   }();
   FNR_PROF(OP_MLP_BWD, N);
+  hipLaunchKernelGGL((k_pack_field_weights<FieldCfgBase>), dim3((FieldCfgBase::LDS_FLOATS + 255) / 256), dim3(256), 0,
+                     st, p, packed);
+  FNR_LAUNCH_CHECK();
   // every branch uses the same number of workgroups so that they share one partial-image buffer
   long long blocks = (n_tiles + 3) / 4;
   if (blocks > max_blocks) blocks = max_blocks;
 #define FNR_BWD_LAUNCH(BR, WV)                                                                                       \
-  hipLaunchKernelGGL((k_field_mlp_bwd<FieldCfgBase, BR, WV>), dim3((unsigned)blocks), dim3(64 * WV), 0, st, p, rd, S, \
-                     N, f2, h_saved, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,          \
+  hipLaunchKernelGGL((k_field_mlp_bwd<FieldCfgBase, BR, WV>), dim3((unsigned)blocks), dim3(64 * WV), 0, st, packed, rd, \
+                     S, N, f2, h_saved, selector, net->embedding, d_density, d_rgb, d_logit, d_h, df2, grads->embedding,          \
                      partials);                                                                                       \
   FNR_LAUNCH_CHECK();
   if (color_waves == 4) {

@@ -187,10 +187,13 @@ int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fn
  * per-ray Embedding[camera_indices] (fruit_field.py:251).
  * h_save (optional) [N,16]: the base MLP's raw output (density logit + geo), kept for fnr_field_mlp_bwd.
  * Outputs per sample: density [N], rgb [N,3], logit [N]; geo_out (optional) [N, geo_feat_dim] = the
- * density embedding `base_mlp_out` returned by get_density (fruit_field.py:187-193). */
+ * density embedding `base_mlp_out` returned by get_density (fruit_field.py:187-193).
+ * workspace: >= fnr_field_mlp_fwd_workspace_bytes() bytes of device scratch (the MFMA fragment image of the
+ * weights is packed there once per call). */
+size_t fnr_field_mlp_fwd_workspace_bytes(void);
 int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays, int S, const float* feats,
                       const uint8_t* selector, const float* mean_embedding, float* density, float* rgb, float* logit,
-                      float* geo_out, float* h_save, void* stream);
+                      float* geo_out, float* h_save, void* workspace, size_t workspace_bytes, void* stream);
 
 /* embedding_appearance.mean(dim=0) (fruit_field.py:219,256): out [appearance_dim]. */
 int fnr_embedding_mean(const float* embedding, int n_images, int dim, float* out, void* stream);
