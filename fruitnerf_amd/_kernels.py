@@ -186,12 +186,14 @@ def hash_encode_lattice(grid: L.fnr_grid, warp: L.fnr_warp, lat: LatticeArg, ray
 _MLP_FWD_WS = {}
 
 
-def _mlp_fwd_workspace(dev) -> Tensor:
-    """Per-device scratch for the packed fragment image (reused: calls are ordered on the device's stream)."""
+def _mlp_fwd_workspace(dev, n_rays: int) -> Tensor:
+    """Per-device scratch for the packed fragment image + per-ray colour bias (reused and grown on demand:
+    calls are ordered on the device's stream)."""
     key = (dev.type, dev.index)
+    need = L.load().fnr_field_mlp_fwd_workspace_bytes(n_rays)
     ws = _MLP_FWD_WS.get(key)
-    if ws is None:
-        ws = torch.empty(L.load().fnr_field_mlp_fwd_workspace_bytes(), dtype=torch.uint8, device=dev)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
         _MLP_FWD_WS[key] = ws
     return ws
 
@@ -205,14 +207,16 @@ def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, se
     rgb = torch.empty(N, 3, device=dev)
     logit = torch.empty(N, device=dev)
     geo = torch.empty(N, net.geo_feat_dim, device=dev) if want_geo else None
+    # saved for field_mlp_bwd: base-MLP output [N,16] and the per-ray part of mlp_head's first layer [R,64]
     h = torch.empty(N, 16, device=dev) if want_h else None
-    ws = _mlp_fwd_workspace(dev)
+    ray_bias = torch.empty(rays.n, 64, device=dev) if want_h else None
+    ws = _mlp_fwd_workspace(dev, rays.n)
     L.check(lib.fnr_field_mlp_fwd(C.byref(net), rays.ref, S, L.ptr(feats), L.ptr(selector), L.ptr(mean_embedding),
-                                  L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.ptr(h), L.ptr(ws),
-                                  ws.numel(), L.stream_ptr(dev)),
+                                  L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.ptr(h), L.ptr(ray_bias),
+                                  L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
             "field_mlp_fwd")
     if want_h:
-        return density, rgb, logit, geo, h
+        return density, rgb, logit, geo, (h, ray_bias)
     return density, rgb, logit, geo
 
 
@@ -323,16 +327,19 @@ def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weig
     return d_density
 
 
-def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, h_saved: Tensor,
+def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, h_saved,
                   selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor) -> Tensor:
+    """h_saved: what field_mlp_fwd(want_h=True) returned — (h [N,16], ray_bias [R,64]); a bare h tensor is accepted
+    too (the per-ray bias is then recomputed)."""
     lib = L.load()
+    h_saved, ray_bias = h_saved if isinstance(h_saved, tuple) else (h_saved, None)
     dev = rays.device
     N = rays.n * S
     d_feats = torch.empty_like(feats)
-    nbytes = lib.fnr_field_mlp_bwd_workspace_bytes(N)
+    nbytes = lib.fnr_field_mlp_bwd_workspace_bytes(rays.n, S)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     L.check(lib.fnr_field_mlp_bwd(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
-                                  L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(ws), nbytes,
+                                  L.ptr(ray_bias), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(ws), nbytes,
                                   L.stream_ptr(dev)), "field_mlp_bwd")
     return d_feats
 

@@ -81,8 +81,8 @@ SIGNATURES = {
     "fnr_prop_density_fwd": (_i, [P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
     "fnr_hash_encode_fwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
     "fnr_hash_encode_lattice": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_lattice), _i64, _i64, _vp, _vp, _vp]),
-    "fnr_field_mlp_fwd_workspace_bytes": (C.c_size_t, []),
-    "fnr_field_mlp_fwd": (_i, [P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "fnr_field_mlp_fwd_workspace_bytes": (C.c_size_t, [_i64]),
+    "fnr_field_mlp_fwd": (_i, [P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.c_size_t, _vp]),
     "fnr_embedding_mean": (_i, [_vp, _i, _i, _vp, _vp]),
     "fnr_composite_fwd": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -91,9 +91,9 @@ SIGNATURES = {
     "fnr_distortion": (_i, [_i64, _i, _vp, _vp, _vp, _vp]),
     "fnr_composite_bwd": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_weights_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "fnr_field_mlp_bwd_workspace_bytes": (C.c_size_t, [_i64]),
+    "fnr_field_mlp_bwd_workspace_bytes": (C.c_size_t, [_i64, _i]),
     "fnr_field_mlp_bwd": (_i, [P(fnr_field_net), P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _vp, C.c_size_t, _vp]),
+                               _vp, _vp, C.c_size_t, _vp]),
     "fnr_hash_scatter_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "fnr_hash_encode_bwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, C.c_size_t, _vp]),
     "fnr_prop_density_bwd_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),

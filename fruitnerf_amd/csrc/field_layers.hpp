@@ -50,9 +50,12 @@ struct FieldCfgBase {
   static constexpr int W_TOTAL = 18432;  // = woff(NLAYERS), floats
   static constexpr int B_TOTAL = 368;    // = boff(NLAYERS)
   static constexpr int LDS_FLOATS = W_TOTAL + B_TOTAL;
+  // packed buffer = LDS image + the ray-constant slice of mlp_head layer 0, transposed: Wt[k][out], k < 48
+  static constexpr int PACKED_FLOATS = LDS_FLOATS + 48 * 64;
 };
 static_assert(FieldCfgBase::woff(FieldCfgBase::NLAYERS) == FieldCfgBase::W_TOTAL, "W_TOTAL");
 static_assert(FieldCfgBase::boff(FieldCfgBase::NLAYERS) == FieldCfgBase::B_TOTAL, "B_TOTAL");
+static_assert(FieldCfgBase::LDS_FLOATS % 4 == 0, "the transposed slice must stay 16-byte aligned");
 
 struct FieldPtrs {
   const float* w[8];
@@ -86,6 +89,11 @@ __device__ __forceinline__ int kmap(int kind, int ib, int g, int r, int in_dim) 
 
 __device__ __forceinline__ int swz_slot(int i, int g) { return (i ^ g) + 16 * g; }
 
+// nn.Linear column of mlp_head layer 0 for ray-constant input k: k < 16 -> SH component k, else embedding k - 16
+template <class Cfg>
+__device__ __forceinline__ int color_const_col(int k) { return k < 16 ? k : 16 + Cfg::GEO + (k - 16); }
+constexpr int COLOR_CONST_K = 48;  // 16 SH + 32 embedding
+
 // value of element `idx` of the fragment image (weights then biases) taken from the nn.Linear tensors
 template <class Cfg>
 __device__ __forceinline__ float packed_value(int idx, const FieldPtrs& p) {
@@ -118,7 +126,17 @@ __device__ __forceinline__ float packed_value(int idx, const FieldPtrs& p) {
 template <class Cfg>
 __global__ __launch_bounds__(256) void k_pack_field_weights(FieldPtrs p, float* __restrict__ packed) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < Cfg::LDS_FLOATS) packed[idx] = packed_value<Cfg>(idx, p);
+  if (idx < Cfg::LDS_FLOATS) {
+    packed[idx] = packed_value<Cfg>(idx, p);
+  } else if (idx < Cfg::PACKED_FLOATS) {
+    const int k = (idx - Cfg::LDS_FLOATS) >> 6, o = (idx - Cfg::LDS_FLOATS) & 63;
+    packed[idx] = p.w[5][o * Cfg::in_dim(5) + color_const_col<Cfg>(k)];
+  }
+}
+
+template <class Cfg>
+static inline void launch_pack_field_weights(const FieldPtrs& p, float* packed, hipStream_t st) {
+  hipLaunchKernelGGL((k_pack_field_weights<Cfg>), dim3((Cfg::PACKED_FLOATS + 255) / 256), dim3(256), 0, st, p, packed);
 }
 
 // fragment image (global, 16-byte aligned) -> LDS
@@ -130,25 +148,49 @@ __device__ __forceinline__ void stage_field_weights(float* __restrict__ lds, con
   for (int i = threadIdx.x; i < Cfg::LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
 }
 
-// one layer: out^T[16 NOB][16] = W * in^T + b ; `in`/`out` are C-layout accumulators
-template <int NOB, int NIB>
-__device__ __forceinline__ void mlp_layer(const float* __restrict__ P, const float* __restrict__ B,
-                                          const f32x4 (&in)[NIB], f32x4 (&out)[NOB], int lane) {
+// out^T[16 NOB][16] += W[:, input blocks 0..NIB-1] * in^T ; `in`/`out` are C-layout accumulators.
+// NIB_STRIDE = number of input blocks of the layer in the image (> NIB when only the leading blocks are used).
+template <int NOB, int NIB, int NIB_STRIDE = NIB>
+__device__ __forceinline__ void mlp_layer_acc(const float* __restrict__ P, const f32x4 (&in)[NIB], f32x4 (&out)[NOB],
+                                              int lane) {
   const int g = lane >> 4, i = lane & 15;
   const int slot = swz_slot(i, g);
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(B + 16 * ob + 4 * g);
 #pragma unroll
   for (int ib = 0; ib < NIB; ++ib) {
     f32x4 w[NOB];
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) w[ob] = *reinterpret_cast<const f32x4*>(P + ((ob * NIB + ib) * 64 + slot) * 4);
+    for (int ob = 0; ob < NOB; ++ob)
+      w[ob] = *reinterpret_cast<const f32x4*>(P + ((ob * NIB_STRIDE + ib) * 64 + slot) * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int ob = 0; ob < NOB; ++ob)
         out[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ob][r], in[ib][r], out[ob], 0, 0, 0);
   }
+}
+
+// one layer: out^T[16 NOB][16] = W * in^T + b
+template <int NOB, int NIB>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ P, const float* __restrict__ B,
+                                          const f32x4 (&in)[NIB], f32x4 (&out)[NOB], int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) out[ob] = *reinterpret_cast<const f32x4*>(B + 16 * ob + 4 * g);
+  mlp_layer_acc<NOB, NIB, NIB>(P, in, out, lane);
+}
+
+// first colour layer (mlp_head layer 0, fruit_field.py:150-158,258-262).  48 of its 63 inputs — SH16(direction) and
+// the appearance embedding — are constant along a ray, so their product with the weights is a per-RAY vector
+// (k_color_ray_bias, 64 floats per ray) that enters here as the accumulator's initial value; only the 16-wide
+// h block (input block 0 of the image) is multiplied per sample: 16 MFMAs instead of 64.
+template <class Cfg>
+__device__ __forceinline__ void color_layer0(const float* __restrict__ lds, const float* __restrict__ ray_bias,
+                                             long long ray, const f32x4 (&h)[1], f32x4 (&c1)[4], int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+    c1[ob] = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)ray * 64 + 16 * ob + 4 * g);
+  mlp_layer_acc<4, 1, 4>(lds + Cfg::woff(5), h, c1, lane);
 }
 
 template <int N>
@@ -159,12 +201,10 @@ __device__ __forceinline__ void relu_(f32x4 (&a)[N]) {
     for (int r = 0; r < 4; ++r) a[b][r] = fmaxf(a[b][r], 0.0f);
 }
 
-// SHEncoding(levels=4) torch path on the shifted direction d' = (d+1)/2 (fruit_field.py:208-210,243-245);
-// returns the 4 components 4g..4g+3 this lane feeds as B operand.
-__device__ __forceinline__ f32x4 sh16_fragment(const float* __restrict__ dir, int g) {
+// SHEncoding(levels=4) torch path on the shifted direction d' = (d+1)/2 (fruit_field.py:208-210,243-245)
+__device__ __forceinline__ void sh16_all(const float* __restrict__ dir, float (&c)[16]) {
   const float x = (dir[0] + 1.0f) / 2.0f, y = (dir[1] + 1.0f) / 2.0f, z = (dir[2] + 1.0f) / 2.0f;
   const float xx = x * x, yy = y * y, zz = z * z;
-  float c[16];
   c[0] = 0.28209479177387814f;
   c[1] = 0.4886025119029199f * y;
   c[2] = 0.4886025119029199f * z;
@@ -181,10 +221,54 @@ __device__ __forceinline__ f32x4 sh16_fragment(const float* __restrict__ dir, in
   c[13] = 0.4570457994644658f * x * (5.0f * zz - 1.0f);
   c[14] = 1.445305721320277f * z * (xx - yy);
   c[15] = 0.5900435899266435f * x * (xx - 3.0f * yy);
-  f32x4 r;
+}
+
+// ray_bias[ray][o] = b[o] + sum_k W[o][const col k] * c_ray[k],  c_ray = [SH16(direction) | embedding row]
+// (embedding row = mean_embedding on the eval/export path, Embedding[camera] in training).  Wave per ray,
+// lane = output feature; the 48 x 64 weight slice (packed buffer, already transposed) is copied to LDS.
+// Two rays per wave and many small workgroups: the per-ray chain camera -> embedding row -> 48 FMAs is pure
+// latency, so it is hidden by occupancy rather than by a long loop.
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_color_ray_bias(const float* __restrict__ packed, RaysDev rays,
+                                                        const float* __restrict__ embedding,
+                                                        const float* __restrict__ mean_embedding,
+                                                        float* __restrict__ ray_bias) {
+  __shared__ __attribute__((aligned(16))) float Wt[COLOR_CONST_K][64];
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(packed + Cfg::LDS_FLOATS);
+    f32x4* dst = reinterpret_cast<f32x4*>(&Wt[0][0]);
+    for (int i = threadIdx.x; i < COLOR_CONST_K * 64 / 4; i += 256) dst[i] = src[i];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float b = packed[Cfg::W_TOTAL + Cfg::boff(5) + lane];
+  __syncthreads();
+  for (long long ray = (long long)blockIdx.x * 4 + wave; ray < rays.n_rays; ray += (long long)gridDim.x * 4) {
+    float c[16];
+    sh16_all(rays.directions + 3 * ray, c);
+    const float* emb = mean_embedding ? mean_embedding : embedding + (size_t)rays.cam[ray] * 32;
+    float e[32];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) r[q] = (g == 0) ? c[q] : (g == 1) ? c[4 + q] : (g == 2) ? c[8 + q] : c[12 + q];
-  return r;
+    for (int k = 0; k < 32; k += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(emb + k);
+      e[k] = v[0], e[k + 1] = v[1], e[k + 2] = v[2], e[k + 3] = v[3];
+    }
+    float acc = b;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fmaf(Wt[k][lane], c[k], acc);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = fmaf(Wt[16 + k][lane], e[k], acc);
+    ray_bias[(size_t)ray * 64 + lane] = acc;
+  }
+}
+
+template <class Cfg>
+static inline void launch_color_ray_bias(const float* packed, const RaysDev& rays, const float* embedding,
+                                         const float* mean_embedding, float* ray_bias, hipStream_t st) {
+  long long blocks = (rays.n_rays + 7) / 8;
+  if (blocks > 8ll * device_cu_count()) blocks = 8ll * device_cu_count();
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((k_color_ray_bias<Cfg>), dim3((unsigned)blocks), dim3(256), 0, st, packed, rays, embedding,
+                     mean_embedding, ray_bias);
 }
 
 }  // namespace fnr

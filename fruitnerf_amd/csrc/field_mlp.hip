@@ -30,11 +30,10 @@ int field_ptrs(const fnr_field_net* net, FieldPtrs& p) {
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(512, 4) void k_field_mlp_fwd(const float* __restrict__ packed, RaysDev rays, int S, long long N,
+__global__ __launch_bounds__(512, 4) void k_field_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ ray_bias,
+                                                          RaysDev rays, int S, long long N,
                                                           const float2* __restrict__ feats,
                                                           const uint8_t* __restrict__ selector,
-                                                          const float* __restrict__ embedding,
-                                                          const float* __restrict__ mean_embedding,
                                                           float* __restrict__ density, float* __restrict__ rgb,
                                                           float* __restrict__ logit, float* __restrict__ geo_out,
                                                           float* __restrict__ h_save) {
@@ -75,15 +74,9 @@ __global__ __launch_bounds__(512, 4) void k_field_mlp_fwd(const float* __restric
     mlp_layer<4, 4>(lds + Cfg::woff(3), Bv + Cfg::boff(3), s1, s2, lane);
     mlp_layer<1, 4>(lds + Cfg::woff(4), Bv + Cfg::boff(4), s2, hd, lane);
 
-    // colour branch: [h | SH16(d') | appearance embedding]
-    f32x4 cin[4];
-    cin[0] = h[0];
-    cin[1] = sh16_fragment(rays.directions + 3 * ray, g);
-    const float* emb = mean_embedding ? mean_embedding : embedding + (size_t)rays.cam[ray] * 32;
-    cin[2] = *reinterpret_cast<const f32x4*>(emb + 4 * g);
-    cin[3] = *reinterpret_cast<const f32x4*>(emb + 16 + 4 * g);
+    // colour branch: [h | SH16(d') | appearance embedding]; the ray-constant part arrives as ray_bias
     f32x4 c1[4], c2[4], c3[1];
-    mlp_layer<4, 4>(lds + Cfg::woff(5), Bv + Cfg::boff(5), cin, c1, lane);
+    color_layer0<Cfg>(lds, ray_bias, ray, h, c1, lane);
     relu_(c1);
     mlp_layer<4, 4>(lds + Cfg::woff(6), Bv + Cfg::boff(6), c1, c2, lane);
     relu_(c2);
@@ -122,12 +115,15 @@ __global__ void k_embedding_mean(const float* __restrict__ emb, int n, int dim, 
 
 using namespace fnr;
 
-extern "C" size_t fnr_field_mlp_fwd_workspace_bytes(void) { return FieldCfgBase::LDS_FLOATS * sizeof(float) + 256; }
+extern "C" size_t fnr_field_mlp_fwd_workspace_bytes(int64_t n_rays) {
+  // fragment image of the weights + per-ray colour bias [n_rays, 64]
+  return (FieldCfgBase::PACKED_FLOATS + 64) * sizeof(float) + 256 + (size_t)(n_rays > 0 ? n_rays : 0) * 64 * sizeof(float);
+}
 
 extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays, int S, const float* feats,
                                  const uint8_t* selector, const float* mean_embedding, float* density, float* rgb,
-                                 float* logit, float* geo_out, float* h_save, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 float* logit, float* geo_out, float* h_save, float* ray_bias_save,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
   FNR_CHECK_ARG(net && rays && feats && density && rgb && logit && S > 0, "field_mlp_fwd: null argument");
   FNR_CHECK_ARG(rays->directions, "field_mlp_fwd: rays.directions is null");
   FNR_CHECK_ARG(mean_embedding || (rays->camera_indices && net->embedding),
@@ -142,15 +138,18 @@ extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays,
   long long blocks = (n_tiles + 7) / 8;
   const long long max_blocks = 2ll * device_cu_count();
   if (blocks > max_blocks) blocks = max_blocks;
-  FNR_CHECK_ARG(workspace && workspace_bytes >= fnr_field_mlp_fwd_workspace_bytes(), "field_mlp_fwd: workspace too small");
+  FNR_CHECK_ARG(workspace && workspace_bytes >= fnr_field_mlp_fwd_workspace_bytes(rays->n_rays), "field_mlp_fwd: workspace too small");
   float* packed = reinterpret_cast<float*>(workspace);
+  float* ray_bias = ray_bias_save ? ray_bias_save : packed + (FieldCfgBase::PACKED_FLOATS + 63) / 64 * 64;
+  const RaysDev rd = make_rays(rays);
   FNR_PROF(OP_MLP_FWD, N);
-  hipLaunchKernelGGL((k_pack_field_weights<FieldCfgBase>), dim3((FieldCfgBase::LDS_FLOATS + 255) / 256), dim3(256), 0,
-                     as_stream(stream), p, packed);
+  launch_pack_field_weights<FieldCfgBase>(p, packed, as_stream(stream));
+  FNR_LAUNCH_CHECK();
+  launch_color_ray_bias<FieldCfgBase>(packed, rd, net->embedding, mean_embedding, ray_bias, as_stream(stream));
   FNR_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_field_mlp_fwd<FieldCfgBase>), dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), packed,
-                     make_rays(rays), S, N, reinterpret_cast<const float2*>(feats), selector, net->embedding,
-                     mean_embedding, density, rgb, logit, geo_out, h_save);
+                     ray_bias, rd, S, N, reinterpret_cast<const float2*>(feats), selector, density, rgb, logit,
+                     geo_out, h_save);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

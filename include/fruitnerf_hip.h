@@ -186,14 +186,17 @@ int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fn
  * mean_embedding: [32] -> eval/export path (fruit_field.py:217-219,253-256); NULL -> training path,
  * per-ray Embedding[camera_indices] (fruit_field.py:251).
  * h_save (optional) [N,16]: the base MLP's raw output (density logit + geo), kept for fnr_field_mlp_bwd.
+ * ray_bias_save (optional) [n_rays,64]: the per-ray part of mlp_head's first layer, kept for fnr_field_mlp_bwd.
  * Outputs per sample: density [N], rgb [N,3], logit [N]; geo_out (optional) [N, geo_feat_dim] = the
  * density embedding `base_mlp_out` returned by get_density (fruit_field.py:187-193).
- * workspace: >= fnr_field_mlp_fwd_workspace_bytes() bytes of device scratch (the MFMA fragment image of the
- * weights is packed there once per call). */
-size_t fnr_field_mlp_fwd_workspace_bytes(void);
+ * workspace: >= fnr_field_mlp_fwd_workspace_bytes(n_rays) bytes of device scratch: the MFMA fragment image of
+ * the weights (packed once per call) and the per-ray part of mlp_head's first layer (SH + appearance
+ * embedding are constant along a ray: [n_rays, 64]). */
+size_t fnr_field_mlp_fwd_workspace_bytes(int64_t n_rays);
 int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays, int S, const float* feats,
                       const uint8_t* selector, const float* mean_embedding, float* density, float* rgb, float* logit,
-                      float* geo_out, float* h_save, void* workspace, size_t workspace_bytes, void* stream);
+                      float* geo_out, float* h_save, float* ray_bias_save, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* embedding_appearance.mean(dim=0) (fruit_field.py:219,256): out [appearance_dim]. */
 int fnr_embedding_mean(const float* embedding, int n_images, int dim, float* out, void* stream);
@@ -237,10 +240,11 @@ int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, const float
 
 /* Backward of fnr_field_mlp_fwd (training path): accumulates (+=) the Linear weight/bias/embedding gradients
  * into `grads` and writes dL/dfeatures d_feats [L][N][2] for fnr_hash_encode_bwd.
- * workspace: >= fnr_field_mlp_bwd_workspace_bytes(N) bytes. */
-size_t fnr_field_mlp_bwd_workspace_bytes(int64_t n_samples);
+ * workspace: >= fnr_field_mlp_bwd_workspace_bytes(n_rays, S) bytes. */
+size_t fnr_field_mlp_bwd_workspace_bytes(int64_t n_rays, int S);
 int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
-                      const float* feats, const float* h_saved, const uint8_t* selector, const float* d_density,
+                      const float* feats, const float* h_saved, const float* ray_bias_saved /* optional */,
+                      const uint8_t* selector, const float* d_density,
                       const float* d_rgb, const float* d_logit, float* d_feats, void* workspace, size_t workspace_bytes,
                       void* stream);
 

@@ -5,7 +5,8 @@ from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
 dev = torch.device('cuda:0')
 m = FruitModel(FruitNerfModelConfig(), num_train_data=10, device=dev); m.train(); m.arena()
 fld = m.field
-for R in (16, 512, 4096):
+import os
+for R in [int(x) for x in os.environ.get("RS", "16,512,4096").split(",")]:
     S = 48; N = R * S
     o = torch.randn(R, 3, device=dev) * 0.3; d = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
     cam = torch.randint(0, 10, (R,), device=dev)

@@ -47,7 +47,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert rc == -1
     net = L.fnr_field_net()
     net.grid.n_levels = 8  # not the built configuration
-    rc = lib.fnr_field_mlp_fwd(C.byref(net), C.byref(rays), 4, 1, None, 1, 1, 1, 1, None, None, 1, 1 << 20, None)
+    rc = lib.fnr_field_mlp_fwd(C.byref(net), C.byref(rays), 4, 1, None, 1, 1, 1, 1, None, None, None, 1, 1 << 20, None)
     assert rc in (-1, -2)
 
 

@@ -45,12 +45,14 @@ def _grad_report(om, hm, tag=""):
     return worst
 
 
-@pytest.mark.parametrize("step", [0, 12])
-def test_losses_and_all_gradients(dev, step):
+@pytest.mark.parametrize("step,n_samples", [(0, 48), (12, 48), (0, 40)])
+def test_losses_and_all_gradients(dev, step, n_samples):
     """step 0: proposal nets are 'updated' (interlevel gradient flows); step 12 with a fresh sampler
-    state: not updated -> proposal-network gradients must be exactly zero on both sides."""
+    state: not updated -> proposal-network gradients must be exactly zero on both sides.
+    40 samples per ray: 16-sample MFMA tiles straddle rays (per-ray colour terms take their slow path)."""
     from fruitnerf_amd.rays import RayBundle
     cfg = util.small_config(log2=15, prop_log2=13)
+    cfg.num_nerf_samples_per_ray = n_samples
     om = util.make_oracle(cfg, seed=5)
     hm = util.make_hip_like(om, dev)
     om.train()
