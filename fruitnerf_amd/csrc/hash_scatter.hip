@@ -65,22 +65,46 @@ __device__ __forceinline__ void corner_weights(const float (&x)[3], int scaling,
   wgt[7] = mx * oy * mz;
 }
 
-// segmented (by equal key in adjacent lanes) inclusive sum of (vx, vy); the LAST lane of a run holds its total
-__device__ __forceinline__ void run_combine(uint32_t key, float& vx, float& vy, bool& is_tail, int lane) {
-  const uint32_t prev = __shfl_up(key, 1, 64);
-  int head = (lane == 0) || (prev != key);
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float ux = __shfl_up(vx, d, 64), uy = __shfl_up(vy, d, 64);
-    const int uh = __shfl_up(head, d, 64);
-    if (lane >= d && !head) {
-      vx += ux;
-      vy += uy;
-      head = uh;
-    }
+// DPP lane movement (VALU only).  The emit kernel was LDS-bound on ds_bpermute: 20 shuffles per corner x 8 corners
+// per thread kept the LDS crossbar ~80 % busy (SQ_LDS_IDX_ACTIVE), four times the traffic of the record staging.
+//   row_shr:n = 0x110+n (lane i <- i-n inside its row of 16), row_bcast:15 = 0x142 / row_bcast:31 = 0x143
+//   (last lane of a row -> the next row / the upper half), wave_shr:1 = 0x138, wave_shl:1 = 0x130.
+// Lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
+
+// segmented (by equal key in adjacent lanes) inclusive sum of (vx, vy); the LAST lane of a run holds its total.
+// Kogge-Stone inside each row of 16 lanes, then the row tails are pushed into the following rows; `head` = the
+// lane's partial sum already starts at its run's first lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(float& vx, float& vy, uint32_t& head) {
+  const float ux = dpp_f32<CTRL, ROW_MASK>(0.0f, vx), uy = dpp_f32<CTRL, ROW_MASK>(0.0f, vy);
+  const uint32_t uh = dpp_u32<CTRL, ROW_MASK>(head, head);  // no source -> unchanged (a later step may still add)
+  if (!head) {
+    vx += ux;
+    vy += uy;
+    head = uh;
   }
-  const uint32_t next = __shfl_down(key, 1, 64);
-  is_tail = (lane == 63) || (next != key);
+}
+__device__ __forceinline__ void run_combine(uint32_t key, float& vx, float& vy, bool& is_tail, int lane) {
+  const uint32_t prev = dpp_u32<0x138>(~key, key);  // lane 0 has no predecessor: ~key != key
+  uint32_t head = (prev != key) ? 1u : 0u;
+  seg_step<0x111, 0xf>(vx, vy, head);
+  seg_step<0x112, 0xf>(vx, vy, head);
+  seg_step<0x114, 0xf>(vx, vy, head);
+  seg_step<0x118, 0xf>(vx, vy, head);
+  seg_step<0x142, 0xa>(vx, vy, head);  // lane 15 -> row 1, lane 47 -> row 3
+  seg_step<0x143, 0xc>(vx, vy, head);  // lane 31 -> rows 2, 3
+  const uint32_t next = dpp_u32<0x130>(~key, key);  // lane 63 has no successor
+  is_tail = next != key;
+  (void)lane;
 }
 
 template <class Source>
