@@ -53,8 +53,8 @@ static ScatterPlan scatter_plan(long long N, int n_levels, int log2_T) {
 }
 
 // the 8 (row, weight) pairs of one sample at one level, in the oracle's corner order
-__device__ __forceinline__ void corner_weights(const float (&x)[3], int scaling, uint32_t mask, uint32_t (&h)[8],
-                                               float (&wgt)[8]) {
+__device__ __forceinline__ GridLevel corner_weights(const float (&x)[3], int scaling, uint32_t mask, uint32_t (&h)[8],
+                                                    float (&wgt)[8]) {
   GridLevel g = grid_cell(x, scaling);
   grid_corners(g, mask, h);
   const float ox = g.o[0], oy = g.o[1], oz = g.o[2];
@@ -67,6 +67,7 @@ __device__ __forceinline__ void corner_weights(const float (&x)[3], int scaling,
   wgt[5] = ox * my * mz;
   wgt[6] = mx * my * mz;
   wgt[7] = mx * oy * mz;
+  return g;
 }
 
 // DPP lane movement (VALU only).  The emit kernel was LDS-bound on ds_bpermute: 20 shuffles per corner x 8 corners
@@ -84,31 +85,44 @@ __device__ __forceinline__ float dpp_f32(float old, float v) {
                                                                  CTRL, ROW_MASK, 0xf, false));
 }
 
-// segmented (by equal key in adjacent lanes) inclusive sum of (vx, vy); the LAST lane of a run holds its total.
-// Kogge-Stone inside each row of 16 lanes, then the row tails are pushed into the following rows; `head` = the
-// lane's partial sum already starts at its run's first lane.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void seg_step(float& vx, float& vy, uint32_t& head) {
-  const float ux = dpp_f32<CTRL, ROW_MASK>(0.0f, vx), uy = dpp_f32<CTRL, ROW_MASK>(0.0f, vy);
-  const uint32_t uh = dpp_u32<CTRL, ROW_MASK>(head, head);  // no source -> unchanged (a later step may still add)
-  if (!head) {
-    vx += ux;
-    vy += uy;
-    head = uh;
-  }
+// Runs of consecutive samples (lanes) that sit in the same grid cell share all 8 corner rows, so their
+// contributions are pre-summed and only the last lane of a run emits.  The run structure is found ONCE per
+// (sample, level) from the exact cell coordinates and cut at rows of 16 lanes: a lane's distance to its run head
+// gives four masks, and each of the 16 value streams (8 corners x 2 features) is a 4-step Kogge-Stone scan of
+// row_shr DPP adds gated by those masks (3 VALU per step; the previous per-corner key/flag scan cost ~45 per
+// corner and made this kernel VALU-bound).
+struct RunMasks {
+  bool m1, m2, m4, m8, tail;
+};
+__device__ __forceinline__ RunMasks run_structure(uint32_t key_a, uint32_t key_b, int lane) {
+  const int j = lane & 15;
+  const uint32_t pa = dpp_u32<0x111>(~key_a, key_a), pb = dpp_u32<0x111>(key_b, key_b);  // j == 0: pa != key_a
+  const bool head = (pa != key_a) || (pb != key_b);
+  const unsigned long long heads = __ballot(head);
+  const uint32_t row = (uint32_t)(heads >> (lane & 48)) & 0xffffu;  // bit 0 (row start) is always set
+  const uint32_t below = row & ((2u << j) - 1u);
+  const int dist = j - (31 - __clz((int)below));
+  RunMasks m;
+  m.m1 = dist >= 1;
+  m.m2 = dist >= 2;
+  m.m4 = dist >= 4;
+  m.m8 = dist >= 8;
+  m.tail = (j == 15) || ((row >> (j + 1)) & 1u);
+  return m;
 }
-__device__ __forceinline__ void run_combine(uint32_t key, float& vx, float& vy, bool& is_tail, int lane) {
-  const uint32_t prev = dpp_u32<0x138>(~key, key);  // lane 0 has no predecessor: ~key != key
-  uint32_t head = (prev != key) ? 1u : 0u;
-  seg_step<0x111, 0xf>(vx, vy, head);
-  seg_step<0x112, 0xf>(vx, vy, head);
-  seg_step<0x114, 0xf>(vx, vy, head);
-  seg_step<0x118, 0xf>(vx, vy, head);
-  seg_step<0x142, 0xa>(vx, vy, head);  // lane 15 -> row 1, lane 47 -> row 3
-  seg_step<0x143, 0xc>(vx, vy, head);  // lane 31 -> rows 2, 3
-  const uint32_t next = dpp_u32<0x130>(~key, key);  // lane 63 has no successor
-  is_tail = next != key;
-  (void)lane;
+__device__ __forceinline__ float run_sum(float v, const RunMasks& m) {
+  // the DPP reads are executed by ALL lanes, then gated: inside a divergent branch the disabled source lanes
+  // would read as invalid
+  float u;
+  u = dpp_f32<0x111>(0.0f, v);
+  v += m.m1 ? u : 0.0f;
+  u = dpp_f32<0x112>(0.0f, v);
+  v += m.m2 ? u : 0.0f;
+  u = dpp_f32<0x114>(0.0f, v);
+  v += m.m4 ? u : 0.0f;
+  u = dpp_f32<0x118>(0.0f, v);
+  v += m.m8 ? u : 0.0f;
+  return v;
 }
 
 template <class Source>
@@ -154,18 +168,20 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       warp_position(warp, px, py, pz, x);
     }
     float wgt[8];
-    corner_weights(x, scaling, mask, hk[q], wgt);
+    const GridLevel g = corner_weights(x, scaling, mask, hk[q], wgt);
+    const bool valid = n < N;
+    // exact cell identity: floor coordinates + whether ceil differs (coordinates < 2^16, checked on the host)
+    const uint32_t key_a = valid ? (g.f[0] | (g.f[1] << 16)) : 0xffffffffu;
+    const uint32_t key_b = valid ? (g.f[2] | ((g.c[0] - g.f[0]) << 16) | ((g.c[1] - g.f[1]) << 17) |
+                                    ((g.c[2] - g.f[2]) << 18))
+                                 : (0x80000000u | (uint32_t)lane);
+    const RunMasks rm = run_structure(key_a, key_b, lane);
     emit_mask[q] = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const bool live = (n < N) && (wgt[k] != 0.0f) && (gf.x != 0.0f || gf.y != 0.0f);
-      vxk[q][k] = live ? wgt[k] * gf.x : 0.0f;
-      vyk[q][k] = live ? wgt[k] * gf.y : 0.0f;
-      // dead contributions get a key that never matches a neighbour
-      const uint32_t key = live ? hk[q][k] : (0x80000000u | (uint32_t)lane);
-      bool tail;
-      run_combine(key, vxk[q][k], vyk[q][k], tail, lane);
-      if (live && tail) {
+      vxk[q][k] = run_sum(valid ? wgt[k] * gf.x : 0.0f, rm);
+      vyk[q][k] = run_sum(valid ? wgt[k] * gf.y : 0.0f, rm);
+      if (rm.tail && (vxk[q][k] != 0.0f || vyk[q][k] != 0.0f)) {
         emit_mask[q] |= 1u << k;
         const int bin = hk[q][k] >> log2_rows;
         atomicAdd(&s_cnt[bin], 1u);
@@ -312,6 +328,8 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
   const long long chunks = (N + SC_CHUNK - 1) / SC_CHUNK;
   FNR_CHECK_ARG(chunks < (1ll << 31), "hash scatter: too many samples");
   const GridDev gd = make_grid(grid_grad);
+  for (int l = 0; l < grid_grad->n_levels; ++l)
+    FNR_CHECK_ARG(gd.scalings[l] > 0 && gd.scalings[l] < 65535, "hash scatter: level resolution %d out of range", gd.scalings[l]);
   hipLaunchKernelGGL((k_scatter_emit<Source>), dim3((unsigned)chunks, (unsigned)grid_grad->n_levels), dim3(SC_EMIT_THREADS), 0, st,
                      gd, warp, src, N, d_feats, queue, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows);
   FNR_LAUNCH_CHECK();
