@@ -95,7 +95,7 @@ def main() -> None:
     from fruitnerf_amd.data import synthetic_apple as sa
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
     from fruitnerf_amd.rays import RayBundle
-    from fruitnerf_amd.training import FusedAdam, train_iteration
+    from fruitnerf_amd.training import FusedAdam, fused_train_iteration as train_iteration
 
     info = L.device_check()
     HW = args.image_size

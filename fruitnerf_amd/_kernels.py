@@ -272,7 +272,7 @@ def losses_fwd(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tensor
     lib = L.load()
     dev = rgb.device
     R = rgb.shape[0]
-    losses = torch.empty(2, device=dev)
+    losses = torch.empty(3, device=dev)  # rgb_loss, semantics_loss, psnr
     d_rgb = torch.empty(R, 3, device=dev)
     d_sem = torch.empty(R, device=dev)
     L.check(lib.fnr_losses_fwd(R, L.ptr(_f32c(rgb)), L.ptr(_f32c(image.reshape(R, 3))),
@@ -293,13 +293,14 @@ def interlevel_fwd(S_f: int, spacing_f: Tensor, weights_f: Tensor, S_p: int, spa
     return d_wp
 
 
-def distortion(S: int, spacing: Tensor, weights: Tensor) -> Tensor:
+def distortion(S: int, spacing: Tensor, weights: Tensor, out: Optional[Tensor] = None) -> Optional[Tensor]:
+    """out: zeroed [FNR_LOSS_SLOTS] accumulator supplied by the caller (who sums it later); None -> returns the sum."""
     lib = L.load()
     dev = spacing.device
-    out = torch.zeros(L.FNR_LOSS_SLOTS, device=dev)
-    L.check(lib.fnr_distortion(spacing.shape[0], S, L.ptr(spacing), L.ptr(weights), L.ptr(out), L.stream_ptr(dev)),
+    slots = torch.zeros(L.FNR_LOSS_SLOTS, device=dev) if out is None else out
+    L.check(lib.fnr_distortion(spacing.shape[0], S, L.ptr(spacing), L.ptr(weights), L.ptr(slots), L.stream_ptr(dev)),
             "distortion")
-    return out.sum()
+    return slots.sum() if out is None else None
 
 
 def composite_bwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, weights: Tensor, g_rgb: Tensor,

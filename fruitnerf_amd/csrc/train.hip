@@ -11,14 +11,17 @@ namespace fnr {
 // ---------------------------------------------------------------------------------------------------
 // rgb MSE + semantic BCE-with-logits: values and unit gradients
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_losses(long long R, const float* __restrict__ rgb,
-                                                const float* __restrict__ image, const float* __restrict__ sem,
-                                                const float* __restrict__ mask, float sem_weight,
-                                                float* __restrict__ losses, float* __restrict__ d_rgb,
-                                                float* __restrict__ d_sem) {
+// One workgroup: a training batch is a few thousand rays, and finishing inside the kernel (block reduction, PSNR)
+// saves the memset, the atomics and three follow-up elementwise launches per step.
+__global__ __launch_bounds__(1024) void k_losses(long long R, const float* __restrict__ rgb,
+                                                 const float* __restrict__ image, const float* __restrict__ sem,
+                                                 const float* __restrict__ mask, float sem_weight,
+                                                 float* __restrict__ losses, float* __restrict__ d_rgb,
+                                                 float* __restrict__ d_sem) {
+  __shared__ float red[2][16];
   float l_rgb = 0.0f, l_sem = 0.0f;
   const float inv3r = 1.0f / (float)(3 * R), invr = 1.0f / (float)R;
-  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long long)gridDim.x * 256) {
+  for (long long r = threadIdx.x; r < R; r += 1024) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float d = rgb[3 * r + c] - image[3 * r + c];
@@ -34,8 +37,20 @@ __global__ __launch_bounds__(256) void k_losses(long long R, const float* __rest
   l_rgb = wave_sum(l_rgb);
   l_sem = wave_sum(l_sem);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&losses[0], l_rgb * inv3r);
-    atomicAdd(&losses[1], sem_weight * l_sem * invr);
+    red[0][threadIdx.x >> 6] = l_rgb;
+    red[1][threadIdx.x >> 6] = l_sem;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, b = 0.0f;
+    for (int w = 0; w < 16; ++w) {
+      a += red[0][w];
+      b += red[1][w];
+    }
+    const float mse = a * inv3r;
+    losses[0] = mse;
+    losses[1] = sem_weight * b * invr;
+    losses[2] = -10.0f * log10f(mse);  // PeakSignalNoiseRatio(data_range=1.0) of the same batch (fruit_nerf.py:398)
   }
 }
 
@@ -281,11 +296,8 @@ extern "C" int fnr_losses_fwd(int64_t n_rays, const float* rgb, const float* ima
                               float* d_semantics, void* stream) {
   FNR_CHECK_ARG(rgb && image && semantics && fruit_mask && losses && d_rgb && d_semantics && n_rays > 0,
                 "losses_fwd: null argument");
-  FNR_HIP(hipMemsetAsync(losses, 0, 2 * sizeof(float), as_stream(stream)));
-  long long blocks = (n_rays + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
   FNR_PROF(OP_LOSSES, n_rays);
-  hipLaunchKernelGGL(k_losses, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (long long)n_rays, rgb, image,
+  hipLaunchKernelGGL(k_losses, dim3(1), dim3(1024), 0, as_stream(stream), (long long)n_rays, rgb, image,
                      semantics, fruit_mask, semantic_loss_weight, losses, d_rgb, d_semantics);
   FNR_LAUNCH_CHECK();
   return FNR_OK;

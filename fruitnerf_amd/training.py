@@ -165,7 +165,7 @@ def metrics(model, outputs, batch) -> Dict[str, Tensor]:
         losses, d_rgb, d_sem = K.losses_fwd(outputs["rgb"].detach(), image, outputs["semantics"].detach(),
                                             batch["fruit_mask"].to(dev), w)
         outputs["_loss_cache"] = (losses, d_rgb, d_sem, batch, w)
-        psnr = -10.0 * torch.log10(losses[0])
+        psnr = losses[2]
         fin = outputs["_ctx"].levels[-1]
         dist = K.distortion(fin["S"], fin["spacing"], fin["weights"])
     return {"psnr": psnr, "distortion": dist}
@@ -240,6 +240,68 @@ def train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, w
     loss.backward()
     scale = sync_gradients(model.arena(), world_size)
     optimizer.step(grad_scale=scale)
+    model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
+    return loss_dict, metrics_dict
+
+
+def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
+                           want_metrics: bool = True):
+    """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
+    the same kernels in the same order, called directly.
+
+    The loss graph of this model is fixed (rgb + semantics through the renderer, interlevel through the proposal
+    networks, unit upstream gradients), so forward, losses and backward are one straight-line sequence of HIP
+    launches; per step that removes ~20 elementwise/fill/reduce launches and the engine's start-up gap that
+    autograd put between them.  Gradients land in the model's arena exactly as with loss.backward()."""
+    from . import _lib as L
+    cfg = model.config
+    dev = model.device
+    with torch.no_grad():
+        ray_bundle = model._collide(ray_bundle)
+        outputs, rctx = model._render(ray_bundle, jitter)
+        rays, fin = rctx.rays, rctx.levels[-1]
+        S = fin["S"]
+        image, mask = batch["image"].to(dev), batch["fruit_mask"].to(dev)
+        losses, d_rgb, d_sem = K.losses_fwd(outputs["rgb"], image, outputs["semantics"], mask, cfg.semantic_loss_weight)
+        slots = torch.zeros(2, L.FNR_LOSS_SLOTS, device=dev)   # [interlevel | distortion] accumulators: one fill
+        d_wps = [K.interlevel_fwd(S, fin["spacing"], fin["weights"], lv["S"], lv["spacing"], lv["weights"],
+                                  cfg.interlevel_loss_mult, slots[0]) for lv in rctx.levels[:-1]]
+        if want_metrics:
+            K.distortion(S, fin["spacing"], fin["weights"], out=slots[1])
+        sums = slots.sum(dim=1)                                # one reduce
+        loss_dict = {"rgb_loss": losses[0], "semantics_loss": losses[1], "interlevel_loss": sums[0]}
+        metrics_dict = {"psnr": losses[2], "distortion": sums[1]} if want_metrics else {}
+
+        # ---- backward (what loss.backward() runs through _LossFn, _RenderFn, _InterlevelFn) ----
+        arena = model.arena()
+        arena.reattach_grads()
+        d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
+                                                      rctx.weights, d_rgb, d_sem)
+        fld = model.field
+        net, gnet = fld.net_struct(), fld.net_struct(grads=True)
+        d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
+                                  d_rgb_s, d_logit)
+        K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
+        if rctx.training and rctx.updated:
+            up = model.__dict__.get("_unit_upstream")
+            if up is None or up.device != dev:
+                up = model.__dict__["_unit_upstream"] = torch.ones(1, device=dev)
+            for i, (lv, d_wp) in enumerate(zip(rctx.levels[:-1], d_wps)):
+                d_dens = K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, up)
+                pn = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
+                K.prop_density_bwd(pn.prop_struct(), pn.prop_struct(grads=True), pn.warp_struct(), rays, lv["euclid"],
+                                   lv["S"], lv["feats"], d_dens)
+    return loss_dict, metrics_dict
+
+
+def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, world_size: int = 1,
+                          jitter: Optional[List[Tensor]] = None, want_metrics: bool = True):
+    """train_iteration() on fused_forward_backward(); returns the same (loss_dict, metrics_dict) tensors."""
+    model.set_anneal(step)                                     # BEFORE_TRAIN_ITERATION callback
+    loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics)
+    with torch.no_grad():
+        scale = sync_gradients(model.arena(), world_size)
+        optimizer.step(grad_scale=scale)
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
 

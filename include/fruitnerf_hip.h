@@ -210,7 +210,8 @@ int fnr_composite_fwd(const fnr_rays* rays, int S, const float* euclid_bins, con
 
 /* ---- training: losses, backward, optimiser --------------------------------------------------- */
 /* get_loss_dict's rgb_loss = MSELoss(image, rgb) and semantics_loss = w * BCEWithLogitsLoss(semantics,
- * fruit_mask) (fruit_nerf.py:171-172,362-366).  losses[0..1] are overwritten with the two scalars;
+ * fruit_mask) (fruit_nerf.py:171-172,362-366).  losses[0..1] are overwritten with the two scalars and losses[2]
+ * with PSNR(rgb, image) = -10 log10(rgb_loss) (get_metrics_dict, fruit_nerf.py:398) — `losses` holds 3 floats;
  * d_rgb [R,3] / d_semantics [R] receive dloss/drgb and dloss/dsemantics (unit upstream). */
 int fnr_losses_fwd(int64_t n_rays, const float* rgb, const float* image, const float* semantics,
                    const float* fruit_mask, float semantic_loss_weight, float* losses, float* d_rgb,

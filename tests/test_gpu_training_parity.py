@@ -155,3 +155,41 @@ def test_three_training_steps_track_the_oracle(dev):
         # the bulk of the entries must agree far better than the size of the update itself
         assert d_abs.median().item() <= 0.05 * max(moved.mean().item(), 1e-9) + 1e-7, name
         assert d_abs.max().item() <= 3 * 3 * 1e-2 + 1e-6, name  # nothing moves further than steps * lr apart
+
+
+def test_fused_step_matches_the_autograd_step(dev):
+    """fused_forward_backward() (no autograd engine, what bench.py times) must leave the same losses, metrics and
+    gradients as model(...) -> get_metrics_dict -> get_loss_dict -> sum -> backward."""
+    from fruitnerf_amd.rays import RayBundle
+    from fruitnerf_amd.training import fused_forward_backward
+    cfg = util.small_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, seed=9)
+    R = 192
+    o, d, pa, cam = util.random_rays(R, 7, seed=4)
+    jit = [torch.rand(R, 1).to(dev) for _ in range(3)]
+    hb = {k: v.to(dev) for k, v in _batch(R, 8).items()}
+    results = []
+    for fused in (False, True):
+        hm = util.make_hip_like(om, dev)
+        hm.train()
+        hm.set_anneal(0)
+        rb = RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev))
+        if fused:
+            ld, md = fused_forward_backward(hm, rb, hb, jitter=jit)
+        else:
+            out = hm(rb, jitter=jit)
+            md = hm.get_metrics_dict(out, hb)
+            ld = hm.get_loss_dict(out, hb)
+            sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        results.append((ld, md, hm.arena().grads.clone()))
+    (ld_a, md_a, g_a), (ld_f, md_f, g_f) = results
+    for k in ld_a:
+        assert abs(float(ld_a[k]) - float(ld_f[k])) <= 1e-6 * max(abs(float(ld_a[k])), 1e-6), k
+    for k in md_a:
+        assert abs(float(md_a[k]) - float(md_f[k])) <= 1e-6 * max(abs(float(md_a[k])), 1e-6), k
+    scale = g_a.abs().max().item()
+    assert scale > 0
+    # same kernels, same inputs; only the order of a few float atomics (weight-gradient partials) may differ
+    assert (g_a - g_f).abs().max().item() <= 1e-5 * scale
+    assert int((g_a != 0).sum()) == int((g_f != 0).sum())
