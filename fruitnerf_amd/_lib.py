@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfruitnerf_hip.so")
 
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
-FNR_LOSS_SLOTS = 32
+FNR_LOSS_SLOTS = 1024
 
 c_float_p = C.POINTER(C.c_float)
 

@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const 
     }
   }
   lsum = wave_sum(lsum);
-  // 4096 same-address global atomics serialise at ~12 ns each (= 51 us); spread them over 32 slots
-  if (lane == 0) atomicAdd(&loss[r & (FNR_LOSS_SLOTS - 1)], lsum * scale);
+  // atomics to one L2 line serialise at ~12 ns each (4096 rays = ~35-50 us): 32 lines, 4 words (waves) per line
+  if (lane == 0) atomicAdd(&loss[(blockIdx.x & 31) * 32 + wave], lsum * scale);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   // d_wp = inclusive scan of the difference array
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_distortion(long long R, int S, const fl
     acc += wi * inner + wi * wi * (t[i + 1] - t[i]) / 3.0f;
   }
   acc = wave_sum(acc);
-  if (lane == 0) atomicAdd(&out[r & (FNR_LOSS_SLOTS - 1)], acc / (float)R);
+  if (lane == 0) atomicAdd(&out[(blockIdx.x & 31) * 32 + wave], acc / (float)R);
 }
 
 // ---------------------------------------------------------------------------------------------------

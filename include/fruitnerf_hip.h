@@ -30,7 +30,10 @@ extern "C" {
 #define FNR_ABI_VERSION 1
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
-#define FNR_LOSS_SLOTS 32 /* per-ray loss partials are spread over this many accumulators (see fnr_interlevel_fwd) */
+/* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
+ * 128-byte lines (atomics to one L2 line serialise at ~12 ns each on MI355X: 4096 rays on one line cost ~35 us);
+ * the caller zeroes the buffer and sums all FNR_LOSS_SLOTS floats (see fnr_interlevel_fwd) */
+#define FNR_LOSS_SLOTS 1024
 
 enum {
   FNR_OK = 0,
