@@ -283,7 +283,7 @@ def main() -> None:
                          f"median {med:.2f} s/step"}
 
     result = {
-        "metric": "train rays/sec, fruit_nerf on synthetic apple 800x800",
+        "metric": f"train rays/sec, fruit_nerf on synthetic apple {HW}x{HW}",
         "value": round(rays_per_s, 1),
         "unit": "rays/s",
         "n_gpus": world,
