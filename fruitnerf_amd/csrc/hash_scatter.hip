@@ -344,24 +344,36 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
 // proposal network backward.  Persistent workgroups; per iteration 256 samples:
 //   phase 1 (thread = sample): recompute the MLP from the saved features, d_out = d_sigma * trunc_exp'(out),
 //            hidden gradients -> LDS, feature gradients -> d_feats [L][N][2] (scattered by binned_scatter);
-//   phase 2 (thread = weight): accumulate dW0[o][k], db0[o], dW1[o], db1 over the 256 samples from LDS.
+//   phase 2 (wave = 64 of the samples): dW0 = dh^T f, db0 = dh^T 1 and dW1 = (relu(h) d_out)^T 1 as 16x16x4 fp32 MFMAs
+//            with the samples on the K axis (3 MFMAs per 4 samples; operands are single conflict-light LDS
+//            reads).  A thread-per-weight loop over the 256 samples read two LDS words per FMA and was LDS-bound
+//            (~45 us of the 73 us this kernel took for 1 M samples).
 // Weight gradients leave the workgroup once, at the end (one atomicAdd per weight per workgroup).
 // ------------------------------------------------------------------------------------------------
+constexpr int PROP_PART = 320;   // floats per workgroup partial: dW0 tile 256 + dW1 16 + db0 16 + db1 (+ pad)
+constexpr int PROP_RED_Y = 16;
+
 template <int L, int H>
 __global__ __launch_bounds__(256) void k_prop_bwd(Warp warp, RaySource src, long long N, const float* __restrict__ w0,
                                                   const float* __restrict__ b0, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float2* __restrict__ feat_save,
                                                   const float* __restrict__ d_density, float2* __restrict__ d_feats,
-                                                  float* __restrict__ g_w0, float* __restrict__ g_b0,
-                                                  float* __restrict__ g_w1, float* __restrict__ g_b1) {
+                                                  float* __restrict__ partials) {
   constexpr int K = 2 * L;
   __shared__ float s_dh[256][H + 1];   // d hidden (pre-activation)
   __shared__ float s_ha[256][H + 1];   // relu(hidden) * d_out  (for dW1)
   __shared__ float s_f[256][K + 1];    // input features
   __shared__ float s_do[256];          // d_out
+  static_assert(H == 16 && K <= 16, "phase 2 is a single 16x16 MFMA tile");
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
   const int tid = threadIdx.x;
-  constexpr int NW = H * K + H + H + 1;  // dW0, db0, dW1, db1
-  float acc[2] = {0.0f, 0.0f};           // this thread's weight-gradient accumulators (tid, tid + 256)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  // accumulators (C layout: lane holds column j, rows 4 g + r): dW0[o][k = j], db0[o] in column 0 of d3,
+  // dW1[o] in column 0 of d2; db1 per thread
+  f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f}, d3 = {0.f, 0.f, 0.f, 0.f};
+  float db1 = 0.0f;
+  const float ones_col0 = (j == 0) ? 1.0f : 0.0f;  // B operand that sums over the samples into column 0
   const long long n_iter = (N + 255) / 256;
   for (long long it = blockIdx.x; it < n_iter; it += gridDim.x) {
     const long long n = it * 256 + tid;
@@ -404,43 +416,82 @@ __global__ __launch_bounds__(256) void k_prop_bwd(Warp warp, RaySource src, long
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) s_f[tid][k] = f[k];
-    s_do[tid] = dout;
+    db1 += dout;
     if (n < N) {
 #pragma unroll
       for (int l = 0; l < L; ++l) d_feats[(size_t)l * N + n] = make_float2(df[2 * l], df[2 * l + 1]);
     }
     __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int widx = tid + 256 * half;
-      if (widx < NW) {
-        float s = 0.0f;
-        if (widx < H * K) {
-          const int o = widx / K, k = widx - o * K;
-          for (int q = 0; q < 256; ++q) s = fmaf(s_dh[q][o], s_f[q][k], s);
-        } else if (widx < H * K + H) {
-          const int o = widx - H * K;
-          for (int q = 0; q < 256; ++q) s += s_dh[q][o];
-        } else if (widx < H * K + 2 * H) {
-          const int o = widx - H * K - H;
-          for (int q = 0; q < 256; ++q) s += s_ha[q][o];
-        } else {
-          for (int q = 0; q < 256; ++q) s += s_do[q];
-        }
-        acc[half] += s;
-      }
+    // phase 2: this wave's 64 samples, 4 per MFMA step.  A[i = o][kk] = dh / ha of sample 4 step + kk,
+    // B[kk][j = k] = feature k of that sample (0 beyond K)
+    const int row0 = 64 * wave + g;
+#pragma unroll 4
+    for (int st = 0; st < 16; ++st) {
+      const int row = row0 + 4 * st;
+      const float a1 = s_dh[row][j], a2 = s_ha[row][j];
+      const float bf = (j < K) ? s_f[row][j < K ? j : 0] : 0.0f;
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, d1, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, ones_col0, d2, 0, 0, 0);
+      d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, ones_col0, d3, 0, 0, 0);
     }
     __syncthreads();
   }
+  // combine the 4 waves through LDS (reusing s_dh), then one atomicAdd per weight per workgroup
+  float* red = &s_dh[0][0];  // [4 waves][3][16 rows][16 cols]
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int widx = tid + 256 * half;
-    if (widx < NW && acc[half] != 0.0f) {
-      if (widx < H * K) atomicAdd(&g_w0[widx], acc[half]);
-      else if (widx < H * K + H) atomicAdd(&g_b0[widx - H * K], acc[half]);
-      else if (widx < H * K + 2 * H) atomicAdd(&g_w1[widx - H * K - H], acc[half]);
-      else atomicAdd(&g_b1[0], acc[half]);
+  for (int r = 0; r < 4; ++r) {
+    red[((wave * 3 + 0) * 16 + 4 * g + r) * 16 + j] = d1[r];
+    red[((wave * 3 + 1) * 16 + 4 * g + r) * 16 + j] = d2[r];
+    red[((wave * 3 + 2) * 16 + 4 * g + r) * 16 + j] = d3[r];
+  }
+  db1 = wave_sum(db1);
+  if (lane == 0) s_do[wave] = db1;
+  __syncthreads();
+  {
+    // one partial vector per workgroup: [dW0 16x16 | dW1 16 | db0 16 | db1], summed by k_prop_reduce.  Atomics
+    // from 768 workgroups onto the same 13 cache lines of the gradient serialised in L2 (~34 us per call).
+    const int o = tid >> 4, k = tid & 15;  // 256 threads = the 16 x 16 tile
+    auto total = [&](int which) {
+      return (red[((0 * 3 + which) * 16 + o) * 16 + k] + red[((1 * 3 + which) * 16 + o) * 16 + k]) +
+             (red[((2 * 3 + which) * 16 + o) * 16 + k] + red[((3 * 3 + which) * 16 + o) * 16 + k]);
+    };
+    float* part = partials + (size_t)blockIdx.x * PROP_PART;
+    part[tid] = total(0);
+    if (k == 0) {
+      part[256 + o] = total(1);
+      part[272 + o] = total(2);
     }
+    if (tid == 0) part[288] = (s_do[0] + s_do[1]) + (s_do[2] + s_do[3]);
+  }
+}
+
+// gradient += sum over workgroups of their partial vectors.  grid (PROP_PART / 64, PROP_RED_Y): thread = one entry,
+// blockIdx.y strides over the rows; <= PROP_RED_Y atomics per gradient address.
+__global__ __launch_bounds__(64) void k_prop_reduce(const float* __restrict__ partials, int nblocks, int K,
+                                                    float* __restrict__ g_w0, float* __restrict__ g_b0,
+                                                    float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e > 288) return;
+  float s = 0.0f;
+  int b = blockIdx.y;
+  for (; b + 7 * (int)gridDim.y < nblocks; b += 8 * gridDim.y) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * gridDim.y) * PROP_PART + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < nblocks; b += gridDim.y) s += partials[(size_t)b * PROP_PART + e];
+  if (s == 0.0f) return;
+  if (e < 256) {
+    const int o = e >> 4, k = e & 15;
+    if (k < K) atomicAdd(&g_w0[o * K + k], s);
+  } else if (e < 272) {
+    atomicAdd(&g_w1[e - 256], s);
+  } else if (e < 288) {
+    atomicAdd(&g_b0[e - 272], s);
+  } else {
+    atomicAdd(&g_b1[0], s);
   }
 }
 
@@ -468,7 +519,8 @@ extern "C" int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* wa
 
 extern "C" size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
   const size_t dfeat = ((size_t)n_levels * (size_t)n_samples * sizeof(float2) + 255) / 256 * 256;
-  return dfeat + fnr_hash_scatter_workspace_bytes(n_samples, n_levels, log2_hashmap_size);
+  const size_t partials = (size_t)3 * device_cu_count() * PROP_PART * sizeof(float);
+  return dfeat + partials + fnr_hash_scatter_workspace_bytes(n_samples, n_levels, log2_hashmap_size);
 }
 
 extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
@@ -492,12 +544,13 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
   const float2* fs = reinterpret_cast<const float2*>(feat_save);
   float2* d_feats = reinterpret_cast<float2*>(workspace);
   const size_t dfeat_bytes = ((size_t)L * (size_t)N * sizeof(float2) + 255) / 256 * 256;
+  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + dfeat_bytes);
+  const size_t partial_bytes = (size_t)max_blocks * PROP_PART * sizeof(float);
   FNR_PROF(OP_PROP_BWD, N);
 #define FNR_PROPB_CASE(LL)                                                                                          \
   case LL:                                                                                                          \
     hipLaunchKernelGGL((k_prop_bwd<LL, 16>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), w, src, N,    \
-                       net->w0, net->b0, net->w1, net->b1, fs, d_density, d_feats, grads->w0, grads->b0, grads->w1, \
-                       grads->b1);                                                                                  \
+                       net->w0, net->b0, net->w1, net->b1, fs, d_density, d_feats, partials);                        \
     break;
   switch (L) {
     FNR_PROPB_CASE(1)
@@ -513,6 +566,9 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
   }
 #undef FNR_PROPB_CASE
   FNR_LAUNCH_CHECK();
-  return binned_scatter(&grads->grid, w, src, N, d_feats, reinterpret_cast<char*>(workspace) + dfeat_bytes,
-                        workspace_bytes - dfeat_bytes, as_stream(stream));
+  hipLaunchKernelGGL(k_prop_reduce, dim3(PROP_PART / 64, PROP_RED_Y), dim3(64), 0, as_stream(stream), partials,
+                     (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1);
+  FNR_LAUNCH_CHECK();
+  return binned_scatter(&grads->grid, w, src, N, d_feats, reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,
+                        workspace_bytes - dfeat_bytes - partial_bytes, as_stream(stream));
 }
