@@ -273,7 +273,8 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   __shared__ unsigned long long s_acc[2 * SC_MAX_ROWS];  // [rows][2] two's-complement fixed point, 128 KiB
   const int rows = 1 << log2_rows;
   const int bins = 1 << (grid.log2_T - log2_rows);
-  const int gbin = blockIdx.x;  // level * bins + bin
+  // fine levels (long queues) are dispatched first, the short coarse-level bins fill the tail
+  const int gbin = (int)gridDim.x - 1 - (int)blockIdx.x;  // level * bins + bin
   const int level = gbin / bins, bin = gbin - level * bins;
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
   const float vmax = __uint_as_float(qmax[(size_t)gbin * SC_CNT_STRIDE]);
