@@ -6,7 +6,8 @@
 //   * features are written level-major [L][N] float2 so a wave's store is one contiguous 512 B run;
 //   * the main-field encode launches one workgroup per (256 samples, level) and maps workgroup b to
 //     XCD b%8 (observed dispatch order) so each XCD's private 4 MiB L2 only ever sees the table
-//     slices of the two levels {x, L-1-x} it owns (one coarse = cache-friendly, one fine = 4 MiB);
+//     slices of the two levels {x, L-1-x} it owns (one coarse = cache-friendly, one fine = 4 MiB), one after
+//     the other;
 //     a different placement changes speed only, never results.
 #include <type_traits>
 
@@ -23,8 +24,10 @@ __device__ __forceinline__ void decode_block(int b, int L, long long nsb, int& l
     const int lpx = L >> 3;
     const int xcd = b & 7;
     const long long q = b >> 3;
-    const int li = (int)(q % lpx);
-    sb = q / lpx;
+    // one level at a time per XCD (all sample blocks of its coarse level, then its fine level): two 4 MiB tables
+    // alternating in one 4 MiB L2 evicted each other
+    const int li = (int)(q / nsb);
+    sb = q - (long long)li * nsb;
     const int base = (li >> 1) * 8 + xcd;  // li even -> ascending from the coarse end
     level = (li & 1) ? (L - 1 - base) : base;
   } else {
@@ -33,23 +36,44 @@ __device__ __forceinline__ void decode_block(int b, int L, long long nsb, int& l
   }
 }
 
+constexpr int ENC_SPT = 2;  // samples per thread: 16 independent 8-byte gathers in flight hide the L2-miss latency
+
 template <class Source>
 __global__ __launch_bounds__(256) void k_hash_encode(GridDev grid, Warp warp, Source src, long long N,
                                                      float2* __restrict__ feats, uint8_t* __restrict__ selector) {
-  const long long nsb = (N + 255) / 256;
+  const long long nsb = (N + 256 * ENC_SPT - 1) / (256 * ENC_SPT);
   int level;
   long long sb;
   decode_block(blockIdx.x, grid.n_levels, nsb, level, sb);
-  const long long n = sb * 256 + threadIdx.x;
-  if (n >= N) return;
-  float px, py, pz, x[3];
-  src.position(n, px, py, pz);
-  const bool sel = warp_position(warp, px, py, pz, x);
   const uint32_t mask = (1u << grid.log2_T) - 1u;
   const float2* lt = grid.table + ((size_t)level << grid.log2_T);
-  float2 f = grid_lookup(lt, x, grid.scalings[level], mask);
-  feats[(size_t)level * N + n] = f;
-  if (level == 0 && selector) selector[n] = sel ? 1 : 0;
+  const int scaling = grid.scalings[level];
+  uint32_t h[ENC_SPT][8];
+  float o[ENC_SPT][3];
+  bool sel[ENC_SPT];
+  long long n[ENC_SPT];
+#pragma unroll
+  for (int u = 0; u < ENC_SPT; ++u) {
+    n[u] = sb * (256 * ENC_SPT) + u * 256 + threadIdx.x;
+    const long long nn = n[u] < N ? n[u] : N - 1;
+    float px, py, pz, x[3];
+    src.position(nn, px, py, pz);
+    sel[u] = warp_position(warp, px, py, pz, x);
+    const GridLevel g = grid_cell(x, scaling);
+    grid_corners(g, mask, h[u]);
+    o[u][0] = g.o[0], o[u][1] = g.o[1], o[u][2] = g.o[2];
+  }
+  float2 v[ENC_SPT][8];
+#pragma unroll
+  for (int u = 0; u < ENC_SPT; ++u)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[u][k] = lt[h[u][k]];
+#pragma unroll
+  for (int u = 0; u < ENC_SPT; ++u) {
+    if (n[u] >= N) continue;
+    feats[(size_t)level * N + n[u]] = grid_interp(v[u], o[u]);
+    if (level == 0 && selector) selector[n[u]] = sel[u] ? 1 : 0;
+  }
 }
 
 template <class Source>
@@ -60,7 +84,7 @@ static int launch_encode(const fnr_grid* grid, const fnr_warp* warp, const Sourc
                 grid->n_levels);
   FNR_CHECK_ARG(grid->log2_hashmap_size >= 1 && grid->log2_hashmap_size <= 28, "hash_encode: log2_hashmap_size");
   if (N == 0) return FNR_OK;
-  const long long nsb = (N + 255) / 256;
+  const long long nsb = (N + 256 * ENC_SPT - 1) / (256 * ENC_SPT);
   const long long nblk = nsb * grid->n_levels;
   FNR_CHECK_ARG(nblk < (1ll << 31), "hash_encode: too many samples for one launch (%lld)", N);
   constexpr int prof_op = std::is_same<Source, LatticeSource>::value ? OP_ENCODE_LATTICE : OP_ENCODE_FWD;
