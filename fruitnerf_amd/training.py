@@ -203,19 +203,44 @@ class FusedAdam:
             return g["lr"]
         return exponential_decay_lr(self.step_count, g["lr"], g["lr_final"], g["max_steps"])
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def begin_step(self) -> Dict[str, float]:
+        """Advance the step counter and return this update's learning rate per parameter group
+        (scheduler.step() runs after optimizer.step(): update k uses lr(k-1))."""
         self.step_count += 1
-        lrs = {name: self.current_lr(name) if self.step_count > 1 else self.groups[name]["lr"]
-               for name in self.groups}
-        # scheduler.step() runs after optimizer.step(): update k uses lr(k-1)
-        lrs = {name: (exponential_decay_lr(self.step_count - 1, g["lr"], g["lr_final"], g["max_steps"])
-                      if g.get("lr_final") is not None else g["lr"]) for name, g in self.groups.items()}
+        return {name: (exponential_decay_lr(self.step_count - 1, g["lr"], g["lr_final"], g["max_steps"])
+                       if g.get("lr_final") is not None else g["lr"]) for name, g in self.groups.items()}
+
+    def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0) -> None:
+        """Adam update (+ zero_grad) of arena elements [a, b); begin_step() must have been called for this step."""
+        if b > a:
+            K.adam_step(self.arena.params[a:b], self.arena.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr,
+                        self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, True)
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        lrs = self.begin_step()
         same = len(set(lrs.values())) == 1
         spans = [("all", (0, self.arena.numel))] if same else list(self.arena.group_ranges.items())
         for name, (a, b) in spans:
-            lr = next(iter(lrs.values())) if same else lrs[name]
-            K.adam_step(self.arena.params[a:b], self.arena.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr,
-                        self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, True)
+            self.step_span(a, b, next(iter(lrs.values())) if same else lrs[name], grad_scale)
+
+
+GRAD_BUCKET_ELEMS = 4 << 20   # 16 MiB fp32 buckets: large enough for xGMI ring bandwidth, small enough to pipeline
+
+
+def start_gradient_sync(arena, span, world_size: int, bucket_elems: int = GRAD_BUCKET_ELEMS):
+    """Launch the all-reduce(SUM) of arena.grads[span] as asynchronous buckets on the process group's communication
+    stream (RCCL over xGMI on GPUs, gloo in the CPU tests) and return [(a, b, work)].  The caller keeps launching
+    compute that does not touch that span (the proposal-network backward runs while the field gradient is in
+    flight), then waits per bucket and applies Adam to it while the next bucket is still being reduced."""
+    if world_size <= 1:
+        return []
+    import torch.distributed as dist
+    a0, b0 = span
+    out = []
+    for a in range(a0, b0, bucket_elems):
+        b = min(a + bucket_elems, b0)
+        out.append((a, b, dist.all_reduce(arena.grads[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+    return out
 
 
 def sync_gradients(arena, world_size: int) -> float:
@@ -245,7 +270,7 @@ def train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, w
 
 
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
-                           want_metrics: bool = True):
+                           want_metrics: bool = True, after_field_backward=None):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -282,6 +307,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
                                   d_rgb_s, d_logit)
         K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
+        if after_field_backward is not None:
+            after_field_backward()  # the field's gradients are final: their exchange can start now
         if rctx.training and rctx.updated:
             up = model.__dict__.get("_unit_upstream")
             if up is None or up.device != dev:
@@ -296,12 +323,28 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
 
 def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, world_size: int = 1,
                           jitter: Optional[List[Tensor]] = None, want_metrics: bool = True):
-    """train_iteration() on fused_forward_backward(); returns the same (loss_dict, metrics_dict) tensors."""
+    """train_iteration() on fused_forward_backward(); returns the same (loss_dict, metrics_dict) tensors.
+
+    world_size > 1 (DDP semantics, fruit_pipeline.py:116-118): the field's gradient (67 MB of the 78 MB arena) is
+    all-reduced in 16 MiB buckets on the communication stream as soon as the field backward has been enqueued, i.e.
+    underneath the proposal-network backward; Adam then consumes bucket k while bucket k+1 is still on the wire."""
     model.set_anneal(step)                                     # BEFORE_TRAIN_ITERATION callback
-    loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics)
+    arena = model.arena()
+    spans = arena.group_ranges
+    pending = []
+    hook = (lambda: pending.extend(start_gradient_sync(arena, spans["fields"], world_size))) if world_size > 1 else None
+    loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, hook)
     with torch.no_grad():
-        scale = sync_gradients(model.arena(), world_size)
-        optimizer.step(grad_scale=scale)
+        if world_size <= 1:
+            optimizer.step()
+        else:
+            pending += start_gradient_sync(arena, spans["proposal_networks"], world_size)
+            lrs = optimizer.begin_step()
+            scale = 1.0 / world_size
+            for a, b, work in pending:
+                work.wait()                                    # the compute stream waits for this bucket only
+                name = "fields" if a >= spans["fields"][0] else "proposal_networks"
+                optimizer.step_span(a, b, lrs[name], scale)
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
 

@@ -24,7 +24,7 @@ def _worker(rank, world, port, q):
     from fruitnerf_amd.data import synthetic_apple as sa
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
     from fruitnerf_amd.params import ParamArena
-    from fruitnerf_amd.training import sync_gradients
+    from fruitnerf_amd.training import start_gradient_sync, sync_gradients
     from tests import util
     cfg = FruitNerfModelConfig(log2_hashmap_size=6)
     cfg.proposal_net_args_list = util.small_config(prop_log2=5).proposal_net_args_list
@@ -41,6 +41,17 @@ def _worker(rank, world, port, q):
     arena.grads.copy_((rank + 1) * pattern)
     scale = sync_gradients(arena, world)
     mean_ok = bool(torch.allclose(arena.grads * scale, pattern * (sum(range(1, world + 1)) / world)))
+    # the bucketed, asynchronous exchange the fused training step uses: same sums, bucket by bucket
+    arena.grads.copy_((rank + 1) * pattern)
+    pending = []
+    for name in ("fields", "proposal_networks"):
+        pending += start_gradient_sync(arena, arena.group_ranges[name], world, bucket_elems=1000)
+    covered = 0
+    for a, b, work in pending:
+        work.wait()
+        covered += b - a
+    bucketed_ok = bool(covered == arena.numel and len(pending) > 2 and
+                       torch.allclose(arena.grads * scale, pattern * (sum(range(1, world + 1)) / world)))
     views_ok = bool(torch.equal(m.field.mlp_head.layers[2].bias.grad,
                                 arena.grads[arena.entries[-1][2] - 0:][:0].new_zeros(0)) or True)
     # rank-specific rays (seed + rank), same dataset
@@ -52,7 +63,7 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(d) for _ in range(world)]
     dist.all_gather(gathered, d)
     different_rays = not torch.equal(gathered[0], gathered[1])
-    q.put((rank, same_init, mean_ok, views_ok, different_rays, scale))
+    q.put((rank, same_init, mean_ok and bucketed_ok, views_ok, different_rays, scale))
     dist.barrier()
     dist.destroy_process_group()
 
