@@ -242,6 +242,48 @@ def main() -> None:
                    "semantic_iou_heldout": round(inter / max(union, 1.0), 4),
                    "final_train_losses": {k: round(float(v), 6) for k, v in ld.items()}}
 
+    # ---- secondary metrics: full-image eval rays/s and volume-export samples/s, trained weights ----
+    secondary = None
+    if not args.no_quality and world == 1:
+        import copy
+        from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
+        from fruitnerf_amd.export.exporter_utils import sample_volume
+        model.eval()
+        with torch.no_grad():
+            ys, xs = torch.meshgrid(torch.arange(HW, device=dev), torch.arange(HW, device=dev), indexing="ij")
+            ci = torch.full((HW * HW,), int(i_eval[0]), device=dev)
+            o, d = sa.pixel_rays(c2w, ci, ys.reshape(-1), xs.reshape(-1), focal, focal, HW / 2.0, HW / 2.0)
+            cam_rb = RayBundle(o.view(HW, HW, 3), d.view(HW, HW, 3), None, None)
+            model.get_outputs_for_camera_ray_bundle(cam_rb)            # warm-up
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model.get_outputs_for_camera_ray_bundle(cam_rb)            # reference semantics: .cpu() per 32768-ray chunk
+            torch.cuda.synchronize()
+            eval_s = time.perf_counter() - t1
+        # volume export (ns-export-semantics): N^3 lattice through the trained field, three thresholded point sets
+        emodel = FruitModel(copy.deepcopy(model.config), num_train_data=len(i_train), device=dev, test_mode="export")
+        emodel.load_state_dict(model.state_dict(), strict=True)
+        emodel.eval()
+        N_EXP = 256
+
+        class _Pipe:
+            pass
+
+        pipe = _Pipe()
+        pipe.model = emodel
+        pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=32768)
+        emodel.setup_inference(True, N_EXP)
+        n_rays = pipe.datamanager.setup_inference(aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), num_points=N_EXP)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sets = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})
+        torch.cuda.synchronize()
+        exp_s = time.perf_counter() - t1
+        secondary = {"eval_rays_per_s": round(HW * HW / eval_s, 1), "eval_image": f"{HW}x{HW}, chunks of 32768 rays",
+                     "export_samples_per_s": round(n_rays * N_EXP / exp_s, 1), "export_lattice": f"{N_EXP}^3",
+                     "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()}}
+        model.train()
+
     # ---- CPU baseline: the oracle's training step on the host cores -------------------------------------------------
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -304,6 +346,7 @@ def main() -> None:
         "cpu_baseline": cpu,
         "breakdown_ms": breakdown,
         "quality": quality,
+        "secondary": secondary,
     }
     if cpu:
         result["speedup_vs_cpu_baseline"] = round(rays_per_s / cpu["value"], 1)
