@@ -346,12 +346,17 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
 
 
 def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
-                    d_feats: Tensor) -> None:
+                    d_feats: Tensor, level_begin: int = 0, level_count: Optional[int] = None) -> None:
+    """Scatter the feature gradients of levels [level_begin, level_begin + level_count) (default: all) into the
+    gradient table."""
     lib = L.load()
-    nbytes = lib.fnr_hash_scatter_workspace_bytes(rays.n * S, grid_grad.n_levels, grid_grad.log2_hashmap_size)
+    if level_count is None:
+        level_count = grid_grad.n_levels - level_begin
+    nbytes = lib.fnr_hash_scatter_workspace_bytes(rays.n * S, level_count, grid_grad.log2_hashmap_size)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=rays.device)
     L.check(lib.fnr_hash_encode_bwd(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
-                                    L.ptr(ws), nbytes, L.stream_ptr(rays.device)), "hash_encode_bwd")
+                                    level_begin, level_count, L.ptr(ws), nbytes, L.stream_ptr(rays.device)),
+            "hash_encode_bwd")
 
 
 def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor,

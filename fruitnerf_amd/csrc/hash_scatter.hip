@@ -129,7 +129,7 @@ template <class Source>
 __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, Warp warp, Source src, long long N,
                                                       const float2* __restrict__ d_feats, float4* __restrict__ queue,
                                                       unsigned* __restrict__ qcount, unsigned* __restrict__ qmax,
-                                                      long long cap, int log2_rows) {
+                                                      long long cap, int log2_rows, int level0) {
   // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs
   __shared__ float4 s_rec[SC_CHUNK * 8];
   __shared__ unsigned s_cnt[SC_MAX_BINS];   // per-bin count, then running cursor
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   __shared__ unsigned s_base[SC_MAX_BINS];  // per-bin start inside the global queue
   __shared__ unsigned s_max[SC_MAX_BINS];   // per-bin max |value| (float bits; order-preserving for >= 0)
   __shared__ unsigned s_wsum[SC_EMIT_THREADS / 64];
-  const int level = blockIdx.y;
+  const int lrel = blockIdx.y;           // level inside this call's range: indexes the counters and queues
+  const int level = level0 + lrel;       // level of the grid: indexes scalings, d_feats and the gradient table
   const int bins = 1 << (grid.log2_T - log2_rows);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) {
@@ -217,8 +218,8 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     const int i = threadIdx.x * SC_BINS_PER_THREAD + t;
     if (i < bins) {
       s_off[i] = run;
-      s_base[i] = c4[t] ? atomicAdd(&qcount[(size_t)(level * bins + i) * SC_CNT_STRIDE], c4[t]) : 0u;
-      if (c4[t]) atomicMax(&qmax[(size_t)(level * bins + i) * SC_CNT_STRIDE], s_max[i]);
+      s_base[i] = c4[t] ? atomicAdd(&qcount[(size_t)(lrel * bins + i) * SC_CNT_STRIDE], c4[t]) : 0u;
+      if (c4[t]) atomicMax(&qmax[(size_t)(lrel * bins + i) * SC_CNT_STRIDE], s_max[i]);
       s_cnt[i] = 0;
       run += c4[t];
     }
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     const unsigned bin = __float_as_uint(r.w);
     const unsigned slot = s_base[bin] + (i - s_off[bin]);
     if ((long long)slot < cap) {
-      queue[((size_t)level * bins + bin) * cap + slot] = r;
+      queue[((size_t)lrel * bins + bin) * cap + slot] = r;
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
       const size_t row = ((size_t)bin << log2_rows) + __float_as_uint(r.x);
       atomicAdd(table + 2 * row, r.y);
@@ -269,13 +270,14 @@ __device__ __forceinline__ void acc_record(unsigned long long* __restrict__ s_ac
 __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float4* __restrict__ queue,
                                                              const unsigned* __restrict__ qcount,
                                                              const unsigned* __restrict__ qmax, long long cap,
-                                                             int log2_rows) {
+                                                             int log2_rows, int level0) {
   __shared__ unsigned long long s_acc[2 * SC_MAX_ROWS];  // [rows][2] two's-complement fixed point, 128 KiB
   const int rows = 1 << log2_rows;
   const int bins = 1 << (grid.log2_T - log2_rows);
   // fine levels (long queues) are dispatched first, the short coarse-level bins fill the tail
-  const int gbin = (int)gridDim.x - 1 - (int)blockIdx.x;  // level * bins + bin
-  const int level = gbin / bins, bin = gbin - level * bins;
+  const int gbin = (int)gridDim.x - 1 - (int)blockIdx.x;  // (level - level0) * bins + bin
+  const int lrel = gbin / bins, bin = gbin - lrel * bins;
+  const int level = level0 + lrel;
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
   const float vmax = __uint_as_float(qmax[(size_t)gbin * SC_CNT_STRIDE]);
   if (n == 0 || !(vmax > 0.0f)) return;
@@ -317,26 +319,29 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
 
 template <class Source>
 static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Source& src, long long N,
-                          const float2* d_feats, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  const ScatterPlan p = scatter_plan(N, grid_grad->n_levels, grid_grad->log2_hashmap_size);
+                          const float2* d_feats, int level0, int level_count, void* workspace, size_t workspace_bytes,
+                          hipStream_t st) {
+  FNR_CHECK_ARG(level0 >= 0 && level_count >= 1 && level0 + level_count <= grid_grad->n_levels,
+                "hash scatter: level range [%d,+%d) outside the %d levels", level0, level_count, grid_grad->n_levels);
+  const ScatterPlan p = scatter_plan(N, level_count, grid_grad->log2_hashmap_size);
   FNR_CHECK_ARG(p.bins_per_level <= SC_MAX_BINS, "hash scatter: log2_hashmap_size %d too large for the bin histogram",
                 grid_grad->log2_hashmap_size);
   FNR_CHECK_ARG(workspace && workspace_bytes >= p.count_bytes + p.queue_bytes, "hash scatter: workspace too small");
   unsigned* qcount = reinterpret_cast<unsigned*>(workspace);
   float4* queue = reinterpret_cast<float4*>(reinterpret_cast<char*>(workspace) + p.count_bytes);
   FNR_HIP(hipMemsetAsync(qcount, 0, p.count_bytes, st));
-  const size_t nbins_all = (size_t)grid_grad->n_levels * p.bins_per_level;
+  const size_t nbins_all = (size_t)level_count * p.bins_per_level;
   const long long chunks = (N + SC_CHUNK - 1) / SC_CHUNK;
   FNR_CHECK_ARG(chunks < (1ll << 31), "hash scatter: too many samples");
   const GridDev gd = make_grid(grid_grad);
   for (int l = 0; l < grid_grad->n_levels; ++l)
     FNR_CHECK_ARG(gd.scalings[l] > 0 && gd.scalings[l] < 65535, "hash scatter: level resolution %d out of range", gd.scalings[l]);
-  hipLaunchKernelGGL((k_scatter_emit<Source>), dim3((unsigned)chunks, (unsigned)grid_grad->n_levels), dim3(SC_EMIT_THREADS), 0, st,
-                     gd, warp, src, N, d_feats, queue, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows);
+  hipLaunchKernelGGL((k_scatter_emit<Source>), dim3((unsigned)chunks, (unsigned)level_count), dim3(SC_EMIT_THREADS), 0, st,
+                     gd, warp, src, N, d_feats, queue, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows, level0);
   FNR_LAUNCH_CHECK();
-  const unsigned nbins = (unsigned)(grid_grad->n_levels * p.bins_per_level);
+  const unsigned nbins = (unsigned)(level_count * p.bins_per_level);
   hipLaunchKernelGGL(k_scatter_accumulate, dim3(nbins), dim3(1024), 0, st, gd,
-                     queue, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows);
+                     queue, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows, level0);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }
@@ -506,16 +511,16 @@ extern "C" size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_leve
 }
 
 extern "C" int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
-                                   const float* euclid_bins, int S, const float* d_feats, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+                                   const float* euclid_bins, int S, const float* d_feats, int level_begin,
+                                   int level_count, void* workspace, size_t workspace_bytes, void* stream) {
   FNR_CHECK_ARG(grid_grad && warp && rays && euclid_bins && d_feats && S > 0, "hash_encode_bwd: null argument");
   FNR_CHECK_ARG(grid_grad->n_levels >= 1 && grid_grad->n_levels <= FNR_MAX_LEVELS, "hash_encode_bwd: n_levels");
   const long long N = rays->n_rays * (long long)S;
   if (N == 0) return FNR_OK;
   RaySource src{make_rays(rays), euclid_bins, S};
   FNR_PROF(OP_ENCODE_BWD, N);
-  return binned_scatter(grid_grad, make_warp(warp), src, N, reinterpret_cast<const float2*>(d_feats), workspace,
-                        workspace_bytes, as_stream(stream));
+  return binned_scatter(grid_grad, make_warp(warp), src, N, reinterpret_cast<const float2*>(d_feats), level_begin,
+                        level_count, workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
@@ -570,6 +575,6 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
   hipLaunchKernelGGL(k_prop_reduce, dim3(PROP_PART / 64, PROP_RED_Y), dim3(64), 0, as_stream(stream), partials,
                      (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1);
   FNR_LAUNCH_CHECK();
-  return binned_scatter(&grads->grid, w, src, N, d_feats, reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,
+  return binned_scatter(&grads->grid, w, src, N, d_feats, 0, L, reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,
                         workspace_bytes - dfeat_bytes - partial_bytes, as_stream(stream));
 }

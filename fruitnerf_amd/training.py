@@ -269,8 +269,37 @@ def train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, w
     return loss_dict, metrics_dict
 
 
+class _FieldGradientExchange:
+    """Data-parallel overlap plan for the field's gradient (67 of the 78 MB arena): the hash-grid scatter runs per
+    group of levels and each group's slice of the gradient table (contiguous: level l owns rows [l T, (l+1) T)) is
+    handed to the communicator as soon as its scatter has been enqueued; the rest of the group's parameters (MLP
+    weights, embedding) follow when the field backward is complete."""
+
+    def __init__(self, model, world_size: int, level_groups: int = 4):
+        self.arena = model.arena()
+        self.world = world_size
+        self.level_groups = level_groups
+        self.pending = []
+        table = model.field.mlp_base_grid.hash_table
+        hit = [(off, n) for _, p, off, n in self.arena.entries if p is table]
+        if len(hit) != 1:
+            raise RuntimeError("hash table not found in the parameter arena")
+        self.table_off, self.table_n = hit[0]
+        self.per_level = self.table_n // int(model.field.mlp_base_grid.num_levels)  # python int (no device sync)
+
+    def levels_done(self, level_begin: int, level_count: int) -> None:
+        a = self.table_off + level_begin * self.per_level
+        self.pending += start_gradient_sync(self.arena, (a, a + level_count * self.per_level), self.world)
+
+    def field_done(self) -> None:
+        f0, f1 = self.arena.group_ranges["fields"]
+        for span in ((f0, self.table_off), (self.table_off + self.table_n, f1)):
+            if span[1] > span[0]:
+                self.pending += start_gradient_sync(self.arena, span, self.world)
+
+
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
-                           want_metrics: bool = True, after_field_backward=None):
+                           want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -306,9 +335,16 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         net, gnet = fld.net_struct(), fld.net_struct(grads=True)
         d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
                                   d_rgb_s, d_logit)
-        K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
-        if after_field_backward is not None:
-            after_field_backward()  # the field's gradients are final: their exchange can start now
+        if exchange is None:
+            K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
+        else:
+            n_lv = int(gnet.grid.n_levels)
+            per = -(-n_lv // max(1, exchange.level_groups))
+            for lb in range(0, n_lv, per):
+                cnt = min(per, n_lv - lb)
+                K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, lb, cnt)
+                exchange.levels_done(lb, cnt)      # this slice of the gradient table is final: all-reduce it now
+            exchange.field_done()
         if rctx.training and rctx.updated:
             up = model.__dict__.get("_unit_upstream")
             if up is None or up.device != dev:
@@ -326,19 +362,19 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
     """train_iteration() on fused_forward_backward(); returns the same (loss_dict, metrics_dict) tensors.
 
     world_size > 1 (DDP semantics, fruit_pipeline.py:116-118): the field's gradient (67 MB of the 78 MB arena) is
-    all-reduced in 16 MiB buckets on the communication stream as soon as the field backward has been enqueued, i.e.
-    underneath the proposal-network backward; Adam then consumes bucket k while bucket k+1 is still on the wire."""
+    all-reduced in 16 MiB buckets on the communication stream, each bucket = the table rows of 4 levels, issued as
+    soon as those levels' scatter has been enqueued — underneath the remaining scatter groups and the whole
+    proposal-network backward; Adam then consumes bucket k while bucket k+1 is still on the wire."""
     model.set_anneal(step)                                     # BEFORE_TRAIN_ITERATION callback
     arena = model.arena()
     spans = arena.group_ranges
-    pending = []
-    hook = (lambda: pending.extend(start_gradient_sync(arena, spans["fields"], world_size))) if world_size > 1 else None
-    loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, hook)
+    exchange = _FieldGradientExchange(model, world_size) if world_size > 1 else None
+    loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange)
     with torch.no_grad():
-        if world_size <= 1:
+        if exchange is None:
             optimizer.step()
         else:
-            pending += start_gradient_sync(arena, spans["proposal_networks"], world_size)
+            pending = exchange.pending + start_gradient_sync(arena, spans["proposal_networks"], world_size)
             lrs = optimizer.begin_step()
             scale = 1.0 / world_size
             for a, b, work in pending:

@@ -253,12 +253,14 @@ int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, cons
                       void* stream);
 
 /* Backward of fnr_hash_encode_fwd: adds (+=) the trilinear scatter of d_feats [L][N][2] into
- * grid_grad->table.  Binned through per-bin queues in `workspace` (>= fnr_hash_scatter_workspace_bytes)
- * because global fp32 atomics top out at ~21 G/s on MI355X (hash_scatter.hip). */
+ * grid_grad->table for the levels [level_begin, level_begin + level_count) (all levels: 0, n_levels; data-parallel
+ * training calls it per group of levels so that a group's rows can be all-reduced while the next group is being
+ * scattered).  Binned through per-bin queues in `workspace` (>= fnr_hash_scatter_workspace_bytes(n_samples,
+ * level_count, log2_hashmap_size)) because global fp32 atomics top out at ~21 G/s on MI355X (hash_scatter.hip). */
 size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size);
 int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
-                        const float* euclid_bins, int S, const float* d_feats, void* workspace, size_t workspace_bytes,
-                        void* stream);
+                        const float* euclid_bins, int S, const float* d_feats, int level_begin, int level_count,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of fnr_prop_density_fwd: d_density [R,S] -> += into grads (table, w0, b0, w1, b1).
  * workspace >= fnr_prop_density_bwd_workspace_bytes(N, L, log2_hashmap_size). */

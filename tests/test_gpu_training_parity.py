@@ -193,3 +193,35 @@ def test_fused_step_matches_the_autograd_step(dev):
     # same kernels, same inputs; only the order of a few float atomics (weight-gradient partials) may differ
     assert (g_a - g_f).abs().max().item() <= 1e-5 * scale
     assert int((g_a != 0).sum()) == int((g_f != 0).sum())
+
+
+def test_level_group_scatter_matches_single_scatter(dev, monkeypatch):
+    """Data-parallel training scatters the hash-grid gradient per group of levels (so each group's rows can be
+    all-reduced early): same gradients as the single scatter, and the exchanged spans tile the field's parameters."""
+    from fruitnerf_amd.rays import RayBundle
+    import fruitnerf_amd.training as T
+    monkeypatch.setattr(T, "start_gradient_sync", lambda arena, span, world, bucket_elems=0: [(span[0], span[1], None)])
+    cfg = util.small_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, seed=9)
+    R = 160
+    o, d, pa, cam = util.random_rays(R, 7, seed=4)
+    jit = [torch.rand(R, 1).to(dev) for _ in range(3)]
+    hb = {k: v.to(dev) for k, v in _batch(R, 8).items()}
+    grads, spans = [], None
+    for grouped in (False, True):
+        hm = util.make_hip_like(om, dev)
+        hm.train()
+        hm.set_anneal(0)
+        ex = T._FieldGradientExchange(hm, 2) if grouped else None
+        T.fused_forward_backward(hm, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), hb, jitter=jit,
+                                 exchange=ex)
+        torch.cuda.synchronize()
+        grads.append(hm.arena().grads.clone())
+        if ex is not None:
+            spans = sorted((a, b) for a, b, _ in ex.pending)
+            f0, f1 = hm.arena().group_ranges["fields"]
+    assert spans[0][0] == f0 and spans[-1][1] == f1
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1)), spans
+    scale = grads[0].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
+    assert int((grads[0] != 0).sum()) == int((grads[1] != 0).sum())
