@@ -166,3 +166,24 @@ def test_synthetic_scene_is_seeded_and_sane():
     o, d, cam, batch = b.sample(64)
     assert o.shape == (64, 3) and torch.allclose(d.norm(dim=-1), torch.ones(64), atol=1e-5)
     assert batch["image"].shape == (64, 3) and batch["fruit_mask"].shape == (64, 1) and cam.max() < 8
+
+
+def test_ply_sink_roundtrip(tmp_path):
+    """Open3D-layout binary PLY (double xyz + uchar rgb): header, size and quantisation."""
+    import numpy as np
+    from fruitnerf_amd.export import ply
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(1000, 3))
+    cols = rng.uniform(-0.2, 1.2, size=(1000, 3))
+    path = str(tmp_path / "scene" / "semantic.ply")
+    counts = ply.write_point_clouds({"semantic": {"points": pts, "colors": cols, "path": path},
+                                     "density": {"points": pts[:0], "colors": cols[:0], "path": None}})
+    assert counts == {"semantic": 1000, "density": 0}
+    raw = open(path, "rb").read()
+    head = raw[:raw.index(b"end_header\n") + len(b"end_header\n")]
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\n") and b"element vertex 1000\n" in head
+    assert b"property double x" in head and b"property uchar blue" in head
+    assert len(raw) == len(head) + 1000 * 27
+    p2, c2 = ply.read_point_cloud(path)
+    assert np.array_equal(p2, pts)
+    assert np.array_equal(c2, np.rint(np.clip(cols, 0, 1) * 255) / 255.0)
