@@ -397,13 +397,13 @@ def smoke_train_step(oracle_model, hip_model, dev) -> None:
     jit = [torch.rand(R, 1) for _ in range(3)]
     g = torch.Generator().manual_seed(5)
     batch = {"image": torch.rand(R, 3, generator=g), "fruit_mask": (torch.rand(R, 1, generator=g) > 0.5).float()}
-    oracle_model.set_anneal(0)  # train_iteration() below runs the same BEFORE_TRAIN_ITERATION callback
+    oracle_model.set_anneal(0)  # fused_train_iteration() below runs the same BEFORE_TRAIN_ITERATION callback
     ref_out = oracle_model(ns.RayBundle(o, d, pa, camera_indices=cam), jitter=jit)
     ref_ld = oracle_model.get_loss_dict(ref_out, batch)
     sum(ref_ld.values()).backward()
     opt = FusedAdam(hip_model)
     rb = RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev))
-    ld, md = train_iteration(hip_model, opt, rb, {k: v.to(dev) for k, v in batch.items()}, 0,
+    ld, md = fused_train_iteration(hip_model, opt, rb, {k: v.to(dev) for k, v in batch.items()}, 0,
                              jitter=[j.to(dev) for j in jit])
     torch.cuda.synchronize()
     for k in ref_ld:
