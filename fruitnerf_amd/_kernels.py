@@ -360,13 +360,37 @@ def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, eucl
 
 
 def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor,
-                     S: int, feats: Tensor, d_density: Tensor) -> None:
+                     S: int, feats: Tensor, d_density: Tensor, want_position_grad: bool = False) -> Optional[Tensor]:
+    """want_position_grad: also return d(loss)/d(unit-cube position) [N,4] for position_grad_reduce(n_levels=1)."""
     lib = L.load()
     nbytes = lib.fnr_prop_density_bwd_workspace_bytes(rays.n * S, net.grid.n_levels, net.grid.log2_hashmap_size)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=rays.device)
+    d_pos = torch.empty(rays.n * S, 4, device=rays.device) if want_position_grad else None
     L.check(lib.fnr_prop_density_bwd(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
-                                     L.ptr(feats), L.ptr(d_density), L.ptr(ws), nbytes, L.stream_ptr(rays.device)),
+                                     L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), L.ptr(ws), nbytes,
+                                     L.stream_ptr(rays.device)),
             "prop_density_bwd")
+    return d_pos
+
+
+def hash_encode_input_grad(grid: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
+                           d_feats: Tensor) -> Tensor:
+    """Per-level gradient w.r.t. the unit-cube sample positions: [L][N][4]."""
+    lib = L.load()
+    partial = torch.empty(grid.n_levels, rays.n * S, 4, device=rays.device)
+    L.check(lib.fnr_hash_encode_input_grad(C.byref(grid), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
+                                           L.ptr(partial), L.stream_ptr(rays.device)), "hash_encode_input_grad")
+    return partial
+
+
+def position_grad_reduce(warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int, partial: Tensor, d_origins: Tensor,
+                         d_directions: Tensor) -> None:
+    """d_origins / d_directions [R,3] += the ray gradient carried by `partial` ([n_levels][N][4] or [N][4])."""
+    lib = L.load()
+    n_levels = partial.shape[0] if partial.dim() == 3 else 1
+    L.check(lib.fnr_position_grad_reduce(C.byref(warp), rays.ref, L.ptr(euclid), S, n_levels, L.ptr(partial),
+                                         L.ptr(d_origins), L.ptr(d_directions), L.stream_ptr(rays.device)),
+            "position_grad_reduce")
 
 
 def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float,

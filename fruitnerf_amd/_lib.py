@@ -98,7 +98,9 @@ SIGNATURES = {
     "fnr_hash_encode_bwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _vp]),
     "fnr_prop_density_bwd_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "fnr_prop_density_bwd": (_i, [P(fnr_prop_net), P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp,
-                                  C.c_size_t, _vp]),
+                                  _vp, C.c_size_t, _vp]),
+    "fnr_hash_encode_input_grad": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
+    "fnr_position_grad_reduce": (_i, [P(fnr_warp), P(fnr_rays), _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fnr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _i, _vp]),
     "fnr_export_workspace_bytes": (C.c_size_t, [_i64]),
     "fnr_export_compact": (_i, [P(fnr_lattice), _i64, _i64, _vp, _i64, _vp, _vp, _vp, P(_vp), P(_vp), _i64, _vp, _vp,
@@ -165,7 +167,8 @@ def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
 
 PROFILE_OPS = ["sample_spaced", "weights_pdf", "prop_density_fwd", "hash_encode_fwd", "hash_encode_lattice",
                "field_mlp_fwd", "composite_fwd", "losses_fwd", "interlevel_fwd", "distortion", "composite_bwd",
-               "weights_bwd", "field_mlp_bwd", "hash_encode_bwd", "prop_density_bwd", "adam_step", "export_compact"]
+               "weights_bwd", "field_mlp_bwd", "hash_encode_bwd", "prop_density_bwd", "adam_step", "export_compact",
+               "position_grad"]
 
 
 def profile_enable(on: bool, ops=None) -> None:

@@ -359,8 +359,9 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
 constexpr int PROP_PART = 320;   // floats per workgroup partial: dW0 tile 256 + dW1 16 + db0 16 + db1 (+ pad)
 constexpr int PROP_RED_Y = 16;
 
-template <int L, int H>
-__global__ __launch_bounds__(256) void k_prop_bwd(Warp warp, RaySource src, long long N, const float* __restrict__ w0,
+template <int L, int H, bool POSGRAD>
+__global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restrict__ d_xw, Warp warp, RaySource src,
+                                                  long long N, const float* __restrict__ w0,
                                                   const float* __restrict__ b0, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float2* __restrict__ feat_save,
                                                   const float* __restrict__ d_density, float2* __restrict__ d_feats,
@@ -387,8 +388,9 @@ __global__ __launch_bounds__(256) void k_prop_bwd(Warp warp, RaySource src, long
 #pragma unroll
     for (int k = 0; k < K; ++k) f[k] = 0.0f;
     bool sel = false;
+    float x[3] = {0.f, 0.f, 0.f};
     if (n < N) {
-      float px, py, pz, x[3];
+      float px, py, pz;
       src.position(n, px, py, pz);
       sel = warp_position(warp, px, py, pz, x);
 #pragma unroll
@@ -426,6 +428,35 @@ __global__ __launch_bounds__(256) void k_prop_bwd(Warp warp, RaySource src, long
     if (n < N) {
 #pragma unroll
       for (int l = 0; l < L; ++l) d_feats[(size_t)l * N + n] = make_float2(df[2 * l], df[2 * l + 1]);
+    }
+    if constexpr (POSGRAD) {
+      // gradient w.r.t. the unit-cube position (camera-pose optimisation): re-gather the corner rows of every level
+      // and contract with d(blend weights)/d(offset) (position_grad.hip has the main-field version)
+      if (n < N) {
+        const uint32_t hmask = (1u << grid.log2_T) - 1u;
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const int scaling = grid.scalings[l];
+          const GridLevel gl = grid_cell(x, scaling);
+          uint32_t hh[8];
+          grid_corners(gl, hmask, hh);
+          const float2* lt = grid.table + ((size_t)l << grid.log2_T);
+          float dk[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float2 v = lt[hh[k]];
+            dk[k] = fmaf(df[2 * l], v.x, df[2 * l + 1] * v.y);
+          }
+          const float ox = gl.o[0], oy = gl.o[1], oz = gl.o[2];
+          const float mx = 1.0f - ox, my = 1.0f - oy, mz = 1.0f - oz;
+          const float s = sel ? (float)scaling : 0.0f;
+          gx += s * (oz * (oy * (dk[0] - dk[3]) + my * (dk[1] - dk[2])) + mz * (oy * (dk[4] - dk[7]) + my * (dk[5] - dk[6])));
+          gy += s * (oz * (ox * (dk[0] - dk[1]) + mx * (dk[3] - dk[2])) + mz * (ox * (dk[4] - dk[5]) + mx * (dk[7] - dk[6])));
+          gz += s * (oy * (ox * (dk[0] - dk[4]) + mx * (dk[3] - dk[7])) + my * (ox * (dk[1] - dk[5]) + mx * (dk[2] - dk[6])));
+        }
+        d_xw[n] = make_float4(gx, gy, gz, 0.0f);
+      }
     }
     __syncthreads();
     // phase 2: this wave's 64 samples, 4 per MFMA step.  A[i = o][kk] = dh / ha of sample 4 step + kk,
@@ -531,7 +562,8 @@ extern "C" size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_
 
 extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
                                     const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
-                                    const float* d_density, void* workspace, size_t workspace_bytes, void* stream) {
+                                    const float* d_density, float* d_position, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   FNR_CHECK_ARG(net && grads && warp && rays && euclid_bins && feat_save && d_density && workspace && S > 0,
                 "prop_density_bwd: null argument");
   FNR_UNSUPPORTED(net->hidden_dim == 16, "prop_density_bwd: hidden_dim %d not built (16 only)", net->hidden_dim);
@@ -553,10 +585,16 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
   float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + dfeat_bytes);
   const size_t partial_bytes = (size_t)max_blocks * PROP_PART * sizeof(float);
   FNR_PROF(OP_PROP_BWD, N);
+  const GridDev pgrid = make_grid(&net->grid);
+  float4* d_xw = reinterpret_cast<float4*>(d_position);
 #define FNR_PROPB_CASE(LL)                                                                                          \
   case LL:                                                                                                          \
-    hipLaunchKernelGGL((k_prop_bwd<LL, 16>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), w, src, N,    \
-                       net->w0, net->b0, net->w1, net->b1, fs, d_density, d_feats, partials);                        \
+    if (d_xw)                                                                                                       \
+      hipLaunchKernelGGL((k_prop_bwd<LL, 16, true>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pgrid, \
+                         d_xw, w, src, N, net->w0, net->b0, net->w1, net->b1, fs, d_density, d_feats, partials);    \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_prop_bwd<LL, 16, false>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pgrid, \
+                         d_xw, w, src, N, net->w0, net->b0, net->w1, net->b1, fs, d_density, d_feats, partials);    \
     break;
   switch (L) {
     FNR_PROPB_CASE(1)

@@ -36,4 +36,23 @@ struct LatticeSource {
   }
 };
 
+// workgroup -> (level, sample block) of the (sample, level) kernels
+__device__ __forceinline__ void decode_block(int b, int L, long long nsb, int& level, long long& sb) {
+  if ((L & 7) == 0) {
+    // XCD-aware: xcd = b % 8 owns L/8 levels, coarse levels paired with fine ones
+    const int lpx = L >> 3;
+    const int xcd = b & 7;
+    const long long q = b >> 3;
+    // one level at a time per XCD (all sample blocks of its coarse level, then its fine level): two 4 MiB tables
+    // alternating in one 4 MiB L2 evicted each other
+    const int li = (int)(q / nsb);
+    sb = q - (long long)li * nsb;
+    const int base = (li >> 1) * 8 + xcd;  // li even -> ascending from the coarse end
+    level = (li & 1) ? (L - 1 - base) : base;
+  } else {
+    level = b % L;
+    sb = b / L;
+  }
+}
+
 }  // namespace fnr

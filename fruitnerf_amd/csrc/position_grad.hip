@@ -1,0 +1,177 @@
+// position_grad.hip — dL/d(ray origins), dL/d(ray directions): the input gradient of the hash grids.
+//
+// In the reference the sample positions carry autograd history (fruit_field.py:171-182: Frustums.get_positions ->
+// SceneContraction -> (x+2)/4 -> * selector -> HashEncoding), so loss.backward() also produces the gradient of the
+// rays the camera-pose optimiser consumes (fruit_nerf_config.py:39-43).  The sampler's bins are detached
+// (PDFSampler), SHEncoding runs under no_grad and the semantic branch sees detached geo features, so the ONLY path
+// to the rays is  p = o + d (t0 + t1)/2  ->  x(p)  ->  trilinear offsets of every level.
+//   k_hash_input_grad   thread = (sample, level), same XCD-aware map as the forward encode: re-gathers the 8 corner
+//                       rows and contracts d feat with d(blend weights)/d(offset) * scaling -> partial [L][N] float4;
+//   k_position_reduce   wave = ray: sums the levels, applies the transposed Jacobian of the contraction (or of the
+//                       AABB normalisation) and reduces over the ray's samples into d_origins / d_directions (+=).
+// HBM/L2-bound like the forward encode (1024 B of table rows per sample) + 2 x 16 B x L per sample of partials.
+#include "hash_sources.hpp"
+
+namespace fnr {
+
+constexpr int PG_SPT = 2;  // samples per thread (gathers in flight), as in k_hash_encode
+
+// d(feature . g)/d(offset) for the oracle's blend (grid_interp): weights are products of o (ceil side) or 1 - o
+// (floor side) per axis, corner order h0..h7 = ccc, cfc, ffc, fcc, ccf, cff, fff, fcf
+__device__ __forceinline__ void blend_input_grad(const float (&d)[8], const float (&o)[3], float (&g)[3]) {
+  const float ox = o[0], oy = o[1], oz = o[2];
+  const float mx = 1.0f - ox, my = 1.0f - oy, mz = 1.0f - oz;
+  g[0] = oz * (oy * (d[0] - d[3]) + my * (d[1] - d[2])) + mz * (oy * (d[4] - d[7]) + my * (d[5] - d[6]));
+  g[1] = oz * (ox * (d[0] - d[1]) + mx * (d[3] - d[2])) + mz * (ox * (d[4] - d[5]) + mx * (d[7] - d[6]));
+  g[2] = oy * (ox * (d[0] - d[4]) + mx * (d[3] - d[7])) + my * (ox * (d[1] - d[5]) + mx * (d[2] - d[6]));
+}
+
+template <class Source>
+__global__ __launch_bounds__(256) void k_hash_input_grad(GridDev grid, Warp warp, Source src, long long N,
+                                                         const float2* __restrict__ d_feats,
+                                                         float4* __restrict__ partial) {
+  const long long nsb = (N + 256 * PG_SPT - 1) / (256 * PG_SPT);
+  int level;
+  long long sb;
+  decode_block(blockIdx.x, grid.n_levels, nsb, level, sb);
+  const uint32_t mask = (1u << grid.log2_T) - 1u;
+  const float2* lt = grid.table + ((size_t)level << grid.log2_T);
+  const int scaling = grid.scalings[level];
+  uint32_t h[PG_SPT][8];
+  float o[PG_SPT][3];
+  bool sel[PG_SPT];
+  long long n[PG_SPT];
+  float2 gf[PG_SPT];
+#pragma unroll
+  for (int u = 0; u < PG_SPT; ++u) {
+    n[u] = sb * (256 * PG_SPT) + u * 256 + threadIdx.x;
+    const long long nn = n[u] < N ? n[u] : N - 1;
+    float px, py, pz, x[3];
+    src.position(nn, px, py, pz);
+    sel[u] = warp_position(warp, px, py, pz, x);
+    const GridLevel g = grid_cell(x, scaling);
+    grid_corners(g, mask, h[u]);
+    o[u][0] = g.o[0], o[u][1] = g.o[1], o[u][2] = g.o[2];
+    gf[u] = d_feats[(size_t)level * N + nn];
+  }
+  float2 v[PG_SPT][8];
+#pragma unroll
+  for (int u = 0; u < PG_SPT; ++u)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[u][k] = lt[h[u][k]];
+#pragma unroll
+  for (int u = 0; u < PG_SPT; ++u) {
+    if (n[u] >= N) continue;
+    float d[8], g[3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = fmaf(gf[u].x, v[u][k].x, gf[u].y * v[u][k].y);
+    blend_input_grad(d, o[u], g);
+    const float s = sel[u] ? (float)scaling : 0.0f;  // positions * selector: no gradient outside the unit cube
+    partial[(size_t)level * N + n[u]] = make_float4(s * g[0], s * g[1], s * g[2], 0.0f);
+  }
+}
+
+// transposed Jacobian of warp_position applied to g (gradient w.r.t. the unit-cube position) at world position p
+__device__ __forceinline__ void warp_backward(const Warp& w, const float (&p)[3], float (&g)[3]) {
+  if (w.mode == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g[a] *= 0.25f;  // x = (x' + 2) / 4
+    const float ax = fabsf(p[0]), ay = fabsf(p[1]), az = fabsf(p[2]);
+    const float m = fmaxf(ax, fmaxf(ay, az));
+    if (!(m < 1.0f)) {
+      // x' = p c(m), c = 2/m - 1/m^2, m = |p|_inf:  dL/dp_b = c g_b + [b == argmax] sign(p_b) c'(m) (g . p)
+      const float inv = 1.0f / m;
+      const float c = 2.0f * inv - inv * inv;
+      const float dc = -2.0f * inv * inv + 2.0f * inv * inv * inv;
+      const float dot = g[0] * p[0] + g[1] * p[1] + g[2] * p[2];
+      const int j = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[a] *= c;
+      const float e = copysignf(1.0f, p[j]) * dc * dot;
+      g[0] += (j == 0) ? e : 0.0f;
+      g[1] += (j == 1) ? e : 0.0f;
+      g[2] += (j == 2) ? e : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g[a] /= w.len[a];
+  }
+}
+
+// wave = ray.  partial: [n_levels][N] float4.  d_origins / d_directions [R,3] are accumulated (+=).
+__global__ __launch_bounds__(256) void k_position_reduce(Warp warp, RaysDev rays, const float* __restrict__ euclid, int S,
+                                                         int n_levels, const float4* __restrict__ partial,
+                                                         float* __restrict__ d_origins, float* __restrict__ d_directions) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= rays.n_rays) return;
+  const long long N = rays.n_rays * (long long)S;
+  const float* o = rays.origins + 3 * r;
+  const float* d = rays.directions + 3 * r;
+  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+  for (int k = lane; k < S; k += 64) {
+    const long long n = r * S + k;
+    float g[3] = {0.f, 0.f, 0.f};
+    for (int l = 0; l < n_levels; ++l) {
+      const float4 q = partial[(size_t)l * N + n];
+      g[0] += q.x, g[1] += q.y, g[2] += q.z;
+    }
+    const float* b = euclid + r * (S + 1) + k;
+    const float tm = (b[0] + b[1]) * 0.5f;
+    float p[3];
+    ray_position(o, d, b[0], b[1], p[0], p[1], p[2]);
+    warp_backward(warp, p, g);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      go[a] += g[a];
+      gd[a] += tm * g[a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    go[a] = wave_sum(go[a]);
+    gd[a] = wave_sum(gd[a]);
+  }
+  if (lane < 3) {
+    const float vo = (lane == 0) ? go[0] : (lane == 1) ? go[1] : go[2];
+    const float vd = (lane == 0) ? gd[0] : (lane == 1) ? gd[1] : gd[2];
+    d_origins[3 * r + lane] += vo;
+    d_directions[3 * r + lane] += vd;
+  }
+}
+
+}  // namespace fnr
+
+using namespace fnr;
+
+extern "C" int fnr_hash_encode_input_grad(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays,
+                                          const float* euclid_bins, int S, const float* d_feats, float* partial,
+                                          void* stream) {
+  FNR_CHECK_ARG(grid && warp && rays && euclid_bins && d_feats && partial && S > 0, "hash_encode_input_grad: null argument");
+  FNR_CHECK_ARG(grid->n_levels >= 1 && grid->n_levels <= FNR_MAX_LEVELS, "hash_encode_input_grad: n_levels");
+  const long long N = rays->n_rays * (long long)S;
+  if (N == 0) return FNR_OK;
+  RaySource src{make_rays(rays), euclid_bins, S};
+  const long long nsb = (N + 256 * PG_SPT - 1) / (256 * PG_SPT);
+  const long long nblk = nsb * grid->n_levels;
+  FNR_CHECK_ARG(nblk < (1ll << 31), "hash_encode_input_grad: too many samples for one launch (%lld)", N);
+  FNR_PROF(OP_POSITION_GRAD, N);
+  hipLaunchKernelGGL((k_hash_input_grad<RaySource>), dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), make_grid(grid),
+                     make_warp(warp), src, N, reinterpret_cast<const float2*>(d_feats), reinterpret_cast<float4*>(partial));
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_position_grad_reduce(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,
+                                        int n_levels, const float* partial, float* d_origins, float* d_directions,
+                                        void* stream) {
+  FNR_CHECK_ARG(warp && rays && euclid_bins && partial && d_origins && d_directions && S > 0 && n_levels >= 1,
+                "position_grad_reduce: null argument");
+  if (rays->n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_POSITION_GRAD, rays->n_rays * (long long)S);
+  hipLaunchKernelGGL(k_position_reduce, dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     make_warp(warp), make_rays(rays), euclid_bins, S, n_levels, reinterpret_cast<const float4*>(partial),
+                     d_origins, d_directions);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}

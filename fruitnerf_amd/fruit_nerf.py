@@ -168,6 +168,7 @@ class RenderContext:
     sample_logit: Optional[Tensor] = None
     sample_density: Optional[Tensor] = None
     weights: Optional[Tensor] = None
+    ray_bundle: Optional[object] = None   # the caller's RayBundle (its origins / directions may carry autograd history)
 
 
 class FruitModel(nn.Module):
@@ -357,6 +358,7 @@ class FruitModel(nn.Module):
                             field_selector=selector, field_h=h_saved, sample_rgb=rgb, sample_logit=logit, sample_density=density,
                             weights=weights)
         ctx.labels = label[:, None]
+        ctx.ray_bundle = ray_bundle
         outputs = {"rgb": out_rgb, "accumulation": acc[:, None], "depth": depth[:, None],
                    "semantics": sem[:, None]}
         for i in range(n_prop):

@@ -34,12 +34,23 @@ def _anchor(model) -> Tensor:
     return a
 
 
+def _field_ray_grads(model, rctx, d_feats: Tensor, d_origins: Tensor, d_directions: Tensor) -> None:
+    """d(loss)/d(ray origins, directions) through the main field's hash grid (position_grad.hip): the only path from
+    the losses to the rays — PDFSampler detaches its bins, SHEncoding runs under no_grad."""
+    fld = model.field
+    lv = rctx.levels[-1]
+    partial = K.hash_encode_input_grad(fld.net_struct().grid, fld.warp_struct(), rctx.rays, lv["euclid"], lv["S"], d_feats)
+    K.position_grad_reduce(fld.warp_struct(), rctx.rays, lv["euclid"], lv["S"], partial, d_origins, d_directions)
+
+
 class _RenderFn(torch.autograd.Function):
     """rays -> (rgb, semantics, accumulation, depth, prop depths); backward runs compositing-bwd,
     field-MLP-bwd (MFMA) and the hash-grid scatter."""
 
     @staticmethod
-    def forward(ctx, anchor, model, ray_bundle, jitter):
+    def forward(ctx, anchor, origins, directions, model, ray_bundle, jitter):
+        # origins / directions are ray_bundle's tensors, passed explicitly so that autograd can hand their gradient
+        # to a camera-pose optimiser when they carry history (fruit_nerf_config.py:39-43)
         outputs, rctx = model._render(ray_bundle, jitter)
         ctx.model = model
         ctx.rctx = rctx
@@ -71,7 +82,12 @@ class _RenderFn(torch.autograd.Function):
         d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density, d_rgb,
                                   d_logit)
         K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, lv["euclid"], S, d_feats)
-        return None, None, None, None
+        d_o = d_d = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            d_o = torch.zeros(rays.n, 3, device=dev)
+            d_d = torch.zeros(rays.n, 3, device=dev)
+            _field_ray_grads(model, rctx, d_feats, d_o, d_d)
+        return None, d_o, d_d, None, None, None
 
 
 class _InterlevelFn(torch.autograd.Function):
@@ -79,7 +95,7 @@ class _InterlevelFn(torch.autograd.Function):
     proposal networks (only when this step 'updated' them)."""
 
     @staticmethod
-    def forward(ctx, anchor, model, rctx, mult):
+    def forward(ctx, anchor, origins, directions, model, rctx, mult):
         fin = rctx.levels[-1]
         dev = rctx.rays.device
         from . import _lib as L
@@ -95,18 +111,31 @@ class _InterlevelFn(torch.autograd.Function):
     def backward(ctx, g):
         model, rctx = ctx.model, ctx.rctx
         if not (rctx.training and rctx.updated):
-            return None, None, None, None  # proposal densities were computed under no_grad
+            return None, None, None, None, None, None  # proposal densities were computed under no_grad
         arena = model.arena()
         arena.reattach_grads()
         rays = rctx.rays
         up = g.reshape(1).float().contiguous()
-        cfg = model.config
-        for i, (lv, d_wp) in enumerate(zip(rctx.levels[:-1], ctx.d_wps)):
-            d_density = K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, up)
-            net = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
-            K.prop_density_bwd(net.prop_struct(), net.prop_struct(grads=True), net.warp_struct(), rays,
-                               lv["euclid"], lv["S"], lv["feats"], d_density)
-        return None, None, None, None
+        want_rays = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        d_o = torch.zeros(rays.n, 3, device=rays.device) if want_rays else None
+        d_d = torch.zeros(rays.n, 3, device=rays.device) if want_rays else None
+        _proposal_backward(model, rctx, ctx.d_wps, up, d_o, d_d)
+        return None, d_o, d_d, None, None, None
+
+
+def _proposal_backward(model, rctx, d_wps, upstream: Tensor, d_origins: Optional[Tensor],
+                       d_directions: Optional[Tensor]) -> None:
+    """Backward of the interlevel loss into the proposal networks (and, when asked, into the rays)."""
+    cfg = model.config
+    rays = rctx.rays
+    for i, (lv, d_wp) in enumerate(zip(rctx.levels[:-1], d_wps)):
+        d_density = K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, upstream)
+        net = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
+        d_pos = K.prop_density_bwd(net.prop_struct(), net.prop_struct(grads=True), net.warp_struct(), rays,
+                                   lv["euclid"], lv["S"], lv["feats"], d_density,
+                                   want_position_grad=d_origins is not None)
+        if d_origins is not None:
+            K.position_grad_reduce(net.warp_struct(), rays, lv["euclid"], lv["S"], d_pos, d_origins, d_directions)
 
 
 class _LossFn(torch.autograd.Function):
@@ -129,7 +158,7 @@ class _LossFn(torch.autograd.Function):
 
 
 def render_with_grad(model, ray_bundle, jitter=None):
-    outs = _RenderFn.apply(_anchor(model), model, ray_bundle, jitter)
+    outs = _RenderFn.apply(_anchor(model), ray_bundle.origins, ray_bundle.directions, model, ray_bundle, jitter)
     rctx = model._last_render_ctx
     n_prop = len(rctx.levels) - 1
     outputs = {"rgb": outs[0], "semantics": outs[1], "accumulation": outs[2], "depth": outs[3]}
@@ -151,7 +180,8 @@ def fused_losses(model, outputs, batch) -> Dict[str, Tensor]:
     loss_dict = {"rgb_loss": rgb_loss, "semantics_loss": sem_loss}
     if model.training:
         rctx = outputs["_ctx"]
-        loss_dict["interlevel_loss"] = _InterlevelFn.apply(_anchor(model), model, rctx,
+        rb = rctx.ray_bundle
+        loss_dict["interlevel_loss"] = _InterlevelFn.apply(_anchor(model), rb.origins, rb.directions, model, rctx,
                                                            model.config.interlevel_loss_mult)
     return loss_dict
 
@@ -299,14 +329,17 @@ class _FieldGradientExchange:
 
 
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
-                           want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None):
+                           want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
+                           ray_grads: Optional[dict] = None):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
     The loss graph of this model is fixed (rgb + semantics through the renderer, interlevel through the proposal
     networks, unit upstream gradients), so forward, losses and backward are one straight-line sequence of HIP
     launches; per step that removes ~20 elementwise/fill/reduce launches and the engine's start-up gap that
-    autograd put between them.  Gradients land in the model's arena exactly as with loss.backward()."""
+    autograd put between them.  Gradients land in the model's arena exactly as with loss.backward().
+    ray_grads: pass a dict to also receive d(loss)/d(origins) and d(loss)/d(directions) [R,3] under the keys
+    "origins" / "directions" (what a camera-pose optimiser back-propagates further)."""
     from . import _lib as L
     cfg = model.config
     dev = model.device
@@ -345,15 +378,16 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, lb, cnt)
                 exchange.levels_done(lb, cnt)      # this slice of the gradient table is final: all-reduce it now
             exchange.field_done()
+        d_o = d_d = None
+        if ray_grads is not None:
+            d_o = ray_grads["origins"] = torch.zeros(rays.n, 3, device=dev)
+            d_d = ray_grads["directions"] = torch.zeros(rays.n, 3, device=dev)
+            _field_ray_grads(model, rctx, d_feats, d_o, d_d)
         if rctx.training and rctx.updated:
             up = model.__dict__.get("_unit_upstream")
             if up is None or up.device != dev:
                 up = model.__dict__["_unit_upstream"] = torch.ones(1, device=dev)
-            for i, (lv, d_wp) in enumerate(zip(rctx.levels[:-1], d_wps)):
-                d_dens = K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, up)
-                pn = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
-                K.prop_density_bwd(pn.prop_struct(), pn.prop_struct(grads=True), pn.warp_struct(), rays, lv["euclid"],
-                                   lv["S"], lv["feats"], d_dens)
+            _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
     return loss_dict, metrics_dict
 
 

@@ -263,11 +263,27 @@ int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const f
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of fnr_prop_density_fwd: d_density [R,S] -> += into grads (table, w0, b0, w1, b1).
+ * d_position (optional) [N,4]: gradient w.r.t. each sample's unit-cube position (xyz, w = 0) for
+ * fnr_position_grad_reduce(n_levels = 1) — only needed when the rays carry gradients (camera-pose optimiser).
  * workspace >= fnr_prop_density_bwd_workspace_bytes(N, L, log2_hashmap_size). */
 size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size);
 int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
                          const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
-                         const float* d_density, void* workspace, size_t workspace_bytes, void* stream);
+                         const float* d_density, float* d_position, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* ---- gradient of the rays (camera-pose optimisation, fruit_nerf_config.py:39-43) ----------------- */
+/* Input gradient of fnr_hash_encode_fwd: partial [L][N][4] = per level d(loss)/d(unit-cube position) of every
+ * sample, from d_feats [L][N][2] and the PARAMETER table (autograd of HashEncoding w.r.t. its input through the
+ * trilinear offsets; `positions * selector` zeroes it outside the unit cube, fruit_field.py:178-179). */
+int fnr_hash_encode_input_grad(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays,
+                               const float* euclid_bins, int S, const float* d_feats, float* partial, void* stream);
+/* Sums `partial` [n_levels][N][4] over the levels, applies the transposed Jacobian of the position warp
+ * (SceneContraction + (x+2)/4, or AABB normalisation) and of Frustums.get_positions (p = o + d (t0+t1)/2, bins
+ * detached), and ADDS the per-ray sums to d_origins [R,3] and d_directions [R,3]. */
+int fnr_position_grad_reduce(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,
+                             int n_levels, const float* partial, float* d_origins, float* d_directions,
+                             void* stream);
 
 /* torch.optim.Adam step (no weight decay, no amsgrad; fruit_nerf_config.py:47-56) over a flat arena of n
  * floats (n % 4 == 0); the gradient is multiplied by grad_scale first (1/world_size after an all-reduce(SUM))

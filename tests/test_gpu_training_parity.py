@@ -225,3 +225,44 @@ def test_level_group_scatter_matches_single_scatter(dev, monkeypatch):
     scale = grads[0].abs().max().item()
     assert (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
     assert int((grads[0] != 0).sum()) == int((grads[1] != 0).sum())
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_ray_gradients_match_autograd(dev, fused):
+    """d(loss)/d(origins), d(loss)/d(directions): the gradient a camera-pose optimiser consumes
+    (fruit_nerf_config.py:39-43).  Oracle: plain autograd with the rays as leaves."""
+    from fruitnerf_amd.rays import RayBundle
+    from fruitnerf_amd.training import fused_forward_backward
+    cfg = util.small_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, seed=11)
+    hm = util.make_hip_like(om, dev)
+    om.train()
+    hm.train()
+    R = 160
+    o, d, pa, cam = util.random_rays(R, 7, seed=33)
+    jit = [torch.rand(R, 1) for _ in range(3)]
+    batch = _batch(R, 5)
+    o_ref, d_ref = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    om.set_anneal(0)
+    out = om(ns.RayBundle(o_ref, d_ref, pa.clone(), camera_indices=cam.clone()), jitter=jit)
+    sum(om.get_loss_dict(out, batch).values()).backward()
+
+    hm.set_anneal(0)
+    hb = {k: v.to(dev) for k, v in batch.items()}
+    hjit = [j.to(dev) for j in jit]
+    if fused:
+        got = {}
+        fused_forward_backward(hm, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), hb, jitter=hjit,
+                               ray_grads=got)
+        g_o, g_d = got["origins"], got["directions"]
+    else:
+        o_h, d_h = o.to(dev).requires_grad_(True), d.to(dev).requires_grad_(True)
+        hout = hm(RayBundle(o_h, d_h, pa.to(dev), cam.to(dev)), jitter=hjit)
+        sum(hm.get_loss_dict(hout, hb).values()).backward()
+        g_o, g_d = o_h.grad, d_h.grad
+    torch.cuda.synchronize()
+    for name, got_g, ref_g in (("origins", g_o, o_ref.grad), ("directions", g_d, d_ref.grad)):
+        scale = ref_g.abs().max().item()
+        err = (got_g.cpu() - ref_g).abs().max().item()
+        print(f"[ray grad fused={fused}] {name}: max|ref| {scale:.3e} max_err {err:.3e} rel {err / scale:.3e}")
+        assert scale > 0 and err <= 2e-3 * scale, name
