@@ -46,6 +46,7 @@ ALG = {
     "prop_density_bwd": ("hbm", 2 * 320.0 + 40.0 + 4.0),
     "field_mlp_fwd": ("mfma", 33024.0),                  # useful FLOP / sample
     "field_mlp_bwd": ("mfma", 2 * 33024.0 + 33024.0),    # recompute + dX + dW ~ 3x forward
+    "position_grad": ("hbm", 1024.0 + 2 * 256.0 + 128.0),  # table rows re-read + per-level partials written and read
     "adam_step": ("hbm", 28.0),                          # p,g,m,v read + p,m,v,g written per parameter (32 B w/ zero)
 }
 
@@ -69,6 +70,9 @@ def main() -> None:
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--image-size", type=int, default=800)
     ap.add_argument("--roofline-op", default="auto")
+    ap.add_argument("--camera-optimizer", default="SO3xR3", choices=["off", "SO3xR3"],
+                    help="the method's datamanager default (fruit_nerf_config.py:39-43): pose corrections learned from "
+                         "the ray gradients; 'off' skips the input gradient of the hash grids")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,15 +117,22 @@ def main() -> None:
     model = FruitModel(FruitNerfModelConfig(), num_train_data=len(i_train), device=dev)
     model.train()
     opt = FusedAdam(model)
+    camera = None
+    if args.camera_optimizer != "off":
+        from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+        cam_opt = CameraOptimizerConfig(mode=args.camera_optimizer).setup(len(i_train), dev)
+        camera = (cam_opt, CameraAdam(cam_opt), batcher)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
     step_idx = [0]
 
     def one_step(want_metrics=True):
-        o, d, cam, batch = batcher.sample(RAYS_PER_BATCH)
+        nonlocal camera
+        o, d, cam, batch = batcher.sample(RAYS_PER_BATCH, camera[0] if camera else None)
         rb = RayBundle(o, d, None, cam)
-        out = train_iteration(model, opt, rb, batch, step_idx[0], world_size=world, want_metrics=want_metrics)
+        out = train_iteration(model, opt, rb, batch, step_idx[0], world_size=world, want_metrics=want_metrics,
+                              camera=camera)
         step_idx[0] += 1
         return out
 
@@ -279,7 +290,20 @@ def main() -> None:
         sets = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})
         torch.cuda.synchronize()
         exp_s = time.perf_counter() - t1
-        secondary = {"eval_rays_per_s": round(HW * HW / eval_s, 1), "eval_image": f"{HW}x{HW}, chunks of 32768 rays",
+        cam_off = None
+        if camera is not None:  # the same loop without the camera optimiser (no input gradient of the hash grids)
+            saved, camera = camera, None
+            for _ in range(10):
+                one_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(100):
+                one_step()
+            torch.cuda.synchronize()
+            cam_off = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
+            camera = saved
+        secondary = {"train_rays_per_s_camera_optimizer_off": cam_off,
+                     "eval_rays_per_s": round(HW * HW / eval_s, 1), "eval_image": f"{HW}x{HW}, chunks of 32768 rays",
                      "export_samples_per_s": round(n_rays * N_EXP / exp_s, 1), "export_lattice": f"{N_EXP}^3",
                      "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()}}
         model.train()
@@ -300,13 +324,26 @@ def main() -> None:
         groups = om.get_param_groups()
         oopts = [torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15),
                  torch.optim.Adam(groups["fields"], lr=1e-2, eps=1e-15)]
-        cb = sa.PixelBatcher({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()},
-                             train_ids.cpu(), seed=99)
+        cdata = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()}
+        cb = sa.PixelBatcher(cdata, train_ids.cpu(), seed=99)
+        ocam = None
+        if args.camera_optimizer != "off":  # same work as the GPU step: pose corrections + their Adam(weight_decay)
+            from oracle import camera_opt as oc
+            ocam = oc.CameraOptimizer(len(i_train))
+            oopts.append(torch.optim.Adam(ocam.parameters(), lr=6e-4, eps=1e-8, weight_decay=1e-2))
+        gen_u = torch.Generator().manual_seed(99)
         times = []
         n_cpu = 2
         for i in range(n_cpu + 1):
-            o, d, cam, batch = cb.sample(CPU_RAYS)
+            u = torch.rand(CPU_RAYS, 3, generator=gen_u)
             t1 = time.perf_counter()
+            o, d, cam, batch = cb.sample_torch(u)
+            if ocam is not None:
+                kk = cam[:, 0]
+                yy = (u[:, 1] * HW).long().clamp_max(HW - 1)
+                xx = (u[:, 2] * HW).long().clamp_max(HW - 1)
+                o, d = oc.generate_rays(cdata["c2w"][train_ids.cpu()[kk]], ocam(kk), yy, xx, focal, focal, HW / 2.0,
+                                        HW / 2.0)
             om.set_anneal(i)
             for op_ in oopts:
                 op_.zero_grad()
@@ -320,7 +357,9 @@ def main() -> None:
                 times.append(time.perf_counter() - t1)
         med = float(np.median(times))
         cpu = {"value": round(CPU_RAYS / med, 1), "unit": "rays/s", "cores": ncores, "kind": "port",
-               "sample": f"{n_cpu} full fruit_nerf training steps (fwd+bwd+Adam over all 19.4 M parameters) of "
+               "sample": f"{n_cpu} full fruit_nerf training steps (pixel sampling + ray generation"
+                         f"{' with the SO3xR3 camera optimizer' if ocam is not None else ''}, fwd+bwd+Adam over all 19.4 M "
+                         f"parameters) of "
                          f"{CPU_RAYS} rays each after 1 warm-up, oracle/ PyTorch-CPU fp32, {ncores} threads, "
                          f"median {med:.2f} s/step"}
 
@@ -339,7 +378,8 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": f"fruit_nerf synthetic apple {HW}x{HW}, {N_CAMERAS} cameras ({len(i_train)} train), "
                                f"{RAYS_PER_BATCH} rays/rank/step, samples 256/96/48, hash 16x2^19x2 + 2x(5x2^17x2), "
-                               "semantic head, fwd+bwd+Adam, proposal-net update schedule from step 0",
+                               "semantic head, fwd+bwd+Adam, proposal-net update schedule from step 0, "
+                               f"camera optimizer {args.camera_optimizer}",
                    "rays_per_rank": RAYS_PER_BATCH, "parallelism": f"dp{world}", "device": info["arch"],
                    "setup_s": round(setup_s, 1)},
         "roofline": roofline,

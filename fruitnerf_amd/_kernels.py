@@ -394,11 +394,12 @@ def position_grad_reduce(warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int
 
 
 def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float,
-              beta2: float, eps: float, step: int, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
+              beta2: float, eps: float, step: int, grad_scale: float = 1.0, zero_grad: bool = True,
+              weight_decay: float = 0.0) -> None:
     lib = L.load()
     L.check(lib.fnr_adam_step(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(),
                               float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
-                              1 if zero_grad else 0, L.stream_ptr(params.device)), "adam_step")
+                              float(weight_decay), 1 if zero_grad else 0, L.stream_ptr(params.device)), "adam_step")
 
 
 # ---- caller side -------------------------------------------------------------------------------------
@@ -416,7 +417,27 @@ class ImageSetArg:
                                  float(cx), float(cy))
 
 
-def sample_pixels(image_set: ImageSetArg, train_ids: Tensor, u: Tensor):
+def camera_adjust(image_set: ImageSetArg, train_ids: Tensor, pose_adjustment: Tensor) -> Tensor:
+    """c2w' [n_train,3,4] = multiply(c2w[train_ids], exp_map_SO3xR3(pose_adjustment))."""
+    lib = L.load()
+    ids = train_ids.to(torch.int64).contiguous()
+    out = torch.empty(ids.numel(), 3, 4, device=pose_adjustment.device)
+    L.check(lib.fnr_camera_adjust(L.ptr(image_set.c2w), L.ptr(ids), ids.numel(), L.ptr(_f32c(pose_adjustment)), L.ptr(out),
+                                  L.stream_ptr(out.device)), "camera_adjust")
+    return out
+
+
+def camera_pose_grad(image_set: ImageSetArg, train_ids: Tensor, u: Tensor, cam: Tensor, pose_adjustment: Tensor,
+                     c2w_adjusted: Tensor, d_origins: Tensor, d_directions: Tensor, pose_grad: Tensor) -> None:
+    """pose_grad [n_train,6] += d(loss)/d(pose_adjustment) from the ray gradients of the rays drawn with `u`."""
+    lib = L.load()
+    ids = train_ids.to(torch.int64).contiguous()
+    L.check(lib.fnr_camera_pose_grad(C.byref(image_set.c), L.ptr(ids), ids.numel(), u.shape[0], L.ptr(_f32c(u)),
+                                     L.ptr(cam), L.ptr(_f32c(pose_adjustment)), L.ptr(c2w_adjusted), L.ptr(d_origins),
+                                     L.ptr(d_directions), L.ptr(pose_grad), L.stream_ptr(u.device)), "camera_pose_grad")
+
+
+def sample_pixels(image_set: ImageSetArg, train_ids: Tensor, u: Tensor, c2w_adjusted: Optional[Tensor] = None):
     lib = L.load()
     dev = u.device
     R = u.shape[0]
@@ -426,7 +447,7 @@ def sample_pixels(image_set: ImageSetArg, train_ids: Tensor, u: Tensor):
     cam = torch.empty(R, dtype=torch.int32, device=dev)
     image = torch.empty(R, 3, device=dev)
     mask = torch.empty(R, device=dev)
-    L.check(lib.fnr_sample_pixels(C.byref(image_set.c), L.ptr(ids), ids.numel(), R, L.ptr(_f32c(u)), L.ptr(origins),
-                                  L.ptr(directions), L.ptr(cam), L.ptr(image), L.ptr(mask), L.stream_ptr(dev)),
+    L.check(lib.fnr_sample_pixels(C.byref(image_set.c), L.ptr(ids), ids.numel(), R, L.ptr(_f32c(u)),
+                                  L.ptr(c2w_adjusted), L.ptr(origins), L.ptr(directions), L.ptr(cam), L.ptr(image), L.ptr(mask), L.stream_ptr(dev)),
             "sample_pixels")
     return origins, directions, cam, image, mask

@@ -1,0 +1,182 @@
+// camera_opt.hip — nerfstudio CameraOptimizer(mode="SO3xR3") on the device: the pose corrections the reference's
+// datamanager applies to the training cameras and learns from the ray gradients
+// (/root/reference/fruit_nerf/fruit_nerf_config.py:39-43; metrics camera_opt_translation / camera_opt_rotation at
+// fruit_pipeline.py:133-142).  nerfstudio 0.3.2 semantics (restated):
+//   delta[k]  = exp_map_SO3xR3(pose_adjustment[k]):  t = tangent[:3],  R = I + f1 K + f2 K^2,  K = skew(tangent[3:]),
+//               theta = sqrt(clamp(|w|^2, 1e-4)), f1 = sin(theta)/theta, f2 = (1 - cos(theta))/theta^2
+//   c2w'[k]   = pose_utils.multiply(c2w[k], delta[k]):  R' = R1 R,  t' = t1 + R1 t
+//   rays      : origins = t', directions = normalize(R' d_cam)      (Cameras._generate_rays_from_coords)
+// k_camera_adjust builds c2w' (thread = camera); k_camera_pose_grad maps d(loss)/d(origins, directions) back to the
+// [n_train, 6] tangent vectors: one workgroup per camera gathers its rays (ballot), so there are no atomics on the
+// shared rows.
+#include "common.hpp"
+
+namespace fnr {
+
+struct SO3 {
+  float R[9];
+  float theta2_raw, theta, f1, f2;
+};
+
+__device__ __forceinline__ SO3 so3_exp(const float* w) {
+  SO3 s;
+  s.theta2_raw = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const float t2 = fmaxf(s.theta2_raw, 1e-4f);
+  s.theta = sqrtf(t2);
+  const float inv = 1.0f / s.theta;
+  s.f1 = inv * sinf(s.theta);
+  s.f2 = inv * inv * (1.0f - cosf(s.theta));
+  // K = [[0,-wz,wy],[wz,0,-wx],[-wy,wx,0]];  K^2 = w w^T - |w|^2 I
+  const float x = w[0], y = w[1], z = w[2];
+  const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+  const float K2[9] = {-(y * y + z * z), x * y, x * z, x * y, -(x * x + z * z), y * z, x * z, y * z, -(x * x + y * y)};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s.R[i] = s.f1 * K[i] + s.f2 * K2[i] + ((i % 4 == 0) ? 1.0f : 0.0f);
+  return s;
+}
+
+// c2w' = multiply(c2w[train_ids[k]], exp_map_SO3xR3(pose[k]))
+__global__ __launch_bounds__(64) void k_camera_adjust(const float* __restrict__ c2w, const long long* __restrict__ train_ids,
+                                                      int n_train, const float* __restrict__ pose,
+                                                      float* __restrict__ c2w_adj) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n_train) return;
+  const float* M = c2w + train_ids[k] * 12;
+  const float* tv = pose + 6 * k;
+  const SO3 s = so3_exp(tv + 3);
+  float* out = c2w_adj + 12 * k;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      out[4 * a + b] = M[4 * a] * s.R[b] + M[4 * a + 1] * s.R[3 + b] + M[4 * a + 2] * s.R[6 + b];
+    out[4 * a + 3] = M[4 * a + 3] + (M[4 * a] * tv[0] + M[4 * a + 1] * tv[1] + M[4 * a + 2] * tv[2]);
+  }
+}
+
+struct PinholeDev {
+  int H, W;
+  float fx, fy, cx, cy;
+};
+
+// pose_grad[k] += d(loss)/d(tangent[k]) from the ray gradients of camera k's rays
+__global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const float* __restrict__ c2w,
+                                                          const long long* __restrict__ train_ids, long long n_rays,
+                                                          const float* __restrict__ u, const int* __restrict__ cam_idx,
+                                                          const float* __restrict__ pose,
+                                                          const float* __restrict__ c2w_adj,
+                                                          const float* __restrict__ d_origins,
+                                                          const float* __restrict__ d_directions,
+                                                          float* __restrict__ pose_grad) {
+  __shared__ float red[4][12];
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* Ma = c2w_adj + 12 * k;  // adjusted camera: R' = rows of Ma[:, :3]
+  float acc[12];                       // G (3x3, dL/dR') row-major, then dL/dt'
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+  for (long long base = 64 * wave; base < n_rays; base += 256) {
+    const long long r = base + lane;
+    if (r < n_rays && cam_idx[r] == k) {
+      int y = (int)(u[3 * r + 1] * (float)cam.H);
+      int x = (int)(u[3 * r + 2] * (float)cam.W);
+      y = min(y, cam.H - 1);
+      x = min(x, cam.W - 1);
+      const float dc[3] = {((float)x + 0.5f - cam.cx) / cam.fx, -(((float)y + 0.5f - cam.cy) / cam.fy), -1.0f};
+      float v[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) v[a] = Ma[4 * a] * dc[0] + Ma[4 * a + 1] * dc[1] + Ma[4 * a + 2] * dc[2];
+      const float n = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+      const float dir[3] = {v[0] / n, v[1] / n, v[2] / n};
+      const float* gd = d_directions + 3 * r;
+      const float dot = dir[0] * gd[0] + dir[1] * gd[1] + dir[2] * gd[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float gv = (gd[a] - dir[a] * dot) / n;  // backward of v / |v|
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[3 * a + b] += gv * dc[b];
+        acc[9 + a] += d_origins[3 * r + a];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float s = wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float G[9], gt[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) G[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) gt[a] = (red[0][9 + a] + red[1][9 + a]) + (red[2][9 + a] + red[3][9 + a]);
+  // R' = R1 R, t' = t1 + R1 t  =>  dL/dR = R1^T G,  dL/dt = R1^T gt
+  const float* M = c2w + train_ids[k] * 12;
+  float GR[9], gtt[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) GR[3 * a + b] = M[a] * G[b] + M[4 + a] * G[3 + b] + M[8 + a] * G[6 + b];
+    gtt[a] = M[a] * gt[0] + M[4 + a] * gt[1] + M[8 + a] * gt[2];
+  }
+  const float* w = pose + 6 * k + 3;
+  const SO3 s = so3_exp(w);
+  // dR/dw_i = f1 K_i + f2 (K_i K + K K_i) + (df1/dw_i) K + (df2/dw_i) K^2;  d theta/d w_i = w_i / theta above the clamp
+  const float th = s.theta, sn = sinf(th), cs = cosf(th);
+  const float df1 = (th * cs - sn) / (th * th);                    // d(sin t / t)/dt
+  const float df2 = (th * sn - 2.0f * (1.0f - cs)) / (th * th * th);  // d((1 - cos t)/t^2)/dt
+  const bool above = s.theta2_raw > 1e-4f;  // clamp(nrms, 1e-4): zero gradient through theta below the threshold
+  const float x = w[0], y = w[1], z = w[2];
+  const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+  const float K2[9] = {-(y * y + z * z), x * y, x * z, x * y, -(x * x + z * z), y * z, x * z, y * z, -(x * x + y * y)};
+  float gk = 0.0f, gk2 = 0.0f;  // <GR, K>, <GR, K^2>
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    gk += GR[i] * K[i];
+    gk2 += GR[i] * K2[i];
+  }
+  // <GR, K_i> with K_0 = skew(e_x) etc.;  <GR, K_i K + K K_i> = d<GR, K^2>/dw_i with K^2 = w w^T - |w|^2 I
+  const float gK[3] = {GR[7] - GR[5], GR[2] - GR[6], GR[3] - GR[1]};
+  const float tr = GR[0] + GR[4] + GR[8];
+  const float Sw[3] = {(GR[0] + GR[0]) * x + (GR[1] + GR[3]) * y + (GR[2] + GR[6]) * z,
+                       (GR[3] + GR[1]) * x + (GR[4] + GR[4]) * y + (GR[5] + GR[7]) * z,
+                       (GR[6] + GR[2]) * x + (GR[7] + GR[5]) * y + (GR[8] + GR[8]) * z};
+  float* out = pose_grad + 6 * k;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float wi = (i == 0) ? x : (i == 1) ? y : z;
+    const float dth = above ? wi / th : 0.0f;
+    const float g = s.f1 * gK[i] + s.f2 * (Sw[i] - 2.0f * wi * tr) + dth * (df1 * gk + df2 * gk2);
+    out[3 + i] += g;
+    out[i] += gtt[i];
+  }
+}
+
+}  // namespace fnr
+
+using namespace fnr;
+
+extern "C" int fnr_camera_adjust(const float* c2w, const int64_t* train_ids, int n_train, const float* pose_adjustment,
+                                 float* c2w_adjusted, void* stream) {
+  FNR_CHECK_ARG(c2w && train_ids && pose_adjustment && c2w_adjusted && n_train > 0, "camera_adjust: null argument");
+  hipLaunchKernelGGL(k_camera_adjust, dim3((unsigned)((n_train + 63) / 64)), dim3(64), 0, as_stream(stream), c2w,
+                     reinterpret_cast<const long long*>(train_ids), n_train, pose_adjustment, c2w_adjusted);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_camera_pose_grad(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays,
+                                    const float* u, const int32_t* camera_indices, const float* pose_adjustment,
+                                    const float* c2w_adjusted, const float* d_origins, const float* d_directions,
+                                    float* pose_grad, void* stream) {
+  FNR_CHECK_ARG(set && set->c2w && train_ids && u && camera_indices && pose_adjustment && c2w_adjusted && d_origins &&
+                    d_directions && pose_grad && n_train > 0,
+                "camera_pose_grad: null argument");
+  if (n_rays == 0) return FNR_OK;
+  PinholeDev cam{set->H, set->W, set->fx, set->fy, set->cx, set->cy};
+  hipLaunchKernelGGL(k_camera_pose_grad, dim3((unsigned)n_train), dim3(256), 0, as_stream(stream), cam, set->c2w,
+                     reinterpret_cast<const long long*>(train_ids), (long long)n_rays, u, camera_indices, pose_adjustment,
+                     c2w_adjusted, d_origins, d_directions, pose_grad);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}

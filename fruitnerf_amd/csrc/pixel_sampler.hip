@@ -17,6 +17,7 @@ struct ImageSetDev {
 
 __global__ __launch_bounds__(256) void k_sample_pixels(ImageSetDev s, const long long* __restrict__ train_ids,
                                                        int n_train, long long n_rays, const float* __restrict__ u,
+                                                       const float* __restrict__ c2w_adjusted,
                                                        float* __restrict__ origins, float* __restrict__ directions,
                                                        int* __restrict__ cam_idx, float* __restrict__ image,
                                                        float* __restrict__ mask) {
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(256) void k_sample_pixels(ImageSetDev s, const long
   const float dx = fdiv(fsub(fadd((float)x, 0.5f), s.cx), s.fx);
   const float dy = -fdiv(fsub(fadd((float)y, 0.5f), s.cy), s.fy);
   const float dz = -1.0f;
-  const float* M = s.c2w + img * 12;
+  // camera-pose optimisation: the slot's corrected camera (fnr_camera_adjust) replaces the dataset's
+  const float* M = c2w_adjusted ? c2w_adjusted + (size_t)k * 12 : s.c2w + img * 12;
   float d[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) d[a] = fadd(fadd(fmul(M[4 * a], dx), fmul(M[4 * a + 1], dy)), fmul(M[4 * a + 2], dz));
@@ -55,8 +57,8 @@ __global__ __launch_bounds__(256) void k_sample_pixels(ImageSetDev s, const long
 using namespace fnr;
 
 extern "C" int fnr_sample_pixels(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays,
-                                 const float* u, float* origins, float* directions, int32_t* camera_indices,
-                                 float* image, float* fruit_mask, void* stream) {
+                                 const float* u, const float* c2w_adjusted, float* origins, float* directions,
+                                 int32_t* camera_indices, float* image, float* fruit_mask, void* stream) {
   FNR_CHECK_ARG(set && train_ids && u && origins && directions && camera_indices && image && fruit_mask,
                 "sample_pixels: null argument");
   FNR_CHECK_ARG(set->images && set->masks && set->c2w && set->n_images > 0 && set->H > 0 && set->W > 0 && n_train > 0,
@@ -64,7 +66,7 @@ extern "C" int fnr_sample_pixels(const fnr_image_set* set, const int64_t* train_
   if (n_rays == 0) return FNR_OK;
   ImageSetDev s{set->n_images, set->H, set->W, set->images, set->masks, set->c2w, set->fx, set->fy, set->cx, set->cy};
   hipLaunchKernelGGL(k_sample_pixels, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, as_stream(stream), s,
-                     reinterpret_cast<const long long*>(train_ids), n_train, (long long)n_rays, u, origins, directions,
+                     reinterpret_cast<const long long*>(train_ids), n_train, (long long)n_rays, u, c2w_adjusted, origins, directions,
                      camera_indices, image, fruit_mask);
   FNR_LAUNCH_CHECK();
   return FNR_OK;

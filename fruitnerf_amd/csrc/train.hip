@@ -260,11 +260,12 @@ __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Adam (torch.optim.Adam, no weight decay / amsgrad), whole arena in one launch; optionally zeroes grads
+// Adam (torch.optim.Adam incl. its L2 weight_decay, no amsgrad), whole arena in one launch; optionally zeroes grads
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                               float4* __restrict__ v, long long n4, float lr, float b1, float b2,
-                                              float eps, float bc1, float bc2_sqrt, float grad_scale, int zero_grad) {
+                                              float eps, float bc1, float bc2_sqrt, float grad_scale, float weight_decay,
+                                              int zero_grad) {
   const float step_size = lr / bc1;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 P = p[i], G = g[i], M = m[i], V = v[i];
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
     float* vp = reinterpret_cast<float*>(&V);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float gr = gp[c] * grad_scale;
+      float gr = gp[c] * grad_scale;
+      if (weight_decay != 0.0f) gr = gr + weight_decay * pp[c];   // grad.add(param, alpha=weight_decay)
       mp[c] = mp[c] + (gr - mp[c]) * (1.0f - b1);           // exp_avg.lerp_(grad, 1 - beta1)
       vp[c] = vp[c] * b2 + (1.0f - b2) * gr * gr;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
       const float denom = sqrtf(vp[c]) / bc2_sqrt + eps;    // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
@@ -358,8 +360,8 @@ extern "C" int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, 
 }
 
 extern "C" int fnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                             float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
-                             void* stream) {
+                             float beta1, float beta2, float eps, int64_t step, float grad_scale, float weight_decay,
+                             int zero_grad, void* stream) {
   FNR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "adam_step: null argument");
   FNR_CHECK_ARG(n % 4 == 0 && step >= 1, "adam_step: n must be a multiple of 4 (arena is padded) and step >= 1");
   if (n == 0) return FNR_OK;
@@ -372,7 +374,7 @@ extern "C" int fnr_adam_step(float* params, float* grads, float* exp_avg, float*
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<float4*>(params), reinterpret_cast<float4*>(grads),
                      reinterpret_cast<float4*>(exp_avg), reinterpret_cast<float4*>(exp_avg_sq), n4, lr, beta1, beta2,
-                     eps, (float)bc1, (float)sqrt(bc2), grad_scale, zero_grad);
+                     eps, (float)bc1, (float)sqrt(bc2), grad_scale, weight_decay, zero_grad);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

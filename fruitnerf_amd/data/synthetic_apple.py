@@ -139,9 +139,11 @@ class PixelBatcher:
         self.gen.manual_seed(seed)
         self._set = None
 
-    def sample(self, n_rays: int):
+    def sample(self, n_rays: int, camera_optimizer=None):
         """On a HIP device: one fused kernel (fnr_sample_pixels).  On the CPU (oracle baseline, host tests):
-        the equivalent torch ops below — this is data preparation for the oracle, not a fallback of the hot path."""
+        the equivalent torch ops below — this is data preparation for the oracle, not a fallback of the hot path.
+        camera_optimizer (cameras.camera_optimizers.CameraOptimizer, mode SO3xR3): rays come from the pose-corrected
+        cameras; `last_draw` keeps what training.camera_backward_and_step needs to back-propagate into the poses."""
         d = self.data
         dev = d["images"].device
         u = torch.rand(n_rays, 3, device=dev, generator=self.gen)
@@ -149,7 +151,9 @@ class PixelBatcher:
             from .. import _kernels as K
             if self._set is None:
                 self._set = K.ImageSetArg(d["images"], d["masks"], d["c2w"], d["fx"], d["fy"], d["cx"], d["cy"])
-            o, dirs, cam, image, mask = K.sample_pixels(self._set, self.image_ids, u)
+            c2w_adj = camera_optimizer.adjusted_cameras(self._set, self.image_ids) if camera_optimizer is not None else None
+            o, dirs, cam, image, mask = K.sample_pixels(self._set, self.image_ids, u, c2w_adj)
+            self.last_draw = {"u": u, "cam": cam, "c2w_adjusted": c2w_adj}
             return o, dirs, cam[:, None], {"image": image, "fruit_mask": mask[:, None]}
         return self.sample_torch(u)
 

@@ -391,8 +391,25 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
     return loss_dict, metrics_dict
 
 
+def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: dict, world_size: int = 1) -> None:
+    """The datamanager side of loss.backward() + optimizer.step() for the camera-pose optimiser
+    (fruit_nerf_config.py:39-43): ray gradients -> pose_adjustment.grad (camera_opt.hip), then its Adam step.
+    With several ranks the 6 x num_cameras gradient is averaged like the model's (nerfstudio leaves the datamanager
+    outside DDP, which lets the ranks' poses drift apart; one 2 KB all-reduce keeps them identical)."""
+    d = batcher.last_draw
+    pose = camera_optimizer.pose_adjustment
+    K.camera_pose_grad(batcher._set, batcher.image_ids, d["u"], d["cam"], pose.data, d["c2w_adjusted"],
+                       ray_grads["origins"], ray_grads["directions"], pose.grad)
+    scale = 1.0
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(pose.grad, op=dist.ReduceOp.SUM)
+        scale = 1.0 / world_size
+    camera_adam.step(grad_scale=scale)
+
+
 def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, world_size: int = 1,
-                          jitter: Optional[List[Tensor]] = None, want_metrics: bool = True):
+                          jitter: Optional[List[Tensor]] = None, want_metrics: bool = True, camera=None):
     """train_iteration() on fused_forward_backward(); returns the same (loss_dict, metrics_dict) tensors.
 
     world_size > 1 (DDP semantics, fruit_pipeline.py:116-118): the field's gradient (67 MB of the 78 MB arena) is
@@ -403,8 +420,12 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
     arena = model.arena()
     spans = arena.group_ranges
     exchange = _FieldGradientExchange(model, world_size) if world_size > 1 else None
-    loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange)
+    ray_grads = {} if camera is not None else None   # camera = (CameraOptimizer, CameraAdam, PixelBatcher)
+    loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
+                                                     ray_grads)
     with torch.no_grad():
+        if camera is not None:
+            camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
         if exchange is None:
             optimizer.step()
         else:

@@ -133,10 +133,23 @@ typedef struct fnr_image_set {
 /* FruitDataManager.next_train (data/fruit_datamanager.py:188-197): PixelSampler (uniform (image, y, x) from
  * u [R,3] in [0,1)) + RayGenerator (pixel centre +0.5, -z forward, unit directions).  train_ids [n_train] maps
  * training slot -> dataset image; camera_indices receives the slot (the appearance-embedding row).
+ * c2w_adjusted (optional) [n_train,3,4]: pose-corrected cameras from fnr_camera_adjust, indexed by slot.
  * Outputs: origins/directions [R,3], camera_indices [R], image [R,3] in [0,1], fruit_mask [R] in {0,1}. */
 int fnr_sample_pixels(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays, const float* u,
-                      float* origins, float* directions, int32_t* camera_indices, float* image, float* fruit_mask,
-                      void* stream);
+                      const float* c2w_adjusted, float* origins, float* directions, int32_t* camera_indices,
+                      float* image, float* fruit_mask, void* stream);
+
+/* nerfstudio CameraOptimizer(mode="SO3xR3") (fruit_nerf_config.py:39-43): c2w_adjusted[k] =
+ * pose_utils.multiply(c2w[train_ids[k]], exp_map_SO3xR3(pose_adjustment[k])), pose_adjustment [n_train,6] =
+ * (translation, so3 log-rotation) per training camera. */
+int fnr_camera_adjust(const float* c2w, const int64_t* train_ids, int n_train, const float* pose_adjustment,
+                      float* c2w_adjusted, void* stream);
+/* Backward of fnr_camera_adjust + the ray generation of fnr_sample_pixels: pose_grad [n_train,6] += d(loss)/d(pose)
+ * from d_origins / d_directions [R,3] (fnr_position_grad_reduce) of the rays drawn with `u`. */
+int fnr_camera_pose_grad(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays,
+                         const float* u, const int32_t* camera_indices, const float* pose_adjustment,
+                         const float* c2w_adjusted, const float* d_origins, const float* d_directions,
+                         float* pose_grad, void* stream);
 
 /* ---- samplers ------------------------------------------------------------------------------- */
 /* SpacedSampler.generate_ray_samples (components/ray_samplers.py:54-104; nerfstudio
@@ -285,11 +298,14 @@ int fnr_position_grad_reduce(const fnr_warp* warp, const fnr_rays* rays, const f
                              int n_levels, const float* partial, float* d_origins, float* d_directions,
                              void* stream);
 
-/* torch.optim.Adam step (no weight decay, no amsgrad; fruit_nerf_config.py:47-56) over a flat arena of n
- * floats (n % 4 == 0); the gradient is multiplied by grad_scale first (1/world_size after an all-reduce(SUM))
- * and zeroed afterwards when zero_grad != 0.  `step` is the 1-based step count for the bias corrections. */
+/* torch.optim.Adam step (no amsgrad; fruit_nerf_config.py:47-56) over a flat arena of n floats (n % 4 == 0); the
+ * gradient is multiplied by grad_scale first (1/world_size after an all-reduce(SUM)), weight_decay is torch's L2 form
+ * (grad += weight_decay * param; 0 for the model's groups, 1e-2 for the camera optimiser, fruit_nerf_config.py:41),
+ * and the gradient is zeroed afterwards when zero_grad != 0.  `step` is the 1-based step count for the bias
+ * corrections. */
 int fnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, int64_t step, float grad_scale, int zero_grad, void* stream);
+                  float beta2, float eps, int64_t step, float grad_scale, float weight_decay, int zero_grad,
+                  void* stream);
 
 /* ---- export --------------------------------------------------------------------------------- */
 /* sample_volume's masks + gathers (export/exporter_utils.py:111-153) as an order-preserving stream

@@ -265,4 +265,87 @@ def test_ray_gradients_match_autograd(dev, fused):
         scale = ref_g.abs().max().item()
         err = (got_g.cpu() - ref_g).abs().max().item()
         print(f"[ray grad fused={fused}] {name}: max|ref| {scale:.3e} max_err {err:.3e} rel {err / scale:.3e}")
-        assert scale > 0 and err <= 2e-3 * scale, name
+        assert scale > 0 and err <= 5e-3 * scale, name  # directions: sum of t * g with t up to the far plane
+
+
+def test_camera_optimizer_pose_gradients_and_step(dev):
+    """CameraOptimizer(SO3xR3) (fruit_nerf_config.py:39-43): corrected cameras, rays, d(loss)/d(pose_adjustment) and the
+    Adam(weight_decay) update, HIP vs the oracle's autograd through exp_map -> multiply -> ray generation -> model."""
+    from oracle import camera_opt as oc
+    from fruitnerf_amd import _kernels as K
+    from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+    from fruitnerf_amd.data import synthetic_apple as sa
+    from fruitnerf_amd.rays import RayBundle
+    from fruitnerf_amd.training import camera_backward_and_step, fused_forward_backward
+    n_cam, HW, focal, R = 8, 64, 90.0, 192
+    cfg = util.small_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, num_images=n_cam, seed=13)
+    hm = util.make_hip_like(om, dev)
+    om.train()
+    hm.train()
+    scene = sa.make_scene(seed=0)
+    c2w = sa.make_cameras(n_cam, seed=0)
+    data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
+    train_ids = torch.arange(n_cam)
+    g = torch.Generator().manual_seed(3)
+    pose0 = torch.cat([torch.randn(n_cam, 3, generator=g) * 0.02, torch.randn(n_cam, 3, generator=g) * 0.03], dim=1)
+    pose0[0, 3:] = 0.0   # one camera below the 1e-4 clamp of the rotation angle
+    u = torch.rand(R, 3, generator=g)
+    jit = [torch.rand(R, 1) for _ in range(3)]
+
+    # ---- oracle: autograd from the losses to the pose parameters ----
+    ocam = oc.CameraOptimizer(n_cam)
+    with torch.no_grad():
+        ocam.pose_adjustment.copy_(pose0)
+    k = (u[:, 0] * n_cam).long().clamp_max(n_cam - 1)
+    y = (u[:, 1] * HW).long().clamp_max(HW - 1)
+    x = (u[:, 2] * HW).long().clamp_max(HW - 1)
+    o_ref, d_ref = oc.generate_rays(c2w[train_ids[k]], ocam(k), y, x, focal, focal, HW / 2.0, HW / 2.0)
+    batch = {"image": data["images"][train_ids[k], y, x].float() / 255.0,
+             "fruit_mask": data["masks"][train_ids[k], y, x].float()[:, None]}
+    om.set_anneal(0)
+    out = om(ns.RayBundle(o_ref, d_ref, torch.ones(R, 1), camera_indices=k[:, None]), jitter=jit)
+    sum(om.get_loss_dict(out, batch).values()).backward()
+    oopt = torch.optim.Adam(ocam.parameters(), lr=6e-4, eps=1e-8, weight_decay=1e-2)
+    g_ref = ocam.pose_adjustment.grad.clone()
+    with torch.no_grad():
+        delta_ref = ocam(torch.arange(n_cam)).clone()
+        c2w_ref = oc.multiply(c2w, delta_ref)
+    oopt.step()
+
+    # ---- HIP ----
+    hcam = CameraOptimizerConfig(mode="SO3xR3").setup(n_cam, dev)
+    with torch.no_grad():
+        hcam.pose_adjustment.copy_(pose0.to(dev))
+    ddev = {kk: (v.to(dev) if torch.is_tensor(v) else v) for kk, v in data.items()}
+    batcher = sa.PixelBatcher(ddev, train_ids.to(dev), seed=0)
+    batcher._set = K.ImageSetArg(ddev["images"], ddev["masks"], ddev["c2w"], focal, focal, HW / 2.0, HW / 2.0)
+    c2w_adj = hcam.adjusted_cameras(batcher._set, batcher.image_ids)
+    a, _ = util.report("camera.c2w_adjusted", c2w_adj, c2w_ref)
+    assert a <= 1e-6
+    b, _ = util.report("camera.forward", hcam(torch.arange(n_cam, device=dev)), delta_ref)
+    assert b <= 1e-6
+    o_h, d_h, cam_h, image, mask = K.sample_pixels(batcher._set, batcher.image_ids, u.to(dev), c2w_adj)
+    assert util.report("camera.origins", o_h, o_ref.detach())[0] <= 1e-6
+    assert util.report("camera.directions", d_h, d_ref.detach())[0] <= 1e-6
+    batcher.last_draw = {"u": u.to(dev), "cam": cam_h, "c2w_adjusted": c2w_adj}
+    hm.set_anneal(0)
+    got = {}
+    fused_forward_backward(hm, RayBundle(o_h, d_h, None, cam_h[:, None]), {"image": image, "fruit_mask": mask[:, None]},
+                           jitter=[j.to(dev) for j in jit], ray_grads=got)
+    hadam = CameraAdam(hcam)
+    hcam.pose_adjustment.grad.zero_()
+    from fruitnerf_amd import _lib as L  # noqa: F401
+    K.camera_pose_grad(batcher._set, batcher.image_ids, batcher.last_draw["u"], cam_h, hcam.pose_adjustment.data, c2w_adj,
+                       got["origins"], got["directions"], hcam.pose_adjustment.grad)
+    torch.cuda.synchronize()
+    g_hip = hcam.pose_adjustment.grad.cpu().clone()
+    scale = g_ref.abs().max().item()
+    err = (g_hip - g_ref).abs().max().item()
+    print(f"[camera] pose grad: max|ref| {scale:.3e} max_err {err:.3e} rel {err / scale:.3e}")
+    assert scale > 0 and err <= 2e-3 * scale
+    assert (g_ref[0, 3:].abs().max() > 0) and (g_hip[0, 3:] - g_ref[0, 3:]).abs().max() <= 2e-3 * scale
+    hadam.step()
+    torch.cuda.synchronize()
+    assert util.report("camera.pose_after_adam", hcam.pose_adjustment.data, ocam.pose_adjustment.data)[0] <= 2e-6
+    assert float(hcam.pose_adjustment.grad.abs().max()) == 0.0
