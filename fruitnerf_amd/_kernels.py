@@ -149,15 +149,18 @@ def prop_density_fwd(net: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, eucli
     return density, feats
 
 
-def hash_encode_fwd(grid: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int):
+def hash_encode_fwd(grid: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
+                    want_jacobian: bool = False):
+    """-> feats [L,N,2], selector [N] (+ the input Jacobian [L,3,N,2] for position_grad_from_jacobian)."""
     lib = L.load()
     dev = rays.device
     N = rays.n * S
     feats = torch.empty(grid.n_levels, N, 2, device=dev)
     selector = torch.empty(N, dtype=torch.uint8, device=dev)
+    jac = torch.empty(grid.n_levels, 3, N, 2, device=dev) if want_jacobian else None
     L.check(lib.fnr_hash_encode_fwd(C.byref(grid), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(feats),
-                                    L.ptr(selector), L.stream_ptr(dev)), "hash_encode_fwd")
-    return feats, selector
+                                    L.ptr(selector), L.ptr(jac), L.stream_ptr(dev)), "hash_encode_fwd")
+    return (feats, selector, jac) if want_jacobian else (feats, selector)
 
 
 class LatticeArg:
@@ -381,6 +384,15 @@ def hash_encode_input_grad(grid: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, eu
     L.check(lib.fnr_hash_encode_input_grad(C.byref(grid), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
                                            L.ptr(partial), L.stream_ptr(rays.device)), "hash_encode_input_grad")
     return partial
+
+
+def position_grad_from_jacobian(warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int, jacobian: Tensor,
+                                d_feats: Tensor, d_origins: Tensor, d_directions: Tensor) -> None:
+    """d_origins / d_directions [R,3] += ray gradient of d_feats [L,N,2] through the saved Jacobian [L,3,N,2]."""
+    lib = L.load()
+    L.check(lib.fnr_position_grad_from_jacobian(C.byref(warp), rays.ref, L.ptr(euclid), S, jacobian.shape[0],
+                                                L.ptr(jacobian), L.ptr(d_feats), L.ptr(d_origins), L.ptr(d_directions),
+                                                L.stream_ptr(rays.device)), "position_grad_from_jacobian")
 
 
 def position_grad_reduce(warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int, partial: Tensor, d_origins: Tensor,

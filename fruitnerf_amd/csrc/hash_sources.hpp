@@ -36,6 +36,16 @@ struct LatticeSource {
   }
 };
 
+// d(feature . g)/d(offset) for the oracle's blend (grid_interp): weights are products of o (ceil side) or 1 - o
+// (floor side) per axis, corner order h0..h7 = ccc, cfc, ffc, fcc, ccf, cff, fff, fcf
+__device__ __forceinline__ void blend_input_grad(const float (&d)[8], const float (&o)[3], float (&g)[3]) {
+  const float ox = o[0], oy = o[1], oz = o[2];
+  const float mx = 1.0f - ox, my = 1.0f - oy, mz = 1.0f - oz;
+  g[0] = oz * (oy * (d[0] - d[3]) + my * (d[1] - d[2])) + mz * (oy * (d[4] - d[7]) + my * (d[5] - d[6]));
+  g[1] = oz * (ox * (d[0] - d[1]) + mx * (d[3] - d[2])) + mz * (ox * (d[4] - d[5]) + mx * (d[7] - d[6]));
+  g[2] = oy * (ox * (d[0] - d[4]) + mx * (d[3] - d[7])) + my * (ox * (d[1] - d[5]) + mx * (d[2] - d[6]));
+}
+
 // workgroup -> (level, sample block) of the (sample, level) kernels
 __device__ __forceinline__ void decode_block(int b, int L, long long nsb, int& level, long long& sb) {
   if ((L & 7) == 0) {

@@ -22,7 +22,8 @@ constexpr int ENC_SPT = 2;  // samples per thread: 16 independent 8-byte gathers
 
 template <class Source>
 __global__ __launch_bounds__(256) void k_hash_encode(GridDev grid, Warp warp, Source src, long long N,
-                                                     float2* __restrict__ feats, uint8_t* __restrict__ selector) {
+                                                     float2* __restrict__ feats, uint8_t* __restrict__ selector,
+                                                     float2* __restrict__ jac) {
   const long long nsb = (N + 256 * ENC_SPT - 1) / (256 * ENC_SPT);
   int level;
   long long sb;
@@ -55,12 +56,24 @@ __global__ __launch_bounds__(256) void k_hash_encode(GridDev grid, Warp warp, So
     if (n[u] >= N) continue;
     feats[(size_t)level * N + n[u]] = grid_interp(v[u], o[u]);
     if (level == 0 && selector) selector[n[u]] = sel[u] ? 1 : 0;
+    if (jac) {
+      // input Jacobian for the ray gradients (position_grad.hip): d feat_f / d x_a = scaling * d(blend)/d(offset_a)
+      // of the corner values, zero outside the unit cube (positions * selector)
+      float dx[8], dy[8], gx[3], gy[3];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dx[k] = v[u][k].x, dy[k] = v[u][k].y;
+      blend_input_grad(dx, o[u], gx);
+      blend_input_grad(dy, o[u], gy);
+      const float s = sel[u] ? (float)scaling : 0.0f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) jac[((size_t)level * 3 + a) * N + n[u]] = make_float2(s * gx[a], s * gy[a]);
+    }
   }
 }
 
 template <class Source>
 static int launch_encode(const fnr_grid* grid, const fnr_warp* warp, const Source& src, long long N, float* feats,
-                         uint8_t* selector, void* stream) {
+                         uint8_t* selector, float* jacobian, void* stream) {
   FNR_CHECK_ARG(grid && warp && feats, "hash_encode: null argument");
   FNR_CHECK_ARG(grid->n_levels >= 1 && grid->n_levels <= FNR_MAX_LEVELS, "hash_encode: n_levels %d out of range",
                 grid->n_levels);
@@ -72,7 +85,8 @@ static int launch_encode(const fnr_grid* grid, const fnr_warp* warp, const Sourc
   constexpr int prof_op = std::is_same<Source, LatticeSource>::value ? OP_ENCODE_LATTICE : OP_ENCODE_FWD;
   FNR_PROF(prof_op, N);
   hipLaunchKernelGGL((k_hash_encode<Source>), dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), make_grid(grid),
-                     make_warp(warp), src, N, reinterpret_cast<float2*>(feats), selector);
+                     make_warp(warp), src, N, reinterpret_cast<float2*>(feats), selector,
+                     reinterpret_cast<float2*>(jacobian));
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }
@@ -117,10 +131,11 @@ __global__ __launch_bounds__(256) void k_prop_density(GridDev grid, Warp warp, R
 using namespace fnr;
 
 extern "C" int fnr_hash_encode_fwd(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays,
-                                   const float* euclid_bins, int S, float* feats, uint8_t* selector, void* stream) {
+                                   const float* euclid_bins, int S, float* feats, uint8_t* selector, float* jacobian,
+                                   void* stream) {
   FNR_CHECK_ARG(rays && euclid_bins && S > 0, "hash_encode_fwd: null rays/bins or S<=0");
   RaySource src{make_rays(rays), euclid_bins, S};
-  return launch_encode(grid, warp, src, rays->n_rays * (long long)S, feats, selector, stream);
+  return launch_encode(grid, warp, src, rays->n_rays * (long long)S, feats, selector, jacobian, stream);
 }
 
 extern "C" int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fnr_lattice* lat,
@@ -131,7 +146,7 @@ extern "C" int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* war
                 "hash_encode_lattice: ray range [%lld,+%lld) outside %d x %d lattice", (long long)ray_begin,
                 (long long)n_rays, lat->n_x, lat->n_y);
   LatticeSource src{lat->xs, lat->ys, lat->zs, lat->n_y, lat->n_z, ray_begin};
-  return launch_encode(grid, warp, src, n_rays * (long long)lat->n_z, feats, selector, stream);
+  return launch_encode(grid, warp, src, n_rays * (long long)lat->n_z, feats, selector, nullptr, stream);
 }
 
 extern "C" int fnr_prop_density_fwd(const fnr_prop_net* net, const fnr_warp* warp, const fnr_rays* rays,

@@ -5,26 +5,18 @@
 // rays the camera-pose optimiser consumes (fruit_nerf_config.py:39-43).  The sampler's bins are detached
 // (PDFSampler), SHEncoding runs under no_grad and the semantic branch sees detached geo features, so the ONLY path
 // to the rays is  p = o + d (t0 + t1)/2  ->  x(p)  ->  trilinear offsets of every level.
-//   k_hash_input_grad   thread = (sample, level), same XCD-aware map as the forward encode: re-gathers the 8 corner
-//                       rows and contracts d feat with d(blend weights)/d(offset) * scaling -> partial [L][N] float4;
-//   k_position_reduce   wave = ray: sums the levels, applies the transposed Jacobian of the contraction (or of the
-//                       AABB normalisation) and reduces over the ray's samples into d_origins / d_directions (+=).
-// HBM/L2-bound like the forward encode (1024 B of table rows per sample) + 2 x 16 B x L per sample of partials.
+//   main field: the forward encode (k_hash_encode) already holds the 8 corner rows of every (sample, level), so in
+//     training it also stores the input Jacobian J = scaling * d(blend)/d(offset) (6 floats per sample and level);
+//     k_position_from_jacobian (wave = ray, lane = sample) contracts it with d_feats, applies the transposed Jacobian
+//     of the contraction (or AABB normalisation) and of p = o + d t, and reduces over the ray — 24 B written + 32 B
+//     read per (sample, level) instead of re-gathering 64 B of random table rows (105 us -> ~25 us per step);
+//   proposal nets: k_prop_bwd re-gathers (5 levels, tables L2-resident) and k_position_reduce finishes;
+//   k_hash_input_grad + k_position_reduce remain as the gather-based path for callers without a saved Jacobian.
 #include "hash_sources.hpp"
 
 namespace fnr {
 
 constexpr int PG_SPT = 2;  // samples per thread (gathers in flight), as in k_hash_encode
-
-// d(feature . g)/d(offset) for the oracle's blend (grid_interp): weights are products of o (ceil side) or 1 - o
-// (floor side) per axis, corner order h0..h7 = ccc, cfc, ffc, fcc, ccf, cff, fff, fcf
-__device__ __forceinline__ void blend_input_grad(const float (&d)[8], const float (&o)[3], float (&g)[3]) {
-  const float ox = o[0], oy = o[1], oz = o[2];
-  const float mx = 1.0f - ox, my = 1.0f - oy, mz = 1.0f - oz;
-  g[0] = oz * (oy * (d[0] - d[3]) + my * (d[1] - d[2])) + mz * (oy * (d[4] - d[7]) + my * (d[5] - d[6]));
-  g[1] = oz * (ox * (d[0] - d[1]) + mx * (d[3] - d[2])) + mz * (ox * (d[4] - d[5]) + mx * (d[7] - d[6]));
-  g[2] = oy * (ox * (d[0] - d[4]) + mx * (d[3] - d[7])) + my * (ox * (d[1] - d[5]) + mx * (d[2] - d[6]));
-}
 
 template <class Source>
 __global__ __launch_bounds__(256) void k_hash_input_grad(GridDev grid, Warp warp, Source src, long long N,
@@ -140,9 +132,88 @@ __global__ __launch_bounds__(256) void k_position_reduce(Warp warp, RaysDev rays
   }
 }
 
+// wave = ray, lane = sample: d(loss)/d(unit-cube position) = sum over levels and features of gf * J, with the input
+// Jacobian J [L][3][N] float2 (axis-major, feature pair) saved by the forward encode — no table gathers in the
+// backward pass; then the same warp / frustum chain as k_position_reduce.
+__global__ __launch_bounds__(256) void k_position_from_jacobian(Warp warp, RaysDev rays, const float* __restrict__ euclid,
+                                                                int S, int n_levels, const float2* __restrict__ jac,
+                                                                const float2* __restrict__ d_feats,
+                                                                float* __restrict__ d_origins,
+                                                                float* __restrict__ d_directions) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= rays.n_rays) return;
+  const long long N = rays.n_rays * (long long)S;
+  const float* o = rays.origins + 3 * r;
+  const float* d = rays.directions + 3 * r;
+  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+  for (int k = lane; k < S; k += 64) {
+    const long long n = r * S + k;
+    float g[3] = {0.f, 0.f, 0.f};
+    int l = 0;
+    for (; l + 4 <= n_levels; l += 4) {  // 16 independent loads in flight (the plain loop is one latency per level)
+      float2 gf[4], j[4][3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        gf[q] = d_feats[(size_t)(l + q) * N + n];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) j[q][a] = jac[((size_t)(l + q) * 3 + a) * N + n];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[a] += gf[q].x * j[q][a].x + gf[q].y * j[q][a].y;
+    }
+    for (; l < n_levels; ++l) {
+      const float2 gf = d_feats[(size_t)l * N + n];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float2 j = jac[((size_t)l * 3 + a) * N + n];
+        g[a] += gf.x * j.x + gf.y * j.y;
+      }
+    }
+    const float* b = euclid + r * (S + 1) + k;
+    const float tm = (b[0] + b[1]) * 0.5f;
+    float p[3];
+    ray_position(o, d, b[0], b[1], p[0], p[1], p[2]);
+    warp_backward(warp, p, g);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      go[a] += g[a];
+      gd[a] += tm * g[a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    go[a] = wave_sum(go[a]);
+    gd[a] = wave_sum(gd[a]);
+  }
+  if (lane < 3) {
+    const float vo = (lane == 0) ? go[0] : (lane == 1) ? go[1] : go[2];
+    const float vd = (lane == 0) ? gd[0] : (lane == 1) ? gd[1] : gd[2];
+    d_origins[3 * r + lane] += vo;
+    d_directions[3 * r + lane] += vd;
+  }
+}
+
 }  // namespace fnr
 
 using namespace fnr;
+
+extern "C" int fnr_position_grad_from_jacobian(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,
+                                               int n_levels, const float* jacobian, const float* d_feats,
+                                               float* d_origins, float* d_directions, void* stream) {
+  FNR_CHECK_ARG(warp && rays && euclid_bins && jacobian && d_feats && d_origins && d_directions && S > 0 && n_levels >= 1,
+                "position_grad_from_jacobian: null argument");
+  if (rays->n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_POSITION_GRAD, rays->n_rays * (long long)S);
+  hipLaunchKernelGGL(k_position_from_jacobian, dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     make_warp(warp), make_rays(rays), euclid_bins, S, n_levels, reinterpret_cast<const float2*>(jacobian),
+                     reinterpret_cast<const float2*>(d_feats), d_origins, d_directions);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
 
 extern "C" int fnr_hash_encode_input_grad(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays,
                                           const float* euclid_bins, int S, const float* d_feats, float* partial,

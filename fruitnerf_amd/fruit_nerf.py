@@ -168,6 +168,7 @@ class RenderContext:
     sample_logit: Optional[Tensor] = None
     sample_density: Optional[Tensor] = None
     weights: Optional[Tensor] = None
+    field_jacobian: Optional[Tensor] = None  # d feats / d(unit-cube position) [L,3,N,2] when the rays want gradients
     ray_bundle: Optional[object] = None   # the caller's RayBundle (its origins / directions may carry autograd history)
 
 
@@ -308,7 +309,8 @@ class FruitModel(nn.Module):
         return ray_bundle
 
     # ---- the hot path ----------------------------------------------------------------------------------------
-    def _render(self, ray_bundle: RayBundle, jitter: Optional[List[Tensor]] = None) -> Tuple[Dict, RenderContext]:
+    def _render(self, ray_bundle: RayBundle, jitter: Optional[List[Tensor]] = None,
+                save_input_jacobian: bool = False) -> Tuple[Dict, RenderContext]:
         """ProposalNetworkSampler.generate_ray_samples + field + weights + renderers (fruit_nerf.py:316-357)."""
         self.arena()
         cfg = self.config
@@ -346,7 +348,11 @@ class FruitModel(nn.Module):
 
         fld = self.field
         net = fld.net_struct()
-        feats, selector = K.hash_encode_fwd(net.grid, fld.warp_struct(), rays, euclid, S)
+        # rays with autograd history (camera-pose optimisation) need the encode's input Jacobian in the backward pass
+        want_jac = training and (save_input_jacobian or ray_bundle.origins.requires_grad
+                                 or ray_bundle.directions.requires_grad)
+        enc = K.hash_encode_fwd(net.grid, fld.warp_struct(), rays, euclid, S, want_jacobian=want_jac)
+        feats, selector, jac = enc if want_jac else (enc[0], enc[1], None)
         mean_emb = fld._mean_embedding() if fld._uses_mean_embedding() else None
         if mean_emb is None and rays.cam is None:
             raise AttributeError("Camera indices are not provided.")
@@ -359,6 +365,7 @@ class FruitModel(nn.Module):
                             weights=weights)
         ctx.labels = label[:, None]
         ctx.ray_bundle = ray_bundle
+        ctx.field_jacobian = jac
         outputs = {"rgb": out_rgb, "accumulation": acc[:, None], "depth": depth[:, None],
                    "semantics": sem[:, None]}
         for i in range(n_prop):

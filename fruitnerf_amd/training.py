@@ -39,6 +39,10 @@ def _field_ray_grads(model, rctx, d_feats: Tensor, d_origins: Tensor, d_directio
     the losses to the rays — PDFSampler detaches its bins, SHEncoding runs under no_grad."""
     fld = model.field
     lv = rctx.levels[-1]
+    if rctx.field_jacobian is not None:   # saved by the forward encode: no table gathers here
+        K.position_grad_from_jacobian(fld.warp_struct(), rctx.rays, lv["euclid"], lv["S"], rctx.field_jacobian, d_feats,
+                                      d_origins, d_directions)
+        return
     partial = K.hash_encode_input_grad(fld.net_struct().grid, fld.warp_struct(), rctx.rays, lv["euclid"], lv["S"], d_feats)
     K.position_grad_reduce(fld.warp_struct(), rctx.rays, lv["euclid"], lv["S"], partial, d_origins, d_directions)
 
@@ -345,7 +349,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
     dev = model.device
     with torch.no_grad():
         ray_bundle = model._collide(ray_bundle)
-        outputs, rctx = model._render(ray_bundle, jitter)
+        outputs, rctx = model._render(ray_bundle, jitter, save_input_jacobian=ray_grads is not None)
         rays, fin = rctx.rays, rctx.levels[-1]
         S = fin["S"]
         image, mask = batch["image"].to(dev), batch["fruit_mask"].to(dev)

@@ -181,9 +181,11 @@ int fnr_prop_density_fwd(const fnr_prop_net* net, const fnr_warp* warp, const fn
 
 /* ---- main field ----------------------------------------------------------------------------- */
 /* HashEncoding forward of FruitField.get_density (fruit_field.py:168-186) at the bin midpoints.
- * feats: [L][N][2] (level-major), selector: [N] bytes (the 0<x<1 mask, fruit_field.py:178). */
+ * feats: [L][N][2] (level-major), selector: [N] bytes (the 0<x<1 mask, fruit_field.py:178).
+ * jacobian (optional) [L][3][N][2]: d feats / d(unit-cube position), kept for fnr_position_grad_from_jacobian when
+ * the rays carry gradients (camera-pose optimisation). */
 int fnr_hash_encode_fwd(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins,
-                        int S, float* feats, uint8_t* selector, void* stream);
+                        int S, float* feats, uint8_t* selector, float* jacobian, void* stream);
 
 /* Same on the orthographic export lattice (data/fruit_datamanager.py:71-121,157-172;
  * components/ray_generators.py:46-66; components/ray_samplers.py:76-94): sample n of the batch is
@@ -297,6 +299,11 @@ int fnr_hash_encode_input_grad(const fnr_grid* grid, const fnr_warp* warp, const
 int fnr_position_grad_reduce(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,
                              int n_levels, const float* partial, float* d_origins, float* d_directions,
                              void* stream);
+/* Same result from the Jacobian fnr_hash_encode_fwd saved: d_origins / d_directions [R,3] += the ray gradient of
+ * d_feats [L][N][2] (no table gathers in the backward pass). */
+int fnr_position_grad_from_jacobian(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,
+                                    int n_levels, const float* jacobian, const float* d_feats, float* d_origins,
+                                    float* d_directions, void* stream);
 
 /* torch.optim.Adam step (no amsgrad; fruit_nerf_config.py:47-56) over a flat arena of n floats (n % 4 == 0); the
  * gradient is multiplied by grad_scale first (1/world_size after an all-reduce(SUM)), weight_decay is torch's L2 form

@@ -227,6 +227,37 @@ def test_level_group_scatter_matches_single_scatter(dev, monkeypatch):
     assert int((grads[0] != 0).sum()) == int((grads[1] != 0).sum())
 
 
+def test_ray_gradient_paths_agree(dev):
+    """The saved-Jacobian path (forward encode stores d feats / d x) and the gather path (backward re-reads the table)
+    of the hash grid's input gradient give the same ray gradients."""
+    from fruitnerf_amd import _kernels as K
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    torch.manual_seed(0)
+    m = FruitModel(FruitNerfModelConfig(log2_hashmap_size=15), num_train_data=4, device=dev)
+    with torch.no_grad():
+        m.field.mlp_base_grid.hash_table.uniform_(-0.5, 0.5)
+    m.train()
+    m.arena()
+    fld = m.field
+    R, S = 96, 48
+    o, d, pa, cam = util.random_rays(R, 4, seed=2)
+    rays = K.RaysArg(o.to(dev), d.to(dev), torch.full((R, 1), 0.05, device=dev), torch.full((R, 1), 6.0, device=dev),
+                     cam.to(dev))
+    _, eu = K.sample_spaced(rays, 1, S, None)
+    net = fld.net_struct()
+    feats, sel, jac = K.hash_encode_fwd(net.grid, fld.warp_struct(), rays, eu, S, want_jacobian=True)
+    d_feats = torch.randn_like(feats)
+    a = [torch.zeros(R, 3, device=dev) for _ in range(2)]
+    b = [torch.zeros(R, 3, device=dev) for _ in range(2)]
+    K.position_grad_from_jacobian(fld.warp_struct(), rays, eu, S, jac, d_feats, a[0], a[1])
+    partial = K.hash_encode_input_grad(net.grid, fld.warp_struct(), rays, eu, S, d_feats)
+    K.position_grad_reduce(fld.warp_struct(), rays, eu, S, partial, b[0], b[1])
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert float(y.abs().max()) > 0
+        assert float((x - y).abs().max()) <= 1e-4 * float(y.abs().max())
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_ray_gradients_match_autograd(dev, fused):
     """d(loss)/d(origins), d(loss)/d(directions): the gradient a camera-pose optimiser consumes
