@@ -150,21 +150,7 @@ __global__ __launch_bounds__(256) void k_position_from_jacobian(Warp warp, RaysD
   for (int k = lane; k < S; k += 64) {
     const long long n = r * S + k;
     float g[3] = {0.f, 0.f, 0.f};
-    int l = 0;
-    for (; l + 4 <= n_levels; l += 4) {  // 16 independent loads in flight (the plain loop is one latency per level)
-      float2 gf[4], j[4][3];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        gf[q] = d_feats[(size_t)(l + q) * N + n];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) j[q][a] = jac[((size_t)(l + q) * 3 + a) * N + n];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) g[a] += gf[q].x * j[q][a].x + gf[q].y * j[q][a].y;
-    }
-    for (; l < n_levels; ++l) {
+    for (int l = 0; l < n_levels; ++l) {
       const float2 gf = d_feats[(size_t)l * N + n];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
