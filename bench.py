@@ -303,6 +303,8 @@ def main() -> None:
             cam_off = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
             camera = saved
         secondary = {"train_rays_per_s_camera_optimizer_off": cam_off,
+                     "train_rays_per_s_camera_optimizer_off_note": f"100 steps measured after step {step_idx[0] - 100} "
+                     "(proposal nets are updated less often by then than in the headline window)",
                      "eval_rays_per_s": round(HW * HW / eval_s, 1), "eval_image": f"{HW}x{HW}, chunks of 32768 rays",
                      "export_samples_per_s": round(n_rays * N_EXP / exp_s, 1), "export_lattice": f"{N_EXP}^3",
                      "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()}}
