@@ -366,6 +366,25 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         # ---- backward (what loss.backward() runs through _LossFn, _RenderFn, _InterlevelFn) ----
         arena = model.arena()
         arena.reattach_grads()
+        d_o = d_d = None
+        if ray_grads is not None:
+            d_o = ray_grads["origins"] = torch.zeros(rays.n, 3, device=dev)
+            d_d = ray_grads["directions"] = torch.zeros(rays.n, 3, device=dev)
+        # The proposal-network backward (interlevel loss) and the field backward (rgb + semantic losses) share no
+        # buffers: the former runs on a second HIP stream, so its ~14 small/medium launches fill the gaps and tails of
+        # the MFMA- and LDS-bound field kernels instead of queueing behind them.
+        main = torch.cuda.current_stream(dev)
+        side = None
+        if rctx.training and rctx.updated:
+            side = model.__dict__.get("_side_stream")
+            if side is None or side.device != dev:
+                side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+            up = model.__dict__.get("_unit_upstream")
+            if up is None or up.device != dev:
+                up = model.__dict__["_unit_upstream"] = torch.ones(1, device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
         d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
                                                       rctx.weights, d_rgb, d_sem)
         fld = model.field
@@ -382,16 +401,10 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, lb, cnt)
                 exchange.levels_done(lb, cnt)      # this slice of the gradient table is final: all-reduce it now
             exchange.field_done()
-        d_o = d_d = None
+        if side is not None:
+            main.wait_stream(side)                 # proposal gradients (and their share of the ray gradients) are final
         if ray_grads is not None:
-            d_o = ray_grads["origins"] = torch.zeros(rays.n, 3, device=dev)
-            d_d = ray_grads["directions"] = torch.zeros(rays.n, 3, device=dev)
-            _field_ray_grads(model, rctx, d_feats, d_o, d_d)
-        if rctx.training and rctx.updated:
-            up = model.__dict__.get("_unit_upstream")
-            if up is None or up.device != dev:
-                up = model.__dict__["_unit_upstream"] = torch.ones(1, device=dev)
-            _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
+            _field_ray_grads(model, rctx, d_feats, d_o, d_d)   # after the join: both chains add into d_o / d_d
     return loss_dict, metrics_dict
 
 
