@@ -316,6 +316,8 @@ class FruitModel(nn.Module):
         cfg = self.config
         sampler = self.proposal_sampler
         training = self.training
+        if ray_bundle.origins.shape[0] == 0:  # empty batch: nothing to launch (zero-size tensors have no storage)
+            return self._empty_render(ray_bundle)
         rays = K.RaysArg(ray_bundle.origins, ray_bundle.directions, ray_bundle.nears, ray_bundle.fars,
                          ray_bundle.camera_indices)
         dev = rays.device
@@ -370,6 +372,22 @@ class FruitModel(nn.Module):
                    "semantics": sem[:, None]}
         for i in range(n_prop):
             outputs[f"prop_depth_{i}"] = levels[i]["depth"][:, None]
+        return outputs, ctx
+
+    def _empty_render(self, ray_bundle: RayBundle) -> Tuple[Dict, RenderContext]:
+        dev = ray_bundle.origins.device
+        sampler = self.proposal_sampler
+        n_prop = sampler.num_proposal_network_iterations
+        counts = list(sampler.num_proposal_samples_per_ray[:n_prop]) + [sampler.num_nerf_samples_per_ray]
+        z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        levels = [dict(S=S, spacing=z(0, S + 1), euclid=z(0, S + 1), density=z(0, S), weights=z(0, S), depth=z(0),
+                       feats=None) for S in counts]
+        ctx = RenderContext(rays=None, levels=levels, updated=False, training=self.training)
+        ctx.labels = z(0, 1, dtype=torch.long)
+        ctx.ray_bundle = ray_bundle
+        outputs = {"rgb": z(0, 3), "accumulation": z(0, 1), "depth": z(0, 1), "semantics": z(0, 1)}
+        for i in range(n_prop):
+            outputs[f"prop_depth_{i}"] = z(0, 1)
         return outputs, ctx
 
     def _samples_lists(self, ray_bundle: RayBundle, ctx: RenderContext):
