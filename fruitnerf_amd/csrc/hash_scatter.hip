@@ -12,7 +12,8 @@
 //                 dense E-row tile to the gradient table with plain coalesced read-modify-writes (it is the
 //                 only writer of those rows).
 // Queue overflow (a pathologically hot bin) falls back to global atomics in step 1, so results never depend on
-// the capacity heuristic.  HBM-bound: 16 B written + read per contribution instead of two serialized atomics.
+// the capacity heuristic.  HBM-bound: 10 B written + read per contribution (value pair + 16-bit row) instead of two
+// serialized atomics.
 #include "hash_sources.hpp"
 
 namespace fnr {
@@ -33,7 +34,8 @@ struct ScatterPlan {
   int log2_rows;         // log2(E)
   int bins_per_level;    // T / E
   long long cap;         // queue capacity per bin (records)
-  size_t count_bytes, queue_bytes;
+  size_t count_bytes, queue_bytes;  // queue = values float2 [nbins][cap] followed by rows uint16 [nbins][cap]
+  size_t value_bytes;
 };
 
 static ScatterPlan scatter_plan(long long N, int n_levels, int log2_T) {
@@ -48,7 +50,9 @@ static ScatterPlan scatter_plan(long long N, int n_levels, int log2_T) {
   if (p.cap < 1024) p.cap = 1024;
   const size_t nbins = (size_t)n_levels * p.bins_per_level;
   p.count_bytes = 2 * nbins * SC_CNT_STRIDE * sizeof(unsigned);  // [nbins] counts + [nbins] max |v| bits, padded
-  p.queue_bytes = nbins * (size_t)p.cap * sizeof(float4);
+  // 10 bytes per record in HBM (8-byte value pair + 16-bit row inside the bin; rows per bin <= 8192)
+  p.value_bytes = nbins * (size_t)p.cap * sizeof(float2);
+  p.queue_bytes = p.value_bytes + (nbins * (size_t)p.cap * sizeof(unsigned short) + 255) / 256 * 256;
   return p;
 }
 
@@ -127,8 +131,8 @@ __device__ __forceinline__ float run_sum(float v, const RunMasks& m) {
 
 template <class Source>
 __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, Warp warp, Source src, long long N,
-                                                      const float2* __restrict__ d_feats, float4* __restrict__ queue,
-                                                      unsigned* __restrict__ qcount, unsigned* __restrict__ qmax,
+                                                      const float2* __restrict__ d_feats, float2* __restrict__ queue_v,
+                                                      unsigned short* __restrict__ queue_r, unsigned* __restrict__ qcount, unsigned* __restrict__ qmax,
                                                       long long cap, int log2_rows, int level0) {
   // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs
   __shared__ float4 s_rec[SC_CHUNK * 8];
@@ -238,14 +242,16 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     }
   }
   __syncthreads();
-  // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 16-byte stores)
+  // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 8-byte + 2-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
   for (unsigned i = threadIdx.x; i < total; i += SC_EMIT_THREADS) {
     const float4 r = s_rec[i];
     const unsigned bin = __float_as_uint(r.w);
     const unsigned slot = s_base[bin] + (i - s_off[bin]);
     if ((long long)slot < cap) {
-      queue[((size_t)lrel * bins + bin) * cap + slot] = r;
+      const size_t q = ((size_t)lrel * bins + bin) * cap + slot;
+      queue_v[q] = make_float2(r.y, r.z);
+      queue_r[q] = (unsigned short)__float_as_uint(r.x);
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
       const size_t row = ((size_t)bin << log2_rows) + __float_as_uint(r.x);
       atomicAdd(table + 2 * row, r.y);
@@ -260,14 +266,15 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
 // |value| queued for it (tracked by the emit kernel) and the record count so that the sum cannot overflow:
 // resolution = max|v| * 2^-41 or better, i.e. finer than fp32 rounding of any partial sum that contains the
 // largest term; exact and order-independent (bitwise deterministic) above that resolution.
-__device__ __forceinline__ void acc_record(unsigned long long* __restrict__ s_acc, const float4& r, double scale) {
-  const unsigned row = __float_as_uint(r.x);
-  const long long ix = __double2ll_rn((double)r.y * scale), iy = __double2ll_rn((double)r.z * scale);
+__device__ __forceinline__ void acc_record(unsigned long long* __restrict__ s_acc, unsigned row, const float2& v,
+                                           double scale) {
+  const long long ix = __double2ll_rn((double)v.x * scale), iy = __double2ll_rn((double)v.y * scale);
   atomicAdd(&s_acc[2 * row], (unsigned long long)ix);
   atomicAdd(&s_acc[2 * row + 1], (unsigned long long)iy);
 }
 
-__global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float4* __restrict__ queue,
+__global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float2* __restrict__ queue_v,
+                                                             const unsigned short* __restrict__ queue_r,
                                                              const unsigned* __restrict__ qcount,
                                                              const unsigned* __restrict__ qmax, long long cap,
                                                              int log2_rows, int level0) {
@@ -291,19 +298,21 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   const double scale = ldexp(1.0, S), inv = ldexp(1.0, -S);
   for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0ull;
   __syncthreads();
-  const float4* qb = queue + (size_t)gbin * cap;
+  const float2* qv = queue_v + (size_t)gbin * cap;
+  const unsigned short* qr = queue_r + (size_t)gbin * cap;
   long long i = threadIdx.x;
-  for (; i + 3 * (long long)blockDim.x < n; i += 4 * (long long)blockDim.x) {  // 4 loads in flight per thread
-    float4 r[4];
+  for (; i + 3 * (long long)blockDim.x < n; i += 4 * (long long)blockDim.x) {  // 8 loads in flight per thread
+    float2 v[4];
+    unsigned row[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) r[u] = qb[i + u * (long long)blockDim.x];
+    for (int u = 0; u < 4; ++u) {
+      v[u] = qv[i + u * (long long)blockDim.x];
+      row[u] = qr[i + u * (long long)blockDim.x];
+    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc_record(s_acc, r[u], scale);
+    for (int u = 0; u < 4; ++u) acc_record(s_acc, row[u], v[u], scale);
   }
-  for (; i < n; i += blockDim.x) {
-    const float4 r = qb[i];
-    acc_record(s_acc, r, scale);
-  }
+  for (; i < n; i += blockDim.x) acc_record(s_acc, qr[i], qv[i], scale);
   __syncthreads();
   float2* dst = grid.table + ((size_t)level << grid.log2_T) + (size_t)bin * rows;
   for (int e2 = threadIdx.x; e2 < rows; e2 += blockDim.x) {
@@ -328,7 +337,8 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
                 grid_grad->log2_hashmap_size);
   FNR_CHECK_ARG(workspace && workspace_bytes >= p.count_bytes + p.queue_bytes, "hash scatter: workspace too small");
   unsigned* qcount = reinterpret_cast<unsigned*>(workspace);
-  float4* queue = reinterpret_cast<float4*>(reinterpret_cast<char*>(workspace) + p.count_bytes);
+  float2* queue_v = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + p.count_bytes);
+  unsigned short* queue_r = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + p.count_bytes + p.value_bytes);
   FNR_HIP(hipMemsetAsync(qcount, 0, p.count_bytes, st));
   const size_t nbins_all = (size_t)level_count * p.bins_per_level;
   const long long chunks = (N + SC_CHUNK - 1) / SC_CHUNK;
@@ -337,11 +347,12 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
   for (int l = 0; l < grid_grad->n_levels; ++l)
     FNR_CHECK_ARG(gd.scalings[l] > 0 && gd.scalings[l] < 65535, "hash scatter: level resolution %d out of range", gd.scalings[l]);
   hipLaunchKernelGGL((k_scatter_emit<Source>), dim3((unsigned)chunks, (unsigned)level_count), dim3(SC_EMIT_THREADS), 0, st,
-                     gd, warp, src, N, d_feats, queue, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows, level0);
+                     gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows,
+                     level0);
   FNR_LAUNCH_CHECK();
   const unsigned nbins = (unsigned)(level_count * p.bins_per_level);
   hipLaunchKernelGGL(k_scatter_accumulate, dim3(nbins), dim3(1024), 0, st, gd,
-                     queue, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows, level0);
+                     queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows, level0);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

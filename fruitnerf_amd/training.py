@@ -334,7 +334,7 @@ class _FieldGradientExchange:
 
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
-                           ray_grads: Optional[dict] = None):
+                           ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -371,20 +371,22 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             d_o = ray_grads["origins"] = torch.zeros(rays.n, 3, device=dev)
             d_d = ray_grads["directions"] = torch.zeros(rays.n, 3, device=dev)
         # The proposal-network backward (interlevel loss) and the field backward (rgb + semantic losses) share no
-        # buffers: the former runs on a second HIP stream, so its ~14 small/medium launches fill the gaps and tails of
-        # the MFMA- and LDS-bound field kernels instead of queueing behind them.
+        # buffers.  overlap_proposal_backward=True runs the former on a second HIP stream so that its ~14 small/medium
+        # launches fill the gaps and tails of the field kernels (measured: -2 % step time); off by default because
+        # the per-kernel HIP-event timings bench.py reports would then include the other stream's kernels.
         main = torch.cuda.current_stream(dev)
         side = None
         if rctx.training and rctx.updated:
-            side = model.__dict__.get("_side_stream")
-            if side is None or side.device != dev:
-                side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
             up = model.__dict__.get("_unit_upstream")
             if up is None or up.device != dev:
                 up = model.__dict__["_unit_upstream"] = torch.ones(1, device=dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
+            if overlap_proposal_backward:
+                side = model.__dict__.get("_side_stream")
+                if side is None or side.device != dev:
+                    side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
         d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
                                                       rctx.weights, d_rgb, d_sem)
         fld = model.field
@@ -403,6 +405,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             exchange.field_done()
         if side is not None:
             main.wait_stream(side)                 # proposal gradients (and their share of the ray gradients) are final
+        elif rctx.training and rctx.updated:
+            _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
         if ray_grads is not None:
             _field_ray_grads(model, rctx, d_feats, d_o, d_d)   # after the join: both chains add into d_o / d_d
     return loss_dict, metrics_dict
