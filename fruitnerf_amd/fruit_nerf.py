@@ -172,6 +172,27 @@ class RenderContext:
     ray_bundle: Optional[object] = None   # the caller's RayBundle (its origins / directions may carry autograd history)
 
 
+def _ssim(a: Tensor, b: Tensor, sigma: float = 1.5, ksize: int = 11, k1: float = 0.01, k2: float = 0.03) -> Tensor:
+    """torchmetrics.functional.structural_similarity_index_measure defaults (gaussian 11x11, sigma 1.5,
+    data_range 1.0): reflect-pad by 5, depthwise gaussian filtering of a, b, a^2, b^2, ab, SSIM map cropped by the
+    pad, mean.  a, b: [1, C, H, W] in [0, 1]."""
+    C_ = a.shape[1]
+    dist = torch.arange((1 - ksize) / 2, (1 + ksize) / 2, 1, device=a.device, dtype=a.dtype)
+    g = torch.exp(-((dist / sigma) ** 2) / 2)
+    g = (g / g.sum())[:, None]
+    kernel = (g @ g.t())[None, None].expand(C_, 1, ksize, ksize)
+    pad = (ksize - 1) // 2
+    ap = torch.nn.functional.pad(a, (pad, pad, pad, pad), mode="reflect")
+    bp = torch.nn.functional.pad(b, (pad, pad, pad, pad), mode="reflect")
+    stack = torch.cat([ap, bp, ap * ap, bp * bp, ap * bp])
+    out = torch.nn.functional.conv2d(stack, kernel, groups=C_)
+    mu_a, mu_b, e_aa, e_bb, e_ab = out.split(a.shape[0])
+    c1, c2 = k1 ** 2, k2 ** 2
+    s_aa, s_bb, s_ab = e_aa - mu_a * mu_a, e_bb - mu_b * mu_b, e_ab - mu_a * mu_b
+    ssim = ((2 * mu_a * mu_b + c1) * (2 * s_ab + c2)) / ((mu_a * mu_a + mu_b * mu_b + c1) * (s_aa + s_bb + c2))
+    return ssim[..., pad:-pad, pad:-pad].mean()
+
+
 class FruitModel(nn.Module):
     config: FruitNerfModelConfig
 
@@ -480,6 +501,37 @@ class FruitModel(nn.Module):
                     continue
                 outputs_lists[output_name].append(output.cpu())
         return {k: torch.cat(v).view(image_height, image_width, -1) for k, v in outputs_lists.items()}
+
+    @torch.no_grad()
+    def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
+        """fruit_nerf.py:403-458 (eval images; not the hot path — plain torch ops on the model's device).
+
+        PSNR and SSIM (torchmetrics defaults: 11x11 gaussian, sigma 1.5, data_range 1) and the reference's IoU, which
+        feeds `softmax(semantics)` over a size-1 class axis (== 1 everywhere) to BinaryJaccardIndex — reproduced as is.
+        Not built: LPIPS (needs pretrained weights; reported as nan) and the matplotlib colormaps of
+        nerfstudio.utils.colormaps (accumulation / depth images are returned as raw single-channel maps)."""
+        dev = self.device
+        image = batch["image"].to(dev)
+        rgb = torch.clamp(outputs["rgb"].to(dev), min=0, max=1)
+        acc = outputs["accumulation"].to(dev)
+        depth = outputs["depth"].to(dev)
+        images_dict = {"img": torch.cat([image, rgb], dim=1), "accumulation": acc, "depth": depth}
+        img_c = torch.moveaxis(image, -1, 0)[None, ...]
+        rgb_c = torch.moveaxis(rgb, -1, 0)[None, ...]
+        mse = torch.mean((img_c - rgb_c) ** 2)
+        psnr = -10.0 * torch.log10(mse)
+        metrics_dict = {"psnr": float(psnr.item()), "ssim": float(_ssim(img_c, rgb_c)), "lpips": float("nan")}
+        for i in range(self.config.num_proposal_iterations):
+            images_dict[f"prop_depth_{i}"] = outputs[f"prop_depth_{i}"].to(dev)
+        images_dict["semantics_colormap"] = torch.sigmoid(outputs["semantics"].to(dev))
+        mask = batch["fruit_mask"].to(dev)
+        images_dict["fruit_mask"] = mask.repeat(1, 1, 3)
+        pred = torch.nn.functional.softmax(outputs["semantics"].to(dev), dim=-1)[..., 0] > 0.5   # all True (quirk)
+        tgt = mask[..., 0] > 0.5
+        inter = (pred & tgt).sum().float()
+        union = (pred | tgt).sum().float()
+        metrics_dict["iou"] = float((inter / union.clamp_min(1.0)).item())
+        return metrics_dict, images_dict
 
     # ---- losses / metrics ----------------------------------------------------------------------------------------
     def get_loss_dict(self, outputs, batch, metrics_dict=None):  # fruit_nerf.py:359-372

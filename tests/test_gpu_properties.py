@@ -135,3 +135,26 @@ def test_adam_leaves_untouched_parameters_alone_and_is_idempotent_on_zero_grad(d
     changed = (arena.params != before).nonzero().flatten()
     assert changed.tolist() == [123456]
     assert float(arena.grads.abs().max()) == 0.0
+
+
+def test_full_image_eval_and_image_metrics(dev):
+    """get_outputs_for_camera_ray_bundle (chunked, CPU outputs [H,W,.]) + get_image_metrics_and_images
+    (fruit_nerf.py:225-249, 403-458) on a small image."""
+    from fruitnerf_amd.rays import RayBundle
+    m = _full_model(dev)
+    m.eval()
+    m.config.eval_num_rays_per_chunk = 500   # several ragged chunks
+    H, W = 24, 40
+    rb = _rays(H * W, dev, seed=12)
+    cam_rb = RayBundle(rb.origins.view(H, W, 3), rb.directions.view(H, W, 3), None, None)
+    out = m.get_outputs_for_camera_ray_bundle(cam_rb)
+    assert out["rgb"].shape == (H, W, 3) and out["rgb"].device.type == "cpu"
+    whole = m(RayBundle(rb.origins, rb.directions, None, None))
+    assert torch.equal(out["rgb"].view(-1, 3), whole["rgb"].cpu())
+    g = torch.Generator().manual_seed(0)
+    batch = {"image": torch.rand(H, W, 3, generator=g), "fruit_mask": (torch.rand(H, W, 1, generator=g) > 0.7).float()}
+    metrics, images = m.get_image_metrics_and_images(out, batch)
+    assert set(metrics) == {"psnr", "ssim", "lpips", "iou"}
+    assert 0 < metrics["psnr"] < 60 and -1 <= metrics["ssim"] <= 1
+    assert abs(metrics["iou"] - float(batch["fruit_mask"].mean())) < 1e-6   # the reference's softmax-over-1-class quirk
+    assert images["img"].shape == (H, 2 * W, 3) and images["fruit_mask"].shape == (H, W, 3)

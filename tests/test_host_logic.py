@@ -187,3 +187,16 @@ def test_ply_sink_roundtrip(tmp_path):
     p2, c2 = ply.read_point_cloud(path)
     assert np.array_equal(p2, pts)
     assert np.array_equal(c2, np.rint(np.clip(cols, 0, 1) * 255) / 255.0)
+
+
+def test_ssim_restatement_basic_properties():
+    """SSIM used by get_image_metrics_and_images: 1 for identical images, symmetric, lower for noisier images."""
+    import torch
+    from fruitnerf_amd.fruit_nerf import _ssim
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(1, 3, 48, 40, generator=g)
+    assert abs(float(_ssim(a, a)) - 1.0) < 1e-6
+    b = (a + 0.05 * torch.randn(a.shape, generator=g)).clamp(0, 1)
+    c = (a + 0.25 * torch.randn(a.shape, generator=g)).clamp(0, 1)
+    assert abs(float(_ssim(a, b)) - float(_ssim(b, a))) < 1e-6
+    assert 0.0 < float(_ssim(a, c)) < float(_ssim(a, b)) < 1.0
