@@ -40,7 +40,7 @@ struct ScatterPlan {
 
 static ScatterPlan scatter_plan(long long N, int n_levels, int log2_T) {
   ScatterPlan p;
-  int log2_rows = log2_T - 6;  // 64 bins per level ...
+  int log2_rows = log2_T - 5;  // at least 32 bins per level (measured best for the 2^17-row proposal tables) ...
   if (log2_rows > 13) log2_rows = 13;  // ... but at most 8192 rows per bin
   if (log2_rows < 0) log2_rows = 0;
   p.log2_rows = log2_rows;
