@@ -348,6 +348,22 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
     return d_feats
 
 
+_SCATTER_WS = {}
+
+
+def _scatter_workspace(dev, nbytes: int, tag: str):
+    """Persistent scatter workspace per (device, stream, size, entry point) -> (buffer, clean flag).  The kernels leave
+    the queue counters zeroed, so after its first use the buffer needs no memset launch (workspace_clean = 1)."""
+    key = (dev.type, dev.index, L.stream_ptr(dev), nbytes, tag)
+    ws = _SCATTER_WS.get(key)
+    if ws is None:
+        if len(_SCATTER_WS) > 32:
+            _SCATTER_WS.clear()
+        ws = _SCATTER_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return ws, 0
+    return ws, 1
+
+
 def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
                     d_feats: Tensor, level_begin: int = 0, level_count: Optional[int] = None) -> None:
     """Scatter the feature gradients of levels [level_begin, level_begin + level_count) (default: all) into the
@@ -356,9 +372,9 @@ def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, eucl
     if level_count is None:
         level_count = grid_grad.n_levels - level_begin
     nbytes = lib.fnr_hash_scatter_workspace_bytes(rays.n * S, level_count, grid_grad.log2_hashmap_size)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=rays.device)
+    ws, clean = _scatter_workspace(rays.device, nbytes, "field")
     L.check(lib.fnr_hash_encode_bwd(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
-                                    level_begin, level_count, L.ptr(ws), nbytes, L.stream_ptr(rays.device)),
+                                    level_begin, level_count, L.ptr(ws), nbytes, clean, L.stream_ptr(rays.device)),
             "hash_encode_bwd")
 
 
@@ -367,10 +383,10 @@ def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_war
     """want_position_grad: also return d(loss)/d(unit-cube position) [N,4] for position_grad_reduce(n_levels=1)."""
     lib = L.load()
     nbytes = lib.fnr_prop_density_bwd_workspace_bytes(rays.n * S, net.grid.n_levels, net.grid.log2_hashmap_size)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=rays.device)
+    ws, clean = _scatter_workspace(rays.device, nbytes, "prop")
     d_pos = torch.empty(rays.n * S, 4, device=rays.device) if want_position_grad else None
     L.check(lib.fnr_prop_density_bwd(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
-                                     L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), L.ptr(ws), nbytes,
+                                     L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), L.ptr(ws), nbytes, clean,
                                      L.stream_ptr(rays.device)),
             "prop_density_bwd")
     return d_pos

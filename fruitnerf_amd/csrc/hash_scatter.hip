@@ -275,8 +275,8 @@ __device__ __forceinline__ void acc_record(unsigned long long* __restrict__ s_ac
 
 __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float2* __restrict__ queue_v,
                                                              const unsigned short* __restrict__ queue_r,
-                                                             const unsigned* __restrict__ qcount,
-                                                             const unsigned* __restrict__ qmax, long long cap,
+                                                             unsigned* __restrict__ qcount,
+                                                             unsigned* __restrict__ qmax, long long cap,
                                                              int log2_rows, int level0) {
   __shared__ unsigned long long s_acc[2 * SC_MAX_ROWS];  // [rows][2] two's-complement fixed point, 128 KiB
   const int rows = 1 << log2_rows;
@@ -287,7 +287,15 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   const int level = level0 + lrel;
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
   const float vmax = __uint_as_float(qmax[(size_t)gbin * SC_CNT_STRIDE]);
-  if (n == 0 || !(vmax > 0.0f)) return;
+  if (n == 0) return;
+  // every thread has its copy: put the counters back to zero, so the NEXT call on this workspace needs no memset
+  // launch (the caller says so with workspace_clean = 1)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    qcount[(size_t)gbin * SC_CNT_STRIDE] = 0u;
+    qmax[(size_t)gbin * SC_CNT_STRIDE] = 0u;
+  }
+  if (!(vmax > 0.0f)) return;
   if (n > cap) n = cap;
   // |v| < 2^e ; n < 2^nb  =>  |sum * 2^S| < 2^62 with S = 62 - nb - e
   int e;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
 template <class Source>
 static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Source& src, long long N,
                           const float2* d_feats, int level0, int level_count, void* workspace, size_t workspace_bytes,
-                          hipStream_t st) {
+                          int workspace_clean, hipStream_t st) {
   FNR_CHECK_ARG(level0 >= 0 && level_count >= 1 && level0 + level_count <= grid_grad->n_levels,
                 "hash scatter: level range [%d,+%d) outside the %d levels", level0, level_count, grid_grad->n_levels);
   const ScatterPlan p = scatter_plan(N, level_count, grid_grad->log2_hashmap_size);
@@ -339,7 +347,7 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
   unsigned* qcount = reinterpret_cast<unsigned*>(workspace);
   float2* queue_v = reinterpret_cast<float2*>(reinterpret_cast<char*>(workspace) + p.count_bytes);
   unsigned short* queue_r = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(workspace) + p.count_bytes + p.value_bytes);
-  FNR_HIP(hipMemsetAsync(qcount, 0, p.count_bytes, st));
+  if (!workspace_clean) FNR_HIP(hipMemsetAsync(qcount, 0, p.count_bytes, st));
   const size_t nbins_all = (size_t)level_count * p.bins_per_level;
   const long long chunks = (N + SC_CHUNK - 1) / SC_CHUNK;
   FNR_CHECK_ARG(chunks < (1ll << 31), "hash scatter: too many samples");
@@ -554,7 +562,8 @@ extern "C" size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_leve
 
 extern "C" int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
                                    const float* euclid_bins, int S, const float* d_feats, int level_begin,
-                                   int level_count, void* workspace, size_t workspace_bytes, void* stream) {
+                                   int level_count, void* workspace, size_t workspace_bytes, int workspace_clean,
+                                   void* stream) {
   FNR_CHECK_ARG(grid_grad && warp && rays && euclid_bins && d_feats && S > 0, "hash_encode_bwd: null argument");
   FNR_CHECK_ARG(grid_grad->n_levels >= 1 && grid_grad->n_levels <= FNR_MAX_LEVELS, "hash_encode_bwd: n_levels");
   const long long N = rays->n_rays * (long long)S;
@@ -562,7 +571,7 @@ extern "C" int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* wa
   RaySource src{make_rays(rays), euclid_bins, S};
   FNR_PROF(OP_ENCODE_BWD, N);
   return binned_scatter(grid_grad, make_warp(warp), src, N, reinterpret_cast<const float2*>(d_feats), level_begin,
-                        level_count, workspace, workspace_bytes, as_stream(stream));
+                        level_count, workspace, workspace_bytes, workspace_clean, as_stream(stream));
 }
 
 extern "C" size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
@@ -574,7 +583,7 @@ extern "C" size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_
 extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
                                     const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
                                     const float* d_density, float* d_position, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    size_t workspace_bytes, int workspace_clean, void* stream) {
   FNR_CHECK_ARG(net && grads && warp && rays && euclid_bins && feat_save && d_density && workspace && S > 0,
                 "prop_density_bwd: null argument");
   FNR_UNSUPPORTED(net->hidden_dim == 16, "prop_density_bwd: hidden_dim %d not built (16 only)", net->hidden_dim);
@@ -625,5 +634,5 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
                      (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1);
   FNR_LAUNCH_CHECK();
   return binned_scatter(&grads->grid, w, src, N, d_feats, 0, L, reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,
-                        workspace_bytes - dfeat_bytes - partial_bytes, as_stream(stream));
+                        workspace_bytes - dfeat_bytes - partial_bytes, workspace_clean, as_stream(stream));
 }

@@ -271,11 +271,14 @@ int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, cons
  * grid_grad->table for the levels [level_begin, level_begin + level_count) (all levels: 0, n_levels; data-parallel
  * training calls it per group of levels so that a group's rows can be all-reduced while the next group is being
  * scattered).  Binned through per-bin queues in `workspace` (>= fnr_hash_scatter_workspace_bytes(n_samples,
- * level_count, log2_hashmap_size)) because global fp32 atomics top out at ~21 G/s on MI355X (hash_scatter.hip). */
+ * level_count, log2_hashmap_size)) because global fp32 atomics top out at ~21 G/s on MI355X (hash_scatter.hip).
+ * workspace_clean: 0 = the library zeroes the queue counters first (any buffer); 1 = the caller passes a buffer whose
+ * last use was a completed call of the same entry point with the same sizes — the kernels leave the counters zeroed,
+ * which saves one memset launch per call. */
 size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size);
 int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
                         const float* euclid_bins, int S, const float* d_feats, int level_begin, int level_count,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        void* workspace, size_t workspace_bytes, int workspace_clean, void* stream);
 
 /* Backward of fnr_prop_density_fwd: d_density [R,S] -> += into grads (table, w0, b0, w1, b1).
  * d_position (optional) [N,4]: gradient w.r.t. each sample's unit-cube position (xyz, w = 0) for
@@ -285,7 +288,7 @@ size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_levels, int
 int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
                          const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
                          const float* d_density, float* d_position, void* workspace, size_t workspace_bytes,
-                         void* stream);
+                         int workspace_clean, void* stream);
 
 /* ---- gradient of the rays (camera-pose optimisation, fruit_nerf_config.py:39-43) ----------------- */
 /* Input gradient of fnr_hash_encode_fwd: partial [L][N][4] = per level d(loss)/d(unit-cube position) of every
