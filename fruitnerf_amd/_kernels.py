@@ -213,13 +213,15 @@ def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, se
     # saved for field_mlp_bwd: base-MLP output [N,16] and the per-ray part of mlp_head's first layer [R,64]
     h = torch.empty(N, 16, device=dev) if want_h else None
     ray_bias = torch.empty(rays.n, 64, device=dev) if want_h else None
-    ws = _mlp_fwd_workspace(dev, rays.n)
+    # training: a private workspace, so that its packed fragment image can be handed to field_mlp_bwd
+    ws = (torch.empty(lib.fnr_field_mlp_fwd_workspace_bytes(0), dtype=torch.uint8, device=dev) if want_h
+          else _mlp_fwd_workspace(dev, rays.n))
     L.check(lib.fnr_field_mlp_fwd(C.byref(net), rays.ref, S, L.ptr(feats), L.ptr(selector), L.ptr(mean_embedding),
                                   L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.ptr(h), L.ptr(ray_bias),
                                   L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
             "field_mlp_fwd")
     if want_h:
-        return density, rgb, logit, geo, (h, ray_bias)
+        return density, rgb, logit, geo, (h, ray_bias, ws)
     return density, rgb, logit, geo
 
 
@@ -333,17 +335,17 @@ def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weig
 
 def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, h_saved,
                   selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor) -> Tensor:
-    """h_saved: what field_mlp_fwd(want_h=True) returned — (h [N,16], ray_bias [R,64]); a bare h tensor is accepted
-    too (the per-ray bias is then recomputed)."""
+    """h_saved: what field_mlp_fwd(want_h=True) returned — (h [N,16], ray_bias [R,64], packed weights); a bare h tensor
+    is accepted too (the per-ray bias and the fragment image are then recomputed)."""
     lib = L.load()
-    h_saved, ray_bias = h_saved if isinstance(h_saved, tuple) else (h_saved, None)
+    h_saved, ray_bias, packed = (tuple(h_saved) + (None, None))[:3] if isinstance(h_saved, tuple) else (h_saved, None, None)
     dev = rays.device
     N = rays.n * S
     d_feats = torch.empty_like(feats)
     nbytes = lib.fnr_field_mlp_bwd_workspace_bytes(rays.n, S)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     L.check(lib.fnr_field_mlp_bwd(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
-                                  L.ptr(ray_bias), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(ws), nbytes,
+                                  L.ptr(ray_bias), L.ptr(packed), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(ws), nbytes,
                                   L.stream_ptr(dev)), "field_mlp_bwd")
     return d_feats
 

@@ -94,7 +94,7 @@ SIGNATURES = {
     "fnr_weights_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_field_mlp_bwd_workspace_bytes": (C.c_size_t, [_i64, _i]),
     "fnr_field_mlp_bwd": (_i, [P(fnr_field_net), P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _vp, _vp, C.c_size_t, _vp]),
+                               _vp, _vp, _vp, C.c_size_t, _vp]),
     "fnr_hash_scatter_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "fnr_hash_encode_bwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _i, _vp]),
     "fnr_prop_density_bwd_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),

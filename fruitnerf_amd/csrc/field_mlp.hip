@@ -138,7 +138,8 @@ extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays,
   long long blocks = (n_tiles + 7) / 8;
   const long long max_blocks = 2ll * device_cu_count();
   if (blocks > max_blocks) blocks = max_blocks;
-  FNR_CHECK_ARG(workspace && workspace_bytes >= fnr_field_mlp_fwd_workspace_bytes(rays->n_rays), "field_mlp_fwd: workspace too small");
+  FNR_CHECK_ARG(workspace && workspace_bytes >= fnr_field_mlp_fwd_workspace_bytes(ray_bias_save ? 0 : rays->n_rays),
+                "field_mlp_fwd: workspace too small");
   float* packed = reinterpret_cast<float*>(workspace);
   float* ray_bias = ray_bias_save ? ray_bias_save : packed + (FieldCfgBase::PACKED_FLOATS + 63) / 64 * 64;
   const RaysDev rd = make_rays(rays);

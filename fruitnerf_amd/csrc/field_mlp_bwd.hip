@@ -563,7 +563,7 @@ extern "C" size_t fnr_field_mlp_bwd_workspace_bytes(int64_t n_rays, int S) {
 
 extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
                                  const float* feats, const float* h_saved, const float* ray_bias_saved,
-                                 const uint8_t* selector, const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
+                                 const float* packed_saved, const uint8_t* selector, const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
                                  void* workspace, size_t workspace_bytes, void* stream) {
   FNR_CHECK_ARG(net && grads && rays && feats && h_saved && d_density && d_rgb && d_logit && d_feats && workspace && S > 0,
                 "field_mlp_bwd: null argument");
@@ -594,8 +594,12 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
     return (e && atoi(e) == 4) ? 4 : 8;
   }();
   FNR_PROF(OP_MLP_BWD, N);
-  launch_pack_field_weights<FieldCfgBase>(p, packed, st);
-  FNR_LAUNCH_CHECK();
+  if (packed_saved) {
+    packed = const_cast<float*>(packed_saved);  // the forward pass's fragment image of the same weights
+  } else {
+    launch_pack_field_weights<FieldCfgBase>(p, packed, st);
+    FNR_LAUNCH_CHECK();
+  }
   const float* ray_bias = ray_bias_saved;
   if (!ray_bias) {
     launch_color_ray_bias<FieldCfgBase>(packed, rd, net->embedding, nullptr, ws.ray_bias, st);

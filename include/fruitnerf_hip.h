@@ -209,7 +209,8 @@ int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fn
  * density embedding `base_mlp_out` returned by get_density (fruit_field.py:187-193).
  * workspace: >= fnr_field_mlp_fwd_workspace_bytes(n_rays) bytes of device scratch: the MFMA fragment image of
  * the weights (packed once per call) and the per-ray part of mlp_head's first layer (SH + appearance
- * embedding are constant along a ray: [n_rays, 64]). */
+ * embedding are constant along a ray: [n_rays, 64]; with ray_bias_save the workspace only needs
+ * fnr_field_mlp_fwd_workspace_bytes(0)).  The image sits at the start of the workspace. */
 size_t fnr_field_mlp_fwd_workspace_bytes(int64_t n_rays);
 int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays, int S, const float* feats,
                       const uint8_t* selector, const float* mean_embedding, float* density, float* rgb, float* logit,
@@ -263,6 +264,8 @@ int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, const float
 size_t fnr_field_mlp_bwd_workspace_bytes(int64_t n_rays, int S);
 int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
                       const float* feats, const float* h_saved, const float* ray_bias_saved /* optional */,
+                      const float* packed_saved /* optional: the start of fnr_field_mlp_fwd's workspace (its fragment
+                      image), valid if the weights have not changed since */,
                       const uint8_t* selector, const float* d_density,
                       const float* d_rgb, const float* d_logit, float* d_feats, void* workspace, size_t workspace_bytes,
                       void* stream);
