@@ -74,9 +74,19 @@ __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const 
   float acc[12];                       // G (3x3, dL/dR') row-major, then dL/dt'
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
-  for (long long base = 64 * wave; base < n_rays; base += 256) {
-    const long long r = base + lane;
-    if (r < n_rays && cam_idx[r] == k) {
+  // the camera of 8 rays per thread is fetched before any of them is processed: a load-compare-branch chain per ray
+  // made this 90-workgroup kernel take 19 us
+  for (long long base0 = 0; base0 < n_rays; base0 += 8 * 256) {
+    int mine[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const long long r = base0 + q * 256 + threadIdx.x;
+      mine[q] = (r < n_rays) ? cam_idx[r] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (mine[q] != k) continue;
+      const long long r = base0 + q * 256 + threadIdx.x;
       int y = (int)(u[3 * r + 1] * (float)cam.H);
       int x = (int)(u[3 * r + 2] * (float)cam.W);
       y = min(y, cam.H - 1);
