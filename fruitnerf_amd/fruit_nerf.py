@@ -368,6 +368,7 @@ class FruitModel(nn.Module):
             spacing, euclid, S = spacing_n, euclid_n, S_next
         if updated:
             sampler._steps_since_update = 0
+        self._last_render_updated = bool(training and updated)   # did this pass keep the proposal nets' graph?
 
         fld = self.field
         net = fld.net_struct()

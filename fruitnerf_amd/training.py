@@ -450,13 +450,21 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
         if exchange is None:
             optimizer.step()
         else:
-            pending = exchange.pending + start_gradient_sync(arena, spans["proposal_networks"], world_size)
+            pending = list(exchange.pending)
+            # the update schedule is a function of the step, identical on every rank: on steps that did not train the
+            # proposal networks their gradients are zero everywhere and the 10.5 MB exchange is skipped
+            prop_updated = bool(getattr(model, "_last_render_updated", True))
+            if prop_updated:
+                pending += start_gradient_sync(arena, spans["proposal_networks"], world_size)
             lrs = optimizer.begin_step()
             scale = 1.0 / world_size
             for a, b, work in pending:
                 work.wait()                                    # the compute stream waits for this bucket only
                 name = "fields" if a >= spans["fields"][0] else "proposal_networks"
                 optimizer.step_span(a, b, lrs[name], scale)
+            if not prop_updated:                               # Adam still runs (moments decay, parameters move)
+                optimizer.step_span(spans["proposal_networks"][0], spans["proposal_networks"][1],
+                                    lrs["proposal_networks"], scale)
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
 
