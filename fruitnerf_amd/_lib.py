@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfruitnerf_hip.so")
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
+ABI_VERSION = 2      # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -127,8 +128,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError -> loud failure on a stale library
         fn.restype = res
         fn.argtypes = args
-    if lib.fnr_abi_version() != 1:
-        raise RuntimeError(f"libfruitnerf_hip.so ABI {lib.fnr_abi_version()} != 1; rebuild")
+    if lib.fnr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libfruitnerf_hip.so ABI {lib.fnr_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

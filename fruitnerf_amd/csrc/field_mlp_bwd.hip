@@ -28,7 +28,6 @@ enum { BR_COLOR = 0, BR_SEM = 1, BR_BASE = 2 };
 // fragment reads (bank 20 j + 4 ks + g) conflict-free; 17 had 2-way conflicts between lane groups on the writes
 constexpr int SCR_LD = 20;
 constexpr int SCR_FLOATS = 2 * 64 * SCR_LD;  // G^T and X^T, 64 feature rows each
-constexpr int BWD_WAVES = 8;
 
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)

@@ -19,7 +19,6 @@
 namespace fnr {
 
 constexpr int SC_MAX_ROWS = 8192;       // rows per bin (64 KiB of float2 in LDS)
-constexpr int SC_MIN_BINS = 64;         // bins per level at least
 constexpr int SC_MAX_BINS = 512;        // per level (LDS histogram size)
 constexpr int SC_CHUNK = 512;           // samples per emit workgroup (512 x 8 records x 16 B = 64 KiB of LDS)
 constexpr int SC_EMIT_THREADS = 512;    // 8 waves, one sample per thread

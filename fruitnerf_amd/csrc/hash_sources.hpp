@@ -50,7 +50,6 @@ __device__ __forceinline__ void blend_input_grad(const float (&d)[8], const floa
 __device__ __forceinline__ void decode_block(int b, int L, long long nsb, int& level, long long& sb) {
   if ((L & 7) == 0) {
     // XCD-aware: xcd = b % 8 owns L/8 levels, coarse levels paired with fine ones
-    const int lpx = L >> 3;
     const int xcd = b & 7;
     const long long q = b >> 3;
     // one level at a time per XCD (all sample blocks of its coarse level, then its fine level): two 4 MiB tables
