@@ -284,12 +284,15 @@ def main() -> None:
         pipe.model = emodel
         pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=32768)
         emodel.setup_inference(True, N_EXP)
-        n_rays = pipe.datamanager.setup_inference(aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), num_points=N_EXP)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        sets = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})
-        torch.cuda.synchronize()
-        exp_s = time.perf_counter() - t1
+        exp_times = []
+        for _ in range(3):  # the first pass pays the allocator's first-touch of the export buffers; report the best
+            n_rays = pipe.datamanager.setup_inference(aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), num_points=N_EXP)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sets = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})
+            torch.cuda.synchronize()
+            exp_times.append(time.perf_counter() - t1)
+        exp_s = min(exp_times)
         cam_off = None
         if camera is not None:  # the same loop without the camera optimiser (no input gradient of the hash grids)
             saved, camera = camera, None
@@ -302,12 +305,26 @@ def main() -> None:
             torch.cuda.synchronize()
             cam_off = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
             camera = saved
+        # end-to-end sanity of the export (SURVEY §8f row 3 is the real clustering stage; this is only a density-based
+        # count of connected blobs in the exported semantic set): DBSCAN on the lattice points, scene has 32 fruits
+        fruit_count = None
+        try:
+            from sklearn.cluster import DBSCAN
+            pts = sets["semantic"]["points"]
+            if pts.shape[0] >= 5:
+                spacing = 2.0 / N_EXP * 2.0     # lattice pitch after sample_volume's x2 scaling
+                labels = DBSCAN(eps=1.8 * spacing, min_samples=4).fit(pts).labels_
+                fruit_count = int(labels.max() + 1)
+        except Exception as e:  # noqa: BLE001  (sklearn is optional)
+            fruit_count = f"unavailable: {e}"
         secondary = {"train_rays_per_s_camera_optimizer_off": cam_off,
                      "train_rays_per_s_camera_optimizer_off_note": f"100 steps measured after step {step_idx[0] - 100} "
                      "(proposal nets are updated less often by then than in the headline window)",
                      "eval_rays_per_s": round(HW * HW / eval_s, 1), "eval_image": f"{HW}x{HW}, chunks of 32768 rays",
                      "export_samples_per_s": round(n_rays * N_EXP / exp_s, 1), "export_lattice": f"{N_EXP}^3",
-                     "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()}}
+                     "export_pass_ms": [round(t * 1e3, 1) for t in exp_times],
+                     "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()},
+                     "fruit_count_dbscan_on_semantic_export": fruit_count, "fruit_count_scene": scene.n_fruits}
         model.train()
 
     # ---- CPU baseline: the oracle's training step on the host cores -------------------------------------------------
