@@ -158,3 +158,42 @@ def test_full_image_eval_and_image_metrics(dev):
     assert 0 < metrics["psnr"] < 60 and -1 <= metrics["ssim"] <= 1
     assert abs(metrics["iou"] - float(batch["fruit_mask"].mean())) < 1e-6   # the reference's softmax-over-1-class quirk
     assert images["img"].shape == (H, 2 * W, 3) and images["fruit_mask"].shape == (H, W, 3)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_export_is_invariant_to_the_ray_batch_size(dev, fused):
+    """sample_volume on a 48^3 lattice with the full-size field: the three point sets (counts AND ordered coordinates)
+    do not depend on eval_num_rays_per_batch — 7 ragged batches vs one (SURVEY §8c pin 3)."""
+    import numpy as np
+    from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
+    from fruitnerf_amd.export.exporter_utils import sample_volume
+    m = _full_model(dev)
+    with torch.no_grad():
+        m.field.field_head_semantics.net.weight.mul_(8.0)
+        m.field.field_head_semantics.net.bias.add_(1.0)
+        m.field.mlp_base_mlp.layers[1].weight[0].mul_(3.0)   # densities around the export threshold (sigma >= 70)
+        m.field.mlp_base_mlp.layers[1].bias[0].add_(2.5)
+    m.test_mode = "export"
+    m.field.test_mode = "export"
+    m.eval()
+    N = 48
+
+    class Pipe:
+        pass
+
+    results = []
+    for per_batch in (N * N, 333):
+        pipe = Pipe()
+        pipe.model = m
+        pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=per_batch)
+        m.setup_inference(True, N)
+        n_rays = pipe.datamanager.setup_inference(aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), num_points=N)
+        if not fused:
+            pipe.datamanager.export_lattice = None
+        results.append(sample_volume(pipe, n_rays, transform_json={"scale": 1.0}))
+    a, b = results
+    assert a["density"]["points"].shape[0] > 50
+    for name in ("semantic_colormap", "semantic", "density"):
+        assert a[name]["points"].shape == b[name]["points"].shape, name
+        assert np.array_equal(a[name]["points"], b[name]["points"]), name
+        assert np.array_equal(a[name]["colors"], b[name]["colors"]), name
