@@ -90,6 +90,15 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
   }
   return v;
 }
+// exclusive prefix sum: the inclusive scan shifted by one lane.  NOT `inclusive - own`: when the own term dwarfs the
+// prefix (delta * sigma ~ 1e8 behind a prefix of ~0.6 on a sharp surface) that subtraction cancels the prefix to 0,
+// the transmittance becomes 1 and the sample gets weight 1 on top of the earlier weights — the gradient spike that
+// blew training up after a few thousand steps.
+__device__ __forceinline__ float wave_excl_scan(float v, int lane) {
+  const float incl = wave_incl_scan(v, lane);
+  const float up = __shfl_up(incl, 1, 64);
+  return lane == 0 ? 0.0f : up;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);

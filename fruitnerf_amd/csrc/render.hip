@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(RaysDev rays, int S, cons
     if (e < E && k < S) dd[e] = fmul(fsub(eb[k + 1], eb[k]), dn[k]);
     local += dd[e];
   }
-  float excl = wave_incl_scan(local, lane) - local;
+  float excl = wave_excl_scan(local, lane);
   float w[CMP_MAXE];
   float acc_l = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, sm = 0.0f;
 #pragma unroll
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(RaysDev rays, int S, cons
     }
   }
   // median depth before the reductions destroy the per-lane partials
-  float cw = wave_incl_scan(acc_l, lane) - acc_l;
+  float cw = wave_excl_scan(acc_l, lane);
   int first = 0x7fffffff;
 #pragma unroll
   for (int e = 0; e < CMP_MAXE; ++e) {

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_weights_pdf(RaysDev rays, int kind, int
     if (e < E && k < S_prev) dd[e] = fmul(fsub(eb[k + 1], eb[k]), dn[k]);
     local += dd[e];
   }
-  float excl = wave_incl_scan(local, lane) - local;  // sum of delta*sigma before this lane's chunk
+  float excl = wave_excl_scan(local, lane);  // sum of delta*sigma before this lane's chunk
   float wsum_local = 0.0f;
 #pragma unroll
   for (int e = 0; e < PDF_MAXE; ++e) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_weights_pdf(RaysDev rays, int kind, int
 
   // ---- DepthRenderer("median") of this level (fruit_nerf.py:299-300) ----------------------------
   if (median_depth) {
-    float cw = wave_incl_scan(wsum_local, lane) - wsum_local;
+    float cw = wave_excl_scan(wsum_local, lane);
     int first = 0x7fffffff;
 #pragma unroll
     for (int e = 0; e < PDF_MAXE; ++e) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_weights_pdf(RaysDev rays, int kind, int
       pdf_local += wa[e];
     }
   }
-  float run = wave_incl_scan(pdf_local, lane) - pdf_local;
+  float run = wave_excl_scan(pdf_local, lane);
   if (lane == 0) cdf[0] = 0.0f;
 #pragma unroll
   for (int e = 0; e < PDF_MAXE; ++e) {

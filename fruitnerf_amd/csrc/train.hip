@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const 
     const int k = lane * E + e;
     if (k < S_p) local += wp[k];
   }
-  float run = wave_incl_scan(local, lane) - local;
+  float run = wave_excl_scan(local, lane);
   if (lane == 0) cy[0] = 0.0f;
   for (int e = 0; e < E; ++e) {
     const int k = lane * E + e;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const 
     const int k = lane * E + e;
     if (k < S_p) l2 += dd[k];
   }
-  float run2 = wave_incl_scan(l2, lane) - l2;
+  float run2 = wave_excl_scan(l2, lane);
   for (int e = 0; e < E; ++e) {
     const int k = lane * E + e;
     if (k < S_p) {
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const f
       wsum_local += wk[e];
     }
   }
-  float cum_dd = wave_incl_scan(dd_local, lane) - dd_local;     // sum_{j<first k of lane}
-  float cum_gww = wave_incl_scan(gww_local, lane) - gww_local;
+  float cum_dd = wave_excl_scan(dd_local, lane);     // sum_{j<first k of lane}
+  float cum_gww = wave_excl_scan(gww_local, lane);
   const float total_gww = wave_sum(gww_local);
   if (COMPOSITE) bgw = 1.0f - wave_sum(wsum_local);
 #pragma unroll
