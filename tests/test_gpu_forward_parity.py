@@ -252,3 +252,45 @@ def test_export_counts_and_points_identical(dev):
             assert torch.equal(torch.from_numpy(got[name]["points"]), ref[name]["points"]), f"{name}: points differ"
             a, _ = util.report(f"export.{name}.colors", torch.from_numpy(got[name]["colors"]), ref[name]["colors"])
             assert a <= 1e-4
+
+
+@pytest.mark.parametrize("S", [48, 96, 256])
+def test_weights_behind_a_huge_density_spike(dev, S):
+    """A sharp surface: delta*sigma ~ 1e8 after a moderate prefix.  The transmittance in front of the spike must
+    survive (an exclusive scan computed as `inclusive - own` cancels it to 0 and the spike gets weight 1 on top of the
+    earlier weights — that blew training up after a few thousand steps).  Checked against float64 closed form for the
+    compositing kernel, the PDF sampler's weights and the weight backward."""
+    from fruitnerf_amd import _kernels as K
+    R = 64
+    g = torch.Generator().manual_seed(S)
+    edges = torch.cumsum(torch.rand(R, S + 1, generator=g) * 0.05 + 0.01, dim=1)
+    density = torch.rand(R, S, generator=g) * 3.0
+    spike = torch.randint(S // 3, S - 2, (R,), generator=g)
+    density[torch.arange(R), spike] = 10.0 ** (6 + 4 * torch.rand(R, generator=g))     # 1e6 .. 1e10
+    rgb = torch.rand(R, S, 3, generator=g)
+    logit = torch.randn(R, S, generator=g)
+    dd = (edges[:, 1:] - edges[:, :-1]).double() * density.double()
+    T = torch.exp(-torch.cat([torch.zeros(R, 1, dtype=torch.float64), torch.cumsum(dd, 1)[:, :-1]], 1))
+    w_ref = ((1 - torch.exp(-dd)) * T).float()
+    o, d, pa, cam = util.random_rays(R, 4, seed=1)
+    rays = K.RaysArg(o.to(dev), d.to(dev), torch.zeros(R, 1, device=dev), torch.ones(R, 1, device=dev), cam.to(dev))
+    w, out_rgb, acc, depth, sem, label = K.composite_fwd(rays, S, edges.to(dev).contiguous(), density.to(dev).view(-1),
+                                                         rgb.to(dev).view(-1, 3), logit.to(dev).view(-1), True)
+    assert util.report(f"spike[{S}].composite.weights", w, w_ref)[0] <= 2e-6
+    assert float(acc.max()) <= 1.0 + 1e-5
+    if S + 1 <= 257:
+        spacing = (edges / edges[:, -1:]).to(dev).contiguous()
+        w2, _, _, _ = K.weights_pdf(rays, 1, S, 32, density.to(dev).contiguous(), spacing, edges.to(dev).contiguous(), 1.0,
+                                    None)
+        assert util.report(f"spike[{S}].pdf.weights", w2, w_ref)[0] <= 2e-6
+    # backward of the weights: d(sum_k g_k w_k)/d sigma vs float64 autograd
+    gw = torch.randn(R, S, generator=g)
+    dref = density.double().clone().requires_grad_(True)
+    ddr = (edges[:, 1:] - edges[:, :-1]).double() * dref
+    Tr = torch.exp(-torch.cat([torch.zeros(R, 1, dtype=torch.float64), torch.cumsum(ddr, 1)[:, :-1]], 1))
+    ((1 - torch.exp(-ddr)) * Tr * gw.double()).sum().backward()
+    d_sigma = K.weights_bwd(S, edges.to(dev).contiguous(), density.to(dev).contiguous(), w, gw.to(dev).contiguous(),
+                            torch.ones(1, device=dev))
+    ref = dref.grad.float()
+    err = (d_sigma.view(R, S).cpu() - ref).abs().max().item()
+    assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
