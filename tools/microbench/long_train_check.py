@@ -38,6 +38,6 @@ def report(tag):
 for step in range(STEPS):
     o, d, cam, batch = batcher.sample(4096)
     ld, md = fused_train_iteration(model, opt, RayBundle(o, d, None, cam), batch, step)
-    if step in (200, 1000, 2000, 4000, 6000, STEPS - 1):
+    if step in (200, 1000, 4000, 8000, 12000, 16000, 20000, 25000, STEPS - 1):
         print(step, {k: round(float(v), 5) for k, v in ld.items()}, {k: round(float(v), 4) for k, v in md.items()})
         report(step)
