@@ -412,7 +412,8 @@ def test_step_at_a_trained_state_matches_the_oracle(dev):
     samp = hm.proposal_sampler
     samp._steps_since_update = 100          # make this an "updated" step: proposal-network gradients are exercised too
     state = (samp._step, samp._steps_since_update)
-    ld, md = fused_forward_backward(hm, RayBundle(o, d, None, cam), batch, jitter=jit)
+    ray_grads = {}
+    ld, md = fused_forward_backward(hm, RayBundle(o, d, None, cam), batch, jitter=jit, ray_grads=ray_grads)
     torch.cuda.synchronize()
     assert float(ld["rgb_loss"]) < 2e-3, "the model did not train"
 
@@ -421,11 +422,17 @@ def test_step_at_a_trained_state_matches_the_oracle(dev):
     om.train()
     om.proposal_sampler._step, om.proposal_sampler._steps_since_update = state
     om.set_anneal(steps)
-    out = om(ns.RayBundle(o.cpu(), d.cpu(), torch.ones(R, 1), camera_indices=cam.cpu().long()), jitter=[j.cpu() for j in jit])
+    o_ref, d_ref = o.cpu().clone().requires_grad_(True), d.cpu().clone().requires_grad_(True)
+    out = om(ns.RayBundle(o_ref, d_ref, torch.ones(R, 1), camera_indices=cam.cpu().long()), jitter=[j.cpu() for j in jit])
     b = {k: v.cpu() for k, v in batch.items()}
     ld_ref = om.get_loss_dict(out, b)
     md_ref = om.get_metrics_dict(out, b)
     sum(ld_ref.values()).backward()
+    for name, got_g, ref_g in (("origins", ray_grads["origins"], o_ref.grad), ("directions", ray_grads["directions"], d_ref.grad)):
+        scale = ref_g.abs().max().item()
+        err = (got_g.cpu() - ref_g).abs().max().item()
+        print(f"[trained state] d loss / d {name}: max|ref| {scale:.3e} max_err {err:.3e} rel {err / scale:.3e}")
+        assert err <= 1e-2 * scale, name
     for k in ld_ref:
         a, r = float(ld[k]), float(ld_ref[k])
         print(f"[trained state] {k}: hip {a:.8e} oracle {r:.8e}")
