@@ -7,8 +7,8 @@
 //   1. emit       every contribution (row, w*gx, w*gy) is appended to the queue of the bin that owns its table
 //                 row (a bin = E consecutive rows of one level, E*8 B <= 64 KiB); a workgroup counts its
 //                 contributions per bin in LDS, reserves queue space with ONE global atomic per non-empty bin,
-//                 then writes 16-byte records;
-//   2. accumulate one workgroup per bin sums its queue into LDS (ds_add_f32 runs at LDS speed) and adds the
+//                 then writes 10-byte records (value pair + 16-bit row inside the bin);
+//   2. accumulate one workgroup per bin sums its queue into LDS (64-bit block fixed point, see below) and adds the
 //                 dense E-row tile to the gradient table with plain coalesced read-modify-writes (it is the
 //                 only writer of those rows).
 // Queue overflow (a pathologically hot bin) falls back to global atomics in step 1, so results never depend on
