@@ -48,7 +48,8 @@ static ScatterPlan scatter_plan(long long N, int n_levels, int log2_T) {
   p.cap = (3 * avg + 1023) / 1024 * 1024;
   if (p.cap < 1024) p.cap = 1024;
   const size_t nbins = (size_t)n_levels * p.bins_per_level;
-  p.count_bytes = 2 * nbins * SC_CNT_STRIDE * sizeof(unsigned);  // [nbins] counts + [nbins] max |v| bits, padded
+  // [nbins] queue counts, then per level: max |v| bits and a 'bins done' counter, each in its own 128-byte line
+  p.count_bytes = (nbins + 2 * (size_t)n_levels) * SC_CNT_STRIDE * sizeof(unsigned);
   // 10 bytes per record in HBM (8-byte value pair + 16-bit row inside the bin; rows per bin <= 8192)
   p.value_bytes = nbins * (size_t)p.cap * sizeof(float2);
   p.queue_bytes = p.value_bytes + (nbins * (size_t)p.cap * sizeof(unsigned short) + 255) / 256 * 256;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   __shared__ unsigned s_cnt[SC_MAX_BINS];   // per-bin count, then running cursor
   __shared__ unsigned s_off[SC_MAX_BINS];   // per-bin start inside s_rec
   __shared__ unsigned s_base[SC_MAX_BINS];  // per-bin start inside the global queue
-  __shared__ unsigned s_max[SC_MAX_BINS];   // per-bin max |value| (float bits; order-preserving for >= 0)
+  __shared__ unsigned s_max;                // max |value| emitted by this workgroup (float bits; order-preserving for >= 0)
   __shared__ unsigned s_wsum[SC_EMIT_THREADS / 64];
   const int lrel = blockIdx.y;           // level inside this call's range: indexes the counters and queues
   const int level = level0 + lrel;       // level of the grid: indexes scalings, d_feats and the gradient table
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) {
     s_cnt[i] = 0;
-    s_max[i] = 0;
   }
+  if (threadIdx.x == 0) s_max = 0;
   __syncthreads();
   const uint32_t mask = (1u << grid.log2_T) - 1u;
   const uint32_t row_mask = (1u << log2_rows) - 1u;
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   // cells at coarse levels) are pre-summed so only the last lane of a run emits a record
   uint32_t hk[SC_PER_THREAD][8];
   float vxk[SC_PER_THREAD][8], vyk[SC_PER_THREAD][8];
+  float tmax = 0.0f;  // largest |value| this thread emits
   unsigned emit_mask[SC_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < SC_PER_THREAD; ++q) {
@@ -189,11 +191,18 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
         emit_mask[q] |= 1u << k;
         const int bin = hk[q][k] >> log2_rows;
         atomicAdd(&s_cnt[bin], 1u);
-        atomicMax(&s_max[bin], __float_as_uint(fmaxf(fabsf(vxk[q][k]), fabsf(vyk[q][k]))));
+        tmax = fmaxf(tmax, fmaxf(fabsf(vxk[q][k]), fabsf(vyk[q][k])));
       }
     }
   }
+  // largest emitted |value| of the level (scale of the accumulate kernel's block fixed point): wave max by DPP-free
+  // shuffles, one LDS atomic per wave, one global atomicMax per workgroup (per-bin maxima cost 8 LDS atomics per
+  // thread and 64 global atomics per workgroup)
+#pragma unroll
+  for (int dsh = 32; dsh >= 1; dsh >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, dsh, 64));
+  if (lane == 0 && tmax > 0.0f) atomicMax(&s_max, __float_as_uint(tmax));
   __syncthreads();
+  if (threadIdx.x == 0 && s_max != 0u) atomicMax(&qmax[(size_t)lrel * SC_CNT_STRIDE], s_max);
   // exclusive scan of the per-bin counts (bins <= 1024 = 4 per thread) + one global reservation per non-empty bin
   unsigned c4[SC_BINS_PER_THREAD], tsum = 0;
 #pragma unroll
@@ -222,7 +231,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     if (i < bins) {
       s_off[i] = run;
       s_base[i] = c4[t] ? atomicAdd(&qcount[(size_t)(lrel * bins + i) * SC_CNT_STRIDE], c4[t]) : 0u;
-      if (c4[t]) atomicMax(&qmax[(size_t)(lrel * bins + i) * SC_CNT_STRIDE], s_max[i]);
       s_cnt[i] = 0;
       run += c4[t];
     }
@@ -275,7 +283,8 @@ __device__ __forceinline__ void acc_record(unsigned long long* __restrict__ s_ac
 __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float2* __restrict__ queue_v,
                                                              const unsigned short* __restrict__ queue_r,
                                                              unsigned* __restrict__ qcount,
-                                                             unsigned* __restrict__ qmax, long long cap,
+                                                             unsigned* __restrict__ qmax,
+                                                             unsigned* __restrict__ qdone, long long cap,
                                                              int log2_rows, int level0) {
   __shared__ unsigned long long s_acc[2 * SC_MAX_ROWS];  // [rows][2] two's-complement fixed point, 128 KiB
   const int rows = 1 << log2_rows;
@@ -285,16 +294,19 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   const int lrel = gbin / bins, bin = gbin - lrel * bins;
   const int level = level0 + lrel;
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
-  const float vmax = __uint_as_float(qmax[(size_t)gbin * SC_CNT_STRIDE]);
-  if (n == 0) return;
+  const float vmax = __uint_as_float(qmax[(size_t)lrel * SC_CNT_STRIDE]);  // largest |value| of the whole level
   // every thread has its copy: put the counters back to zero, so the NEXT call on this workspace needs no memset
-  // launch (the caller says so with workspace_clean = 1)
+  // launch (the caller says so with workspace_clean = 1).  The level's max is shared by its `bins` workgroups: the
+  // last of them to have read it clears it.
   __syncthreads();
   if (threadIdx.x == 0) {
     qcount[(size_t)gbin * SC_CNT_STRIDE] = 0u;
-    qmax[(size_t)gbin * SC_CNT_STRIDE] = 0u;
+    if (atomicAdd(&qdone[(size_t)lrel * SC_CNT_STRIDE], 1u) == (unsigned)bins - 1u) {
+      qmax[(size_t)lrel * SC_CNT_STRIDE] = 0u;
+      qdone[(size_t)lrel * SC_CNT_STRIDE] = 0u;
+    }
   }
-  if (!(vmax > 0.0f)) return;
+  if (n == 0 || !(vmax > 0.0f)) return;
   if (n > cap) n = cap;
   // |v| < 2^e ; n < 2^nb  =>  |sum * 2^S| < 2^62 with S = 62 - nb - e
   int e;
@@ -359,7 +371,8 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
   FNR_LAUNCH_CHECK();
   const unsigned nbins = (unsigned)(level_count * p.bins_per_level);
   hipLaunchKernelGGL(k_scatter_accumulate, dim3(nbins), dim3(1024), 0, st, gd,
-                     queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap, p.log2_rows, level0);
+                     queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE,
+                     qcount + (nbins_all + level_count) * SC_CNT_STRIDE, p.cap, p.log2_rows, level0);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }
