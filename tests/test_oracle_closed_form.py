@@ -200,3 +200,55 @@ def test_export_boundary_rays_are_masked_and_counts_on_analytic_field():
     assert out["semantic"]["points"].shape[0] == inside
     assert out["semantic_colormap"]["points"].shape[0] == inside
     assert out["density"]["points"].abs().max().item() <= 2.0 + 1e-9  # x2 rescale (exporter_utils.py:191)
+
+
+def test_camera_optimizer_exp_map_is_a_rotation_and_matches_matrix_exp():
+    """oracle/camera_opt.py::exp_map_SO3xR3 (restated nerfstudio lie_groups): above the 1e-4 clamp the rotation block
+    is exp(skew(w)) (independent formula: torch.matrix_exp), it is orthonormal with det 1, the translation is copied;
+    below the clamp it is the small-angle series around the clamped angle; multiply() composes poses."""
+    import torch
+    from oracle import camera_opt as oc
+    g = torch.Generator().manual_seed(0)
+    tv = torch.cat([torch.randn(16, 3, generator=g), torch.randn(16, 3, generator=g) * 0.7], dim=1).double()
+    M = oc.exp_map_SO3xR3(tv)
+    R, t = M[:, :, :3], M[:, :, 3]
+    assert torch.equal(t, tv[:, :3])
+    w = tv[:, 3:]
+    K = torch.zeros(16, 3, 3, dtype=torch.float64)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -w[:, 2], w[:, 1], w[:, 2], -w[:, 0], -w[:, 1], w[:, 0]
+    assert torch.allclose(R, torch.matrix_exp(K), atol=1e-12)
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=torch.float64).expand(16, 3, 3), atol=1e-12)
+    assert torch.allclose(torch.linalg.det(R), torch.ones(16, dtype=torch.float64), atol=1e-12)
+    # below the clamp (|w|^2 < 1e-4): theta is clamped to 0.01, R = I + f1 K + f2 K^2 with the clamped factors
+    small = torch.zeros(1, 6, dtype=torch.float64)
+    small[0, 3:] = torch.tensor([1e-3, -2e-3, 5e-4])
+    Rs = oc.exp_map_SO3xR3(small)[0, :, :3]
+    Ks = torch.zeros(3, 3, dtype=torch.float64)
+    Ks[0, 1], Ks[0, 2], Ks[1, 0], Ks[1, 2], Ks[2, 0], Ks[2, 1] = -5e-4, -2e-3, 5e-4, -1e-3, 2e-3, 1e-3
+    th = torch.tensor(0.01, dtype=torch.float64)
+    want = torch.eye(3, dtype=torch.float64) + torch.sin(th) / th * Ks + (1 - torch.cos(th)) / th ** 2 * (Ks @ Ks)
+    assert torch.allclose(Rs, want, atol=1e-15)
+    # zero tangent -> identity; composition
+    I = oc.exp_map_SO3xR3(torch.zeros(2, 6, dtype=torch.float64))
+    assert torch.allclose(I[:, :, :3], torch.eye(3, dtype=torch.float64).expand(2, 3, 3)) and float(I[:, :, 3].abs().max()) == 0
+    A, B = M[:8], M[8:]
+    AB = oc.multiply(A, B)
+    assert torch.allclose(AB[:, :, :3], A[:, :, :3] @ B[:, :, :3]) and torch.allclose(
+        AB[:, :, 3], A[:, :, 3] + (A[:, :, :3] @ B[:, :, 3:]).squeeze(-1))
+
+
+def test_camera_ray_generation_conventions():
+    """Pinhole rays through the (identity-corrected) camera: pixel centre +0.5, -z forward, unit directions, origins =
+    camera position — and a pure translation tangent moves the origins by R1 t only."""
+    import torch
+    from oracle import camera_opt as oc
+    c2w = torch.eye(4)[None, :3, :4].clone()
+    c2w[0, :, 3] = torch.tensor([0.1, -0.2, 0.3])
+    y, x = torch.tensor([5]), torch.tensor([7])
+    o, d = oc.generate_rays(c2w, oc.exp_map_SO3xR3(torch.zeros(1, 6)), y, x, 10.0, 10.0, 8.0, 8.0)
+    v = torch.tensor([(7 + 0.5 - 8) / 10, -(5 + 0.5 - 8) / 10, -1.0])
+    assert torch.allclose(d[0], v / v.norm(), atol=1e-7) and torch.allclose(o[0], c2w[0, :, 3])
+    tv = torch.zeros(1, 6)
+    tv[0, :3] = torch.tensor([0.01, 0.02, -0.03])
+    o2, d2 = oc.generate_rays(c2w, oc.exp_map_SO3xR3(tv), y, x, 10.0, 10.0, 8.0, 8.0)
+    assert torch.allclose(o2[0] - o[0], tv[0, :3], atol=1e-7) and torch.allclose(d2, d, atol=1e-6)
