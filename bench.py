@@ -51,6 +51,41 @@ ALG = {
 }
 
 
+# kernels launched by each entry point (for the PMC traffic lookup below)
+OP_KERNELS = {
+    "field_mlp_bwd": ["k_field_mlp_bwd<fnr::FieldCfgBase, 0", "k_field_mlp_bwd<fnr::FieldCfgBase, 1",
+                      "k_field_mlp_bwd<fnr::FieldCfgBase, 2", "k_color_ray_grads", "k_embedding_grad", "k_reduce_dw"],
+    "field_mlp_fwd": ["k_field_mlp_fwd", "k_color_ray_bias", "k_pack_field_weights"],
+    "hash_encode_fwd": ["k_hash_encode"],
+    "adam_step": ["k_adam"],
+}
+
+
+def pmc_traffic(op: str):
+    """HBM-side traffic of one call of `op` from the committed rocprofv3 PMC passes (profiles/r01_raw: separate
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same command, KiB per launch): FETCH_SIZE x2 (gfx950 counts
+    128-byte requests of coalesced streams as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, in bytes; None if absent."""
+    try:
+        def load(fn, counter):
+            out, cur = {}, None
+            for line in open(os.path.join(ROOT, "profiles", "r01_raw", fn)):
+                if line.startswith("fnr::"):
+                    cur = line.split(" dispatches")[0].strip()
+                elif cur and counter in line:
+                    out[cur] = float(line.split()[1])
+            return out
+        fetch, write = load("prof_fetch.txt", "FETCH_SIZE"), load("prof_write.txt", "WRITE_SIZE")
+        total = 0.0
+        for frag in OP_KERNELS[op]:
+            ks = [k for k in fetch if frag in k]
+            if not ks:
+                return None
+            total += sum(2.0 * fetch[k] + write.get(k, 0.0) for k in ks) * 1024.0
+        return int(total)
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
+
+
 def split_indices(n: int, frac: float):
     """Nerfstudio-style 'fraction' split (fruitnerf_dataparser.py:171-186): evenly spaced train images."""
     num_train = int(np.ceil(n * frac))
@@ -198,15 +233,19 @@ def main() -> None:
         if bound == "hbm":
             achieved = per_unit * units / (avg_ms * 1e-3) / 1e9
             roofline = {"kernel": roof_op, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(roof_op),
                         "avg_launch_ms": round(avg_ms, 5), "launches": len(sel), "units_per_launch": int(units),
                         "alg_bytes_per_unit": per_unit}
         else:
             achieved = per_unit * units / (avg_ms * 1e-3) / 1e12
             roofline = {"kernel": roof_op, "bound": "mfma", "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TF, 4), "traffic": pmc_traffic(roof_op),
                         "avg_launch_ms": round(avg_ms, 5), "launches": len(sel), "units_per_launch": int(units),
                         "alg_flop_per_unit": per_unit}
+
+    if roofline is not None and roofline["traffic"] is not None:
+        roofline["traffic_source"] = ("bytes per call from the committed rocprofv3 PMC passes of this command "
+                                      "(profiles/r01_raw: FETCH_SIZE x2 + WRITE_SIZE, summed over the entry point's kernels)")
 
     # ---- per-entry-point breakdown (short instrumented pass, outside the timed region; N = 1 only: the
     # other ranks have left, so no collective may run here) ------------------------------------------------
