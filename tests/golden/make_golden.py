@@ -39,9 +39,11 @@ def main():
     # train forward + losses + gradients (step 0: proposal nets updated)
     om.train()
     om.set_anneal(0)
-    tr = om(ns.RayBundle(o, d, pa, camera_indices=cam), jitter=jit)
+    o_leaf, d_leaf = o.clone().requires_grad_(True), d.clone().requires_grad_(True)   # ray gradients (camera optimiser)
+    tr = om(ns.RayBundle(o_leaf, d_leaf, pa, camera_indices=cam), jitter=jit)
     ld = om.get_loss_dict(tr, batch)
     sum(ld.values()).backward()
+    out["grad::origins"], out["grad::directions"] = o_leaf.grad.numpy(), d_leaf.grad.numpy()
     for k in ("rgb", "semantics", "accumulation"):
         out["train::" + k] = tr[k].detach().numpy()
     for i in range(3):
@@ -54,6 +56,36 @@ def main():
         else:
             out["grad::" + name] = p.grad.numpy()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fruit_nerf_small.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    camera_golden()
+
+
+def camera_golden():
+    """CameraOptimizer(SO3xR3): corrected cameras, rays and the pose gradient of L = sum(o . Go + d . Gd)."""
+    from oracle import camera_opt as oc
+    from fruitnerf_amd.data import synthetic_apple as sa
+    n_cam, HW, focal, R = 6, 32, 40.0, 128
+    g = torch.Generator().manual_seed(31)
+    c2w = sa.make_cameras(n_cam, seed=4)
+    pose = torch.cat([torch.randn(n_cam, 3, generator=g) * 0.03, torch.randn(n_cam, 3, generator=g) * 0.05], dim=1)
+    pose[1, 3:] = torch.tensor([2e-3, -1e-3, 3e-3])          # below the 1e-4 clamp of |w|^2
+    u = torch.rand(R, 3, generator=g)
+    Go, Gd = torch.randn(R, 3, generator=g), torch.randn(R, 3, generator=g)
+    cam_opt = oc.CameraOptimizer(n_cam)
+    with torch.no_grad():
+        cam_opt.pose_adjustment.copy_(pose)
+    k = (u[:, 0] * n_cam).long().clamp_max(n_cam - 1)
+    y = (u[:, 1] * HW).long().clamp_max(HW - 1)
+    x = (u[:, 2] * HW).long().clamp_max(HW - 1)
+    o, d = oc.generate_rays(c2w[k], cam_opt(k), y, x, focal, focal, HW / 2.0, HW / 2.0)
+    ((o * Go).sum() + (d * Gd).sum()).backward()
+    with torch.no_grad():
+        adj = oc.multiply(c2w, cam_opt(torch.arange(n_cam)))
+    out = dict(c2w=c2w.numpy(), pose=pose.numpy(), u=u.numpy(), Go=Go.numpy(), Gd=Gd.numpy(), HW=np.int32(HW),
+               focal=np.float32(focal), c2w_adjusted=adj.numpy(), origins=o.detach().numpy(), directions=d.detach().numpy(),
+               pose_grad=cam_opt.pose_adjustment.grad.numpy())
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "camera_optimizer_small.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 
