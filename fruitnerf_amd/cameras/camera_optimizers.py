@@ -6,7 +6,7 @@ matrices before ray generation and trained from the ray gradients of the hot pat
 libfruitnerf_hip.so (camera_opt.hip); there is no CPU path."""
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional
 
 import torch

@@ -6,7 +6,6 @@ runs in libfruitnerf_hip.so (fnr_hash_encode_fwd + fnr_field_mlp_fwd).  There is
 """
 from __future__ import annotations
 
-import ctypes as C
 from enum import Enum
 from typing import Dict, Optional, Tuple
 

@@ -7,7 +7,6 @@ kernel launches on PyTorch's current HIP stream.  There is no PyTorch fallback f
 """
 from __future__ import annotations
 
-import ctypes as C
 from collections import defaultdict
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple, Type, Union
@@ -21,7 +20,7 @@ from . import _lib as L
 from .components.ray_samplers import UniformSamplerWithNoise
 from .fruit_field import FieldHeadNames, FruitField, SceneContraction
 from .params import HashEncoding, MLP, ParamArena
-from .rays import RayBundle, RaySamples
+from .rays import RayBundle
 
 
 @dataclass

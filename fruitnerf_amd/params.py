@@ -17,7 +17,7 @@ from __future__ import annotations
 from typing import Dict, List, Tuple
 
 import torch
-from torch import Tensor, nn
+from torch import nn
 
 from ._kernels import hash_scalings
 

@@ -16,7 +16,6 @@ Gradients are written by the HIP backward kernels straight into the model's flat
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional
 
 import numpy as np

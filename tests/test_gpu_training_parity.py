@@ -308,7 +308,7 @@ def test_camera_optimizer_pose_gradients_and_step(dev):
     from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
     from fruitnerf_amd.data import synthetic_apple as sa
     from fruitnerf_amd.rays import RayBundle
-    from fruitnerf_amd.training import camera_backward_and_step, fused_forward_backward
+    from fruitnerf_amd.training import fused_forward_backward
     n_cam, HW, focal, R = 8, 64, 90.0, 192
     cfg = util.small_config(log2=15, prop_log2=13)
     om = util.make_oracle(cfg, num_images=n_cam, seed=13)
@@ -367,7 +367,6 @@ def test_camera_optimizer_pose_gradients_and_step(dev):
                            jitter=[j.to(dev) for j in jit], ray_grads=got)
     hadam = CameraAdam(hcam)
     hcam.pose_adjustment.grad.zero_()
-    from fruitnerf_amd import _lib as L  # noqa: F401
     K.camera_pose_grad(batcher._set, batcher.image_ids, batcher.last_draw["u"], cam_h, hcam.pose_adjustment.data, c2w_adj,
                        got["origins"], got["directions"], hcam.pose_adjustment.grad)
     torch.cuda.synchronize()

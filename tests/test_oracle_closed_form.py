@@ -1,6 +1,5 @@
 """CPU: pins for the oracle.  The reference ships no tests or golden vectors ("parity
 unpinned"), so these closed-form checks are what anchors the restatement in oracle/."""
-import math
 
 import numpy as np
 import pytest

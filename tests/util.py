@@ -4,7 +4,6 @@ import copy
 import torch
 
 from oracle import fruit_oracle as fo
-from oracle import ns_torch as ns
 
 
 def small_config(log2=14, prop_log2=12, max_res=2048):
