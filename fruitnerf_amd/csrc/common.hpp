@@ -105,6 +105,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 __device__ __forceinline__ float wave_bcast(float v, int src) { return __shfl(v, src, 64); }
+// per-lane source (lane permutation), e.g. 63 - lane reverses the wave
+__device__ __forceinline__ float wave_bcast_lane(float v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 // ---- position warp (fruit_field.py:168-179) -------------------------------------------------------
 struct Warp {

@@ -234,18 +234,25 @@ __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const f
     }
   }
   float cum_dd = wave_excl_scan(dd_local, lane);     // sum_{j<first k of lane}
-  float cum_gww = wave_excl_scan(gww_local, lane);
-  const float total_gww = wave_sum(gww_local);
+  // sum_{i>k} g_i w_i as a true SUFFIX sum (reverse scan), not `total - prefix`: behind a surface the suffix is a sum of
+  // tiny terms while total and prefix agree to 7 digits, and dL/dsigma there is multiplied by sigma (up to e^15) in the
+  // trunc_exp backward — the cancellation error was comparable to the real gradient (autograd's cumsum backward is a
+  // reverse cumsum, i.e. exact in this sense).
+  float suffix = wave_bcast_lane(wave_excl_scan(wave_bcast_lane(gww_local, 63 - lane), lane), 63 - lane);
   if (COMPOSITE) bgw = 1.0f - wave_sum(wsum_local);
+  float suf[WB_MAXE];   // suffix AFTER element e of this lane's chunk
+#pragma unroll
+  for (int e = WB_MAXE - 1; e >= 0; --e) {
+    suf[e] = suffix;
+    suffix += gw[e] * wk[e];   // gw / wk are 0 for e >= E or k >= S
+  }
 #pragma unroll
   for (int e = 0; e < WB_MAXE; ++e) {
     const int k = lane * E + e;
     if (e < E && k < S) {
       cum_dd += delta[e] * dn[k];   // inclusive of k
-      cum_gww += gw[e] * wk[e];     // inclusive of k
       const float T_next = expf(-cum_dd);
-      const float suffix = total_gww - cum_gww;  // sum_{i>k} g_i w_i
-      d_density[r * S + k] = delta[e] * (gw[e] * T_next - suffix);
+      d_density[r * S + k] = delta[e] * (gw[e] * T_next - suf[e]);
       if (COMPOSITE) {
         float f = wk[e];
         if (k == S - 1) f += bgw;  // background = last sample's colour (RGBRenderer "last_sample")
