@@ -432,6 +432,16 @@ def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
                               float(weight_decay), 1 if zero_grad else 0, L.stream_ptr(params.device)), "adam_step")
 
 
+def radam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float,
+               beta2: float, eps: float, step: int, grad_scale: float = 1.0, zero_grad: bool = True,
+               weight_decay: float = 0.0) -> None:
+    """torch.optim.RAdam (the optimiser of the fruit_nerf_big / fruit_nerf_huge configs) over a flat buffer."""
+    lib = L.load()
+    L.check(lib.fnr_radam_step(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(),
+                               float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
+                               float(weight_decay), 1 if zero_grad else 0, L.stream_ptr(params.device)), "radam_step")
+
+
 # ---- caller side -------------------------------------------------------------------------------------
 
 

@@ -79,7 +79,12 @@ class CameraAdam:
     """The camera optimiser's torch.optim.Adam(lr, eps, weight_decay) + ExponentialDecay schedule as one fused launch
     (same kernel as the model's optimiser: fnr_adam_step with the L2 weight_decay term)."""
 
-    def __init__(self, camera_optimizer: CameraOptimizer, betas=(0.9, 0.999)):
+    def __init__(self, camera_optimizer: CameraOptimizer, betas=(0.9, 0.999), algorithm: str = "adam"):
+        # algorithm="radam": the big/huge configs' camera optimiser (RAdamOptimizerConfig(lr=6e-4, eps=1e-8,
+        # weight_decay=1e-3), fruit_nerf_config.py:77-80,125-128)
+        if algorithm not in ("adam", "radam"):
+            raise ValueError(f"unknown optimiser algorithm {algorithm!r}")
+        self.algorithm = algorithm
         self.opt = camera_optimizer
         self.cfg = camera_optimizer.config
         self.betas = betas
@@ -96,5 +101,6 @@ class CameraAdam:
         c = self.cfg
         lr = c.lr if c.lr_final is None else exponential_decay_lr(self.step_count - 1, c.lr, c.lr_final, c.max_steps)
         p = self.opt.pose_adjustment
-        K.adam_step(p.data.view(-1), p.grad.view(-1), self.exp_avg.view(-1), self.exp_avg_sq.view(-1), lr,
-                    self.betas[0], self.betas[1], c.eps, self.step_count, grad_scale, True, weight_decay=c.weight_decay)
+        fn = K.adam_step if self.algorithm == "adam" else K.radam_step
+        fn(p.data.view(-1), p.grad.view(-1), self.exp_avg.view(-1), self.exp_avg_sq.view(-1), lr,
+           self.betas[0], self.betas[1], c.eps, self.step_count, grad_scale, True, weight_decay=c.weight_decay)

@@ -296,6 +296,40 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
   }
 }
 
+// torch.optim.RAdam (fruit_nerf_big / fruit_nerf_huge use it for every group, fruit_nerf_config.py:97-106,148-160):
+// same moments as Adam; the update is rectified once the variance estimate is tractable (rho_t > 5), plain momentum
+// before.  `rect` < 0 encodes "not rectified"; all step-dependent scalars are computed on the host in double.
+__global__ __launch_bounds__(256) void k_radam(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                               float4* __restrict__ v, long long n4, float lr, float b1, float b2,
+                                               float eps, float bc1, float bc2_sqrt, float rect, float grad_scale,
+                                               float weight_decay, int zero_grad) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 P = p[i], G = g[i], M = m[i], V = v[i];
+    float* pp = reinterpret_cast<float*>(&P);
+    float* gp = reinterpret_cast<float*>(&G);
+    float* mp = reinterpret_cast<float*>(&M);
+    float* vp = reinterpret_cast<float*>(&V);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float gr = gp[c] * grad_scale;
+      if (weight_decay != 0.0f) gr = gr + weight_decay * pp[c];
+      mp[c] = mp[c] + (gr - mp[c]) * (1.0f - b1);
+      vp[c] = vp[c] * b2 + (1.0f - b2) * gr * gr;
+      const float mhat = mp[c] / bc1;                        // bias_corrected_exp_avg
+      if (rect >= 0.0f) {
+        const float adaptive = bc2_sqrt / (sqrtf(vp[c]) + eps);   // sqrt(bias_correction2) / (exp_avg_sq.sqrt() + eps)
+        pp[c] = pp[c] - lr * (mhat * rect * adaptive);
+      } else {
+        pp[c] = pp[c] - lr * mhat;
+      }
+    }
+    p[i] = P;
+    m[i] = M;
+    v[i] = V;
+    if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 }  // namespace fnr
 
 using namespace fnr;
@@ -382,6 +416,32 @@ extern "C" int fnr_adam_step(float* params, float* grads, float* exp_avg, float*
                      reinterpret_cast<float4*>(params), reinterpret_cast<float4*>(grads),
                      reinterpret_cast<float4*>(exp_avg), reinterpret_cast<float4*>(exp_avg_sq), n4, lr, beta1, beta2,
                      eps, (float)bc1, (float)sqrt(bc2), grad_scale, weight_decay, zero_grad);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_radam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, int64_t step, float grad_scale, float weight_decay,
+                              int zero_grad, void* stream) {
+  FNR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "radam_step: null argument");
+  FNR_CHECK_ARG(n % 4 == 0 && step >= 1, "radam_step: n must be a multiple of 4 (arena is padded) and step >= 1");
+  if (n == 0) return FNR_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double b2t = pow((double)beta2, (double)step);
+  const double bc2 = 1.0 - b2t;
+  const double rho_inf = 2.0 / (1.0 - (double)beta2) - 1.0;
+  const double rho_t = rho_inf - 2.0 * (double)step * b2t / bc2;
+  double rect = -1.0;  // not rectified
+  if (rho_t > 5.0)
+    rect = sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+  long long n4 = n / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  FNR_PROF(OP_ADAM, n);
+  hipLaunchKernelGGL(k_radam, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<float4*>(params),
+                     reinterpret_cast<float4*>(grads), reinterpret_cast<float4*>(exp_avg),
+                     reinterpret_cast<float4*>(exp_avg_sq), n4, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
+                     (float)rect, grad_scale, weight_decay, zero_grad);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

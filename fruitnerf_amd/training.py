@@ -220,7 +220,13 @@ class FusedAdam:
     scaling of the all-reduced gradient and with zero_grad."""
 
     def __init__(self, model, lr: float = 1e-2, eps: float = 1e-15, betas=(0.9, 0.999), lr_final: float = 1e-4,
-                 max_steps: int = 200000, group_lr: Optional[Dict[str, dict]] = None):
+                 max_steps: int = 200000, group_lr: Optional[Dict[str, dict]] = None, algorithm: str = "adam",
+                 weight_decay: float = 0.0):
+        # algorithm="radam": torch.optim.RAdam, the optimiser of the fruit_nerf_big / fruit_nerf_huge method configs
+        # (RAdamOptimizerConfig, fruit_nerf_config.py:97-106,148-160)
+        if algorithm not in ("adam", "radam"):
+            raise ValueError(f"unknown optimiser algorithm {algorithm!r}")
+        self.algorithm, self.weight_decay = algorithm, weight_decay
         self.model = model
         self.arena = model.arena()
         self.betas, self.eps = betas, eps
@@ -246,8 +252,10 @@ class FusedAdam:
     def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0) -> None:
         """Adam update (+ zero_grad) of arena elements [a, b); begin_step() must have been called for this step."""
         if b > a:
-            K.adam_step(self.arena.params[a:b], self.arena.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr,
-                        self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, True)
+            fn = K.adam_step if self.algorithm == "adam" else K.radam_step
+            fn(self.arena.params[a:b], self.arena.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr,
+               self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, True,
+               weight_decay=self.weight_decay)
 
     def step(self, grad_scale: float = 1.0) -> None:
         lrs = self.begin_step()

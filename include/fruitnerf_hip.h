@@ -319,6 +319,12 @@ int fnr_position_grad_from_jacobian(const fnr_warp* warp, const fnr_rays* rays, 
 int fnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int64_t step, float grad_scale, float weight_decay, int zero_grad,
                   void* stream);
+/* torch.optim.RAdam step with the same conventions (RAdamOptimizerConfig of fruit_nerf_big / fruit_nerf_huge,
+ * fruit_nerf_config.py:77-80,97-106,125-160): rectified adaptive update once rho_t > 5, plain bias-corrected momentum
+ * before. */
+int fnr_radam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t step, float grad_scale, float weight_decay, int zero_grad,
+                   void* stream);
 
 /* ---- export --------------------------------------------------------------------------------- */
 /* sample_volume's masks + gathers (export/exporter_utils.py:111-153) as an order-preserving stream

@@ -511,3 +511,24 @@ def test_export_at_a_trained_state_matches_the_oracle(dev):
         a, b = got[name]["points"], ref[name]["points"].numpy()
         print(f"[trained export] {name}: hip {a.shape[0]} oracle {b.shape[0]}")
         assert a.shape == b.shape and np.array_equal(a, b), name
+
+
+def test_radam_matches_torch(dev):
+    """fnr_radam_step vs torch.optim.RAdam (CPU) across the rectification threshold (rho_t > 5 from step 6 on for
+    beta2 = 0.999), with and without weight decay."""
+    from fruitnerf_amd import _kernels as K
+    for wd in (0.0, 1e-3):
+        g0 = torch.Generator().manual_seed(7)
+        p_ref = torch.randn(4096, generator=g0).requires_grad_(True)
+        opt = torch.optim.RAdam([p_ref], lr=1e-2, eps=1e-15, weight_decay=wd)
+        p = p_ref.detach().clone().to(dev)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in range(1, 13):
+            grad = torch.randn(4096, generator=g0) * (10.0 ** float(torch.randint(-6, 1, (1,), generator=g0)))
+            p_ref.grad = grad.clone()
+            opt.step()
+            gd = (grad * 2.0).to(dev)
+            K.radam_step(p, gd, m, v, 1e-2, 0.9, 0.999, 1e-15, step, grad_scale=0.5, zero_grad=True, weight_decay=wd)
+            assert float(gd.abs().max()) == 0.0
+            err = (p.cpu() - p_ref.detach()).abs().max().item()
+            assert err <= 5e-6, (wd, step, err)
