@@ -265,6 +265,9 @@ class FusedAdam:
             self.step_span(a, b, next(iter(lrs.values())) if same else lrs[name], grad_scale)
 
 
+# 2 in production; the single-GPU RCCL self-test (tools/microbench/rccl_single_rank.py) lowers it to 1 so that a
+# one-rank process group runs the full exchange code path (all-reduce over one rank is the identity)
+EXCHANGE_MIN_WORLD = 2
 GRAD_BUCKET_ELEMS = 4 << 20   # 16 MiB fp32 buckets: large enough for xGMI ring bandwidth, small enough to pipeline
 
 
@@ -273,7 +276,7 @@ def start_gradient_sync(arena, span, world_size: int, bucket_elems: int = GRAD_B
     stream (RCCL over xGMI on GPUs, gloo in the CPU tests) and return [(a, b, work)].  The caller keeps launching
     compute that does not touch that span (the proposal-network backward runs while the field gradient is in
     flight), then waits per bucket and applies Adam to it while the next bucket is still being reduced."""
-    if world_size <= 1:
+    if world_size < EXCHANGE_MIN_WORLD:
         return []
     import torch.distributed as dist
     a0, b0 = span
@@ -288,7 +291,7 @@ def sync_gradients(arena, world_size: int) -> float:
     """DDP's gradient exchange (fruit_pipeline.py:116-118) as ONE all-reduce(SUM) over the flat gradient
     arena (RCCL over xGMI on GPUs; gloo in the CPU tests).  Returns the scale (1/world) the optimiser must
     apply — folding the mean into the Adam kernel saves a pass over the 78 MB buffer."""
-    if world_size <= 1:
+    if world_size < EXCHANGE_MIN_WORLD:
         return 1.0
     import torch.distributed as dist
     dist.all_reduce(arena.grads, op=dist.ReduceOp.SUM)
@@ -429,7 +432,7 @@ def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: 
     K.camera_pose_grad(batcher._set, batcher.image_ids, d["u"], d["cam"], pose.data, d["c2w_adjusted"],
                        ray_grads["origins"], ray_grads["directions"], pose.grad)
     scale = 1.0
-    if world_size > 1:
+    if world_size >= EXCHANGE_MIN_WORLD:
         import torch.distributed as dist
         dist.all_reduce(pose.grad, op=dist.ReduceOp.SUM)
         scale = 1.0 / world_size
@@ -447,7 +450,7 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
     model.set_anneal(step)                                     # BEFORE_TRAIN_ITERATION callback
     arena = model.arena()
     spans = arena.group_ranges
-    exchange = _FieldGradientExchange(model, world_size) if world_size > 1 else None
+    exchange = _FieldGradientExchange(model, world_size) if world_size >= EXCHANGE_MIN_WORLD else None
     ray_grads = {} if camera is not None else None   # camera = (CameraOptimizer, CameraAdam, PixelBatcher)
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads)
