@@ -442,6 +442,70 @@ def radam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tenso
                                float(weight_decay), 1 if zero_grad else 0, L.stream_ptr(params.device)), "radam_step")
 
 
+# ---- point-cloud front-end of the counting stage ------------------------------------------------------
+
+
+def _cloud_args(xyz: Tensor):
+    if xyz.dtype != torch.float64 or xyz.dim() != 2 or xyz.shape[1] != 3 or not xyz.is_cuda:
+        raise ValueError("point clouds are [n,3] float64 device tensors (Open3D / PLY precision)")
+    xyz = xyz.contiguous()
+    n = xyz.shape[0]
+    ws = torch.empty(L.load().fnr_cloud_workspace_bytes(n), dtype=torch.uint8, device=xyz.device)
+    return xyz, n, ws
+
+
+def _bounds(xyz: Tensor):
+    """Host copies of the cloud's axis-aligned bounds (Open3D GetMinBound / GetMaxBound); one small D2H sync."""
+    lo_hi = torch.stack([xyz.amin(0), xyz.amax(0)]).cpu()
+    return (C.c_double * 3)(*lo_hi[0].tolist()), (C.c_double * 3)(*lo_hi[1].tolist())
+
+
+def cloud_radius_count(xyz: Tensor, radius: float, inclusive: bool) -> Tensor:
+    """-> int32 [n]: neighbours within radius (strict < unless inclusive), the point itself included."""
+    xyz, n, ws = _cloud_args(xyz)
+    counts = torch.empty(n, dtype=torch.int32, device=xyz.device)
+    if n == 0:
+        return counts
+    lo, hi = _bounds(xyz)
+    L.check(L.load().fnr_cloud_radius_count(L.ptr(xyz), n, lo, hi, float(radius), 1 if inclusive else 0, L.ptr(counts),
+                                            L.ptr(ws), ws.numel(), L.stream_ptr(xyz.device)), "cloud_radius_count")
+    return counts
+
+
+def cloud_dbscan(xyz: Tensor, eps: float, min_samples: int):
+    """-> (labels int32 [n], n_clusters int32 [1] device)."""
+    xyz, n, ws = _cloud_args(xyz)
+    labels = torch.empty(n, dtype=torch.int32, device=xyz.device)
+    n_clusters = torch.zeros(1, dtype=torch.int32, device=xyz.device)
+    if n == 0:
+        return labels, n_clusters
+    lo, hi = _bounds(xyz)
+    L.check(L.load().fnr_cloud_dbscan(L.ptr(xyz), n, lo, hi, float(eps), int(min_samples), L.ptr(labels),
+                                      L.ptr(n_clusters), L.ptr(ws), ws.numel(), L.stream_ptr(xyz.device)),
+            "cloud_dbscan")
+    return labels, n_clusters
+
+
+def cloud_voxel_down_sample(xyz: Tensor, rgb: Optional[Tensor], voxel_size: float):
+    """-> (xyz_out [m,3], rgb_out [m,3] | None), one point per occupied voxel in ascending (iz, iy, ix) order."""
+    xyz, n, ws = _cloud_args(xyz)
+    if rgb is not None:
+        if rgb.shape != xyz.shape or rgb.dtype != torch.float64:
+            raise ValueError("colours are [n,3] float64 like the points")
+        rgb = rgb.contiguous()
+    if n == 0:
+        return xyz.clone(), (None if rgb is None else rgb.clone())
+    xyz_out = torch.empty_like(xyz)
+    rgb_out = None if rgb is None else torch.empty_like(rgb)
+    n_out = torch.zeros(1, dtype=torch.int32, device=xyz.device)
+    lo, hi = _bounds(xyz)
+    L.check(L.load().fnr_cloud_voxel_down_sample(L.ptr(xyz), L.ptr(rgb), n, lo, hi, float(voxel_size), L.ptr(xyz_out),
+                                                 L.ptr(rgb_out), L.ptr(n_out), L.ptr(ws), ws.numel(),
+                                                 L.stream_ptr(xyz.device)), "cloud_voxel_down_sample")
+    m = int(n_out.item())
+    return xyz_out[:m], (None if rgb_out is None else rgb_out[:m])
+
+
 # ---- caller side -------------------------------------------------------------------------------------
 
 

@@ -105,6 +105,13 @@ SIGNATURES = {
     "fnr_position_grad_reduce": (_i, [P(fnr_warp), P(fnr_rays), _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fnr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
     "fnr_radam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
+    "fnr_cloud_workspace_bytes": (C.c_size_t, [_i64]),
+    "fnr_cloud_radius_count": (_i, [_vp, _i64, P(C.c_double), P(C.c_double), C.c_double, _i, _vp, _vp, C.c_size_t,
+                                    _vp]),
+    "fnr_cloud_dbscan": (_i, [_vp, _i64, P(C.c_double), P(C.c_double), C.c_double, C.c_int32, _vp, _vp, _vp,
+                              C.c_size_t, _vp]),
+    "fnr_cloud_voxel_down_sample": (_i, [_vp, _vp, _i64, P(C.c_double), P(C.c_double), C.c_double, _vp, _vp, _vp, _vp,
+                                         C.c_size_t, _vp]),
     "fnr_camera_adjust": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "fnr_camera_pose_grad": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_export_workspace_bytes": (C.c_size_t, [_i64]),
@@ -180,7 +187,7 @@ def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
 PROFILE_OPS = ["sample_spaced", "weights_pdf", "prop_density_fwd", "hash_encode_fwd", "hash_encode_lattice",
                "field_mlp_fwd", "composite_fwd", "losses_fwd", "interlevel_fwd", "distortion", "composite_bwd",
                "weights_bwd", "field_mlp_bwd", "hash_encode_bwd", "prop_density_bwd", "adam_step", "export_compact",
-               "position_grad"]
+               "position_grad", "cloud"]
 
 
 def profile_enable(on: bool, ops=None) -> None:

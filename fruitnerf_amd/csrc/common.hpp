@@ -54,7 +54,7 @@ int device_cu_count();
 enum ProfOp : int {
   OP_SAMPLE_SPACED = 0, OP_WEIGHTS_PDF, OP_PROP_FWD, OP_ENCODE_FWD, OP_ENCODE_LATTICE, OP_MLP_FWD, OP_COMPOSITE_FWD,
   OP_LOSSES, OP_INTERLEVEL, OP_DISTORTION, OP_COMPOSITE_BWD, OP_WEIGHTS_BWD, OP_MLP_BWD, OP_ENCODE_BWD, OP_PROP_BWD,
-  OP_ADAM, OP_EXPORT_COMPACT, OP_POSITION_GRAD, OP_COUNT
+  OP_ADAM, OP_EXPORT_COMPACT, OP_POSITION_GRAD, OP_CLOUD, OP_COUNT
 };
 struct ProfScope {
   ProfScope(int op, long long units, void* stream);

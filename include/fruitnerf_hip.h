@@ -342,6 +342,30 @@ int fnr_export_compact(const fnr_lattice* lat, int64_t ray_begin, int64_t n_rays
                        const float* rgb, const float* logit, float* const points[3], float* const colors[3],
                        int64_t capacity, uint64_t* counts, void* workspace, void* stream);
 
+/* ---- point-cloud front-end of the counting stage ---------------------------------------------- */
+/* FruitClustering.cluster (clustering/clustering_base.py:183-207) runs, on the exported cloud, Open3D's
+ * remove_radius_outlier (:141-143), Open3D's voxel_down_sample (:138-139) and sklearn.cluster.DBSCAN (:199-200).
+ * These three entry points replace those library calls; clouds are [n][3] float64 device arrays (Open3D / PLY
+ * precision), every integer result (counts, labels) is bit-exact with the CPU libraries.  lo/hi/min_bound/max_bound
+ * are HOST pointers to 3 doubles: the axis-aligned bounds of the cloud (Open3D's GetMinBound/GetMaxBound).
+ * workspace: >= fnr_cloud_workspace_bytes(n) bytes, caller-owned, contents undefined afterwards. */
+size_t fnr_cloud_workspace_bytes(int64_t n_points);
+/* counts[i] = #{j : |p_i - p_j|^2 < radius^2} (inclusive != 0: <=), the point itself included.
+ * Open3D's RemoveRadiusOutliers keeps i when counts[i] > nb_points (strict search, inclusive = 0). */
+int fnr_cloud_radius_count(const double* xyz, int64_t n, const double* lo, const double* hi, double radius,
+                           int inclusive, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+/* scikit-learn's DBSCAN(eps, min_samples).fit(X).labels_: labels[n] (-1 = noise, clusters numbered by their first core
+ * point in input order, border points join the lowest-numbered adjacent cluster); n_clusters: device int32 (nullable). */
+int fnr_cloud_dbscan(const double* xyz, int64_t n, const double* lo, const double* hi, double eps, int32_t min_samples,
+                     int32_t* labels, int32_t* n_clusters, void* workspace, size_t workspace_bytes, void* stream);
+/* Open3D's VoxelDownSample: one output point per occupied voxel (index = floor((p - (min_bound - voxel_size/2)) /
+ * voxel_size)) = mean of its points (and colours; rgb / rgb_out nullable together), summed in input order.  Voxels are
+ * emitted in ascending (iz, iy, ix) order (Open3D's order is unspecified).  xyz_out / rgb_out: capacity [n][3];
+ * n_out: device int32 = number of occupied voxels. */
+int fnr_cloud_voxel_down_sample(const double* xyz, const double* rgb, int64_t n, const double* min_bound,
+                                const double* max_bound, double voxel_size, double* xyz_out, double* rgb_out,
+                                int32_t* n_out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
