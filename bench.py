@@ -95,6 +95,59 @@ def split_indices(n: int, frac: float):
     return i_train, i_eval
 
 
+def counting_stage_bench(dev, cpu: bool):
+    """The counting stage's three library calls (Open3D remove_radius_outlier / voxel_down_sample, sklearn DBSCAN;
+    clustering_base.py:183-207) with the reference's synthetic-apple parameters (config_synthetic.py:2-15) on a
+    synthetic 1.1 M-point export cloud: GPU kernels (best of 3, cloud resident in HBM) vs the CPU libraries that are
+    importable here (scipy's KD-tree for the radius search, scikit-learn's DBSCAN, all host cores)."""
+    import numpy as np
+    import torch
+    from fruitnerf_amd import _kernels as K
+    from fruitnerf_amd.data.synthetic_cloud import make_export_cloud
+    X = make_export_cloud(80)
+    x = torch.as_tensor(X, device=dev)
+
+    def timed(fn, reps=3):
+        best, out = 1e9, None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t)
+        return out, best * 1e3
+    K.cloud_radius_count(x[:1024].contiguous(), 0.01, False)        # module load
+    counts, t_cnt = timed(lambda: K.cloud_radius_count(x, 0.01, False))
+    xk = x[counts > 200].contiguous()
+    (vx, _), t_vox = timed(lambda: K.cloud_voxel_down_sample(xk, None, 0.001))
+    (labels, k), t_db = timed(lambda: K.cloud_dbscan(vx, 0.01, 100))
+    hits = float(counts.double().sum())
+    out = {"cloud": f"{len(X)} lattice points, 80 spheres + 5% clutter, mean {hits / len(X):.0f} neighbours in r=0.01",
+           "params": "radius 0.01 / nb_points 200, voxel 0.001, eps 0.01 / min_samples 100",
+           "gpu_ms": {"radius_count": round(t_cnt, 2), "voxel_down_sample": round(t_vox, 2), "dbscan": round(t_db, 2)},
+           "points_after": {"outlier_removal": int(xk.shape[0]), "voxel_down_sample": int(vx.shape[0])},
+           "clusters": int(k.item()),
+           "gpu_points_per_s": round(len(X) / ((t_cnt + t_vox + t_db) * 1e-3), 1)}
+    if cpu:
+        try:
+            from scipy.spatial import cKDTree
+            from sklearn.cluster import DBSCAN
+            t = time.perf_counter()
+            c_cpu = cKDTree(X).query_ball_point(X, 0.01, return_length=True, workers=-1)
+            t_c = time.perf_counter() - t
+            Xv = vx.cpu().numpy()
+            t = time.perf_counter()
+            lab = DBSCAN(eps=0.01, min_samples=100, n_jobs=-1).fit(Xv).labels_
+            t_d = time.perf_counter() - t
+            out["cpu_ms"] = {"radius_count_scipy_ckdtree": round(t_c * 1e3, 1), "dbscan_sklearn": round(t_d * 1e3, 1),
+                             "cores": os.cpu_count()}
+            out["labels_equal_sklearn"] = bool(np.array_equal(lab, labels.cpu().numpy()))
+            out["counts_close_to_ckdtree"] = float(np.mean(c_cpu == counts.cpu().numpy()))  # <= vs < differ on ties
+        except Exception as e:  # noqa: BLE001
+            out["cpu_ms"] = f"unavailable: {e}"
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,18 +397,17 @@ def main() -> None:
             torch.cuda.synchronize()
             cam_off = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
             camera = saved
-        # end-to-end sanity of the export (SURVEY §8f row 3 is the real clustering stage; this is only a density-based
-        # count of connected blobs in the exported semantic set): DBSCAN on the lattice points, scene has 32 fruits
+        # counting stage front-end on the exported semantic set: radius-outlier removal -> voxel
+        # down-sampling -> DBSCAN -> centre-distance merge, all three library calls on the GPU; the scene has 32 fruits
+        from fruitnerf_amd.clustering import FruitClustering, PointCloud
+        pts = sets["semantic"]["points"]
+        spacing = 2.0 / N_EXP * 2.0                     # lattice pitch after sample_volume's x2 scaling
         fruit_count = None
-        try:
-            from sklearn.cluster import DBSCAN
-            pts = sets["semantic"]["points"]
-            if pts.shape[0] >= 5:
-                spacing = 2.0 / N_EXP * 2.0     # lattice pitch after sample_volume's x2 scaling
-                labels = DBSCAN(eps=1.8 * spacing, min_samples=4).fit(pts).labels_
-                fruit_count = int(labels.max() + 1)
-        except Exception as e:  # noqa: BLE001  (sklearn is optional)
-            fruit_count = f"unavailable: {e}"
+        if pts.shape[0] >= 5:
+            fc = FruitClustering(voxel_size_down_sample=spacing / 4, remove_outliers_nb_points=2,
+                                 remove_outliers_radius=1.8 * spacing, cluster_merge_distance=0.04)
+            fruit_count = fc.first_stage_count(PointCloud(pts, None, dev), eps=1.8 * spacing, min_samples=4)
+        counting = counting_stage_bench(dev, cpu=not args.no_cpu_baseline)
         secondary = {"train_rays_per_s_camera_optimizer_off": cam_off,
                      "train_rays_per_s_camera_optimizer_off_note": f"100 steps measured after step {step_idx[0] - 100} "
                      "(proposal nets are updated less often by then than in the headline window)",
@@ -363,7 +415,8 @@ def main() -> None:
                      "export_samples_per_s": round(n_rays * N_EXP / exp_s, 1), "export_lattice": f"{N_EXP}^3",
                      "export_pass_ms": [round(t * 1e3, 1) for t in exp_times],
                      "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()},
-                     "fruit_count_dbscan_on_semantic_export": fruit_count, "fruit_count_scene": scene.n_fruits}
+                     "fruit_count_first_stage_on_semantic_export": fruit_count, "fruit_count_scene": scene.n_fruits,
+                     "counting_front_end": counting}
         model.train()
 
     # ---- CPU baseline: the oracle's training step on the host cores -------------------------------------------------

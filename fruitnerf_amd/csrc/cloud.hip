@@ -5,10 +5,10 @@
 //
 // One search structure serves the two neighbourhood queries: points are sorted by the key of a uniform grid whose
 // cell edge is (just above) the search radius, with x fastest in the key, so the 27 neighbour cells of a point are
-// 9 CONTIGUOUS runs of the sorted array, each found with two binary searches (the lanes of a wave mostly sit in the
-// same cell, so the searches and the candidate loads are wave-wide broadcasts out of L1/L2).  A thread owns one point
-// and tests every candidate in fp64 with the operation order of the CPU libraries (((dx*dx)+dy*dy)+dz*dz, no FMA), so
-// the integer results (counts, masks, labels) are bit-exact.  The cost is the pair tests: fp64 VALU bound.
+// 9 CONTIGUOUS runs of the sorted array, each found with two binary searches.  A wave owns one occupied cell: its lanes
+// hold the cell's points, the candidates are walked with a wave-uniform index (scalar loads) and tested in fp64 with
+// the operation order of the CPU libraries (((dx*dx)+dy*dy)+dz*dz, no FMA), so the integer results (counts, masks,
+// labels) are bit-exact.  The cost is the pair tests: fp64 VALU bound (10 instructions per candidate and wave).
 //
 // DBSCAN = (1) inclusive neighbour counts -> core flags, (2) lock-free union-find over core-core pairs in ORIGINAL
 // index space, always hooking the larger root under the smaller, so a cluster's root is its first core point in input
@@ -36,11 +36,13 @@ struct CloudWs {
   u64* keys;      // sorted
   int* idx_a;
   int* order;     // sorted position -> input index
-  double* sxyz;   // [n][3] positions in sorted order
+  double4* sxyz;  // [n] positions in sorted order, padded to 32 B (two aligned 16-byte loads per candidate)
   int* aux0;      // per sorted position: core flag / head flag
   int* aux1;      // per input index: union-find parent
   int* aux2;      // per input index: core flag, then root flag
   int* aux3;      // scan output
+  int* cell_first;  // [n_cells + 1] first sorted position of every occupied cell
+  int* ctrl;      // [0] n_cells, [1..7] work counters of the cell sweeps
   void* temp;
   size_t temp_bytes;
 };
@@ -49,7 +51,7 @@ static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 static size_t cloud_fixed_bytes(int64_t n) {
   const size_t m = (size_t)(n < 1 ? 1 : n);
-  return 2 * align256(m * 8) + 2 * align256(m * 4) + align256(m * 24) + 4 * align256(m * 4);
+  return 2 * align256(m * 8) + 2 * align256(m * 4) + align256(m * 32) + 4 * align256(m * 4) + align256((m + 1) * 4) + 256;
 }
 static size_t cloud_temp_reserve(int64_t n) { return (size_t)(n < 1 ? 1 : n) * 16 + ((size_t)8 << 20); }
 
@@ -61,11 +63,13 @@ static bool carve_cloud(void* ws, size_t bytes, int64_t n, CloudWs* out) {
   out->keys = reinterpret_cast<u64*>(p);    p += align256(m * 8);
   out->idx_a = reinterpret_cast<int*>(p);   p += align256(m * 4);
   out->order = reinterpret_cast<int*>(p);   p += align256(m * 4);
-  out->sxyz = reinterpret_cast<double*>(p); p += align256(m * 24);
+  out->sxyz = reinterpret_cast<double4*>(p); p += align256(m * 32);
   out->aux0 = reinterpret_cast<int*>(p);    p += align256(m * 4);
   out->aux1 = reinterpret_cast<int*>(p);    p += align256(m * 4);
   out->aux2 = reinterpret_cast<int*>(p);    p += align256(m * 4);
   out->aux3 = reinterpret_cast<int*>(p);    p += align256(m * 4);
+  out->cell_first = reinterpret_cast<int*>(p); p += align256((m + 1) * 4);
+  out->ctrl = reinterpret_cast<int*>(p);    p += 256;
   out->temp = p;
   out->temp_bytes = bytes - (size_t)(p - static_cast<char*>(ws));
   return true;
@@ -88,13 +92,11 @@ __global__ __launch_bounds__(256) void k_cloud_keys(const double* __restrict__ x
 }
 
 __global__ __launch_bounds__(256) void k_cloud_gather(const double* __restrict__ xyz, const int* __restrict__ order,
-                                                      int n, double* __restrict__ sxyz) {
+                                                      int n, double4* __restrict__ sxyz) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= n) return;
   const size_t i = (size_t)order[s];
-  sxyz[3 * (size_t)s + 0] = xyz[3 * i + 0];
-  sxyz[3 * (size_t)s + 1] = xyz[3 * i + 1];
-  sxyz[3 * (size_t)s + 2] = xyz[3 * i + 2];
+  sxyz[s] = make_double4(xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2], 0.0);
 }
 
 __device__ inline int lower_bound_key(const u64* __restrict__ keys, int lo, int hi, u64 k) {
@@ -112,56 +114,92 @@ __device__ inline int upper_bound_key(const u64* __restrict__ keys, int lo, int 
   return lo;
 }
 
-// f(t, d2) for every sorted position t in the 3x3x3 cell neighbourhood of sorted position s (s itself included)
-template <class F>
-__device__ inline void for_each_candidate(const u64* __restrict__ keys, const double* __restrict__ sxyz, int n,
-                                          const CloudGrid& g, int s, F&& f) {
-  const u64 key = keys[s];
+// squared distance in the CPU libraries' operation order: ((dx*dx) + dy*dy) + dz*dz, every op rounded
+__device__ inline double pair_d2(const double4& p, const double4& q) {
+  const double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+// ---- cell-cooperative neighbourhood sweep ---------------------------------------------------------------------------
+// A wave takes one occupied cell at a time (dynamic: one atomic per cell).  The cell's 9 candidate runs are found once
+// (lanes 0..8 search one run each) and live in SGPRs; the lanes hold up to 64 of the cell's points (the targets) and
+// the wave walks the candidates with a wave-uniform index, so each candidate is ONE scalar load (32 B through the
+// scalar cache) feeding 64 fp64 tests whose second operand is an SGPR pair: no vector-memory or LDS traffic in the
+// inner loop, the fp64 VALU is the only busy unit.
+struct CellRuns {
+  int b[9], e[9];
+};
+
+__device__ inline int wave_lane() { return (int)(threadIdx.x & 63u); }
+
+__device__ inline bool next_cell(int* counter, int n_cells, int* c) {
+  int v = 0;
+  if (wave_lane() == 0) v = atomicAdd(counter, 1);
+  *c = __builtin_amdgcn_readfirstlane(v);
+  return *c < n_cells;
+}
+
+__device__ inline CellRuns cell_runs(const u64* __restrict__ keys, int n, const CloudGrid& g, u64 key) {
   const long long nx = g.dim[0], ny = g.dim[1], nz = g.dim[2];
   const long long cx = (long long)(key % (u64)nx);
   const long long cy = (long long)((key / (u64)nx) % (u64)ny);
   const long long cz = (long long)(key / (u64)(nx * ny));
-  const double px = sxyz[3 * (size_t)s + 0], py = sxyz[3 * (size_t)s + 1], pz = sxyz[3 * (size_t)s + 2];
   const long long x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < nx ? cx + 1 : nx - 1;
-  for (int dz = -1; dz <= 1; ++dz) {
-    const long long zz = cz + dz;
-    if (zz < 0 || zz >= nz) continue;
-    for (int dy = -1; dy <= 1; ++dy) {
-      const long long yy = cy + dy;
-      if (yy < 0 || yy >= ny) continue;
-      const u64 row = (u64)((zz * ny + yy) * nx);
-      const int b = lower_bound_key(keys, 0, n, row + (u64)x0);
-      const int e = upper_bound_key(keys, b, n, row + (u64)x1);
-      for (int t = b; t < e; ++t) {
-        const double dx = px - sxyz[3 * (size_t)t + 0];
-        const double dy_ = py - sxyz[3 * (size_t)t + 1];
-        const double dz_ = pz - sxyz[3 * (size_t)t + 2];
-        const double d2 = (dx * dx + dy_ * dy_) + dz_ * dz_;
-        f(t, d2);
-      }
-    }
+  const int k = wave_lane() < 9 ? wave_lane() : 8;
+  const long long yy = cy + (k % 3) - 1, zz = cz + (k / 3) - 1;
+  int b = 0, e = 0;
+  if (yy >= 0 && yy < ny && zz >= 0 && zz < nz) {
+    const u64 row = (u64)((zz * ny + yy) * nx);
+    b = lower_bound_key(keys, 0, n, row + (u64)x0);
+    e = upper_bound_key(keys, b, n, row + (u64)x1);
   }
+  CellRuns r;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    r.b[j] = __builtin_amdgcn_readlane(b, j);
+    r.e[j] = __builtin_amdgcn_readlane(e, j);
+  }
+  return r;
 }
 
 // counts[input index] = neighbours with d2 < r2 (INCL: <=), the point itself included.
 // CORE: additionally core_sorted[s] / core_input[i] = count >= min_samples and parent[i] = i.
 template <bool INCL, bool CORE>
-__global__ __launch_bounds__(256) void k_cloud_count(const u64* __restrict__ keys, const double* __restrict__ sxyz,
+__global__ __launch_bounds__(256) void k_cloud_count(const u64* __restrict__ keys, const double4* __restrict__ sxyz,
                                                      const int* __restrict__ order, int n, CloudGrid g, double r2,
+                                                     const int* __restrict__ cell_first, int* ctrl, int pass,
                                                      int* __restrict__ counts, int min_samples,
                                                      int* __restrict__ core_sorted, int* __restrict__ core_input,
                                                      int* __restrict__ parent) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= n) return;
-  int c = 0;
-  for_each_candidate(keys, sxyz, n, g, s, [&](int, double d2) { c += INCL ? (d2 <= r2) : (d2 < r2); });
-  const int i = order[s];
-  if (counts) counts[i] = c;
-  if (CORE) {
-    const int is_core = c >= min_samples;
-    core_sorted[s] = is_core;
-    core_input[i] = is_core;
-    parent[i] = i;
+  const int n_cells = ctrl[0];
+  int c;
+  while (next_cell(&ctrl[1 + pass], n_cells, &c)) {
+    const int s0 = cell_first[c], s1 = cell_first[c + 1];
+    const CellRuns runs = cell_runs(keys, n, g, keys[s0]);
+    for (int base = s0; base < s1; base += 64) {
+      const int s = base + wave_lane();
+      const bool act = s < s1;
+      const double4 p = sxyz[act ? s : s0];
+      int cnt = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+#pragma unroll 4
+        for (int t = runs.b[k]; t < runs.e[k]; ++t) {
+          const double d2 = pair_d2(p, sxyz[t]);
+          cnt += INCL ? (d2 <= r2) : (d2 < r2);
+        }
+      }
+      if (act) {
+        const int i = order[s];
+        if (counts) counts[i] = cnt;
+        if (CORE) {
+          const int is_core = cnt >= min_samples;
+          core_sorted[s] = is_core;
+          core_input[i] = is_core;
+          parent[i] = i;
+        }
+      }
+    }
   }
 }
 
@@ -189,25 +227,44 @@ __device__ inline void uf_unite(int* parent, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_cloud_union(const u64* __restrict__ keys, const double* __restrict__ sxyz,
+__global__ __launch_bounds__(256) void k_cloud_union(const u64* __restrict__ keys, const double4* __restrict__ sxyz,
                                                      const int* __restrict__ order, int n, CloudGrid g, double r2,
+                                                     const int* __restrict__ cell_first, int* ctrl, int pass,
                                                      const int* __restrict__ core_sorted, int* parent) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= n || !core_sorted[s]) return;
-  const int i = order[s];
-  int mine = uf_find(parent, i);
-  for_each_candidate(keys, sxyz, n, g, s, [&](int t, double d2) {
-    if (d2 <= r2 && core_sorted[t]) {
-      const int j = order[t];
-      if (j < i) {                                        // every core-core pair is handled from its larger end
-        const int rj = uf_find(parent, j);
-        if (rj != mine) {
-          uf_unite(parent, mine, rj);
-          mine = uf_find(parent, i);
+  const int n_cells = ctrl[0];
+  int c;
+  while (next_cell(&ctrl[1 + pass], n_cells, &c)) {
+    const int s0 = cell_first[c], s1 = cell_first[c + 1];
+    bool runs_ready = false;
+    CellRuns runs;
+    for (int base = s0; base < s1; base += 64) {
+      const int s = base + wave_lane();
+      const bool core = s < s1 && core_sorted[s] != 0;
+      if (__ballot(core) == 0) continue;                  // no core target in this chunk
+      if (!runs_ready) {
+        runs = cell_runs(keys, n, g, keys[s0]);
+        runs_ready = true;
+      }
+      const double4 p = sxyz[s < s1 ? s : s0];
+      const int i = core ? order[s] : -1;
+      int mine = core ? uf_find(parent, i) : -1;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        for (int t = runs.b[k]; t < runs.e[k]; ++t) {
+          if (!core_sorted[t]) continue;                  // wave-uniform: only core-core pairs connect
+          const double d2 = pair_d2(p, sxyz[t]);
+          const int j = order[t];
+          if (core && j < i && d2 <= r2) {                // every core-core pair is handled from its larger end
+            const int rj = uf_find(parent, j);
+            if (rj != mine) {
+              uf_unite(parent, mine, rj);
+              mine = uf_find(parent, i);
+            }
+          }
         }
       }
     }
-  });
+  }
 }
 
 __global__ __launch_bounds__(256) void k_cloud_roots(int* parent, int* __restrict__ core_input_to_root_flag, int n) {
@@ -222,28 +279,57 @@ __global__ __launch_bounds__(256) void k_cloud_roots(int* parent, int* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void k_cloud_labels(const u64* __restrict__ keys, const double* __restrict__ sxyz,
+__global__ __launch_bounds__(256) void k_cloud_labels(const u64* __restrict__ keys, const double4* __restrict__ sxyz,
                                                       const int* __restrict__ order, int n, CloudGrid g, double r2,
+                                                      const int* __restrict__ cell_first, int* ctrl, int pass,
                                                       const int* __restrict__ core_sorted,
                                                       const int* __restrict__ root, const int* __restrict__ root_flag,
                                                       const int* __restrict__ ids, int* __restrict__ labels,
                                                       int* __restrict__ n_clusters) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s == 0 && n_clusters) *n_clusters = ids[n - 1] + root_flag[n - 1];
-  if (s >= n) return;
-  const int i = order[s];
-  if (core_sorted[s]) {
-    labels[i] = ids[root[i]];
-    return;
-  }
-  int best = 0x7fffffff;                                   // smallest root = smallest cluster number
-  for_each_candidate(keys, sxyz, n, g, s, [&](int t, double d2) {
-    if (d2 <= r2 && core_sorted[t]) {
-      const int r = root[order[t]];
-      best = r < best ? r : best;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_clusters) *n_clusters = ids[n - 1] + root_flag[n - 1];
+  const int n_cells = ctrl[0];
+  int c;
+  while (next_cell(&ctrl[1 + pass], n_cells, &c)) {
+    const int s0 = cell_first[c], s1 = cell_first[c + 1];
+    for (int base = s0; base < s1; base += 64) {
+      const int s = base + wave_lane();
+      const bool act = s < s1;
+      const bool core = act && core_sorted[s] != 0;
+      const bool border = act && !core;
+      int best = 0x7fffffff;                               // smallest root = smallest cluster number
+      if (__ballot(border) != 0) {
+        const CellRuns runs = cell_runs(keys, n, g, keys[s0]);
+        const double4 p = sxyz[act ? s : s0];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          for (int t = runs.b[k]; t < runs.e[k]; ++t) {
+            if (!core_sorted[t]) continue;
+            const double d2 = pair_d2(p, sxyz[t]);
+            const int r = root[order[t]];
+            if (border && d2 <= r2) best = r < best ? r : best;
+          }
+        }
+      }
+      if (act) {
+        const int i = order[s];
+        labels[i] = core ? ids[root[i]] : (best == 0x7fffffff ? -1 : ids[best]);
+      }
     }
-  });
-  labels[i] = best == 0x7fffffff ? -1 : ids[best];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cell_list(const int* __restrict__ heads, const int* __restrict__ vid, int n,
+                                                   int* __restrict__ cell_first, int* __restrict__ ctrl) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  if (heads[s]) cell_first[vid[s]] = s;
+  if (s == n - 1) {
+    const int n_cells = vid[s] + heads[s];
+    cell_first[n_cells] = n;
+    ctrl[0] = n_cells;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) ctrl[k] = 0;              // the passes' work counters
+  }
 }
 
 // ---- voxel down-sampling -------------------------------------------------------------------------------------------
@@ -360,7 +446,21 @@ static int build_search_grid(const double* xyz, int n, const double* lo, const d
   if (rc != FNR_OK) return rc;
   hipLaunchKernelGGL(k_cloud_gather, dim3(blocks), dim3(256), 0, st, xyz, w.order, n, w.sxyz);
   FNR_LAUNCH_CHECK();
+  // occupied cells: head flags of the sorted keys -> ranks -> first position per cell
+  hipLaunchKernelGGL(k_voxel_heads, dim3(blocks), dim3(256), 0, st, w.keys, n, w.aux0);
+  FNR_LAUNCH_CHECK();
+  rc = scan_flags(w, w.aux0, w.aux3, n, st);
+  if (rc != FNR_OK) return rc;
+  hipLaunchKernelGGL(k_cell_list, dim3(blocks), dim3(256), 0, st, w.aux0, w.aux3, n, w.cell_first, w.ctrl);
+  FNR_LAUNCH_CHECK();
   return FNR_OK;
+}
+
+// persistent launch of the cell sweeps: enough waves to fill the chip, never more than one per cell
+static unsigned sweep_blocks(int n) {
+  const long long cap = (long long)device_cu_count() * 8;
+  const long long need = ((long long)n + 3) / 4;
+  return (unsigned)(need < cap ? need : cap);
 }
 
 }  // namespace fnr
@@ -386,14 +486,14 @@ extern "C" int fnr_cloud_radius_count(const double* xyz, int64_t n, const double
   CloudGrid g;
   int rc = build_search_grid(xyz, (int)n, lo, hi, radius, w, &g, st, "cloud_radius_count");
   if (rc != FNR_OK) return rc;
-  const unsigned blocks = (unsigned)((n + 255) / 256);
+  const unsigned sweep = sweep_blocks((int)n);
   const double r2 = radius * radius;
   if (inclusive)
-    hipLaunchKernelGGL((k_cloud_count<true, false>), dim3(blocks), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g,
-                       r2, counts, 0, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_cloud_count<true, false>), dim3(sweep), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g,
+                       r2, w.cell_first, w.ctrl, 0, counts, 0, nullptr, nullptr, nullptr);
   else
-    hipLaunchKernelGGL((k_cloud_count<false, false>), dim3(blocks), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n,
-                       g, r2, counts, 0, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_cloud_count<false, false>), dim3(sweep), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n,
+                       g, r2, w.cell_first, w.ctrl, 0, counts, 0, nullptr, nullptr, nullptr);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }
@@ -422,18 +522,19 @@ extern "C" int fnr_cloud_dbscan(const double* xyz, int64_t n, const double* lo, 
   int* parent = w.aux1;
   int* core_input = w.aux2;   // becomes the root flag
   int* ids = w.aux3;
-  hipLaunchKernelGGL((k_cloud_count<true, true>), dim3(blocks), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g, r2,
-                     (int*)nullptr, (int)min_samples, core_sorted, core_input, parent);
+  const unsigned sweep = sweep_blocks((int)n);
+  hipLaunchKernelGGL((k_cloud_count<true, true>), dim3(sweep), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g, r2,
+                     w.cell_first, w.ctrl, 0, (int*)nullptr, (int)min_samples, core_sorted, core_input, parent);
   FNR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_cloud_union, dim3(blocks), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g, r2, core_sorted,
-                     parent);
+  hipLaunchKernelGGL(k_cloud_union, dim3(sweep), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g, r2,
+                     w.cell_first, w.ctrl, 1, core_sorted, parent);
   FNR_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_cloud_roots, dim3(blocks), dim3(256), 0, st, parent, core_input, (int)n);
   FNR_LAUNCH_CHECK();
   rc = scan_flags(w, core_input, ids, (int)n, st);
   if (rc != FNR_OK) return rc;
-  hipLaunchKernelGGL(k_cloud_labels, dim3(blocks), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g, r2,
-                     core_sorted, parent, core_input, ids, labels, n_clusters);
+  hipLaunchKernelGGL(k_cloud_labels, dim3(sweep), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g, r2,
+                     w.cell_first, w.ctrl, 2, core_sorted, parent, core_input, ids, labels, n_clusters);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -7,20 +7,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fruitnerf_amd import _kernels as K
 from fruitnerf_amd.clustering import FruitClustering, PointCloud
-
-
-def make_cloud(n_fruits, seed=0, h=0.0024, r=0.035, clutter=0.05):
-    rng = np.random.default_rng(seed)
-    cent = rng.uniform(-0.8, 0.8, (n_fruits, 3))
-    k = int(np.ceil(r / h))
-    g = np.stack(np.meshgrid(*[np.arange(-k, k + 1)] * 3, indexing="ij"), -1).reshape(-1, 3) * h
-    ball = g[(g * g).sum(1) <= r * r]
-    parts = [np.round(c / h) * h + ball for c in cent]
-    n = sum(len(p) for p in parts)
-    parts.append(np.round(rng.uniform(-1, 1, (int(n * clutter), 3)) / h) * h)
-    X = np.concatenate(parts)
-    rng.shuffle(X)
-    return X
+from fruitnerf_amd.data.synthetic_cloud import make_export_cloud as make_cloud
 
 
 def timed(fn, reps=3):
