@@ -477,30 +477,3 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
                                     lrs["proposal_networks"], scale)
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
-
-
-def smoke_train_step(oracle_model, hip_model, dev) -> None:
-    """Used by __graft_entry__.smoke(): one training step on 64 rays, HIP vs oracle loss values."""
-    from tests import util
-    from oracle import ns_torch as ns
-    from .rays import RayBundle
-    oracle_model.train()
-    hip_model.train()
-    R = 64
-    o, d, pa, cam = util.random_rays(R, oracle_model.field.num_images, seed=2)
-    jit = [torch.rand(R, 1) for _ in range(3)]
-    g = torch.Generator().manual_seed(5)
-    batch = {"image": torch.rand(R, 3, generator=g), "fruit_mask": (torch.rand(R, 1, generator=g) > 0.5).float()}
-    oracle_model.set_anneal(0)  # fused_train_iteration() below runs the same BEFORE_TRAIN_ITERATION callback
-    ref_out = oracle_model(ns.RayBundle(o, d, pa, camera_indices=cam), jitter=jit)
-    ref_ld = oracle_model.get_loss_dict(ref_out, batch)
-    sum(ref_ld.values()).backward()
-    opt = FusedAdam(hip_model)
-    rb = RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev))
-    ld, md = fused_train_iteration(hip_model, opt, rb, {k: v.to(dev) for k, v in batch.items()}, 0,
-                             jitter=[j.to(dev) for j in jit])
-    torch.cuda.synchronize()
-    for k in ref_ld:
-        a, b = float(ld[k]), float(ref_ld[k])
-        print(f"smoke.{k}: hip {a:.6e} oracle {b:.6e}")
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), k
