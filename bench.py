@@ -170,14 +170,19 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # FNR_BENCH_BACKEND=gloo + FNR_BENCH_ONE_DEVICE=1: self-test of the multi-rank control flow on a 1-GPU box
     # (RCCL refuses two ranks on one device); the driver's runs use the defaults (nccl = RCCL, one GPU per rank)
+    # FNR_BENCH_FORCE_DIST=1 (single process): a ONE-rank nccl group with the exchange forced on, so that this file's
+    # own multi-rank code (init, barriers, MAX-reduce of the timing, teardown) and the bucketed exchange run over real
+    # RCCL on a 1-GPU box; the all-reduces move no bytes, the number measures the exchange path's fixed cost
+    dist_on = world > 1 or os.environ.get("FNR_BENCH_FORCE_DIST") == "1"
     backend = os.environ.get("FNR_BENCH_BACKEND", "nccl")
     if os.environ.get("FNR_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
         else:
@@ -189,6 +194,9 @@ def main() -> None:
     from fruitnerf_amd.rays import RayBundle
     from fruitnerf_amd.training import FusedAdam, fused_train_iteration as train_iteration
 
+    if dist_on and world == 1:
+        import fruitnerf_amd.training as _training
+        _training.EXCHANGE_MIN_WORLD = 1
     info = L.device_check()
     HW = args.image_size
     focal = 1111.0 * HW / 800.0
@@ -225,7 +233,7 @@ def main() -> None:
         return out
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
 
@@ -262,7 +270,7 @@ def main() -> None:
     dt = time.perf_counter() - t0
     recs = L.profile_collect()
     L.profile_enable(False)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -270,7 +278,7 @@ def main() -> None:
     rays_per_s = world * args.steps * RAYS_PER_BATCH / dt
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
             dist.destroy_process_group()
@@ -502,7 +510,7 @@ def main() -> None:
     if cpu:
         result["speedup_vs_cpu_baseline"] = round(rays_per_s / cpu["value"], 1)
     print(json.dumps(result))
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -422,20 +422,26 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
     return loss_dict, metrics_dict
 
 
-def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: dict, world_size: int = 1) -> None:
-    """The datamanager side of loss.backward() + optimizer.step() for the camera-pose optimiser
-    (fruit_nerf_config.py:39-43): ray gradients -> pose_adjustment.grad (camera_opt.hip), then its Adam step.
-    With several ranks the 6 x num_cameras gradient is averaged like the model's (nerfstudio leaves the datamanager
-    outside DDP, which lets the ranks' poses drift apart; one 2 KB all-reduce keeps them identical)."""
+def camera_backward(camera_optimizer, batcher, ray_grads: dict, world_size: int = 1):
+    """The datamanager side of loss.backward() for the camera-pose optimiser (fruit_nerf_config.py:39-43): ray
+    gradients -> pose_adjustment.grad (camera_opt.hip).  With several ranks the 6 x num_cameras gradient is averaged
+    like the model's (nerfstudio leaves the datamanager outside DDP, which lets the ranks' poses drift apart; one 2 KB
+    all-reduce keeps them identical); it is issued asynchronously -> (work | None, gradient scale)."""
     d = batcher.last_draw
     pose = camera_optimizer.pose_adjustment
     K.camera_pose_grad(batcher._set, batcher.image_ids, d["u"], d["cam"], pose.data, d["c2w_adjusted"],
                        ray_grads["origins"], ray_grads["directions"], pose.grad)
-    scale = 1.0
     if world_size >= EXCHANGE_MIN_WORLD:
         import torch.distributed as dist
-        dist.all_reduce(pose.grad, op=dist.ReduceOp.SUM)
-        scale = 1.0 / world_size
+        return dist.all_reduce(pose.grad, op=dist.ReduceOp.SUM, async_op=True), 1.0 / world_size
+    return None, 1.0
+
+
+def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: dict, world_size: int = 1) -> None:
+    """camera_backward() + the camera optimiser's Adam step."""
+    work, scale = camera_backward(camera_optimizer, batcher, ray_grads, world_size)
+    if work is not None:
+        work.wait()
     camera_adam.step(grad_scale=scale)
 
 
@@ -455,9 +461,9 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads)
     with torch.no_grad():
-        if camera is not None:
-            camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
         if exchange is None:
+            if camera is not None:
+                camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
             optimizer.step()
         else:
             pending = list(exchange.pending)
@@ -466,6 +472,10 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             prop_updated = bool(getattr(model, "_last_render_updated", True))
             if prop_updated:
                 pending += start_gradient_sync(arena, spans["proposal_networks"], world_size)
+            # collectives run in issue order on the communicator's stream: the 2 KB pose-gradient exchange goes LAST so
+            # that nothing on the compute stream waits behind the big buckets before their own Adam launches
+            cam_work, cam_scale = (camera_backward(camera[0], camera[2], ray_grads, world_size)
+                                   if camera is not None else (None, 1.0))
             lrs = optimizer.begin_step()
             scale = 1.0 / world_size
             for a, b, work in pending:
@@ -475,5 +485,9 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             if not prop_updated:                               # Adam still runs (moments decay, parameters move)
                 optimizer.step_span(spans["proposal_networks"][0], spans["proposal_networks"][1],
                                     lrs["proposal_networks"], scale)
+            if camera is not None:
+                if cam_work is not None:
+                    cam_work.wait()
+                camera[1].step(grad_scale=cam_scale)
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
