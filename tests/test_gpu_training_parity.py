@@ -223,6 +223,7 @@ def test_level_group_scatter_matches_single_scatter(dev, monkeypatch):
             f0, f1 = hm.arena().group_ranges["fields"]
     assert spans[0][0] == f0 and spans[-1][1] == f1
     assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1)), spans
+    assert len(spans) == 4      # one collective per level group: the MLP weights ride with the first / last group
     scale = grads[0].abs().max().item()
     assert (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
     assert int((grads[0] != 0).sum()) == int((grads[1] != 0).sum())
