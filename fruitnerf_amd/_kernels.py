@@ -455,9 +455,13 @@ def _cloud_args(xyz: Tensor):
 
 
 def _bounds(xyz: Tensor):
-    """Host copies of the cloud's axis-aligned bounds (Open3D GetMinBound / GetMaxBound); one small D2H sync."""
-    lo_hi = torch.stack([xyz.amin(0), xyz.amax(0)]).cpu()
-    return (C.c_double * 3)(*lo_hi[0].tolist()), (C.c_double * 3)(*lo_hi[1].tolist())
+    """Host copies of the cloud's axis-aligned bounds (Open3D GetMinBound / GetMaxBound); one 48-byte D2H sync."""
+    lo_hi = torch.empty(6, dtype=torch.float64, device=xyz.device)
+    ws = torch.empty(64, dtype=torch.uint8, device=xyz.device)
+    L.check(L.load().fnr_cloud_bounds(L.ptr(xyz), xyz.shape[0], L.ptr(lo_hi), L.ptr(ws), ws.numel(),
+                                      L.stream_ptr(xyz.device)), "cloud_bounds")
+    v = lo_hi.cpu().tolist()
+    return (C.c_double * 3)(*v[:3]), (C.c_double * 3)(*v[3:])
 
 
 def cloud_radius_count(xyz: Tensor, radius: float, inclusive: bool) -> Tensor:

@@ -106,6 +106,7 @@ SIGNATURES = {
     "fnr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
     "fnr_radam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
     "fnr_cloud_workspace_bytes": (C.c_size_t, [_i64]),
+    "fnr_cloud_bounds": (_i, [_vp, _i64, _vp, _vp, C.c_size_t, _vp]),
     "fnr_cloud_radius_count": (_i, [_vp, _i64, P(C.c_double), P(C.c_double), C.c_double, _i, _vp, _vp, C.c_size_t,
                                     _vp]),
     "fnr_cloud_dbscan": (_i, [_vp, _i64, P(C.c_double), P(C.c_double), C.c_double, C.c_int32, _vp, _vp, _vp,

@@ -75,6 +75,55 @@ static bool carve_cloud(void* ws, size_t bytes, int64_t n, CloudWs* out) {
   return true;
 }
 
+// ---- axis-aligned bounds (Open3D GetMinBound / GetMaxBound) ---------------------------------------------------------
+// doubles are mapped to unsigned keys with the same order, reduced per wave with shuffles, then one atomic per wave
+__device__ inline u64 order_key(double v) {
+  const u64 b = (u64)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ inline double key_value(u64 k) {
+  const u64 b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+__global__ __launch_bounds__(256) void k_cloud_bounds(const double* __restrict__ xyz, int n, u64* keys6) {
+  __shared__ u64 part[4][6];
+  u64 lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const u64 key = order_key(xyz[3 * (size_t)i + k]);
+      lo[k] = key < lo[k] ? key : lo[k];
+      hi[k] = key > hi[k] ? key : hi[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const u64 a = __shfl_xor(lo[k], off), b = __shfl_xor(hi[k], off);
+      lo[k] = a < lo[k] ? a : lo[k];
+      hi[k] = b > hi[k] ? b : hi[k];
+    }
+    if ((threadIdx.x & 63u) == 0) {
+      part[threadIdx.x >> 6][k] = lo[k];
+      part[threadIdx.x >> 6][3 + k] = hi[k];
+    }
+  }
+  __syncthreads();
+  // the six results share one cache line, where atomics retire one at a time (~12 ns): one set per WORKGROUP, and
+  // the launch is capped at one workgroup per CU
+  if (threadIdx.x < 6) {
+    const int k = (int)threadIdx.x;
+    u64 v = part[0][k];
+    for (int w = 1; w < 4; ++w) v = k < 3 ? (part[w][k] < v ? part[w][k] : v) : (part[w][k] > v ? part[w][k] : v);
+    if (k < 3) atomicMin(&keys6[k], v); else atomicMax(&keys6[k], v);
+  }
+}
+
+__global__ void k_cloud_bounds_decode(const u64* __restrict__ keys6, double* __restrict__ out6) {
+  if (threadIdx.x < 6) out6[threadIdx.x] = key_value(keys6[threadIdx.x]);
+}
+
 __device__ inline long long cell_index(double p, double lo, double cell, long long dim) {
   long long c = (long long)floor((p - lo) / cell);
   return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
@@ -204,7 +253,9 @@ __global__ __launch_bounds__(256) void k_cloud_count(const u64* __restrict__ key
 }
 
 // ---- lock-free union-find (roots only ever hook under SMALLER indices) -------------------------------------------
-__device__ inline int uf_load(int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+// device scope: L2 is the coherence point for the kernel's own traffic (system scope would go past it)
+__device__ inline int uf_load(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void uf_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ inline int uf_find(int* parent, int x) {
   while (true) {
@@ -212,7 +263,7 @@ __device__ inline int uf_find(int* parent, int x) {
     if (p == x) return x;
     const int gp = uf_load(&parent[p]);
     if (gp == p) return p;
-    __atomic_store_n(&parent[x], gp, __ATOMIC_RELAXED);   // path halving: gp is an ancestor of x, x is not a root
+    uf_store(&parent[x], gp);                             // path halving: gp is an ancestor of x, x is not a root
     x = gp;
   }
 }
@@ -248,17 +299,37 @@ __global__ __launch_bounds__(256) void k_cloud_union(const u64* __restrict__ key
       const double4 p = sxyz[s < s1 ? s : s0];
       const int i = core ? order[s] : -1;
       int mine = core ? uf_find(parent, i) : -1;
+      int known = mine;   // a node already proven to be in this target's set (sets only ever merge): typically the
+                          // previous root that most neighbours still hang under after a merge moved the root
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        for (int t = runs.b[k]; t < runs.e[k]; ++t) {
-          if (!core_sorted[t]) continue;                  // wave-uniform: only core-core pairs connect
-          const double d2 = pair_d2(p, sxyz[t]);
-          const int j = order[t];
-          if (core && j < i && d2 <= r2) {                // every core-core pair is handled from its larger end
-            const int rj = uf_find(parent, j);
-            if (rj != mine) {
-              uf_unite(parent, mine, rj);
-              mine = uf_find(parent, i);
+        for (int t0 = runs.b[k]; t0 < runs.e[k]; t0 += 4) {
+          // four candidates per round: their (wave-uniform) parent words are fetched together, so the common case —
+          // the candidate already hangs directly under this target's root — costs no dependent memory round trip
+          const int m = runs.e[k] - t0;
+          bool cc[4];
+          int jj[4], pj[4];
+          double dd[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = t0 + (u < m ? u : 0);
+            cc[u] = u < m && core_sorted[t] != 0;         // wave-uniform: only core-core pairs connect
+            jj[u] = order[t];
+            dd[u] = pair_d2(p, sxyz[t]);
+            pj[u] = uf_load(&parent[jj[u]]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            // every core-core pair is handled from its larger end
+            if (cc[u] && core && jj[u] < i && dd[u] <= r2 && pj[u] != mine && pj[u] != known) {
+              const int rj = uf_find(parent, jj[u]);
+              if (rj != mine) {
+                uf_unite(parent, mine, rj);
+                mine = uf_find(parent, i);
+              } else {
+                known = pj[u];                            // j's parent is in this set: so is everything under it
+                if (pj[u] != jj[u]) uf_store(&parent[jj[u]], rj);   // j is not a root: hang it under the common root
+              }
             }
           }
         }
@@ -272,7 +343,7 @@ __global__ __launch_bounds__(256) void k_cloud_roots(int* parent, int* __restric
   if (i >= n) return;
   if (core_input_to_root_flag[i]) {
     const int r = uf_find(parent, i);
-    __atomic_store_n(&parent[i], r, __ATOMIC_RELAXED);    // i is a non-root or r == i: never races with a hook
+    uf_store(&parent[i], r);                              // i is a non-root or r == i: never races with a hook
     core_input_to_root_flag[i] = (r == i);
   } else {
     parent[i] = -1;
@@ -469,6 +540,24 @@ using namespace fnr;
 
 extern "C" size_t fnr_cloud_workspace_bytes(int64_t n_points) {
   return cloud_fixed_bytes(n_points) + cloud_temp_reserve(n_points);
+}
+
+extern "C" int fnr_cloud_bounds(const double* xyz, int64_t n, double* lo_hi, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  FNR_CHECK_ARG(n >= 1 && n < 2147483647LL, "cloud_bounds: n out of range (an empty cloud has no bounds)");
+  FNR_CHECK_ARG(xyz && lo_hi && workspace && workspace_bytes >= 64, "cloud_bounds: null argument / workspace < 64 B");
+  hipStream_t st = as_stream(stream);
+  u64* keys6 = static_cast<u64*>(workspace);
+  FNR_HIP(hipMemsetAsync(keys6, 0xff, 3 * sizeof(u64), st));
+  FNR_HIP(hipMemsetAsync(keys6 + 3, 0, 3 * sizeof(u64), st));
+  long long blocks = (n + 255) / 256;
+  const long long cap = (long long)device_cu_count();
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_cloud_bounds, dim3((unsigned)blocks), dim3(256), 0, st, xyz, (int)n, keys6);
+  FNR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cloud_bounds_decode, dim3(1), dim3(64), 0, st, keys6, lo_hi);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
 }
 
 extern "C" int fnr_cloud_radius_count(const double* xyz, int64_t n, const double* lo, const double* hi, double radius,

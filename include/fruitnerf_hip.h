@@ -350,6 +350,9 @@ int fnr_export_compact(const fnr_lattice* lat, int64_t ray_begin, int64_t n_rays
  * are HOST pointers to 3 doubles: the axis-aligned bounds of the cloud (Open3D's GetMinBound/GetMaxBound).
  * workspace: >= fnr_cloud_workspace_bytes(n) bytes, caller-owned, contents undefined afterwards. */
 size_t fnr_cloud_workspace_bytes(int64_t n_points);
+/* lo_hi[6] (device) = min x, y, z, max x, y, z of the cloud (n >= 1); workspace >= 64 bytes. */
+int fnr_cloud_bounds(const double* xyz, int64_t n, double* lo_hi, void* workspace, size_t workspace_bytes,
+                     void* stream);
 /* counts[i] = #{j : |p_i - p_j|^2 < radius^2} (inclusive != 0: <=), the point itself included.
  * Open3D's RemoveRadiusOutliers keeps i when counts[i] > nb_points (strict search, inclusive = 0). */
 int fnr_cloud_radius_count(const double* xyz, int64_t n, const double* lo, const double* hi, double radius,
