@@ -25,6 +25,14 @@ namespace fnr {
 
 typedef unsigned long long u64;
 
+// one sorted point: position + what the sweeps need to know about it as a CANDIDATE, so that a candidate is one 32-byte
+// scalar load (input index and core flag ride in what would be padding)
+struct alignas(32) CloudPoint {
+  double x, y, z;
+  int index;   // input index (order[s])
+  int core;    // DBSCAN core flag, filled in after the count pass
+};
+
 struct CloudGrid {
   double lo[3];
   double cell;
@@ -36,7 +44,7 @@ struct CloudWs {
   u64* keys;      // sorted
   int* idx_a;
   int* order;     // sorted position -> input index
-  double4* sxyz;  // [n] positions in sorted order, padded to 32 B (two aligned 16-byte loads per candidate)
+  CloudPoint* sxyz;  // [n] points in sorted order
   int* aux0;      // per sorted position: core flag / head flag
   int* aux1;      // per input index: union-find parent
   int* aux2;      // per input index: core flag, then root flag
@@ -63,7 +71,7 @@ static bool carve_cloud(void* ws, size_t bytes, int64_t n, CloudWs* out) {
   out->keys = reinterpret_cast<u64*>(p);    p += align256(m * 8);
   out->idx_a = reinterpret_cast<int*>(p);   p += align256(m * 4);
   out->order = reinterpret_cast<int*>(p);   p += align256(m * 4);
-  out->sxyz = reinterpret_cast<double4*>(p); p += align256(m * 32);
+  out->sxyz = reinterpret_cast<CloudPoint*>(p); p += align256(m * 32);
   out->aux0 = reinterpret_cast<int*>(p);    p += align256(m * 4);
   out->aux1 = reinterpret_cast<int*>(p);    p += align256(m * 4);
   out->aux2 = reinterpret_cast<int*>(p);    p += align256(m * 4);
@@ -141,11 +149,24 @@ __global__ __launch_bounds__(256) void k_cloud_keys(const double* __restrict__ x
 }
 
 __global__ __launch_bounds__(256) void k_cloud_gather(const double* __restrict__ xyz, const int* __restrict__ order,
-                                                      int n, double4* __restrict__ sxyz) {
+                                                      int n, CloudPoint* __restrict__ sxyz) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= n) return;
-  const size_t i = (size_t)order[s];
-  sxyz[s] = make_double4(xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2], 0.0);
+  const int o = order[s];
+  const size_t i = (size_t)o;
+  CloudPoint pt;
+  pt.x = xyz[3 * i + 0];
+  pt.y = xyz[3 * i + 1];
+  pt.z = xyz[3 * i + 2];
+  pt.index = o;
+  pt.core = 0;
+  sxyz[s] = pt;
+}
+
+__global__ __launch_bounds__(256) void k_cloud_pack_core(const int* __restrict__ core_sorted, int n,
+                                                         CloudPoint* __restrict__ sxyz) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < n) sxyz[s].core = core_sorted[s];
 }
 
 __device__ inline int lower_bound_key(const u64* __restrict__ keys, int lo, int hi, u64 k) {
@@ -164,7 +185,7 @@ __device__ inline int upper_bound_key(const u64* __restrict__ keys, int lo, int 
 }
 
 // squared distance in the CPU libraries' operation order: ((dx*dx) + dy*dy) + dz*dz, every op rounded
-__device__ inline double pair_d2(const double4& p, const double4& q) {
+__device__ inline double pair_d2(const CloudPoint& p, const CloudPoint& q) {
   const double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
   return (dx * dx + dy * dy) + dz * dz;
 }
@@ -214,7 +235,7 @@ __device__ inline CellRuns cell_runs(const u64* __restrict__ keys, int n, const 
 // counts[input index] = neighbours with d2 < r2 (INCL: <=), the point itself included.
 // CORE: additionally core_sorted[s] / core_input[i] = count >= min_samples and parent[i] = i.
 template <bool INCL, bool CORE>
-__global__ __launch_bounds__(256) void k_cloud_count(const u64* __restrict__ keys, const double4* __restrict__ sxyz,
+__global__ __launch_bounds__(256) void k_cloud_count(const u64* __restrict__ keys, const CloudPoint* __restrict__ sxyz,
                                                      const int* __restrict__ order, int n, CloudGrid g, double r2,
                                                      const int* __restrict__ cell_first, int* ctrl, int pass,
                                                      int* __restrict__ counts, int min_samples,
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(256) void k_cloud_count(const u64* __restrict__ key
     for (int base = s0; base < s1; base += 64) {
       const int s = base + wave_lane();
       const bool act = s < s1;
-      const double4 p = sxyz[act ? s : s0];
+      const CloudPoint p = sxyz[act ? s : s0];
       int cnt = 0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
@@ -278,7 +299,7 @@ __device__ inline void uf_unite(int* parent, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_cloud_union(const u64* __restrict__ keys, const double4* __restrict__ sxyz,
+__global__ __launch_bounds__(256) void k_cloud_union(const u64* __restrict__ keys, const CloudPoint* __restrict__ sxyz,
                                                      const int* __restrict__ order, int n, CloudGrid g, double r2,
                                                      const int* __restrict__ cell_first, int* ctrl, int pass,
                                                      const int* __restrict__ core_sorted, int* parent) {
@@ -296,39 +317,37 @@ __global__ __launch_bounds__(256) void k_cloud_union(const u64* __restrict__ key
         runs = cell_runs(keys, n, g, keys[s0]);
         runs_ready = true;
       }
-      const double4 p = sxyz[s < s1 ? s : s0];
-      const int i = core ? order[s] : -1;
+      const CloudPoint p = sxyz[s < s1 ? s : s0];
+      const int i = core ? p.index : -1;
       int mine = core ? uf_find(parent, i) : -1;
       int known = mine;   // a node already proven to be in this target's set (sets only ever merge): typically the
                           // previous root that most neighbours still hang under after a merge moved the root
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         for (int t0 = runs.b[k]; t0 < runs.e[k]; t0 += 4) {
-          // four candidates per round: their (wave-uniform) parent words are fetched together, so the common case —
-          // the candidate already hangs directly under this target's root — costs no dependent memory round trip
+          // four candidates per round: one 32-byte scalar load each, then their (wave-uniform) parent words together,
+          // so the common case — the candidate already hangs under this target's root — has no dependent round trip
           const int m = runs.e[k] - t0;
-          bool cc[4];
-          int jj[4], pj[4];
-          double dd[4];
+          CloudPoint q[4];
+          int pj[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) q[u] = sxyz[t0 + (u < m ? u : 0)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pj[u] = uf_load(&parent[q[u].index]);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int t = t0 + (u < m ? u : 0);
-            cc[u] = u < m && core_sorted[t] != 0;         // wave-uniform: only core-core pairs connect
-            jj[u] = order[t];
-            dd[u] = pair_d2(p, sxyz[t]);
-            pj[u] = uf_load(&parent[jj[u]]);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            // every core-core pair is handled from its larger end
-            if (cc[u] && core && jj[u] < i && dd[u] <= r2 && pj[u] != mine && pj[u] != known) {
-              const int rj = uf_find(parent, jj[u]);
+            // only core-core pairs connect; every pair is handled from its larger end
+            const bool pair = (u < m) & (q[u].core != 0) & core & (q[u].index < i) & (pair_d2(p, q[u]) <= r2) &
+                              (pj[u] != mine) & (pj[u] != known);
+            if (pair) {
+              const int j = q[u].index;
+              const int rj = uf_find(parent, j);
               if (rj != mine) {
                 uf_unite(parent, mine, rj);
                 mine = uf_find(parent, i);
               } else {
                 known = pj[u];                            // j's parent is in this set: so is everything under it
-                if (pj[u] != jj[u]) uf_store(&parent[jj[u]], rj);   // j is not a root: hang it under the common root
+                if (pj[u] != j) uf_store(&parent[j], rj); // j is not a root: hang it directly under the common root
               }
             }
           }
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(256) void k_cloud_roots(int* parent, int* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void k_cloud_labels(const u64* __restrict__ keys, const double4* __restrict__ sxyz,
+__global__ __launch_bounds__(256) void k_cloud_labels(const u64* __restrict__ keys, const CloudPoint* __restrict__ sxyz,
                                                       const int* __restrict__ order, int n, CloudGrid g, double r2,
                                                       const int* __restrict__ cell_first, int* ctrl, int pass,
                                                       const int* __restrict__ core_sorted,
@@ -370,14 +389,14 @@ __global__ __launch_bounds__(256) void k_cloud_labels(const u64* __restrict__ ke
       int best = 0x7fffffff;                               // smallest root = smallest cluster number
       if (__ballot(border) != 0) {
         const CellRuns runs = cell_runs(keys, n, g, keys[s0]);
-        const double4 p = sxyz[act ? s : s0];
+        const CloudPoint p = sxyz[act ? s : s0];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           for (int t = runs.b[k]; t < runs.e[k]; ++t) {
-            if (!core_sorted[t]) continue;
-            const double d2 = pair_d2(p, sxyz[t]);
-            const int r = root[order[t]];
-            if (border && d2 <= r2) best = r < best ? r : best;
+            const CloudPoint q = sxyz[t];
+            if (!q.core) continue;                         // wave-uniform
+            const int r = root[q.index];
+            if (border && pair_d2(p, q) <= r2) best = r < best ? r : best;
           }
         }
       }
@@ -614,6 +633,8 @@ extern "C" int fnr_cloud_dbscan(const double* xyz, int64_t n, const double* lo, 
   const unsigned sweep = sweep_blocks((int)n);
   hipLaunchKernelGGL((k_cloud_count<true, true>), dim3(sweep), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g, r2,
                      w.cell_first, w.ctrl, 0, (int*)nullptr, (int)min_samples, core_sorted, core_input, parent);
+  FNR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cloud_pack_core, dim3(blocks), dim3(256), 0, st, core_sorted, (int)n, w.sxyz);
   FNR_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_cloud_union, dim3(sweep), dim3(256), 0, st, w.keys, w.sxyz, w.order, (int)n, g, r2,
                      w.cell_first, w.ctrl, 1, core_sorted, parent);
