@@ -37,10 +37,14 @@ def _compact_batch(lat, ray_begin, n_rays, positions, density, rgb, logit, state
 
 
 def sample_volume(pipeline, num_points: int, output_dir: Optional[Path] = None, config=None,
-                  transform_json: Optional[dict] = None) -> Dict[str, dict]:
+                  transform_json: Optional[dict] = None, rank: int = 0, world_size: int = 1) -> Dict[str, dict]:
     """`pipeline` needs `.model` (FruitModel in test_mode='export' after setup_inference) and
     `.datamanager` (setup_inference done; `next_sample_volume`).  `num_points` = number of rays, as in the
-    reference (exporter_utils.py:94,172)."""
+    reference (exporter_utils.py:94,172).
+
+    world_size > 1: the ray batches (x-major ray order, data/fruit_datamanager.py:105-111) are split into
+    contiguous runs, one per rank; each rank compacts its batches locally and the variable-length point lists are
+    all-gathered in rank order — the single-process lists, point for point, on every rank."""
     model = pipeline.model
     dm = pipeline.datamanager
     pts = {k: [] for k in SET_NAMES}
@@ -50,8 +54,14 @@ def sample_volume(pipeline, num_points: int, output_dir: Optional[Path] = None, 
     lat = None
     if lattice is not None and lattice["n_samples"] == getattr(model, "num_inference_samples", None):
         lat = K.LatticeArg(lattice["xs"], lattice["ys"], lattice["zs"])
-    done = 0
-    while done < num_points:
+    batch = dm.orthographic_ray_generator.ray_batch_size
+    n_batches = -(-num_points // batch)
+    lo, hi = 0, n_batches
+    if world_size > 1:
+        from ..sharding import shard_range
+        lo, hi = shard_range(n_batches, rank, world_size)
+        dm.train_count = lo                     # batch `count` is 1-based: the next one drawn is lo + 1
+    for _ in range(lo, hi):
         if lat is not None:
             # fused path: same batches as OrthographicRayGenerator (ray_generators.py:52-58), positions implicit
             dm.train_count += 1
@@ -69,9 +79,18 @@ def sample_volume(pipeline, num_points: int, output_dir: Optional[Path] = None, 
                                outputs["rgb"].reshape(-1, 3).contiguous(),
                                outputs["semantics"].reshape(-1).contiguous(), state)
         for s, name in enumerate(SET_NAMES):
-            pts[name].append(state["points"][s][:c[s]].cpu())
-            cols[name].append(state["colors"][s][:c[s]].cpu())
-        done += n_rays
+            # copy=True: the stream buffers are reused by the next batch (a no-op distinction on a GPU, where the
+            # transfer already copies)
+            pts[name].append(state["points"][s][:c[s]].to("cpu", copy=True))
+            cols[name].append(state["colors"][s][:c[s]].to("cpu", copy=True))
+
+    if world_size > 1:
+        from ..sharding import gather_chunks
+        dev = model.device
+        for name in SET_NAMES:
+            pts[name] = [gather_chunks([t.to(dev) for t in pts[name]], world_size, torch.empty(0, 3, device=dev)).cpu()]
+            cols[name] = [gather_chunks([t.to(dev) for t in cols[name]], world_size,
+                                        torch.empty(0, 4, device=dev)).cpu()]
 
     scale = 1.0 if transform_json is None else float(transform_json["scale"])
     pcd_list = {}

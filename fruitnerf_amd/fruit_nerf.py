@@ -487,20 +487,42 @@ class FruitModel(nn.Module):
         return self.get_outputs(ray_bundle, jitter=jitter)
 
     @torch.no_grad()
-    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
-        """fruit_nerf.py:225-249: chunked full-image evaluation, outputs moved to the CPU per chunk."""
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle, rank: int = 0,
+                                          world_size: int = 1) -> Dict[str, Tensor]:
+        """fruit_nerf.py:225-249: chunked full-image evaluation, outputs moved to the CPU per chunk.
+
+        world_size > 1 (SURVEY §8e): each rank renders a contiguous block of whole image rows with the same chunking;
+        the blocks are all-gathered in rank order, so every rank returns the full image the single process returns."""
         num_rays_per_chunk = self.config.eval_num_rays_per_chunk
         image_height, image_width = camera_ray_bundle.origins.shape[:2]
         num_rays = len(camera_ray_bundle)
         outputs_lists = defaultdict(list)
-        for i in range(0, num_rays, num_rays_per_chunk):
-            ray_bundle = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + num_rays_per_chunk)
+        if world_size <= 1:
+            for i in range(0, num_rays, num_rays_per_chunk):
+                ray_bundle = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + num_rays_per_chunk)
+                outputs = self.forward(ray_bundle=ray_bundle)
+                for output_name, output in outputs.items():
+                    if not torch.is_tensor(output):
+                        continue
+                    outputs_lists[output_name].append(output.cpu())
+            return {k: torch.cat(v).view(image_height, image_width, -1) for k, v in outputs_lists.items()}
+        from .sharding import all_gather_rows, shard_range
+        lo, hi = shard_range(num_rays, rank, world_size, granule=image_width)
+        for i in range(lo, hi, num_rays_per_chunk):
+            ray_bundle = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, min(i + num_rays_per_chunk, hi))
             outputs = self.forward(ray_bundle=ray_bundle)
             for output_name, output in outputs.items():
-                if not torch.is_tensor(output):
-                    continue
-                outputs_lists[output_name].append(output.cpu())
-        return {k: torch.cat(v).view(image_height, image_width, -1) for k, v in outputs_lists.items()}
+                if torch.is_tensor(output):
+                    outputs_lists[output_name].append(output)
+        if not outputs_lists:   # a rank without rows (more ranks than image rows) still joins the collectives: the
+            outputs_lists = self._eval_output_templates(camera_ray_bundle)   # key set is fixed by the model
+        full = {k: all_gather_rows(torch.cat(v), world_size) for k, v in sorted(outputs_lists.items())}
+        return {k: v.cpu().view(image_height, image_width, -1) for k, v in full.items()}
+
+    def _eval_output_templates(self, camera_ray_bundle: RayBundle) -> Dict[str, list]:
+        """Zero-row tensors with the keys / dtypes / trailing shapes of an eval forward (from a one-ray pass)."""
+        one = self.forward(ray_bundle=camera_ray_bundle.get_row_major_sliced_ray_bundle(0, 1))
+        return {k: [v[:0]] for k, v in one.items() if torch.is_tensor(v)}
 
     @torch.no_grad()
     def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
