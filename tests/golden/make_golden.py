@@ -15,8 +15,17 @@ from oracle import ns_torch as ns  # noqa: E402
 from tests import util  # noqa: E402
 
 
-def main():
-    cfg = util.small_config(log2=10, prop_log2=8)
+def big_config():
+    """The parts of fruit_nerf_big that reach FruitField (fruit_nerf.py:88-103, fruit_nerf_config.py:82-95) on small
+    tables: geo 30, semantic MLP 30->128->128->64, max_res 4096, anneal over 5000 steps."""
+    cfg = util.small_config(log2=10, prop_log2=8, max_res=4096)
+    cfg.geo_feat_dim, cfg.num_layers_semantic, cfg.hidden_dim_semantics = 30, 3, 128
+    cfg.proposal_weights_anneal_max_num_iters = 5000
+    return cfg
+
+
+def main(cfg=None, file_name="fruit_nerf_small.npz", with_camera=True):
+    cfg = util.small_config(log2=10, prop_log2=8) if cfg is None else cfg
     om = util.make_oracle(cfg, num_images=5, seed=123)
     R = 96
     o, d, pa, cam = util.random_rays(R, 5, seed=77)
@@ -55,10 +64,11 @@ def main():
             out["gradsum::" + name] = np.float64(p.grad.double().abs().sum().item())
         else:
             out["grad::" + name] = p.grad.numpy()
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fruit_nerf_small.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), file_name)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
-    camera_golden()
+    if with_camera:
+        camera_golden()
 
 
 def camera_golden():
@@ -91,4 +101,7 @@ def camera_golden():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "big":      # python tests/golden/make_golden.py big
+        main(big_config(), "fruit_nerf_big_small.npz", with_camera=False)
+    else:
+        main()
