@@ -1,5 +1,7 @@
 """Oracle part 2: restatement of the in-tree FruitNeRF hot path on top of oracle/ns_torch.py
-(TEST INFRASTRUCTURE, parity unpinned: see oracle/__init__.py).
+(TEST INFRASTRUCTURE; see oracle/__init__.py).  FruitField, the export lattice / ray batches / export sampler are
+pinned against the reference's own code executed over ns_torch (tests/golden/make_reference_*golden.py ->
+tests/test_reference_pins.py); the nerfstudio components underneath remain an unpinned restatement.
 
 Each function cites the reference file:line (relative to /root/reference/) it follows.
 Pure PyTorch, CPU, fp32 (nerfstudio disables mixed precision on CPU).
@@ -70,6 +72,8 @@ class FruitField(nn.Module):
         selector = ((positions > 0.0) & (positions < 1.0)).all(dim=-1)
         positions = positions * selector[..., None]
         self._sample_locations = positions
+        if not self._sample_locations.requires_grad:      # fruit_field.py:181-182
+            self._sample_locations.requires_grad = True
         positions_flat = positions.view(-1, 3)
         h = self.mlp_base(positions_flat).view(*ray_samples.frustums.shape, -1)
         density_before_activation, base_mlp_out = torch.split(h, [1, self.geo_feat_dim], dim=-1)

@@ -103,3 +103,55 @@ def test_merge_small_clusters_matches_the_reference(pins):
         assert np.array_equal(x, pins[f"merge::cluster::{i}"])
         assert np.array_equal(lab, pins[f"merge::cluster_labels::{i}"])
     assert np.array_equal(np.vstack(fc.cluster_center), pins["merge::centres"])
+
+
+# ---- the reference's own FruitField class, run over oracle/ns_torch.py (tests/golden/reference_field.npz) -----------
+
+FIELD_PINS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_field.npz")
+
+
+def _field_case(g, name):
+    from oracle import ns_torch as ns
+    t = lambda k: torch.from_numpy(g[f"{name}::in::{k}"])  # noqa: E731
+    edges = t("edges")
+    rb = ns.RayBundle(t("origins"), t("directions"), torch.full((edges.shape[0], 1), 1e-6), camera_indices=t("cam"),
+                      nears=edges[:, :1], fars=edges[:, -1:])
+    return rb.get_ray_samples(bin_starts=edges[:, :-1, None], bin_ends=edges[:, 1:, None])
+
+
+@pytest.mark.parametrize("name,test_mode,contract,training", [("train", None, True, True), ("eval", None, True, False),
+                                                               ("inference", "inference", True, False),
+                                                               ("export", "export", False, False)])
+def test_oracle_field_is_the_reference_field(name, test_mode, contract, training):
+    """oracle/fruit_oracle.py::FruitField vs the outputs of /root/reference/fruit_nerf/fruit_field.py::FruitField
+    (executed by tests/golden/make_reference_field_golden.py over the same nerfstudio restatement): bit for bit, in
+    every mode, including the gradients of a fixed scalar through all branches."""
+    from oracle import fruit_oracle as fo
+    from oracle import ns_torch as ns
+    g = np.load(FIELD_PINS)
+    small = np.load(os.path.join(os.path.dirname(FIELD_PINS), "fruit_nerf_small.npz"))
+    sd = {k[len("sd::field."):]: torch.from_numpy(small[k]) for k in small.files if k.startswith("sd::field.")}
+    field = fo.FruitField(sd["aabb"], num_images=int(g["n_images"]), log2_hashmap_size=10, test_mode=test_mode,
+                          use_average_appearance_embedding=True,
+                          spatial_distortion=ns.SceneContraction(order=float("inf")) if contract else None)
+    assert sorted(field.state_dict().keys()) == list(g["state_dict_keys"])
+    field.load_state_dict(sd, strict=True)
+    field.train(training)
+    res = field(_field_case(g, name))
+    for head, v in res.items():
+        assert np.array_equal(v.detach().numpy(), g[f"{name}::out::{head}"]), (name, head)
+    assert np.array_equal(field._sample_locations.detach().numpy(), g[f"{name}::out::sample_locations"])
+    assert np.array_equal(field._density_before_activation.detach().numpy(),
+                          g[f"{name}::out::density_before_activation"])
+    if not training:
+        return
+    gen = torch.Generator().manual_seed(9)
+    loss = sum((res[k] * torch.rand(res[k].shape, generator=gen)).sum() for k in ("semantics", "rgb", "density"))
+    loss.backward()
+    assert loss.item() == float(g[f"{name}::loss"])
+    for pname, p in field.named_parameters():
+        if "hash_table" in pname:
+            assert p.grad.double().abs().sum().item() == float(g[f"{name}::gradsum::{pname}"])
+        elif p.grad is not None:
+            assert np.array_equal(p.grad.numpy(), g[f"{name}::grad::{pname}"]), pname
+    assert np.array_equal(field._sample_locations.grad.numpy(), g[f"{name}::grad::sample_locations"])
