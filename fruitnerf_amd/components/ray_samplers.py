@@ -1,7 +1,13 @@
 """UniformSamplerWithNoise — mirror of /root/reference/fruit_nerf/components/ray_samplers.py:31-104.
 
 Export-time sampler: `num_samples` uniform bins in [near, far] (spacing fn = identity); stratified jitter
-only when `self.training` (never true during export).  Bins are produced by fnr_sample_spaced.
+only when `self.training`.  Bins are produced by fnr_sample_spaced.
+
+Behavioural note (pinned by tests/test_reference_pins.py): the reference builds this sampler inside
+`FruitModel.setup_inference` AFTER `eval_setup()` has put the pipeline in eval mode (scripts/exporter.py:86-94), so the
+new module is still in training mode and the reference's export jitters every bin edge with `torch.rand`.  This
+implementation follows the model's mode (bin centres when evaluating): a deterministic lattice, which is what makes
+the exported point counts reproducible.  Per-bin jitter (single_jitter=False while training) is not built.
 """
 from __future__ import annotations
 
@@ -32,8 +38,8 @@ class UniformSamplerWithNoise(nn.Module):
                          ray_bundle.camera_indices)
         if self.train_stratified and self.training:
             if not self.single_jitter:
-                raise NotImplementedError("per-bin jitter (single_jitter=False) in training mode is not built; "
-                                          "the reference only uses this sampler in eval mode (fruit_nerf.py:182)")
+                raise NotImplementedError("per-bin jitter (single_jitter=False) in training mode is not built: the "
+                                          "export uses bin centres (see the module docstring)")
             if t_rand is None:
                 t_rand = torch.rand(rays.n, device=rays.device)
         else:

@@ -285,11 +285,17 @@ class FruitModel(nn.Module):
         self.binary_cross_entropy_loss = nn.BCEWithLogitsLoss(reduction="mean")
 
     # fruit_nerf.py:179-183
-    def setup_inference(self, render_rgb, num_inference_samples):
+    def setup_inference(self, render_rgb, num_inference_samples, sampler_mode_as_in_reference: bool = False):
+        """The reference constructs the sampler here, after eval_setup() has already put the pipeline in eval mode
+        (scripts/exporter.py:86-94), and a fresh nn.Module is in TRAINING mode: as the reference runs it, the export
+        sampler jitters every bin edge (ray_samplers.py:79-87) — pinned by tests/test_reference_pins.py with
+        sampler_mode_as_in_reference=True.  The default follows the model's mode instead (bin centres when evaluating):
+        the deterministic lattice the product's export implements and the point-count parity tests rely on."""
         self.render_rgb = render_rgb
         self.num_inference_samples = num_inference_samples
         self.proposal_sampler = UniformSamplerWithNoise(num_samples=num_inference_samples, single_jitter=False)
-        self.proposal_sampler.train(self.training)
+        if not sampler_mode_as_in_reference:
+            self.proposal_sampler.train(self.training)
         self.field.spatial_distortion = None
 
     def get_param_groups(self):  # fruit_nerf.py:185-189
