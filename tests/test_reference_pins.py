@@ -264,3 +264,43 @@ def test_oracle_model_exports_like_the_reference_model(name):
     if name == "export":        # the jitter moves samples off the lattice planes: z differs between rays
         z = g["export::point_location"][..., 2]
         assert np.ptp(z[:, 0]) > 0 and np.ptp(g["export_centres::point_location"][..., 2][:, 0]) == 0
+
+
+# ---- the reference's own export loop (tests/golden/reference_export.npz) ----------------------------------------------
+
+EXPORT_PINS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_export.npz")
+
+
+@pytest.mark.parametrize("name", ["as_run", "centres"])
+def test_oracle_sample_volume_is_the_reference_sample_volume(name):
+    """exporter_utils.py::sample_volume driven by the reference's datamanager methods, ray generator and model:
+    identical point lists, colours (incl. the per-set normalisation) and batch order — with the sampler as the
+    reference leaves it (training mode, jitter from the seeded generator) and with bin centres."""
+    from oracle import fruit_oracle as fo
+    from tests import util
+    from tests.golden.make_reference_export_golden import export_state_dict
+    g = np.load(EXPORT_PINS)
+    sd = export_state_dict()
+    m = fo.FruitModel(util.small_config(log2=10, prop_log2=8), num_train_data=5, aabb=sd["field.aabb"],
+                      test_mode="export")
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    m.setup_inference(render_rgb=True, num_inference_samples=int(g["n_side"]),
+                      sampler_mode_as_in_reference=(name == "as_run"))
+    aabb = tuple(map(tuple, g["aabb"].tolist()))
+    torch.manual_seed(123)
+    sets = fo.sample_volume(m, aabb, int(g["n_side"]), int(g["batch"]), dataparser_scale=float(g["scale"]))
+    counts = {}
+    for set_name in ("semantic_colormap", "semantic", "density"):
+        assert np.array_equal(sets[set_name]["points"].numpy(), g[f"{name}::{set_name}::points"]), set_name
+        assert np.array_equal(sets[set_name]["colors"].numpy(), g[f"{name}::{set_name}::colors"]), set_name
+        counts[set_name] = sets[set_name]["points"].shape[0]
+    assert counts["density"] > counts["semantic_colormap"] > counts["semantic"] > 0
+    assert str(g[f"{name}::density::path"]).endswith("scene/density.ply")
+
+
+def test_reference_export_counts_depend_on_its_sampler_noise():
+    g = np.load(EXPORT_PINS)
+    a = [g[f"as_run::{s}::points"].shape[0] for s in ("semantic_colormap", "semantic", "density")]
+    b = [g[f"centres::{s}::points"].shape[0] for s in ("semantic_colormap", "semantic", "density")]
+    assert a != b
