@@ -1,5 +1,5 @@
 """Volume export (256^3 lattice) timing with the per-entry-point breakdown."""
-import sys, time, copy, torch, collections
+import sys, time, torch, collections
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd import _lib as L
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig

@@ -1,6 +1,6 @@
 """Train until the gradient spikes, then replay THAT step in the CPU oracle (same weights, rays, jitter, batch) and
 compare the gradients: is the spike a property of the model or of the HIP path?"""
-import sys, torch, collections, copy
+import sys, torch, collections
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
