@@ -528,8 +528,11 @@ class FruitModel(nn.Module):
     def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
         """fruit_nerf.py:403-458 (eval images; not the hot path — plain torch ops on the model's device).
 
-        PSNR and SSIM (torchmetrics defaults: 11x11 gaussian, sigma 1.5, data_range 1) and the reference's IoU, which
-        feeds `softmax(semantics)` over a size-1 class axis (== 1 everywhere) to BinaryJaccardIndex — reproduced as is.
+        PSNR and SSIM (torchmetrics defaults: 11x11 gaussian, sigma 1.5, data_range 1) and the reference's IoU
+        (fruit_nerf.py:449-453): `F.softmax(outputs["semantics"])` WITHOUT a dim on the [H,W,1] map — torch's legacy
+        implicit dim for a 3-D tensor is 0, so the softmax runs over image ROWS, every value is ~1/H < 0.5, and
+        BinaryJaccardIndex (threshold 0.5) sees an all-False prediction: "iou" is ~0 whatever the model learned.
+        Reproduced as is under "iou"; "iou_sigmoid" additionally reports the meaningful sigmoid(semantics) > 0.5 IoU.
         Not built: LPIPS (needs pretrained weights; reported as nan) and the matplotlib colormaps of
         nerfstudio.utils.colormaps (accumulation / depth images are returned as raw single-channel maps)."""
         dev = self.device
@@ -548,11 +551,17 @@ class FruitModel(nn.Module):
         images_dict["semantics_colormap"] = torch.sigmoid(outputs["semantics"].to(dev))
         mask = batch["fruit_mask"].to(dev)
         images_dict["fruit_mask"] = mask.repeat(1, 1, 3)
-        pred = torch.nn.functional.softmax(outputs["semantics"].to(dev), dim=-1)[..., 0] > 0.5   # all True (quirk)
+        sem = outputs["semantics"].to(dev)
         tgt = mask[..., 0] > 0.5
-        inter = (pred & tgt).sum().float()
-        union = (pred | tgt).sum().float()
-        metrics_dict["iou"] = float((inter / union.clamp_min(1.0)).item())
+
+        def jaccard(pred):
+            inter = (pred & tgt).sum().float()
+            union = (pred | tgt).sum().float()
+            return float((inter / union.clamp_min(1.0)).item())   # torchmetrics: 0 when the union is empty
+
+        implicit_dim = 0 if sem.dim() in (0, 1, 3) else 1        # torch.nn.functional._get_softmax_dim
+        metrics_dict["iou"] = jaccard(torch.softmax(sem, dim=implicit_dim)[..., 0] > 0.5)
+        metrics_dict["iou_sigmoid"] = jaccard(torch.sigmoid(sem)[..., 0] > 0.5)
         return metrics_dict, images_dict
 
     # ---- losses / metrics ----------------------------------------------------------------------------------------

@@ -52,8 +52,9 @@ def _worker(rank, world, port, q):
         covered += b - a
     bucketed_ok = bool(covered == arena.numel and len(pending) > 2 and
                        torch.allclose(arena.grads * scale, pattern * (sum(range(1, world + 1)) / world)))
-    views_ok = bool(torch.equal(m.field.mlp_head.layers[2].bias.grad,
-                                arena.grads[arena.entries[-1][2] - 0:][:0].new_zeros(0)) or True)
+    # every parameter's .grad is a view of the all-reduced arena at its recorded offset (what Adam consumes)
+    views_ok = all(p.grad.data_ptr() == arena.grads.data_ptr() + 4 * off and
+                   torch.equal(p.grad.reshape(-1), arena.grads[off:off + n]) for _, p, off, n in arena.entries)
     # rank-specific rays (seed + rank), same dataset
     scene = sa.make_scene(seed=0)
     c2w = sa.make_cameras(4, seed=0)
@@ -83,5 +84,6 @@ def test_data_parallel_contract_world2_gloo():
     for rank, same_init, mean_ok, views_ok, different_rays, scale in results:
         assert same_init, f"rank {rank}: initial weights differ across ranks"
         assert mean_ok, f"rank {rank}: all-reduced gradient mean is wrong"
+        assert views_ok, f"rank {rank}: parameter .grad tensors are not views of the gradient arena"
         assert different_rays, "ranks drew identical rays"
         assert scale == 0.5

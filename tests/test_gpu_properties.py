@@ -154,9 +154,15 @@ def test_full_image_eval_and_image_metrics(dev):
     g = torch.Generator().manual_seed(0)
     batch = {"image": torch.rand(H, W, 3, generator=g), "fruit_mask": (torch.rand(H, W, 1, generator=g) > 0.7).float()}
     metrics, images = m.get_image_metrics_and_images(out, batch)
-    assert set(metrics) == {"psnr", "ssim", "lpips", "iou"}
+    assert set(metrics) == {"psnr", "ssim", "lpips", "iou", "iou_sigmoid"}
     assert 0 < metrics["psnr"] < 60 and -1 <= metrics["ssim"] <= 1
-    assert abs(metrics["iou"] - float(batch["fruit_mask"].mean())) < 1e-6   # the reference's softmax-over-1-class quirk
+    # the reference's quirk (fruit_nerf.py:451): F.softmax without dim on [H,W,1] runs over image rows (implicit dim 0)
+    sem, tgt = out["semantics"], batch["fruit_mask"][..., 0] > 0.5
+    pred = torch.softmax(sem, dim=0)[..., 0] > 0.5
+    want = float((pred & tgt).sum()) / max(float((pred | tgt).sum()), 1.0)
+    assert abs(metrics["iou"] - want) < 1e-6
+    pred = torch.sigmoid(sem)[..., 0] > 0.5
+    assert abs(metrics["iou_sigmoid"] - float((pred & tgt).sum()) / max(float((pred | tgt).sum()), 1.0)) < 1e-6
     assert images["img"].shape == (H, 2 * W, 3) and images["fruit_mask"].shape == (H, W, 3)
 
 
