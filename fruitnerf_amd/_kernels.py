@@ -210,8 +210,12 @@ def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, se
     rgb = torch.empty(N, 3, device=dev)
     logit = torch.empty(N, device=dev)
     geo = torch.empty(N, net.geo_feat_dim, device=dev) if want_geo else None
-    # saved for field_mlp_bwd: base-MLP output [N,16] and the per-ray part of mlp_head's first layer [R,64]
-    h = torch.empty(N, 16, device=dev) if want_h else None
+    # base-MLP output [N, 16 | 32]: saved for field_mlp_bwd; the fruit_nerf_big shape always needs it (its two
+    # launches hand h over through it); + the per-ray part of mlp_head's first layer [R,64]
+    h_dim = lib.fnr_field_h_dim(C.byref(net))
+    if h_dim < 0:
+        raise RuntimeError("fruitnerf_hip field_mlp_fwd: " + L.last_error())
+    h = torch.empty(N, h_dim, device=dev) if (want_h or h_dim > 16) else None
     ray_bias = torch.empty(rays.n, 64, device=dev) if want_h else None
     # training: a private workspace, so that its packed fragment image can be handed to field_mlp_bwd
     ws = (torch.empty(lib.fnr_field_mlp_fwd_workspace_bytes(0), dtype=torch.uint8, device=dev) if want_h

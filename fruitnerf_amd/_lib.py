@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfruitnerf_hip.so")
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 2      # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 3      # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -84,6 +84,7 @@ SIGNATURES = {
     "fnr_position_grad_from_jacobian": (_i, [P(fnr_warp), P(fnr_rays), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "fnr_hash_encode_lattice": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_lattice), _i64, _i64, _vp, _vp, _vp]),
     "fnr_field_mlp_fwd_workspace_bytes": (C.c_size_t, [_i64]),
+    "fnr_field_h_dim": (_i, [P(fnr_field_net)]),
     "fnr_field_mlp_fwd": (_i, [P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                C.c_size_t, _vp]),
     "fnr_embedding_mean": (_i, [_vp, _i, _i, _vp, _vp]),

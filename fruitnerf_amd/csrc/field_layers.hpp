@@ -23,11 +23,22 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 enum KMap : int { KM_LINEAR = 0, KM_HASH = 1, KM_GEO = 2, KM_COLOR = 3 };
 
-// base configuration `fruit_nerf`: L=16,F=2 -> 32; hidden 64; geo 15; semantic 15->64->64 + head;
-// colour 63->64->64->3.
+// Two field shapes are built, selected per call from the fnr_field_net dimensions:
+//   FieldCfgBase  `fruit_nerf`      (fruit_nerf_config.py:27-61): hash 32 -> 64 -> 1+15; semantic
+//                 15 -> 64 -> 64 (+ head 64 -> 1); colour 16+15+32 -> 64 -> 64 -> 3.
+//   FieldCfgBig   `fruit_nerf_big` / `fruit_nerf_huge` (fruit_nerf_config.py:63-160): of the widths those configs set
+//                 only geo_feat_dim = 30, num_layers_semantic = 3, hidden_dim_semantics = 128 reach FruitField
+//                 (fruit_nerf.py:88-103): hash 32 -> 64 -> 1+30; semantic 30 -> 128 -> 128 -> 64 (+ head);
+//                 colour 16+30+32 -> 64 -> 64 -> 3.
+// A Cfg names its layers (L_*), gives every layer's block counts and nn.Linear dimensions, and orders the layers so
+// that the set a kernel needs is a contiguous range of the fragment image (a kernel stages only its range into LDS:
+// the Big image is 176 KB, more than the 160 KB of a CU).
+//   HB   = 16-wide blocks of the base MLP's output h = [density logit | geo | zero padding]
+//   NSEM = layers of mlp_semantics, SEMB = 16-wide blocks of its hidden layers
 struct FieldCfgBase {
-  static constexpr int GEO = 15;
+  static constexpr int GEO = 15, HB = 1, NSEM = 2, SEMB = 4;
   static constexpr int NLAYERS = 8;
+  enum { L_BASE0 = 0, L_BASE1 = 1, L_SEM0 = 2, L_SEM1 = 3, L_SEM2 = -1, L_HEAD = 4, L_COL0 = 5, L_COL1 = 6, L_COL2 = 7 };
   // layer ids:                 base0 base1 sem0 sem1 head col0 col1 col2
   static constexpr int nob(int l) { constexpr int a[NLAYERS] = {4, 1, 4, 4, 1, 4, 4, 1}; return a[l]; }
   static constexpr int nib(int l) { constexpr int a[NLAYERS] = {2, 4, 1, 4, 4, 4, 4, 4}; return a[l]; }
@@ -50,16 +61,71 @@ struct FieldCfgBase {
   static constexpr int W_TOTAL = 18432;  // = woff(NLAYERS), floats
   static constexpr int B_TOTAL = 368;    // = boff(NLAYERS)
   static constexpr int LDS_FLOATS = W_TOTAL + B_TOTAL;
-  // packed buffer = LDS image + the ray-constant slice of mlp_head layer 0, transposed: Wt[k][out], k < 48
+  // packed buffer = fragment image + the ray-constant slice of mlp_head layer 0, transposed: Wt[k][out], k < 48
   static constexpr int PACKED_FLOATS = LDS_FLOATS + 48 * 64;
 };
 static_assert(FieldCfgBase::woff(FieldCfgBase::NLAYERS) == FieldCfgBase::W_TOTAL, "W_TOTAL");
 static_assert(FieldCfgBase::boff(FieldCfgBase::NLAYERS) == FieldCfgBase::B_TOTAL, "B_TOTAL");
 static_assert(FieldCfgBase::LDS_FLOATS % 4 == 0, "the transposed slice must stay 16-byte aligned");
 
+struct FieldCfgBig {
+  static constexpr int GEO = 30, HB = 2, NSEM = 3, SEMB = 8;
+  static constexpr int NLAYERS = 9;
+  // image order: [base0 base1 | col0 col1 col2 | sem0 sem1 sem2 head] — one contiguous range per kernel family
+  enum { L_BASE0 = 0, L_BASE1 = 1, L_COL0 = 2, L_COL1 = 3, L_COL2 = 4, L_SEM0 = 5, L_SEM1 = 6, L_SEM2 = 7, L_HEAD = 8 };
+  static constexpr int nob(int l) { constexpr int a[NLAYERS] = {4, 2, 4, 4, 1, 8, 8, 4, 1}; return a[l]; }
+  static constexpr int nib(int l) { constexpr int a[NLAYERS] = {2, 4, 5, 4, 4, 2, 8, 8, 4}; return a[l]; }
+  static constexpr int out_dim(int l) { constexpr int a[NLAYERS] = {64, 31, 64, 64, 3, 128, 128, 64, 1}; return a[l]; }
+  static constexpr int in_dim(int l) { constexpr int a[NLAYERS] = {32, 64, 78, 64, 64, 30, 128, 128, 64}; return a[l]; }
+  static constexpr int km(int l) {
+    constexpr int a[NLAYERS] = {KM_HASH, KM_LINEAR, KM_COLOR, KM_LINEAR, KM_LINEAR, KM_GEO, KM_LINEAR, KM_LINEAR, KM_LINEAR};
+    return a[l];
+  }
+  static constexpr int woff(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += nob(i) * nib(i) * 256;
+    return o;
+  }
+  static constexpr int boff(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += nob(i) * 16;
+    return o;
+  }
+  static constexpr int W_TOTAL = 44032;
+  static constexpr int B_TOTAL = 576;
+  static constexpr int LDS_FLOATS = W_TOTAL + B_TOTAL;  // size of the image in global memory (never all in LDS)
+  static constexpr int PACKED_FLOATS = LDS_FLOATS + 48 * 64;
+};
+static_assert(FieldCfgBig::woff(FieldCfgBig::NLAYERS) == FieldCfgBig::W_TOTAL, "W_TOTAL");
+static_assert(FieldCfgBig::boff(FieldCfgBig::NLAYERS) == FieldCfgBig::B_TOTAL, "B_TOTAL");
+static_assert(FieldCfgBig::LDS_FLOATS % 4 == 0, "the transposed slice must stay 16-byte aligned");
+constexpr int FIELD_MAX_LAYERS = 9;
+constexpr int FIELD_MAX_PACKED_FLOATS = FieldCfgBig::PACKED_FLOATS;
+constexpr int FIELD_MAX_IMAGE_FLOATS = FieldCfgBig::LDS_FLOATS;
+constexpr int FIELD_MAX_HB = 2;
+
 struct FieldPtrs {
-  const float* w[8];
-  const float* b[8];
+  const float* w[FIELD_MAX_LAYERS];
+  const float* b[FIELD_MAX_LAYERS];
+};
+
+// The part of the fragment image a kernel keeps in LDS: layers [LA, LB) — weights first, then their biases.
+template <class Cfg, int LA, int LB>
+struct LdsRange {
+  static constexpr int W0 = Cfg::woff(LA), W1 = Cfg::woff(LB), B0 = Cfg::boff(LA), B1 = Cfg::boff(LB);
+  static constexpr int W_FLOATS = W1 - W0, B_FLOATS = B1 - B0, FLOATS = W_FLOATS + B_FLOATS;
+  static_assert(W_FLOATS % 4 == 0 && B_FLOATS % 4 == 0 && W0 % 4 == 0 && (Cfg::W_TOTAL + B0) % 4 == 0, "float4 copies");
+  __device__ static __forceinline__ const float* w(const float* lds, int l) { return lds + (Cfg::woff(l) - W0); }
+  __device__ static __forceinline__ float* w(float* lds, int l) { return lds + (Cfg::woff(l) - W0); }
+  __device__ static __forceinline__ const float* b(const float* lds, int l) { return lds + W_FLOATS + (Cfg::boff(l) - B0); }
+  // fragment image (global, 16-byte aligned) -> LDS
+  __device__ static __forceinline__ void stage(float* __restrict__ lds, const float* __restrict__ packed) {
+    const f32x4* sw = reinterpret_cast<const f32x4*>(packed + W0);
+    const f32x4* sb = reinterpret_cast<const f32x4*>(packed + Cfg::W_TOTAL + B0);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int i = threadIdx.x; i < W_FLOATS / 4; i += blockDim.x) dst[i] = sw[i];
+    for (int i = threadIdx.x; i < B_FLOATS / 4; i += blockDim.x) dst[W_FLOATS / 4 + i] = sb[i];
+  }
 };
 
 // input column of nn.Linear weight for K-slot (ib, g, r); -1 -> structural zero
@@ -73,13 +139,18 @@ __device__ __forceinline__ int kmap(int kind, int ib, int g, int r, int in_dim) 
       col = 2 * (4 * (s >> 1) + g) + (s & 1);
       break;
     }
-    case KM_GEO:  // input block = base-MLP output h (h[0] = density logit is not an input)
-      col = k - 1;
+    case KM_GEO:  // input blocks = base-MLP output h (h[0] = density logit is not an input)
+      col = 16 * ib + k - 1;
       break;
-    case KM_COLOR:  // [h | SH16 | emb32] -> nn.Linear columns [SH16, geo, emb]
-      if (ib == 0) col = (k == 0) ? -1 : 16 + (k - 1);
-      else if (ib == 1) col = k;
-      else col = 16 + Cfg::GEO + 16 * (ib - 2) + k;
+    case KM_COLOR:  // [h (HB blocks) | SH16 | emb32] -> nn.Linear columns [SH16, geo, emb]
+      if (ib < Cfg::HB) {
+        const int hk = 16 * ib + k;  // h index: 0 = density logit, 1..GEO = geo features, beyond = padding
+        col = (hk >= 1 && hk <= Cfg::GEO) ? 16 + (hk - 1) : -1;
+      } else if (ib == Cfg::HB) {
+        col = k;
+      } else {
+        col = 16 + Cfg::GEO + 16 * (ib - Cfg::HB - 1) + k;
+      }
       break;
     default:
       col = 16 * ib + k;
@@ -130,22 +201,13 @@ __global__ __launch_bounds__(256) void k_pack_field_weights(FieldPtrs p, float* 
     packed[idx] = packed_value<Cfg>(idx, p);
   } else if (idx < Cfg::PACKED_FLOATS) {
     const int k = (idx - Cfg::LDS_FLOATS) >> 6, o = (idx - Cfg::LDS_FLOATS) & 63;
-    packed[idx] = p.w[5][o * Cfg::in_dim(5) + color_const_col<Cfg>(k)];
+    packed[idx] = p.w[Cfg::L_COL0][o * Cfg::in_dim(Cfg::L_COL0) + color_const_col<Cfg>(k)];
   }
 }
 
 template <class Cfg>
 static inline void launch_pack_field_weights(const FieldPtrs& p, float* packed, hipStream_t st) {
   hipLaunchKernelGGL((k_pack_field_weights<Cfg>), dim3((Cfg::PACKED_FLOATS + 255) / 256), dim3(256), 0, st, p, packed);
-}
-
-// fragment image (global, 16-byte aligned) -> LDS
-template <class Cfg>
-__device__ __forceinline__ void stage_field_weights(float* __restrict__ lds, const float* __restrict__ packed) {
-  static_assert(Cfg::LDS_FLOATS % 4 == 0, "image must be float4-copyable");
-  const f32x4* src = reinterpret_cast<const f32x4*>(packed);
-  f32x4* dst = reinterpret_cast<f32x4*>(lds);
-  for (int i = threadIdx.x; i < Cfg::LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
 }
 
 // out^T[16 NOB][16] += W[:, input blocks 0..NIB-1] * in^T ; `in`/`out` are C-layout accumulators.
@@ -179,18 +241,19 @@ __device__ __forceinline__ void mlp_layer(const float* __restrict__ P, const flo
   mlp_layer_acc<NOB, NIB, NIB>(P, in, out, lane);
 }
 
-// first colour layer (mlp_head layer 0, fruit_field.py:150-158,258-262).  48 of its 63 inputs — SH16(direction) and
+// first colour layer (mlp_head layer 0, fruit_field.py:150-158,258-262).  48 of its inputs — SH16(direction) and
 // the appearance embedding — are constant along a ray, so their product with the weights is a per-RAY vector
-// (k_color_ray_bias, 64 floats per ray) that enters here as the accumulator's initial value; only the 16-wide
-// h block (input block 0 of the image) is multiplied per sample: 16 MFMAs instead of 64.
+// (k_color_ray_bias, 64 floats per ray) that enters here as the accumulator's initial value; only the h blocks
+// (input blocks 0..HB-1 of the image) are multiplied per sample: 16 HB MFMAs instead of 64 (80).
+// W0 = the layer's weight block in LDS.
 template <class Cfg>
-__device__ __forceinline__ void color_layer0(const float* __restrict__ lds, const float* __restrict__ ray_bias,
-                                             long long ray, const f32x4 (&h)[1], f32x4 (&c1)[4], int lane) {
+__device__ __forceinline__ void color_layer0(const float* __restrict__ W0, const float* __restrict__ ray_bias,
+                                             long long ray, const f32x4 (&h)[Cfg::HB], f32x4 (&c1)[4], int lane) {
   const int g = lane >> 4;
 #pragma unroll
   for (int ob = 0; ob < 4; ++ob)
     c1[ob] = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)ray * 64 + 16 * ob + 4 * g);
-  mlp_layer_acc<4, 1, 4>(lds + Cfg::woff(5), h, c1, lane);
+  mlp_layer_acc<4, Cfg::HB, Cfg::HB + 3>(W0, h, c1, lane);
 }
 
 template <int N>
@@ -240,7 +303,7 @@ __global__ __launch_bounds__(256) void k_color_ray_bias(const float* __restrict_
     for (int i = threadIdx.x; i < COLOR_CONST_K * 64 / 4; i += 256) dst[i] = src[i];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float b = packed[Cfg::W_TOTAL + Cfg::boff(5) + lane];
+  const float b = packed[Cfg::W_TOTAL + Cfg::boff(Cfg::L_COL0) + lane];
   __syncthreads();
   for (long long ray = (long long)blockIdx.x * 4 + wave; ray < rays.n_rays; ray += (long long)gridDim.x * 4) {
     float c[16];

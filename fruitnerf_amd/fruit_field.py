@@ -87,6 +87,17 @@ class FruitField(nn.Module):
         if num_layers != 2 or num_layers_color != 3 or num_semantic_classes != 1:
             raise NotImplementedError("gfx950 field kernels are built for num_layers=2, num_layers_color=3, "
                                       "num_semantic_classes=1 (what FruitModel constructs, fruit_nerf.py:88-103)")
+        # the two MLP shapes compiled into libfruitnerf_hip.so (csrc/field_layers.hpp: FieldCfgBase / FieldCfgBig):
+        # fail at construction, not at the first kernel call
+        shape = (geo_feat_dim, num_layers_semantic, hidden_dim_semantics)
+        fixed = (num_levels, features_per_level, hidden_dim, hidden_dim_color, hidden_dim_transient,
+                 appearance_embedding_dim)
+        if shape not in ((15, 2, 64), (30, 3, 128)) or fixed != (16, 2, 64, 64, 64, 32):
+            raise NotImplementedError(
+                "gfx950 field kernels are built for the `fruit_nerf` shape (geo_feat_dim 15, num_layers_semantic 2, "
+                "hidden_dim_semantics 64) and the `fruit_nerf_big` / `fruit_nerf_huge` shape (30, 3, 128) with 16 levels "
+                "x 2 features, hidden_dim 64, hidden_dim_color 64, hidden_dim_transient 64, appearance 32 "
+                f"(fruit_nerf_config.py:27-160); got {shape} / {fixed}")
         self._arena: Optional[ParamArena] = None
         self._net_c: Optional[L.fnr_field_net] = None
         self._net_ptr_key = None

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 2
+#define FNR_ABI_VERSION 3
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -83,20 +83,25 @@ typedef struct fnr_prop_net {
 } fnr_prop_net;
 
 /* FruitField (fruit_field.py:43-301).  Linear weights are nn.Linear layout [out, in].
- * A second instance of this struct with pointers into the gradient arena describes the gradients. */
+ * A second instance of this struct with pointers into the gradient arena describes the gradients.
+ * Two shapes are built (everything else returns FNR_ERR_UNSUPPORTED):
+ *   `fruit_nerf`                       geo_feat_dim 15, num_layers_semantic 2, hidden_dim_semantics 64
+ *   `fruit_nerf_big` / `fruit_nerf_huge` geo_feat_dim 30, num_layers_semantic 3, hidden_dim_semantics 128
+ * (fruit_nerf_config.py:27-160; of the widths those configs set only these three reach FruitField,
+ * fruit_nerf.py:88-103), both with base / colour width 64, semantic_out_dim 64, appearance 32, 16 hash levels. */
 typedef struct fnr_field_net {
   fnr_grid grid;
-  int32_t geo_feat_dim;         /* 15 */
+  int32_t geo_feat_dim;         /* 15 | 30 */
   int32_t hidden_dim;           /* 64 (base MLP width)  */
   int32_t hidden_dim_color;     /* 64 */
-  int32_t hidden_dim_semantics; /* 64 */
-  int32_t num_layers_semantic;  /* 2  */
+  int32_t hidden_dim_semantics; /* 64 | 128 */
+  int32_t num_layers_semantic;  /* 2 | 3 */
   int32_t semantic_out_dim;     /* 64 (hidden_dim_transient, fruit_field.py:150) */
   int32_t appearance_dim;       /* 32 */
   int32_t n_images;
   float* base_w0; float* base_b0;           /* [64, 2L], [64] */
   float* base_w1; float* base_b1;           /* [1+geo, 64], [1+geo] */
-  float* sem_w[FNR_MAX_SEM_LAYERS];         /* mlp_semantics layers */
+  float* sem_w[FNR_MAX_SEM_LAYERS];         /* mlp_semantics layers: [64,15],[64,64] | [128,30],[128,128],[64,128] */
   float* sem_b[FNR_MAX_SEM_LAYERS];
   float* head_w; float* head_b;             /* SemanticFieldHead: [1, 64], [1] (components/field_heads.py:29-40) */
   float* col_w[3]; float* col_b[3];         /* mlp_head: [64,16+geo+32],[64,64],[3,64] */
@@ -203,7 +208,10 @@ int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fn
  * (fruit_field.py:187-193, 195-232, 234-281) on MFMA.
  * mean_embedding: [32] -> eval/export path (fruit_field.py:217-219,253-256); NULL -> training path,
  * per-ray Embedding[camera_indices] (fruit_field.py:251).
- * h_save (optional) [N,16]: the base MLP's raw output (density logit + geo), kept for fnr_field_mlp_bwd.
+ * h_save [N, fnr_field_h_dim(net)]: the base MLP's raw output (density logit | geo | zero padding to a multiple of
+ * 16: 16 floats for geo 15, 32 for geo 30), kept for fnr_field_mlp_bwd.  Optional for the `fruit_nerf` shape; REQUIRED
+ * for the `fruit_nerf_big` shape, whose 176 KB of weights do not fit one CU's LDS: it runs as two launches (base +
+ * colour, then semantic) that hand h over through this buffer.
  * ray_bias_save (optional) [n_rays,64]: the per-ray part of mlp_head's first layer, kept for fnr_field_mlp_bwd.
  * Outputs per sample: density [N], rgb [N,3], logit [N]; geo_out (optional) [N, geo_feat_dim] = the
  * density embedding `base_mlp_out` returned by get_density (fruit_field.py:187-193).
@@ -212,6 +220,8 @@ int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fn
  * embedding are constant along a ray: [n_rays, 64]; with ray_bias_save the workspace only needs
  * fnr_field_mlp_fwd_workspace_bytes(0)).  The image sits at the start of the workspace. */
 size_t fnr_field_mlp_fwd_workspace_bytes(int64_t n_rays);
+/* Row length of h_save / h_saved for this field shape (16 or 32); -1 if the shape is not built. */
+int fnr_field_h_dim(const fnr_field_net* net);
 int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays, int S, const float* feats,
                       const uint8_t* selector, const float* mean_embedding, float* density, float* rgb, float* logit,
                       float* geo_out, float* h_save, float* ray_bias_save, void* workspace, size_t workspace_bytes,

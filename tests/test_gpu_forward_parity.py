@@ -125,10 +125,11 @@ def test_sampler_chain_and_prop_density(dev):
         assert bad <= 1, f"{bad} median-depth mismatches"
 
 
+@pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
 @pytest.mark.parametrize("training", [True, False])
-def test_field_forward_per_sample(dev, training):
-    """FruitField.forward on generic RaySamples: density / rgb / semantic logit per sample."""
-    cfg = util.small_config(log2=16)
+def test_field_forward_per_sample(dev, training, shape):
+    """FruitField.forward on generic RaySamples: density / rgb / semantic logit per sample, for both built MLP shapes."""
+    cfg = util.small_config(log2=16) if shape == "fruit_nerf" else util.big_config(log2=16)
     om = util.make_oracle(cfg, seed=2)
     hm = util.make_hip_like(om, dev)
     om.train(training)
@@ -153,7 +154,7 @@ def test_field_forward_per_sample(dev, training):
     with torch.no_grad():
         rd, rg = om.field.get_density(rs)
     a, _ = util.report("field.geo", geo, rg)
-    assert a <= 1e-5
+    assert a <= 1e-5 and geo.shape[-1] == cfg.geo_feat_dim
 
 
 @pytest.mark.parametrize("training", [False, True])
@@ -185,6 +186,33 @@ def test_model_forward_end_to_end(dev, training):
     assert torch.equal(got["semantics_colormap"].cpu().float().view(-1), ref["semantics_colormap"].float().view(-1))
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_model_forward_end_to_end_fruit_nerf_big(dev, training):
+    """FruitModel.forward at the real `fruit_nerf_big` sizes (fruit_nerf_config.py:82-95): hash 16 x 2^21, max_res 4096,
+    samples 512/256/128, geo 30, semantic 30 -> 128 -> 128 -> 64."""
+    cfg = util.fruit_nerf_big_config()
+    om = util.make_oracle(cfg, seed=13)
+    hm = util.make_hip_like(om, dev)
+    om.train(training)
+    hm.train(training)
+    om.proposal_sampler._anneal = 0.4
+    hm.proposal_sampler._anneal = 0.4
+    R = 80
+    o, d, pa, cam = util.random_rays(R, 7, seed=17)
+    jit = [torch.rand(R, 1) for _ in range(3)] if training else None
+    with torch.no_grad():
+        ref = om(_bundle(o, d, pa, cam), jitter=jit)
+        got = hm(_hip_bundle(o, d, pa, cam, dev), jitter=None if jit is None else [j.to(dev) for j in jit])
+    a_rgb, _ = util.report(f"big.rgb[train={training}]", got["rgb"], ref["rgb"])
+    a_sem, _ = util.report(f"big.semantics[train={training}]", got["semantics"], ref["semantics"])
+    a_acc, _ = util.report(f"big.accumulation[train={training}]", got["accumulation"], ref["accumulation"])
+    for i in range(3):
+        assert got["weights_list"][i].shape == ref["weights_list"][i].shape == (R, (512, 256, 128)[i], 1)
+        util.report(f"big.weights[{i}]", got["weights_list"][i], ref["weights_list"][i])
+    assert a_rgb <= 1e-4 and a_sem <= 1e-4 and a_acc <= 1e-4
+    assert torch.equal(got["semantics_colormap"].cpu().float().view(-1), ref["semantics_colormap"].float().view(-1))
+
+
 def test_pixel_sampler_matches_torch_mirror(dev):
     """fnr_sample_pixels (PixelSampler + RayGenerator) vs the torch ops the CPU baseline uses."""
     from fruitnerf_amd.data import synthetic_apple as sa
@@ -209,22 +237,21 @@ def test_pixel_sampler_matches_torch_mirror(dev):
     assert torch.equal(gimg.cpu(), batch["image"]) and torch.equal(gmask.cpu(), batch["fruit_mask"][:, 0])
 
 
-def test_export_counts_and_points_identical(dev):
+@pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
+def test_export_counts_and_points_identical(dev, shape):
     """Volume export: identical point counts and identical ordered point lists for the three sets."""
     from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
     from fruitnerf_amd.export.exporter_utils import sample_volume
-    cfg = util.small_config(log2=15)
+    cfg = util.small_config(log2=15) if shape == "fruit_nerf" else util.big_config(log2=15)
     om = util.make_oracle(cfg, seed=4, test_mode="export")
     util.randomize_(om, 9, density_boost=3.0)
-    with torch.no_grad():  # make the logit >= 3 and sigmoid > 0.9 sets non-trivial
-        om.field.field_head_semantics.net.weight.mul_(8.0)
-        om.field.field_head_semantics.net.bias.add_(1.5)
     om.field.test_mode = "export"
+    aabb = ((-1.0, -0.6, -1.0), (1.0, 0.6, 1.0))  # non-cubic: n_y = int(0.6 * N)
+    util.straddle_export_thresholds(om, aabb)   # the three thresholds cut through the middle of the lattice's samples
     om.eval()
     hm = util.make_hip_like(om, dev, test_mode="export")
     hm.eval()
     N = 40
-    aabb = ((-1.0, -0.6, -1.0), (1.0, 0.6, 1.0))  # non-cubic: n_y = int(0.6 * N)
     om.setup_inference(True, N)
     ref = fo.sample_volume(om, aabb, N, num_rays_per_batch=333, dataparser_scale=0.7)
 
@@ -245,8 +272,10 @@ def test_export_counts_and_points_identical(dev):
             n_ref, n_got = ref[name]["points"].shape[0], got[name]["points"].shape[0]
             print(f"[export fused={fused}] {name}: oracle {n_ref} points, hip {n_got} points")
             near[name] = (n_ref, n_got)
-        assert ref["density"]["points"].shape[0] > 100, "test field produced too few dense samples"
-        assert ref["semantic"]["points"].shape[0] > 10
+        n_total = N * int(0.6 * N) * N
+        assert 0.2 * n_total < ref["density"]["points"].shape[0] < 0.8 * n_total, "density threshold is not discriminating"
+        assert 0.1 * ref["density"]["points"].shape[0] < ref["semantic"]["points"].shape[0] < \
+            ref["semantic_colormap"]["points"].shape[0] < 0.9 * ref["density"]["points"].shape[0]
         for name in ("semantic_colormap", "semantic", "density"):
             assert near[name][0] == near[name][1], f"{name}: count mismatch {near[name]}"
             assert torch.equal(torch.from_numpy(got[name]["points"]), ref[name]["points"]), f"{name}: points differ"

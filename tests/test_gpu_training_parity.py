@@ -27,33 +27,45 @@ def _oracle_step(om, o, d, pa, cam, jit, batch, step):
     return out, ld, md
 
 
-def _grad_report(om, hm, tag=""):
-    worst = 0.0
+def _grad_report(om, hm, tag="", with_aggregate=False):
+    """Worst max-norm relative gradient error over the parameters (and, with_aggregate, the worst L1-relative error:
+    sum|hip - ref| / sum|ref| per parameter)."""
+    worst, worst_agg = 0.0, 0.0
     named_h = dict(hm.named_parameters())
     for name, p in om.named_parameters():
         g_ref = p.grad if p.grad is not None else torch.zeros_like(p)
         g_hip = named_h[name].grad.detach().cpu()
         scale = g_ref.abs().max().item()
-        err = (g_hip - g_ref).abs().max().item()
+        diff = (g_hip - g_ref).abs()
+        err = diff.max().item()
         rel = err / max(scale, 1e-12)
+        agg = diff.double().sum().item() / max(g_ref.abs().double().sum().item(), 1e-30)
         nnz_ref = int((g_ref != 0).sum())
         nnz_hip = int((g_hip != 0).sum())
-        print(f"[grad{tag}] {name}: max|ref| {scale:.3e} max_err {err:.3e} rel {rel:.3e} nnz ref/hip {nnz_ref}/{nnz_hip}")
+        print(f"[grad{tag}] {name}: max|ref| {scale:.3e} max_err {err:.3e} rel {rel:.3e} L1-rel {agg:.3e} "
+              f"nnz ref/hip {nnz_ref}/{nnz_hip}")
         if scale > 0:
             worst = max(worst, rel)
+            worst_agg = max(worst_agg, agg)
         else:
             assert err == 0.0, f"{name}: oracle grad is zero but HIP grad is not"
-    return worst
+    return (worst, worst_agg) if with_aggregate else worst
 
 
-@pytest.mark.parametrize("step,n_samples", [(0, 48), (12, 48), (0, 40)])
-def test_losses_and_all_gradients(dev, step, n_samples):
+@pytest.mark.parametrize("step,n_samples,shape", [(0, 48, "fruit_nerf"), (12, 48, "fruit_nerf"), (0, 40, "fruit_nerf"),
+                                                  (0, 128, "fruit_nerf_big"), (12, 40, "fruit_nerf_big")])
+def test_losses_and_all_gradients(dev, step, n_samples, shape):
     """step 0: proposal nets are 'updated' (interlevel gradient flows); step 12 with a fresh sampler
     state: not updated -> proposal-network gradients must be exactly zero on both sides.
-    40 samples per ray: 16-sample MFMA tiles straddle rays (per-ray colour terms take their slow path)."""
+    40 samples per ray: 16-sample MFMA tiles straddle rays (per-ray colour terms take their slow path).
+    fruit_nerf_big: the second built MLP shape (geo 30, semantic 30 -> 128 -> 128 -> 64; FieldCfgBig)."""
     from fruitnerf_amd.rays import RayBundle
-    cfg = util.small_config(log2=15, prop_log2=13)
+    cfg = (util.small_config if shape == "fruit_nerf" else util.big_config)(log2=15, prop_log2=13)
     cfg.num_nerf_samples_per_ray = n_samples
+    # this test is about the MLP shape: keep the sampler in the regime of the fruit_nerf cases (an anneal exponent of
+    # 0.02 at step 12 of 5000 makes the PDF sampler's inverse CDF ill-conditioned, and max_res 4096 on a RANDOM table
+    # turns 1e-6 of sample position into 4e-3 of a finest-level cell)
+    cfg.proposal_weights_anneal_max_num_iters, cfg.max_res = 1000, 2048
     om = util.make_oracle(cfg, seed=5)
     hm = util.make_hip_like(om, dev)
     om.train()
@@ -77,13 +89,23 @@ def test_losses_and_all_gradients(dev, step, n_samples):
     for k in ld_ref:
         a, b = float(ld[k]), float(ld_ref[k])
         print(f"[loss step={step}] {k}: hip {a:.8e} oracle {b:.8e}")
-        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), k
+        # interlevel: a mean of squared CLIPPED histogram overlaps (~1e-4 here), ill-conditioned in the sampled bin
+        # edges (sampler parity 2e-6) when the anneal exponent is tiny (fruit_nerf_big anneals over 5000 steps): 1e-3
+        tol = 1e-3 * abs(b) + 1e-8 if (k == "interlevel_loss" and shape != "fruit_nerf") else 2e-5 * max(abs(b), 1e-3)
+        assert abs(a - b) <= tol, k
     for k in md_ref:
         a, b = float(md[k]), float(md_ref[k])
         print(f"[metric step={step}] {k}: hip {a:.6e} oracle {b:.6e}")
         assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), k
-    worst = _grad_report(om, hm, f" step={step}")
-    assert worst <= 2e-3, f"worst relative gradient error {worst}"
+    worst, worst_agg = _grad_report(om, hm, f" step={step}", with_aggregate=True)
+    if shape == "fruit_nerf":
+        assert worst <= 2e-3, f"worst relative gradient error {worst}"
+    else:
+        # 20 480 samples x 448 hidden units: a ReLU pre-activation within fp32 rounding of 0 is expected for ~1 of them;
+        # that unit takes the other branch than in the oracle (MFMA K-order) and ONE sample's contribution moves one
+        # weight row and, through dX, that sample's 128 table rows — visible in the max norm (gradients ~1e-6), invisible
+        # in L1.  A wrong kernel moves every entry: bound both.
+        assert worst <= 2e-2 and worst_agg <= 2e-3, f"gradient error: max-norm {worst}, L1 {worst_agg}"
 
 
 def test_adam_matches_torch(dev):
@@ -158,12 +180,13 @@ def test_three_training_steps_track_the_oracle(dev):
         assert d_abs.max().item() <= 3 * 3 * 1e-2 + 1e-6, name  # nothing moves further than steps * lr apart
 
 
-def test_fused_step_matches_the_autograd_step(dev):
+@pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
+def test_fused_step_matches_the_autograd_step(dev, shape):
     """fused_forward_backward() (no autograd engine, what bench.py times) must leave the same losses, metrics and
     gradients as model(...) -> get_metrics_dict -> get_loss_dict -> sum -> backward."""
     from fruitnerf_amd.rays import RayBundle
     from fruitnerf_amd.training import fused_forward_backward
-    cfg = util.small_config(log2=15, prop_log2=13)
+    cfg = (util.small_config if shape == "fruit_nerf" else util.big_config)(log2=15, prop_log2=13)
     om = util.make_oracle(cfg, seed=9)
     R = 192
     o, d, pa, cam = util.random_rays(R, 7, seed=4)

@@ -19,6 +19,24 @@ def full_config():
     return fo.FruitNerfModelConfig()
 
 
+def big_config(log2=14, prop_log2=12, max_res=4096):
+    """What `fruit_nerf_big` / `fruit_nerf_huge` change in the FIELD (fruit_nerf_config.py:82-95 via fruit_nerf.py:88-103):
+    geo 30, semantic MLP 30 -> 128 -> 128 -> 64, max_res 4096 — on small tables."""
+    cfg = small_config(log2=log2, prop_log2=prop_log2, max_res=max_res)
+    cfg.geo_feat_dim, cfg.num_layers_semantic, cfg.hidden_dim_semantics = 30, 3, 128
+    cfg.proposal_weights_anneal_max_num_iters = 5000
+    return cfg
+
+
+def fruit_nerf_big_config():
+    """The model part of the `fruit_nerf_big` method at its real sizes (fruit_nerf_config.py:82-95)."""
+    cfg = fo.FruitNerfModelConfig(log2_hashmap_size=21, max_res=4096)
+    cfg.geo_feat_dim, cfg.num_layers_semantic, cfg.hidden_dim_semantics = 30, 3, 128
+    cfg.num_nerf_samples_per_ray, cfg.num_proposal_samples_per_ray = 128, (512, 256)
+    cfg.proposal_weights_anneal_max_num_iters = 5000
+    return cfg
+
+
 def randomize_(model: fo.FruitModel, seed: int, density_boost: float = 2.0):
     """'Trained-like' parameters: O(1) hash features, non-trivial densities and logits."""
     g = torch.Generator().manual_seed(seed)
@@ -33,6 +51,31 @@ def randomize_(model: fo.FruitModel, seed: int, density_boost: float = 2.0):
         f.field_head_semantics.net.weight.mul_(6.0)
         f.embedding_appearance.embedding.weight.copy_(
             torch.randn(f.embedding_appearance.embedding.weight.shape, generator=g))
+    return model
+
+
+def straddle_export_thresholds(model: fo.FruitModel, aabb, n_side: int = 24, logit_spread: float = 1.5):
+    """Re-centre an export-mode oracle model so that the exporter's thresholds (density >= 70, logit >= 3,
+    sigmoid(logit) > 0.9; exporter_utils.py:111-114) cut through the middle of the sample distribution instead of
+    keeping ~all or ~none of the lattice: shifts the density-logit bias and rescales / shifts SemanticFieldHead."""
+    was_training = model.training
+    model.eval()
+    model.setup_inference(True, n_side)
+    corners = fo.get_corners_of_aabb(aabb)
+    pts, vec = fo.sample_surface_points(corners, n=n_side)
+    with torch.no_grad():
+        out = model(fo.OrthographicRayGenerator(pts, vec, pts.shape[0])(1))
+        dens, logit = out["density"].reshape(-1), out["semantics"].reshape(-1)
+        inside = dens > 0
+        f = model.field
+        # + 0.0123: the median sample must not sit exactly ON the threshold (it would, to fp32 rounding)
+        f.mlp_base_mlp.layers[1].bias[0].add_(float(torch.log(torch.tensor(70.0)) - dens[inside].log().median()) + 0.0123)
+        head = f.field_head_semantics.net
+        z = logit[inside] - head.bias
+        k = logit_spread / float(z.std())
+        head.weight.mul_(k)
+        head.bias.fill_(2.6 - k * float(z.median()))
+    model.train(was_training)
     return model
 
 
