@@ -234,7 +234,8 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(self.arena.params)
         self.groups = group_lr or {name: dict(lr=lr, lr_final=lr_final, max_steps=max_steps)
                                    for name in self.arena.group_ranges}
-        self.step_count = 0
+        self.step_count = 0                                   # scheduler steps (every iteration, every group)
+        self.group_steps = {name: 0 for name in self.arena.group_ranges}   # optimiser steps a group actually took
 
     def current_lr(self, name: str) -> float:
         g = self.groups[name]
@@ -242,27 +243,54 @@ class FusedAdam:
             return g["lr"]
         return exponential_decay_lr(self.step_count, g["lr"], g["lr_final"], g["max_steps"])
 
-    def begin_step(self) -> Dict[str, float]:
-        """Advance the step counter and return this update's learning rate per parameter group
-        (scheduler.step() runs after optimizer.step(): update k uses lr(k-1))."""
+    def begin_step(self, skip=()) -> Dict[str, float]:
+        """Advance the counters and return this update's learning rate per parameter group (scheduler.step() runs
+        after optimizer.step(): update k uses lr(k-1)).
+
+        skip: groups that received NO gradient this iteration.  The reference's proposal networks are evaluated under
+        no_grad on 4 of 5 steps after warm-up (fruit_nerf.py:131-136 via ProposalNetworkSampler), zero_grad() leaves
+        their .grad = None (torch >= 2.0: set_to_none), and torch.optim.Adam / RAdam skip such parameters entirely —
+        no moment decay, no movement, and their per-parameter `step` (bias correction, RAdam's rho_t) does not advance.
+        The learning-rate schedulers still tick every iteration."""
         self.step_count += 1
+        for name in self.group_steps:
+            if name not in skip:
+                self.group_steps[name] += 1
         return {name: (exponential_decay_lr(self.step_count - 1, g["lr"], g["lr_final"], g["max_steps"])
                        if g.get("lr_final") is not None else g["lr"]) for name, g in self.groups.items()}
 
-    def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0) -> None:
-        """Adam update (+ zero_grad) of arena elements [a, b); begin_step() must have been called for this step."""
+    def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0, group: Optional[str] = None) -> None:
+        """Adam update (+ zero_grad) of arena elements [a, b); begin_step() must have been called for this step.
+        group: whose step counter feeds the bias corrections (default: the group that contains a)."""
         if b > a:
+            if group is None:
+                group = next(n for n, (ga, gb) in self.arena.group_ranges.items() if ga <= a < gb)
             fn = K.adam_step if self.algorithm == "adam" else K.radam_step
             fn(self.arena.params[a:b], self.arena.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr,
-               self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, True,
+               self.betas[0], self.betas[1], self.eps, self.group_steps[group], grad_scale, True,
                weight_decay=self.weight_decay)
 
-    def step(self, grad_scale: float = 1.0) -> None:
-        lrs = self.begin_step()
-        same = len(set(lrs.values())) == 1
-        spans = [("all", (0, self.arena.numel))] if same else list(self.arena.group_ranges.items())
-        for name, (a, b) in spans:
-            self.step_span(a, b, next(iter(lrs.values())) if same else lrs[name], grad_scale)
+    def step(self, grad_scale: float = 1.0, skip=()) -> None:
+        """One optimiser step over every group except `skip` (see begin_step).  Adjacent groups whose learning rate AND
+        step count coincide share one launch."""
+        lrs = self.begin_step(skip)
+        runs = []   # [a, b, lr, group]
+        for name, (a, b) in self.arena.group_ranges.items():
+            if name in skip:
+                continue
+            if runs and runs[-1][1] == a and runs[-1][2] == lrs[name] and \
+                    self.group_steps[runs[-1][3]] == self.group_steps[name]:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b, lrs[name], name])
+        for a, b, lr, name in runs:
+            self.step_span(a, b, lr, grad_scale, group=name)
+
+
+def skipped_groups(model) -> tuple:
+    """Parameter groups that got no gradient in the last training render (the proposal networks on steps that did not
+    'update' them)."""
+    return () if bool(getattr(model, "_last_render_updated", True)) else ("proposal_networks",)
 
 
 # 2 in production; the single-GPU RCCL self-test (tools/microbench/rccl_single_rank.py) lowers it to 1 so that a
@@ -308,7 +336,7 @@ def train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, w
     loss = sum(loss_dict.values())                             # functools.reduce(torch.add, loss_dict.values())
     loss.backward()
     scale = sync_gradients(model.arena(), world_size)
-    optimizer.step(grad_scale=scale)
+    optimizer.step(grad_scale=scale, skip=skipped_groups(model))
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
 
@@ -475,7 +503,7 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
         if exchange is None:
             if camera is not None:
                 camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
-            optimizer.step()
+            optimizer.step(skip=skipped_groups(model))
         else:
             pending = list(exchange.pending)
             # the update schedule is a function of the step, identical on every rank: on steps that did not train the
@@ -487,15 +515,13 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             # that nothing on the compute stream waits behind the big buckets before their own Adam launches
             cam_work, cam_scale = (camera_backward(camera[0], camera[2], ray_grads, world_size)
                                    if camera is not None else (None, 1.0))
-            lrs = optimizer.begin_step()
+            # ... and, as in the reference (grad = None -> torch.optim skips them), neither is their optimiser step
+            lrs = optimizer.begin_step(skip=() if prop_updated else ("proposal_networks",))
             scale = 1.0 / world_size
             for a, b, work in pending:
                 work.wait()                                    # the compute stream waits for this bucket only
                 name = "fields" if a >= spans["fields"][0] else "proposal_networks"
-                optimizer.step_span(a, b, lrs[name], scale)
-            if not prop_updated:                               # Adam still runs (moments decay, parameters move)
-                optimizer.step_span(spans["proposal_networks"][0], spans["proposal_networks"][1],
-                                    lrs["proposal_networks"], scale)
+                optimizer.step_span(a, b, lrs[name], scale, group=name)
             if camera is not None:
                 if cam_work is not None:
                     cam_work.wait()

@@ -180,6 +180,63 @@ def test_three_training_steps_track_the_oracle(dev):
         assert d_abs.max().item() <= 3 * 3 * 1e-2 + 1e-6, name  # nothing moves further than steps * lr apart
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_optimizer_skips_the_proposal_networks_on_steps_that_do_not_update_them(dev, fused):
+    """Steps 9..12 cross the end of the every-step phase (ProposalNetworkSampler: step < 10).  On iteration 11 the
+    proposal densities are computed under no_grad, the reference's zero_grad() leaves those .grad = None and
+    torch.optim skips the parameters: no movement, no moment decay, no step-count advance (bias correction).  The
+    oracle side is driven with torch.optim exactly as nerfstudio's Optimizers does; the HIP side must show the same
+    pattern and the same per-group step counts."""
+    from fruitnerf_amd.rays import RayBundle
+    from fruitnerf_amd.training import FusedAdam, fused_train_iteration, train_iteration
+    cfg = util.small_config(log2=12, prop_log2=10)
+    om = util.make_oracle(cfg, seed=31)
+    hm = util.make_hip_like(om, dev)
+    om.train()
+    hm.train()
+    groups = om.get_param_groups()
+    opts = {"proposal_networks": torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15),
+            "fields": torch.optim.Adam(groups["fields"], lr=1e-2, eps=1e-15)}
+    hopt = FusedAdam(hm)
+    for m in (om, hm):                       # as after 9 warm-up iterations
+        m.proposal_sampler._step = 8
+        m.proposal_sampler._steps_since_update = 1
+    hopt.step_count = 9
+    hopt.group_steps = {k: 9 for k in hopt.group_steps}
+    R = 96
+    a, b = hm.arena().group_ranges["proposal_networks"]
+    moved_ref, moved_hip = [], []
+    for step in range(9, 13):
+        o, d, pa, cam = util.random_rays(R, 7, seed=300 + step)
+        jit = [torch.rand(R, 1) for _ in range(3)]
+        batch = _batch(R, 70 + step)
+        before_ref = [p.detach().clone() for p in groups["proposal_networks"]]
+        for op in opts.values():
+            op.zero_grad()                  # torch >= 2.0: set_to_none=True
+        _oracle_step(om, o, d, pa, cam, jit, batch, step)
+        for op in opts.values():
+            op.step()
+        om.proposal_sampler.step_cb(step)
+        moved_ref.append(any(not torch.equal(x, p.detach()) for x, p in zip(before_ref, groups["proposal_networks"])))
+        before = hm.arena().params[a:b].clone()
+        m_before, v_before = hopt.exp_avg[a:b].clone(), hopt.exp_avg_sq[a:b].clone()
+        fn = fused_train_iteration if fused else train_iteration
+        fn(hm, hopt, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), {k: v.to(dev) for k, v in batch.items()},
+           step, jitter=[j.to(dev) for j in jit])
+        torch.cuda.synchronize()
+        moved_hip.append(not torch.equal(before, hm.arena().params[a:b]))
+        if not moved_hip[-1]:
+            assert torch.equal(m_before, hopt.exp_avg[a:b]) and torch.equal(v_before, hopt.exp_avg_sq[a:b])
+        assert float(hm.arena().grads.abs().max()) == 0.0       # zero_grad fused into the step, skipped span included
+    print("[optimizer skip] proposal networks moved on steps 9..12: oracle", moved_ref, "hip", moved_hip)
+    # nerfstudio's rule: updated iff steps_since_update > update_sched(step) or step < 10, evaluated with the step
+    # number the AFTER_TRAIN_ITERATION callback stored -> iterations 9 and 10 still update, 11 does not, 12 does
+    assert moved_ref == [True, True, False, True] and moved_hip == moved_ref
+    ref_steps = {int(opts["proposal_networks"].state[p]["step"]) for p in groups["proposal_networks"]}
+    assert ref_steps == {3} and hopt.group_steps["proposal_networks"] == 9 + 3
+    assert hopt.group_steps["fields"] == 9 + 4 and hopt.step_count == 9 + 4
+
+
 @pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
 def test_fused_step_matches_the_autograd_step(dev, shape):
     """fused_forward_backward() (no autograd engine, what bench.py times) must leave the same losses, metrics and
