@@ -104,14 +104,20 @@ def host_linspace(start: float, end: float, steps: int, device) -> Tensor:
 
 
 def sample_spaced(rays: RaysArg, spacing_kind: int, S: int, t_rand: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """t_rand: None (bin edges = linspace), [R] / [R,1] (one jitter per ray) or [R, S+1] (one per bin edge)."""
     lib = L.load()
     dev = rays.device
     base = host_linspace(0.0, 1.0, S + 1, dev)
     spacing = torch.empty(rays.n, S + 1, device=dev)
     euclid = torch.empty(rays.n, S + 1, device=dev)
     tr = None if t_rand is None else _f32c(t_rand.reshape(-1))
-    L.check(lib.fnr_sample_spaced(rays.ref, spacing_kind, S, L.ptr(base), L.ptr(tr), L.ptr(spacing), L.ptr(euclid),
-                                  L.stream_ptr(dev)), "sample_spaced")
+    per_bin = 0
+    if tr is not None and tr.numel() != rays.n:
+        if tr.numel() != rays.n * (S + 1):
+            raise ValueError(f"t_rand has {tr.numel()} entries; expected {rays.n} (per ray) or {rays.n * (S + 1)} (per bin)")
+        per_bin = 1
+    L.check(lib.fnr_sample_spaced(rays.ref, spacing_kind, S, L.ptr(base), L.ptr(tr), per_bin, L.ptr(spacing),
+                                  L.ptr(euclid), L.stream_ptr(dev)), "sample_spaced")
     return spacing, euclid
 
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfruitnerf_hip.so")
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 3      # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 4      # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -77,7 +77,7 @@ SIGNATURES = {
     "fnr_profile_enable": (_i, [_i, C.c_uint64]),
     "fnr_profile_collect": (_i64, [P(C.c_int32), P(C.c_int64), P(C.c_float), _i64]),
     "fnr_sample_pixels": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "fnr_sample_spaced":(_i, [P(fnr_rays), _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_sample_spaced": (_i, [P(fnr_rays), _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "fnr_weights_pdf": (_i, [P(fnr_rays), _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_prop_density_fwd": (_i, [P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
     "fnr_hash_encode_fwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp, _vp]),

@@ -5,9 +5,11 @@ only when `self.training`.  Bins are produced by fnr_sample_spaced.
 
 Behavioural note (pinned by tests/test_reference_pins.py): the reference builds this sampler inside
 `FruitModel.setup_inference` AFTER `eval_setup()` has put the pipeline in eval mode (scripts/exporter.py:86-94), so the
-new module is still in training mode and the reference's export jitters every bin edge with `torch.rand`.  This
-implementation follows the model's mode (bin centres when evaluating): a deterministic lattice, which is what makes
-the exported point counts reproducible.  Per-bin jitter (single_jitter=False while training) is not built.
+new module is still in training mode and the reference's export jitters every bin edge with `torch.rand`
+(single_jitter=False -> t_rand [R, S+1]).  FruitModel.setup_inference here puts the sampler in the MODEL's mode (bin
+centres when evaluating): a deterministic lattice, which is what makes exported point counts reproducible.  The
+as-run behaviour is one call away — `model.proposal_sampler.train()` — and is reproduced exactly when the same jitter
+is supplied (`jitter_fn`; tests/test_gpu_reference_pins.py::test_hip_export_matches_the_reference_export_as_run).
 """
 from __future__ import annotations
 
@@ -26,6 +28,10 @@ class UniformSamplerWithNoise(nn.Module):
         self.num_samples = num_samples
         self.train_stratified = train_stratified
         self.single_jitter = single_jitter
+        # source of the stratified jitter: callable(shape) -> tensor (any device); default torch.rand on the rays'
+        # device.  `lambda shape: torch.rand(shape)` draws from the CPU generator exactly as the reference's CPU path
+        # does (ray_samplers.py:80-83), which makes an export reproducible against it.
+        self.jitter_fn = None
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, num_samples: Optional[int] = None,
                              t_rand: Optional[torch.Tensor] = None) -> RaySamples:
@@ -37,11 +43,10 @@ class UniformSamplerWithNoise(nn.Module):
         rays = K.RaysArg(ray_bundle.origins, ray_bundle.directions, ray_bundle.nears, ray_bundle.fars,
                          ray_bundle.camera_indices)
         if self.train_stratified and self.training:
-            if not self.single_jitter:
-                raise NotImplementedError("per-bin jitter (single_jitter=False) in training mode is not built: the "
-                                          "export uses bin centres (see the module docstring)")
-            if t_rand is None:
-                t_rand = torch.rand(rays.n, device=rays.device)
+            if t_rand is None:   # ray_samplers.py:80-83
+                shape = (rays.n, 1) if self.single_jitter else (rays.n, num_samples + 1)
+                t_rand = (torch.rand(shape, device=rays.device) if self.jitter_fn is None
+                          else self.jitter_fn(shape).to(rays.device))
         else:
             t_rand = None
         spacing, euclid = K.sample_spaced(rays, 0, num_samples, t_rand)

@@ -23,7 +23,7 @@ __device__ __forceinline__ float spacing_to_euclid(int kind, float x, float s_ne
 
 __global__ __launch_bounds__(256) void k_sample_spaced(RaysDev rays, int kind, int S,
                                                        const float* __restrict__ base_bins,
-                                                       const float* __restrict__ t_rand,
+                                                       const float* __restrict__ t_rand, int t_rand_per_bin,
                                                        float* __restrict__ spacing, float* __restrict__ euclid) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = rays.n_rays * (long long)(S + 1);
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void k_sample_spaced(RaysDev rays, int kind, i
     // bin_centers / bin_upper / bin_lower of components/ray_samplers.py:84-87
     const float upper = (j < S) ? fdiv(fadd(base_bins[j + 1], base_bins[j]), 2.0f) : base_bins[S];
     const float lower = (j > 0) ? fdiv(fadd(base_bins[j], base_bins[j - 1]), 2.0f) : base_bins[0];
-    b = fadd(lower, fmul(fsub(upper, lower), t_rand[r]));
+    // single_jitter: one number per ray; otherwise one per bin edge, t_rand [R, S+1] (ray_samplers.py:79-83)
+    b = fadd(lower, fmul(fsub(upper, lower), t_rand[t_rand_per_bin ? idx : r]));
   }
   const float s_near = spacing_fn(kind, rays.nears[r]), s_far = spacing_fn(kind, rays.fars[r]);
   spacing[idx] = b;
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(256) void k_weights_pdf(RaysDev rays, int kind, int
 using namespace fnr;
 
 extern "C" int fnr_sample_spaced(const fnr_rays* rays, int spacing_kind, int S, const float* base_bins,
-                                 const float* t_rand, float* spacing_bins, float* euclid_bins, void* stream) {
+                                 const float* t_rand, int t_rand_per_bin, float* spacing_bins, float* euclid_bins,
+                                 void* stream) {
   FNR_CHECK_ARG(rays && base_bins && spacing_bins && euclid_bins && S > 0, "sample_spaced: null argument");
   FNR_CHECK_ARG(rays->nears && rays->fars, "sample_spaced: rays.nears/fars must be set (collider, fruit_nerf.py:382)");
   FNR_CHECK_ARG(spacing_kind == 0 || spacing_kind == 1, "sample_spaced: spacing_kind %d", spacing_kind);
@@ -183,7 +185,7 @@ extern "C" int fnr_sample_spaced(const fnr_rays* rays, int spacing_kind, int S, 
   if (total == 0) return FNR_OK;
   FNR_PROF(OP_SAMPLE_SPACED, total);
   hipLaunchKernelGGL(k_sample_spaced, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                     make_rays(rays), spacing_kind, S, base_bins, t_rand, spacing_bins, euclid_bins);
+                     make_rays(rays), spacing_kind, S, base_bins, t_rand, t_rand_per_bin, spacing_bins, euclid_bins);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

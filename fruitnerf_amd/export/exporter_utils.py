@@ -64,7 +64,11 @@ def sample_volume(pipeline, num_points: int, output_dir: Optional[Path] = None, 
     state = {"cap": 1 << 20}
     lattice = getattr(dm, "export_lattice", None)
     lat = None
-    if lattice is not None and lattice["n_samples"] == getattr(model, "num_inference_samples", None):
+    smp = getattr(model, "proposal_sampler", None)
+    jittered = bool(getattr(smp, "training", False) and getattr(smp, "train_stratified", False))
+    if lattice is not None and lattice["n_samples"] == getattr(model, "num_inference_samples", None) and not jittered:
+        # fused lattice path: sample positions are implicit (bin centres); a jittering sampler (the reference's as-run
+        # export, see components/ray_samplers.py) takes the generic path below
         lat = K.LatticeArg(lattice["xs"], lattice["ys"], lattice["zs"])
     batch = dm.orthographic_ray_generator.ray_batch_size
     n_batches = -(-num_points // batch)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 3
+#define FNR_ABI_VERSION 4
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -162,10 +162,13 @@ int fnr_camera_pose_grad(const fnr_image_set* set, const int64_t* train_ids, int
  * spacing_kind 0: identity (UniformSamplerWithNoise, export); 1: lin/disparity piecewise.
  * base_bins: [S+1] = torch.linspace(0, 1, S+1) evaluated on the HOST (ray_samplers.py:76), so the bins
  *            carry ATen's exact linspace rounding.
- * t_rand: [R] single-jitter random numbers (training) or NULL (eval: no jitter).
+ * t_rand: stratified jitter (training mode) or NULL (eval: the bins are base_bins).  t_rand_per_bin = 0: [R], one
+ *         number per ray (single_jitter=True: the proposal sampler's level 0); != 0: [R,S+1], one per bin edge
+ *         (single_jitter=False, components/ray_samplers.py:79-83 — what the reference's exporter runs, because
+ *         FruitModel.setup_inference builds its UniformSamplerWithNoise after eval_setup(), fruit_nerf.py:179-183).
  * Outputs: spacing bins [R,S+1] and euclidean bins [R,S+1]. */
 int fnr_sample_spaced(const fnr_rays* rays, int spacing_kind, int S, const float* base_bins, const float* t_rand,
-                      float* spacing_bins, float* euclid_bins, void* stream);
+                      int t_rand_per_bin, float* spacing_bins, float* euclid_bins, void* stream);
 
 /* RaySamples.get_weights on the previous level + PDFSampler (nerfstudio; driven from
  * ProposalNetworkSampler, fruit_nerf.py:151-158,318): weights of the S_prev samples, annealed

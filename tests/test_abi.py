@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/fruitnerf_hip.h but not exported"
         assert name in L.SIGNATURES, f"{name} has no ctypes signature in fruitnerf_amd/_lib.py"
     assert set(L.SIGNATURES) == set(declared)
-    assert lib.fnr_abi_version() == 3
+    assert lib.fnr_abi_version() == 4
 
 
 def test_struct_layouts_match_header_sizes():
@@ -41,7 +41,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     from fruitnerf_amd import _lib as L
     lib = L.load()
     rays = L.fnr_rays(0, None, None, None, None, None)
-    rc = lib.fnr_sample_spaced(C.byref(rays), 1, 16, None, None, None, None, None)
+    rc = lib.fnr_sample_spaced(C.byref(rays), 1, 16, None, None, 0, None, None, None)
     assert rc == -1 and b"null" in lib.fnr_last_error()
     rc = lib.fnr_composite_fwd(C.byref(rays), 0, None, None, None, None, 0, None, None, None, None, None, None, None)
     assert rc == -1
