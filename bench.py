@@ -213,6 +213,7 @@ def main() -> None:
     from fruitnerf_amd import _lib as L
     from fruitnerf_amd.data import synthetic_apple as sa
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     from fruitnerf_amd.rays import RayBundle
     from fruitnerf_amd.training import FusedAdam, fused_train_iteration as train_iteration
 
@@ -236,7 +237,7 @@ def main() -> None:
     RAYS_PER_BATCH = M["rays"]
     ALG = alg_table(M["mlp_flop"])
     model_cfg = FruitNerfModelConfig(**M["model"])
-    model = FruitModel(model_cfg, num_train_data=len(i_train), device=dev)
+    model = FruitModel(model_cfg, apple_metadata(), num_train_data=len(i_train), device=dev)
     model.train()
     opt = FusedAdam(model, algorithm=M["algorithm"], group_lr={k: dict(v) for k, v in M["groups"].items()})
     n_params = model.arena().numel
@@ -399,7 +400,7 @@ def main() -> None:
             torch.cuda.synchronize()
             eval_s = time.perf_counter() - t1
         # volume export (ns-export-semantics): N^3 lattice through the trained field, three thresholded point sets
-        emodel = FruitModel(copy.deepcopy(model.config), num_train_data=len(i_train), device=dev, test_mode="export")
+        emodel = FruitModel(copy.deepcopy(model.config), apple_metadata(), num_train_data=len(i_train), device=dev, test_mode="export")
         emodel.load_state_dict(model.state_dict(), strict=True)
         emodel.eval()
         N_EXP = args.export_n

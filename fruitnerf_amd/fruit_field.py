@@ -201,22 +201,74 @@ class FruitField(nn.Module):
             shape = (rays.n, S)
         else:
             rays, euclid, S, shape = self._flatten(ray_samples)
-        net = self.net_struct()
-        feats, selector = K.hash_encode_fwd(net.grid, self.warp_struct(), rays, euclid, S)
         mean_emb = self._mean_embedding() if self._uses_mean_embedding() else None
         if mean_emb is None and rays.cam is None:
             raise AttributeError("Camera indices are not provided.")  # fruit_field.py:240-241
-        density, rgb, logit, geo = K.field_mlp_fwd(net, rays, S, feats, selector, mean_emb, want_geo=want_geo)
+        self._last_ray_samples = ray_samples
+        if torch.is_grad_enabled() and self.training and mean_emb is None:
+            # differentiable field query (autograd.Function over the same kernels; gradients land in the arena)
+            from .training import field_with_grad
+            density, rgb, logit, geo = field_with_grad(self, rays, euclid, S, want_geo)
+        else:
+            with torch.no_grad():
+                net = self.net_struct()
+                feats, selector = K.hash_encode_fwd(net.grid, self.warp_struct(), rays, euclid, S)
+                density, rgb, logit, geo = K.field_mlp_fwd(net, rays, S, feats, selector, mean_emb, want_geo=want_geo)
         return density.view(*shape, 1), rgb.view(*shape, 3), logit.view(*shape, 1), \
             (None if geo is None else geo.view(*shape, self.geo_feat_dim))
 
-    @torch.no_grad()
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
-        """fruit_field.py:168-193 -> (density [...,1], base_mlp_out [...,geo])."""
+        """fruit_field.py:168-193 -> (density [...,1], base_mlp_out [...,geo]).
+
+        The HIP field evaluates density, semantics and colour in ONE fused pass; the rgb / semantics of that pass are
+        kept for the get_outputs call that follows (the reference's forward(), fruit_field.py:283-301).  In training
+        mode with autograd enabled the pass is differentiable with respect to the field's parameters (density, rgb
+        and semantics carry one shared autograd node); `base_mlp_out` is returned detached — the kernels route the
+        colour branch's gradient into the base MLP internally, exactly as autograd would through the reference's graph."""
         density, rgb, logit, geo = self._evaluate(ray_samples, want_geo=True)
         self._last = (ray_samples, rgb, logit)
         self._last_geo = geo
         return density, geo
+
+    # ---- side-effect attributes of the reference's get_density (fruit_field.py:180-186) -----------------------------
+    # Nerfstudio reads them for normals (Field.get_normals); FruitNeRF's hot path never does, so they are produced on
+    # demand from the last ray samples instead of costing a launch + 16 B/sample in every field query.
+    @property
+    def _sample_locations(self) -> Tensor:
+        """The masked unit-cube positions of the last get_density call, requires_grad=True (fruit_field.py:169-182)."""
+        rs = getattr(self, "_last_ray_samples", None)
+        if rs is None:
+            raise AttributeError("_sample_locations is set by get_density / forward")
+        with torch.no_grad():
+            positions = rs.frustums.get_positions().float()
+            if self.spatial_distortion is not None:      # SceneContraction(order=inf), then (x + 2) / 4
+                mag = positions.abs().amax(dim=-1, keepdim=True)
+                positions = torch.where(mag < 1, positions, (2 - 1 / mag) * (positions / mag))
+                positions = (positions + 2.0) / 4.0
+            else:                                        # SceneBox.get_normalized_positions
+                positions = (positions - self.aabb[0]) / (self.aabb[1] - self.aabb[0])
+            selector = ((positions > 0.0) & (positions < 1.0)).all(dim=-1)
+            positions = positions * selector[..., None]
+        return positions.requires_grad_(True)
+
+    @property
+    def _density_before_activation(self) -> Tensor:
+        """Raw density output of mlp_base for the last get_density call [..., 1] (fruit_field.py:185-186): the first
+        column of the base MLP's output h, re-evaluated on demand."""
+        rs = getattr(self, "_last_ray_samples", None)
+        if rs is None:
+            raise AttributeError("_density_before_activation is set by get_density / forward")
+        with torch.no_grad():
+            if getattr(rs, "_structured", None) is not None:
+                rays, euclid, S = rs._structured
+                shape = (rays.n, S)
+            else:
+                rays, euclid, S, shape = self._flatten(rs)
+            net = self.net_struct()
+            feats, selector = K.hash_encode_fwd(net.grid, self.warp_struct(), rays, euclid, S)
+            emb = self._mean_embedding() if (self._uses_mean_embedding() or rays.cam is None) else None
+            h = K.field_mlp_fwd(net, rays, S, feats, selector, emb, want_h=True)[4][0]
+        return h[:, 0].reshape(*shape, 1)
 
     def _outputs_from_last(self, ray_samples, density_embedding):
         if density_embedding is None or density_embedding is not self._last_geo:
@@ -234,9 +286,8 @@ class FruitField(nn.Module):
                               render_rgb: bool = False):
         return self._outputs_from_last(ray_samples, density_embedding)
 
-    @torch.no_grad()
     def forward(self, ray_samples: RaySamples) -> Dict[FieldHeadNames, Tensor]:
-        """fruit_field.py:283-301.  (Differentiable training runs through FruitModel's fused render
-        function; this entry point is the no-grad field query.)"""
+        """fruit_field.py:283-301.  Differentiable w.r.t. the field's parameters in training mode (see get_density);
+        FruitModel's own training step uses the fused render function, which also covers compositing."""
         density, rgb, logit, _ = self._evaluate(ray_samples, want_geo=False)
         return {FieldHeadNames.SEMANTICS: logit, FieldHeadNames.RGB: rgb, FieldHeadNames.DENSITY: density}

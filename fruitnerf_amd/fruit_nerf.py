@@ -195,12 +195,17 @@ def _ssim(a: Tensor, b: Tensor, sigma: float = 1.5, ksize: int = 11, k1: float =
 class FruitModel(nn.Module):
     config: FruitNerfModelConfig
 
-    def __init__(self, config: FruitNerfModelConfig, metadata: Optional[Dict] = None, scene_box=None,
+    def __init__(self, config: FruitNerfModelConfig, metadata: Dict, scene_box=None,
                  num_train_data: int = 1, device: Union[str, torch.device] = "cuda", grad_scaler=None,
                  test_mode: Optional[str] = None, render_rgb_inference: bool = True, **kwargs) -> None:
+        """fruit_nerf.py:71-76 + nerfstudio Model.__init__; called by FruitPipeline with exactly
+        (config, scene_box=, num_train_data=, metadata=, device=, grad_scaler=, test_mode=, render_rgb_inference=)
+        (fruit_pipeline.py:104-112).  `metadata["semantics"]` is required, as in the reference (a nerfstudio
+        `Semantics`; only `.colors` is read, so the check is duck-typed — a host passes nerfstudio's class)."""
         super().__init__()
-        # fruit_nerf.py:71-76
-        self.semantics = None if metadata is None else metadata.get("semantics")
+        assert "semantics" in metadata.keys() and hasattr(metadata["semantics"], "colors"), \
+            'FruitModel needs metadata["semantics"] (nerfstudio Semantics: filenames, classes, colors, mask_classes)'
+        self.semantics = metadata["semantics"]
         self.test_mode = test_mode
         self.config = config
         self.num_train_data = num_train_data
@@ -211,8 +216,7 @@ class FruitModel(nn.Module):
             aabb = scene_box.aabb if hasattr(scene_box, "aabb") else torch.as_tensor(scene_box)
         self.scene_aabb = aabb.float()
         self._device = torch.device(device)
-        colors = getattr(self.semantics, "colors", None)
-        self.colormap = (colors.clone().detach() if colors is not None else torch.tensor([0.0, 1.0]))
+        self.colormap = torch.as_tensor(self.semantics.colors).clone().detach()   # fruit_nerf.py:76
         self._arena: Optional[ParamArena] = None
         self.populate_modules()
         if self._device.type == "cuda":
@@ -305,12 +309,17 @@ class FruitModel(nn.Module):
 
         self.proposal_sampler.set_anneal(bias(train_frac, self.config.proposal_weights_anneal_slope))
 
-    def get_training_callbacks(self, training_callback_attributes=None) -> List[Tuple[str, Callable]]:
-        """fruit_nerf.py:191-223 as (location, fn(step)) pairs (nerfstudio's TrainingCallback is not importable)."""
+    def get_training_callbacks(self, training_callback_attributes=None) -> List["TrainingCallback"]:
+        """fruit_nerf.py:191-223: the anneal callback before and the sampler's step callback after every training
+        iteration, as TrainingCallback objects (the host's class inside Nerfstudio, engine/callbacks.py otherwise) — a
+        Trainer drives them through `run_callback_at_location(step, location)`."""
+        from .engine.callbacks import TrainingCallback, TrainingCallbackLocation
         callbacks = []
         if self.config.use_proposal_weight_anneal:
-            callbacks.append(("BEFORE_TRAIN_ITERATION", self.set_anneal))
-            callbacks.append(("AFTER_TRAIN_ITERATION", self.proposal_sampler.step_cb))
+            callbacks.append(TrainingCallback(where_to_run=[TrainingCallbackLocation.BEFORE_TRAIN_ITERATION],
+                                              update_every_num_iters=1, func=self.set_anneal))
+            callbacks.append(TrainingCallback(where_to_run=[TrainingCallbackLocation.AFTER_TRAIN_ITERATION],
+                                              update_every_num_iters=1, func=self.proposal_sampler.step_cb))
         return callbacks
 
     def _collide(self, ray_bundle: RayBundle) -> RayBundle:  # NearFarCollider, fruit_nerf.py:161,382-383

@@ -93,6 +93,46 @@ class _RenderFn(torch.autograd.Function):
         return None, d_o, d_d, None, None, None
 
 
+class _FieldFn(torch.autograd.Function):
+    """FruitField.forward / get_density as one autograd node: (density, rgb, logit[, geo]) per sample; backward =
+    field-MLP backward (MFMA) + hash-grid scatter, gradients accumulate into the field's arena (`param.grad`)."""
+
+    @staticmethod
+    def forward(ctx, anchor, field, rays, euclid, S, want_geo):
+        net = field.net_struct()
+        feats, selector = K.hash_encode_fwd(net.grid, field.warp_struct(), rays, euclid, S)
+        density, rgb, logit, geo, saved = K.field_mlp_fwd(net, rays, S, feats, selector, None, want_geo=want_geo,
+                                                          want_h=True)
+        ctx.field, ctx.rays, ctx.euclid, ctx.S = field, rays, euclid, S
+        ctx.saved = (feats, selector, saved)
+        if geo is None:
+            geo = density.new_empty(0)
+        ctx.mark_non_differentiable(geo)
+        return density, rgb, logit, geo
+
+    @staticmethod
+    def backward(ctx, g_density, g_rgb, g_logit, _):
+        field, rays, S = ctx.field, ctx.rays, ctx.S
+        feats, selector, saved = ctx.saved
+        field._arena.reattach_grads()
+        N = rays.n * S
+        dev = rays.device
+        z = lambda g, *shape: (torch.zeros(*shape, device=dev) if g is None else g.reshape(*shape).float().contiguous())  # noqa: E731
+        net, gnet = field.net_struct(), field.net_struct(grads=True)
+        d_feats = K.field_mlp_bwd(net, gnet, rays, S, feats, saved, selector, z(g_density, N), z(g_rgb, N, 3),
+                                  z(g_logit, N))
+        K.hash_encode_bwd(gnet.grid, field.warp_struct(), rays, ctx.euclid, S, d_feats)
+        return None, None, None, None, None, None
+
+
+def field_with_grad(field, rays, euclid, S: int, want_geo: bool):
+    anchor = getattr(field, "_grad_anchor", None)
+    if anchor is None or anchor.device != rays.device:
+        anchor = field._grad_anchor = torch.zeros(1, device=rays.device, requires_grad=True)
+    density, rgb, logit, geo = _FieldFn.apply(anchor, field, rays, euclid, S, want_geo)
+    return density, rgb, logit, (geo if want_geo else None)
+
+
 class _InterlevelFn(torch.autograd.Function):
     """interlevel_loss(weights_list, ray_samples_list) (fruit_nerf.py:368-370); backward trains the
     proposal networks (only when this step 'updated' them)."""

@@ -23,13 +23,14 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fruitnerf_amd.data import synthetic_apple as sa
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     from fruitnerf_amd.params import ParamArena
     from fruitnerf_amd.training import start_gradient_sync, sync_gradients
     from tests import util
     cfg = FruitNerfModelConfig(log2_hashmap_size=6)
     cfg.proposal_net_args_list = util.small_config(prop_log2=5).proposal_net_args_list
     torch.manual_seed(0)  # same seed on every rank == DDP's rank-0 broadcast
-    m = FruitModel(cfg, num_train_data=4, device="cpu")
+    m = FruitModel(cfg, apple_metadata(), num_train_data=4, device="cpu")
     arena = ParamArena([("proposal_networks", list(m.proposal_networks.parameters())),
                         ("fields", list(m.field.parameters()))], "cpu")
     # identical parameters everywhere

@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 
 def _full_model(dev, seed=0, num_images=16):
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     torch.manual_seed(seed)
-    m = FruitModel(FruitNerfModelConfig(), num_train_data=num_images, device=dev)
+    m = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=num_images, device=dev)
     g = torch.Generator(device=dev).manual_seed(seed + 1)
     with torch.no_grad():  # 'trained-like': O(1) features, non-trivial densities
         m.field.mlp_base_grid.hash_table.copy_(

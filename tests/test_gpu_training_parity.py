@@ -180,6 +180,106 @@ def test_three_training_steps_track_the_oracle(dev):
         assert d_abs.max().item() <= 3 * 3 * 1e-2 + 1e-6, name  # nothing moves further than steps * lr apart
 
 
+@pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
+def test_field_api_is_differentiable(dev, shape):
+    """FruitField.forward / get_density -> get_outputs in training mode carry autograd history w.r.t. the field's
+    parameters (fruit_field.py:168-301 is an ordinary differentiable nn.Module in the reference): a loss on the
+    per-sample density, rgb and semantics back-propagates into every field parameter like the oracle's autograd."""
+    from fruitnerf_amd.fruit_field import FieldHeadNames
+    from fruitnerf_amd.rays import RayBundle
+    cfg = (util.small_config if shape == "fruit_nerf" else util.big_config)(log2=14)
+    om = util.make_oracle(cfg, seed=41)
+    hm = util.make_hip_like(om, dev)
+    om.train()
+    hm.train()
+    R, S = 64, 24
+    o, d, pa, cam = util.random_rays(R, 7, seed=5)
+    euclid = torch.sort(torch.rand(R, S + 1) * 1.6 + 0.2, dim=-1).values
+    g = torch.Generator().manual_seed(3)
+    wd, wr, ws = torch.rand(R, S, 1, generator=g) * 1e-3, torch.randn(R, S, 3, generator=g), torch.randn(R, S, 1, generator=g)
+    rs = ns.RayBundle(o, d, pa, camera_indices=cam).get_ray_samples(euclid[:, :-1, None], euclid[:, 1:, None])
+    ref = om.field(rs)
+    ((ref["density"] * wd).sum() + (ref["rgb"] * wr).sum() + (ref["semantics"] * ws).sum()).backward()
+    hb = RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev))
+    hs = hb.get_ray_samples(euclid[:, :-1, None].to(dev), euclid[:, 1:, None].to(dev))
+    for two_calls in (False, True):
+        hm.arena().grads.zero_()
+        if two_calls:                                           # the Field base class's own forward()
+            dens, emb = hm.field.get_density(hs)
+            out = hm.field.get_outputs(hs, density_embedding=emb)
+            rgb, sem = out[FieldHeadNames.RGB], out[FieldHeadNames.SEMANTICS]
+            assert not emb.requires_grad
+        else:
+            out = hm.field(hs)
+            dens, rgb, sem = out[FieldHeadNames.DENSITY], out[FieldHeadNames.RGB], out[FieldHeadNames.SEMANTICS]
+        assert dens.requires_grad and rgb.requires_grad and sem.requires_grad
+        ((dens * wd.to(dev)).sum() + (rgb * wr.to(dev)).sum() + (sem * ws.to(dev)).sum()).backward()
+        torch.cuda.synchronize()
+        named_h = dict(hm.field.named_parameters())
+        for name, p in om.field.named_parameters():
+            g_ref = p.grad if p.grad is not None else torch.zeros_like(p)
+            diff = (named_h[name].grad.cpu() - g_ref).abs()
+            scale = g_ref.abs().max().item()
+            l1 = diff.double().sum().item() / max(g_ref.abs().double().sum().item(), 1e-30)
+            print(f"[field api two_calls={two_calls}] {name}: max|ref| {scale:.3e} max_err {diff.max().item():.3e} L1-rel {l1:.3e}")
+            assert diff.max().item() <= 2e-2 * scale + 1e-12 and l1 <= 2e-3, name    # ReLU kinks: see the big-shape note above
+    # the side-effect attributes of get_density (fruit_field.py:180-186)
+    loc, dba = hm.field._sample_locations, hm.field._density_before_activation
+    assert loc.shape == (R, S, 3) and loc.requires_grad and dba.shape == (R, S, 1)
+    with torch.no_grad():
+        om.field.get_density(rs)
+    assert (loc.detach().cpu() - om.field._sample_locations.detach()).abs().max().item() <= 1e-6
+    assert (dba.cpu() - om.field._density_before_activation.detach()).abs().max().item() <= 1e-4
+    # eval mode: the same API without autograd history
+    hm.eval()
+    assert not hm.field(hs)[FieldHeadNames.RGB].requires_grad
+
+
+def test_trainer_shaped_loop_over_the_plugin_api(dev):
+    """Nerfstudio's Trainer.train_iteration, spelled out over the plugin surface only (callbacks by location, forward,
+    get_metrics_dict, get_loss_dict, reduce(add), backward, optimiser) — must leave the model exactly where
+    fused_train_iteration() (what bench.py times) leaves its twin."""
+    import functools
+    from fruitnerf_amd.engine.callbacks import TrainingCallbackAttributes, TrainingCallbackLocation as Loc
+    from fruitnerf_amd.rays import RayBundle
+    from fruitnerf_amd.training import FusedAdam, fused_train_iteration, skipped_groups
+    cfg = util.small_config(log2=13, prop_log2=11)
+    om = util.make_oracle(cfg, seed=23)
+    a, b = util.make_hip_like(om, dev), util.make_hip_like(om, dev)
+    a.train()
+    b.train()
+    opt_a, opt_b = FusedAdam(a), FusedAdam(b)
+    callbacks = a.get_training_callbacks(TrainingCallbackAttributes(optimizers=None, grad_scaler=None, pipeline=None))
+    R = 128
+    for step in range(12):                                       # crosses the end of the every-step update phase
+        o, d, pa, cam = util.random_rays(R, 7, seed=500 + step)
+        batch = {k: v.to(dev) for k, v in _batch(R, 90 + step).items()}
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=Loc.BEFORE_TRAIN_ITERATION)
+        torch.manual_seed(1000 + step)                           # the model draws its jitter from the device generator
+        outputs = a(RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)))
+        metrics_dict = a.get_metrics_dict(outputs, batch)
+        loss_dict = a.get_loss_dict(outputs, batch, metrics_dict)
+        functools.reduce(torch.add, loss_dict.values()).backward()
+        opt_a.step(skip=skipped_groups(a))
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=Loc.AFTER_TRAIN_ITERATION)
+        torch.manual_seed(1000 + step)
+        ld_b, md_b = fused_train_iteration(b, opt_b, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), batch, step)
+        for k in loss_dict:
+            # same kernels on both sides; only the order of a few float atomics differs, and Adam (eps 1e-15) turns
+            # rounding-level gradient noise into +-lr steps, so the twins agree to ~1e-3, not to fp32 rounding
+            tol = 5e-2 if k == "interlevel_loss" else 2e-3
+            assert abs(float(loss_dict[k]) - float(ld_b[k])) <= tol * max(abs(float(ld_b[k])), 1e-6), (step, k)
+    torch.cuda.synchronize()
+    pa_, pb_ = a.arena().params, b.arena().params
+    moved = (pb_ - util.make_hip_like(om, dev).arena().params).abs()
+    assert (pa_ - pb_).abs().median().item() <= 0.05 * moved.mean().item() + 1e-7
+    assert (pa_ - pb_).abs().max().item() <= 3 * 12 * 1e-2
+    assert a.proposal_sampler._step == b.proposal_sampler._step == 11
+    assert opt_a.group_steps == opt_b.group_steps
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_optimizer_skips_the_proposal_networks_on_steps_that_do_not_update_them(dev, fused):
     """Steps 9..12 cross the end of the every-step phase (ProposalNetworkSampler: step < 10).  On iteration 11 the
@@ -314,8 +414,9 @@ def test_ray_gradient_paths_agree(dev):
     of the hash grid's input gradient give the same ray gradients."""
     from fruitnerf_amd import _kernels as K
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     torch.manual_seed(0)
-    m = FruitModel(FruitNerfModelConfig(log2_hashmap_size=15), num_train_data=4, device=dev)
+    m = FruitModel(FruitNerfModelConfig(log2_hashmap_size=15), apple_metadata(), num_train_data=4, device=dev)
     with torch.no_grad():
         m.field.mlp_base_grid.hash_table.uniform_(-0.5, 0.5)
     m.train()
@@ -470,6 +571,7 @@ def test_step_at_a_trained_state_matches_the_oracle(dev):
     the check that exposed the cancelling exclusive scan; the random-weight tests above cannot.)"""
     from fruitnerf_amd.data import synthetic_apple as sa
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     from fruitnerf_amd.rays import RayBundle
     from fruitnerf_amd.training import FusedAdam, fused_forward_backward, fused_train_iteration
     HW, focal, n_train = 96, 1111.0 * 96 / 800, 40
@@ -478,7 +580,7 @@ def test_step_at_a_trained_state_matches_the_oracle(dev):
     data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
     batcher = sa.PixelBatcher(data, torch.arange(n_train, device=dev), seed=1)
     torch.manual_seed(0)
-    hm = FruitModel(FruitNerfModelConfig(), num_train_data=n_train, device=dev)
+    hm = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=n_train, device=dev)
     hm.train()
     opt = FusedAdam(hm)
     steps = 2500
@@ -552,6 +654,7 @@ def test_export_at_a_trained_state_matches_the_oracle(dev):
     from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
     from fruitnerf_amd.export.exporter_utils import sample_volume
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     from fruitnerf_amd.rays import RayBundle
     from fruitnerf_amd.training import FusedAdam, fused_train_iteration
     HW, focal, n_train = 96, 1111.0 * 96 / 800, 40
@@ -560,14 +663,14 @@ def test_export_at_a_trained_state_matches_the_oracle(dev):
     data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
     batcher = sa.PixelBatcher(data, torch.arange(n_train, device=dev), seed=1)
     torch.manual_seed(0)
-    hm = FruitModel(FruitNerfModelConfig(), num_train_data=n_train, device=dev)
+    hm = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=n_train, device=dev)
     hm.train()
     opt = FusedAdam(hm)
     for step in range(2000):
         o, d, cam, batch = batcher.sample(4096)
         fused_train_iteration(hm, opt, RayBundle(o, d, None, cam), batch, step, want_metrics=False)
     N = 64
-    em = FruitModel(copy.deepcopy(hm.config), num_train_data=n_train, device=dev, test_mode="export")
+    em = FruitModel(copy.deepcopy(hm.config), apple_metadata(), num_train_data=n_train, device=dev, test_mode="export")
     em.load_state_dict(hm.state_dict(), strict=True)
     em.eval()
 

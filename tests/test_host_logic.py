@@ -10,13 +10,14 @@ from tests import util
 
 def _models(cfg=None):
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     cfg = cfg or util.small_config(log2=8, prop_log2=6)
     om = util.make_oracle(cfg, num_images=5, seed=0, randomize=False)
     hc = FruitNerfModelConfig()
     for k, v in vars(cfg).items():
         if hasattr(hc, k):
             setattr(hc, k, v)
-    hm = FruitModel(hc, num_train_data=5, device="cpu")
+    hm = FruitModel(hc, apple_metadata(), num_train_data=5, device="cpu")
     return om, hm
 
 
@@ -35,7 +36,8 @@ def test_state_dict_keys_and_shapes_match_the_torch_layout():
 
 def test_full_config_parameter_count():
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
-    hm = FruitModel(FruitNerfModelConfig(), num_train_data=90, device="cpu")
+    from fruitnerf_amd.data.semantics import apple_metadata
+    hm = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device="cpu")
     n = sum(p.numel() for p in hm.parameters())
     assert n == 16 * 2 ** 19 * 2 + 2 * (5 * 2 ** 17 * 2 + 16 * 10 + 16 + 16 + 1) + (64 * 32 + 64 + 16 * 64 + 16) \
         + (64 * 15 + 64 + 64 * 64 + 64 + 64 + 1) + (64 * 63 + 64 + 64 * 64 + 64 + 3 * 64 + 3) + 90 * 32
@@ -48,9 +50,10 @@ def test_full_config_parameter_count():
 def test_ignored_config_fields_do_not_reach_the_field():
     """hidden_dim / hidden_dim_color / appearance_embed_dim of fruit_nerf_big are silently ignored."""
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     cfg = FruitNerfModelConfig(log2_hashmap_size=6, hidden_dim=128, hidden_dim_color=128, appearance_embed_dim=128)
     cfg.proposal_net_args_list = util.small_config(prop_log2=5).proposal_net_args_list
-    hm = FruitModel(cfg, num_train_data=3, device="cpu")
+    hm = FruitModel(cfg, apple_metadata(), num_train_data=3, device="cpu")
     assert hm.field.mlp_base_mlp.layers[0].weight.shape == (64, 32)
     assert hm.field.mlp_head.layers[0].weight.shape == (64, 16 + 15 + 32)
     assert hm.field.embedding_appearance.embedding.weight.shape == (3, 32)
@@ -141,13 +144,14 @@ def test_exponential_decay_schedule():
 
 def test_unsupported_configurations_fail_loudly():
     from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.data.semantics import apple_metadata
     with pytest.raises(NotImplementedError):
-        FruitModel(FruitNerfModelConfig(log2_hashmap_size=4, proposal_initial_sampler="uniform"), num_train_data=1,
+        FruitModel(FruitNerfModelConfig(log2_hashmap_size=4, proposal_initial_sampler="uniform"), apple_metadata(), num_train_data=1,
                    device="cpu")
     with pytest.raises(NotImplementedError):
-        FruitModel(FruitNerfModelConfig(log2_hashmap_size=4, pass_semantic_gradients=True), num_train_data=1,
+        FruitModel(FruitNerfModelConfig(log2_hashmap_size=4, pass_semantic_gradients=True), apple_metadata(), num_train_data=1,
                    device="cpu")
-    hm = FruitModel(FruitNerfModelConfig(log2_hashmap_size=4), num_train_data=1, device="cpu")
+    hm = FruitModel(FruitNerfModelConfig(log2_hashmap_size=4), apple_metadata(), num_train_data=1, device="cpu")
     with pytest.raises(RuntimeError, match="no CPU path"):
         hm.arena()
 
@@ -193,6 +197,7 @@ def test_ssim_restatement_basic_properties():
     """SSIM used by get_image_metrics_and_images: 1 for identical images, symmetric, lower for noisier images."""
     import torch
     from fruitnerf_amd.fruit_nerf import _ssim
+    from fruitnerf_amd.data.semantics import apple_metadata
     g = torch.Generator().manual_seed(0)
     a = torch.rand(1, 3, 48, 40, generator=g)
     assert abs(float(_ssim(a, a)) - 1.0) < 1e-6
@@ -224,3 +229,48 @@ def test_product_package_never_imports_the_oracle_or_the_tests():
                     if m.split(".")[0] in ("oracle", "tests"):
                         offenders.append(f"{os.path.relpath(path, root)}:{node.lineno} imports {m}")
     assert not offenders, offenders
+
+
+def test_model_is_constructed_and_driven_the_way_fruit_pipeline_and_the_trainer_do():
+    """FruitPipeline builds the model with exactly these keyword arguments (fruit_pipeline.py:104-112); Nerfstudio's
+    Trainer then asks for the training callbacks and runs them by location around every iteration
+    (fruit_nerf.py:191-223).  No GPU needed: construction, parameter groups and the callback protocol are host logic."""
+    from fruitnerf_amd.data.semantics import Semantics
+    from fruitnerf_amd.engine.callbacks import TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+
+    class SceneBox:                      # nerfstudio.data.scene_box.SceneBox: the model reads .aabb
+        aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+
+    cfg = FruitNerfModelConfig(log2_hashmap_size=6)
+    cfg.proposal_net_args_list = [dict(a, log2_hashmap_size=5) for a in cfg.proposal_net_args_list]
+    metadata = {"semantics": Semantics(filenames=[], classes=["apple", "stuff"], colors=torch.tensor([0.0, 1.0]),
+                                       mask_classes=["apple", "stuff"])}
+    model = cfg.setup(scene_box=SceneBox(), num_train_data=7, metadata=metadata, device="cpu", grad_scaler=None,
+                      test_mode="val", render_rgb_inference=True)
+    assert isinstance(model, FruitModel) and model.test_mode == "val" and model.field.num_images == 7
+    assert set(model.get_param_groups()) == {"proposal_networks", "fields"}       # optimiser keys, fruit_nerf_config.py:47-56
+    with pytest.raises(AssertionError):                                           # fruit_nerf.py:72
+        FruitModel(cfg, {}, num_train_data=1, device="cpu")
+    with pytest.raises(TypeError):                                                # metadata is a required argument
+        FruitModel(cfg, num_train_data=1, device="cpu")                           # noqa
+
+    callbacks = model.get_training_callbacks(TrainingCallbackAttributes(optimizers=None, grad_scaler=None, pipeline=None))
+    assert len(callbacks) == 2 and all(isinstance(c, TrainingCallback) for c in callbacks)
+    assert callbacks[0].where_to_run == [TrainingCallbackLocation.BEFORE_TRAIN_ITERATION]
+    assert callbacks[1].where_to_run == [TrainingCallbackLocation.AFTER_TRAIN_ITERATION]
+    assert all(c.update_every_num_iters == 1 for c in callbacks)
+    N, slope = cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope
+    smp = model.proposal_sampler
+    for step in (0, 1, 250, 999, 1000, 5000):                                     # Trainer.train_iteration's skeleton
+        for c in callbacks:
+            c.run_callback_at_location(step, location=TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        frac = min(max(step / N, 0), 1)
+        assert smp._anneal == pytest.approx(slope * frac / ((slope - 1) * frac + 1))   # fruit_nerf.py:199-207
+        before = smp._steps_since_update
+        for c in callbacks:
+            c.run_callback_at_location(step, location=TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+        assert smp._step == step and smp._steps_since_update == before + 1        # ProposalNetworkSampler.step_cb
+    cfg2 = FruitNerfModelConfig(log2_hashmap_size=6, use_proposal_weight_anneal=False)
+    cfg2.proposal_net_args_list = cfg.proposal_net_args_list
+    assert FruitModel(cfg2, metadata, num_train_data=1, device="cpu").get_training_callbacks(None) == []

@@ -7,6 +7,7 @@ import torch.distributed as dist
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.rays import RayBundle
 from fruitnerf_amd.training import FusedAdam, fused_train_iteration
 from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
@@ -20,7 +21,7 @@ scene = sa.make_scene(seed=0, device=dev); c2w = sa.make_cameras(n_train, seed=0
 data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
 batcher = sa.PixelBatcher(data, torch.arange(n_train, device=dev), seed=100 + rank)
 torch.manual_seed(0)
-model = FruitModel(FruitNerfModelConfig(), num_train_data=n_train, device=dev); model.train()
+model = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=n_train, device=dev); model.train()
 opt = FusedAdam(model)
 co = CameraOptimizerConfig(mode="SO3xR3").setup(n_train, dev); camera = (co, CameraAdam(co), batcher)
 for step in range(12):

@@ -2,9 +2,10 @@ import sys, torch
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd import _lib as L, _kernels as K
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 dev = torch.device('cuda:0')
 for log2 in (19, 16, 12):
-    m = FruitModel(FruitNerfModelConfig(log2_hashmap_size=log2), num_train_data=10, device=dev); m.train(); m.arena()
+    m = FruitModel(FruitNerfModelConfig(log2_hashmap_size=log2), apple_metadata(), num_train_data=10, device=dev); m.train(); m.arena()
     fld = m.field
     R, S = 4096, 48
     o = torch.randn(R, 3, device=dev) * 0.3; d = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)

@@ -2,12 +2,13 @@
 import cProfile, io, pstats, sys, time, torch
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
 from fruitnerf_amd.export.exporter_utils import sample_volume
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 N = 256
-m = FruitModel(FruitNerfModelConfig(), num_train_data=90, device=dev, test_mode="export"); m.eval()
+m = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev, test_mode="export"); m.eval()
 class P: pass
 pipe = P(); pipe.model = m; pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=32768)
 m.setup_inference(True, N)

@@ -4,13 +4,14 @@ import collections, gc, sys, time, torch
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd import _lib as L
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
 from fruitnerf_amd.export.exporter_utils import sample_volume
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-m = FruitModel(FruitNerfModelConfig(), num_train_data=90, device=dev, test_mode="export"); m.eval()
+m = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev, test_mode="export"); m.eval()
 class P: pass
 pipe = P(); pipe.model = m; pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=32768)
 m.setup_inference(True, N)

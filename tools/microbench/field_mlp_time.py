@@ -2,8 +2,9 @@ import sys, torch
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd import _lib as L, _kernels as K
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 dev = torch.device('cuda:0')
-m = FruitModel(FruitNerfModelConfig(), num_train_data=10, device=dev); m.train(); m.arena()
+m = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=10, device=dev); m.train(); m.arena()
 fld = m.field
 import os
 for R in [int(x) for x in os.environ.get("RS", "16,512,4096").split(",")]:

@@ -3,6 +3,7 @@ sys.path.insert(0, '/root/repo')
 from tests import util
 from tests.test_golden import _load, _inputs
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.rays import RayBundle
 from fruitnerf_amd.training import fused_forward_backward
 import fruitnerf_amd.training as T
@@ -16,7 +17,7 @@ for k, v in vars(oc).items():
 o, d, pa, cam, jit, batch = _inputs(g, dev)
 ref_o, ref_d = torch.from_numpy(g["grad::origins"]), torch.from_numpy(g["grad::directions"])
 def run(tag, mult=None, no_jac=False):
-    hm = FruitModel(cfg, num_train_data=5, device=dev); hm.load_state_dict(sd, strict=True); hm.train(); hm.set_anneal(0)
+    hm = FruitModel(cfg, apple_metadata(), num_train_data=5, device=dev); hm.load_state_dict(sd, strict=True); hm.train(); hm.set_anneal(0)
     if mult is not None: hm.config.interlevel_loss_mult = mult
     if no_jac:
         orig = T._field_ray_grads
@@ -54,7 +55,7 @@ xw.retain_grad()
 ld = om.get_loss_dict(tr, {k: v.cpu() for k, v in batch.items()})
 (ld["rgb_loss"] + ld["semantics_loss"]).backward()
 gx_ref = xw.grad            # [R, S, 3]
-hm = FruitModel(cfg, num_train_data=5, device=dev); hm.load_state_dict(sd, strict=True); hm.train(); hm.set_anneal(0)
+hm = FruitModel(cfg, apple_metadata(), num_train_data=5, device=dev); hm.load_state_dict(sd, strict=True); hm.train(); hm.set_anneal(0)
 hm.config.interlevel_loss_mult = 0.0
 captured = {}
 orig = T._field_ray_grads
@@ -80,7 +81,7 @@ def f2(model, rctx, d_feats, a, b):
     captured["d_feats"] = d_feats.clone()
     return orig(model, rctx, d_feats, a, b)
 T._field_ray_grads = f2
-hm2 = FruitModel(cfg, num_train_data=5, device=dev); hm2.load_state_dict(sd, strict=True); hm2.train(); hm2.set_anneal(0)
+hm2 = FruitModel(cfg, apple_metadata(), num_train_data=5, device=dev); hm2.load_state_dict(sd, strict=True); hm2.train(); hm2.set_anneal(0)
 hm2.config.interlevel_loss_mult = 0.0
 fused_forward_backward(hm2, RayBundle(o, d, pa, cam), batch, jitter=jit, ray_grads={})
 torch.cuda.synchronize()

@@ -4,6 +4,7 @@ sys.path.insert(0, '/root/repo')
 import numpy as np
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.rays import RayBundle
 from fruitnerf_amd.training import FusedAdam, fused_train_iteration
 from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
@@ -15,7 +16,7 @@ data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=1111.0 * HW / 800, fy=1111.0
 ids = torch.arange(90, device=dev)
 batcher = sa.PixelBatcher(data, ids, seed=1)
 torch.manual_seed(0)
-model = FruitModel(FruitNerfModelConfig(), num_train_data=90, device=dev); model.train()
+model = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev); model.train()
 opt = FusedAdam(model)
 for cam_mode in ("off", "SO3xR3"):
     camera = None

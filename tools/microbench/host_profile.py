@@ -3,6 +3,7 @@ import cProfile, pstats, sys, torch
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.rays import RayBundle
 from fruitnerf_amd.training import FusedAdam, fused_train_iteration
 from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
@@ -12,7 +13,7 @@ scene = sa.make_scene(seed=0, device=dev); c2w = sa.make_cameras(100, seed=0, de
 data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=1111.0 * HW / 800, fy=1111.0 * HW / 800)
 batcher = sa.PixelBatcher(data, torch.arange(90, device=dev), seed=1)
 torch.manual_seed(0)
-model = FruitModel(FruitNerfModelConfig(), num_train_data=90, device=dev); model.train()
+model = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev); model.train()
 opt = FusedAdam(model)
 co = CameraOptimizerConfig(mode="SO3xR3").setup(90, dev); camera = (co, CameraAdam(co), batcher)
 step = [0]

@@ -4,6 +4,7 @@ sys.path.insert(0, '/root/repo')
 import numpy as np
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.rays import RayBundle
 from fruitnerf_amd.training import FusedAdam, fused_train_iteration
 from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
@@ -14,7 +15,7 @@ scene = sa.make_scene(seed=0, device=dev); c2w = sa.make_cameras(100, seed=0, de
 data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
 batcher = sa.PixelBatcher(data, torch.arange(90, device=dev), seed=1)
 torch.manual_seed(0)
-model = FruitModel(FruitNerfModelConfig(), num_train_data=90, device=dev); model.train()
+model = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev); model.train()
 opt = FusedAdam(model)
 CAM = len(sys.argv) > 2 and sys.argv[2] == "camera"
 co = CameraOptimizerConfig(mode="SO3xR3").setup(90, dev) if CAM else None

@@ -3,6 +3,7 @@ import sys, torch, collections
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.rays import RayBundle
 from fruitnerf_amd.training import FusedAdam, fused_forward_backward
 dev = torch.device('cuda:0')
@@ -11,7 +12,7 @@ scene = sa.make_scene(seed=0, device=dev); c2w = sa.make_cameras(100, seed=0, de
 data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
 batcher = sa.PixelBatcher(data, torch.arange(90, device=dev), seed=1)
 torch.manual_seed(0)
-model = FruitModel(FruitNerfModelConfig(), num_train_data=90, device=dev); model.train()
+model = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev); model.train()
 opt = FusedAdam(model); arena = model.arena()
 groups = {}
 for gname, p, off, n in arena.entries:

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import fruitnerf_amd.training as T
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.rays import RayBundle
 from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
 
@@ -26,7 +27,7 @@ def run(min_world):
     T.EXCHANGE_MIN_WORLD = min_world
     batcher = sa.PixelBatcher(data, torch.arange(n_train, device=dev), seed=100)
     torch.manual_seed(0)
-    model = FruitModel(FruitNerfModelConfig(), num_train_data=n_train, device=dev); model.train()
+    model = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=n_train, device=dev); model.train()
     opt = T.FusedAdam(model)
     co = CameraOptimizerConfig(mode="SO3xR3").setup(n_train, dev); camera = (co, CameraAdam(co), batcher)
     snap = None

@@ -3,6 +3,7 @@ import sys, torch, copy
 sys.path.insert(0, '/root/repo')
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.rays import RayBundle
 from fruitnerf_amd.training import FusedAdam, fused_train_iteration
 from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
@@ -14,13 +15,13 @@ scene = sa.make_scene(seed=0, device=dev); c2w = sa.make_cameras(n_train, seed=0
 data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
 batcher = sa.PixelBatcher(data, torch.arange(n_train, device=dev), seed=1)
 torch.manual_seed(0)
-hm = FruitModel(FruitNerfModelConfig(), num_train_data=n_train, device=dev); hm.train()
+hm = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=n_train, device=dev); hm.train()
 opt = FusedAdam(hm)
 for step in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3000):
     o, d, cam, batch = batcher.sample(4096)
     fused_train_iteration(hm, opt, RayBundle(o, d, None, cam), batch, step, want_metrics=False)
 N = 96
-em = FruitModel(copy.deepcopy(hm.config), num_train_data=n_train, device=dev, test_mode="export")
+em = FruitModel(copy.deepcopy(hm.config), apple_metadata(), num_train_data=n_train, device=dev, test_mode="export")
 em.load_state_dict(hm.state_dict(), strict=True); em.eval()
 class P: pass
 pipe = P(); pipe.model = em; pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=4096)
