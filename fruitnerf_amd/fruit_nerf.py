@@ -60,6 +60,7 @@ class FruitNerfModelConfig:
     disable_scene_contraction: bool = False
     use_gradient_scaling: bool = False
     eval_num_rays_per_chunk: int = 1 << 15
+    eval_outputs_on_cpu: bool = False   # True: full-image eval returns CPU tensors like the reference (fruit_nerf.py:245)
     # FruitNerfModelConfig proper
     semantic_loss_weight: float = 1.0
     pass_semantic_gradients: bool = False
@@ -498,7 +499,11 @@ class FruitModel(nn.Module):
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle, rank: int = 0,
                                           world_size: int = 1) -> Dict[str, Tensor]:
-        """fruit_nerf.py:225-249: chunked full-image evaluation, outputs moved to the CPU per chunk.
+        """fruit_nerf.py:225-249: chunked full-image evaluation.  The reference moves every chunk to the CPU
+        (`output.cpu()`, :245 — one blocking D2H per output and chunk); here the chunks stay on the device, are
+        concatenated there and the image is returned on the device (get_image_metrics_and_images moves its inputs to
+        the device anyway).  `config.eval_outputs_on_cpu = True` restores the reference's CPU tensors with ONE copy
+        per output after the last chunk.
 
         world_size > 1 (SURVEY §8e): each rank renders a contiguous block of whole image rows with the same chunking;
         the blocks are all-gathered in rank order, so every rank returns the full image the single process returns."""
@@ -513,8 +518,9 @@ class FruitModel(nn.Module):
                 for output_name, output in outputs.items():
                     if not torch.is_tensor(output):
                         continue
-                    outputs_lists[output_name].append(output.cpu())
-            return {k: torch.cat(v).view(image_height, image_width, -1) for k, v in outputs_lists.items()}
+                    outputs_lists[output_name].append(output)
+            full = {k: torch.cat(v).view(image_height, image_width, -1) for k, v in outputs_lists.items()}
+            return {k: v.cpu() for k, v in full.items()} if self.config.eval_outputs_on_cpu else full
         from .sharding import all_gather_rows, shard_range
         lo, hi = shard_range(num_rays, rank, world_size, granule=image_width)
         for i in range(lo, hi, num_rays_per_chunk):
@@ -526,7 +532,8 @@ class FruitModel(nn.Module):
         if not outputs_lists:   # a rank without rows (more ranks than image rows) still joins the collectives: the
             outputs_lists = self._eval_output_templates(camera_ray_bundle)   # key set is fixed by the model
         full = {k: all_gather_rows(torch.cat(v), world_size) for k, v in sorted(outputs_lists.items())}
-        return {k: v.cpu().view(image_height, image_width, -1) for k, v in full.items()}
+        full = {k: v.view(image_height, image_width, -1) for k, v in full.items()}
+        return {k: v.cpu() for k, v in full.items()} if self.config.eval_outputs_on_cpu else full
 
     def _eval_output_templates(self, camera_ray_bundle: RayBundle) -> Dict[str, list]:
         """Zero-row tensors with the keys / dtypes / trailing shapes of an eval forward (from a one-ray pass)."""
