@@ -520,7 +520,7 @@ class FruitModel(nn.Module):
                         continue
                     outputs_lists[output_name].append(output)
             full = {k: torch.cat(v).view(image_height, image_width, -1) for k, v in outputs_lists.items()}
-            return {k: v.cpu() for k, v in full.items()} if self.config.eval_outputs_on_cpu else full
+            return {k: v.cpu() for k, v in full.items()} if getattr(self.config, "eval_outputs_on_cpu", False) else full
         from .sharding import all_gather_rows, shard_range
         lo, hi = shard_range(num_rays, rank, world_size, granule=image_width)
         for i in range(lo, hi, num_rays_per_chunk):
@@ -533,7 +533,7 @@ class FruitModel(nn.Module):
             outputs_lists = self._eval_output_templates(camera_ray_bundle)   # key set is fixed by the model
         full = {k: all_gather_rows(torch.cat(v), world_size) for k, v in sorted(outputs_lists.items())}
         full = {k: v.view(image_height, image_width, -1) for k, v in full.items()}
-        return {k: v.cpu() for k, v in full.items()} if self.config.eval_outputs_on_cpu else full
+        return {k: v.cpu() for k, v in full.items()} if getattr(self.config, "eval_outputs_on_cpu", False) else full
 
     def _eval_output_templates(self, camera_ray_bundle: RayBundle) -> Dict[str, list]:
         """Zero-row tensors with the keys / dtypes / trailing shapes of an eval forward (from a one-ray pass)."""
