@@ -139,7 +139,7 @@ def test_adam_leaves_untouched_parameters_alone_and_is_idempotent_on_zero_grad(d
 
 
 def test_full_image_eval_and_image_metrics(dev):
-    """get_outputs_for_camera_ray_bundle (chunked, CPU outputs [H,W,.]) + get_image_metrics_and_images
+    """get_outputs_for_camera_ray_bundle (chunked, outputs [H,W,.] on the device; CPU with eval_outputs_on_cpu) + get_image_metrics_and_images
     (fruit_nerf.py:225-249, 403-458) on a small image."""
     from fruitnerf_amd.rays import RayBundle
     m = _full_model(dev)
@@ -149,16 +149,20 @@ def test_full_image_eval_and_image_metrics(dev):
     rb = _rays(H * W, dev, seed=12)
     cam_rb = RayBundle(rb.origins.view(H, W, 3), rb.directions.view(H, W, 3), None, None)
     out = m.get_outputs_for_camera_ray_bundle(cam_rb)
-    assert out["rgb"].shape == (H, W, 3) and out["rgb"].device.type == "cpu"
+    assert out["rgb"].shape == (H, W, 3) and out["rgb"].device.type == "cuda"
     whole = m(RayBundle(rb.origins, rb.directions, None, None))
-    assert torch.equal(out["rgb"].view(-1, 3), whole["rgb"].cpu())
+    assert torch.equal(out["rgb"].view(-1, 3), whole["rgb"])
+    m.config.eval_outputs_on_cpu = True     # the reference's behaviour (fruit_nerf.py:245)
+    out_cpu = m.get_outputs_for_camera_ray_bundle(cam_rb)
+    assert out_cpu["rgb"].device.type == "cpu" and torch.equal(out_cpu["rgb"], out["rgb"].cpu())
+    m.config.eval_outputs_on_cpu = False
     g = torch.Generator().manual_seed(0)
     batch = {"image": torch.rand(H, W, 3, generator=g), "fruit_mask": (torch.rand(H, W, 1, generator=g) > 0.7).float()}
     metrics, images = m.get_image_metrics_and_images(out, batch)
     assert set(metrics) == {"psnr", "ssim", "lpips", "iou", "iou_sigmoid"}
     assert 0 < metrics["psnr"] < 60 and -1 <= metrics["ssim"] <= 1
     # the reference's quirk (fruit_nerf.py:451): F.softmax without dim on [H,W,1] runs over image rows (implicit dim 0)
-    sem, tgt = out["semantics"], batch["fruit_mask"][..., 0] > 0.5
+    sem, tgt = out["semantics"].cpu(), batch["fruit_mask"][..., 0] > 0.5
     pred = torch.softmax(sem, dim=0)[..., 0] > 0.5
     want = float((pred & tgt).sum()) / max(float((pred | tgt).sum()), 1.0)
     assert abs(metrics["iou"] - want) < 1e-6
