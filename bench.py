@@ -36,6 +36,8 @@ N_CAMERAS = 100
 TRAIN_SPLIT = 0.9              # fruitnerf_dataparser.py:62
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA (the roofline of --mlp-precision bf16 / bf16x3)
+MFMA_PEAK_TF = MFMA_F32_PEAK_TF  # set in main() from --mlp-precision
 
 # The two method configurations of the reference that this bench can run (fruit_nerf_config.py:27-110).  Only the model
 # fields that reach the hot path are listed (fruit_nerf.py:88-103: hidden_dim / hidden_dim_color / appearance_embed_dim of
@@ -93,7 +95,7 @@ def roofline_entry(op, units, avg_ms, launches, alg):
         peak, unit, key = HBM_PEAK_GBS, "GB/s", "alg_bytes_per_unit"
     else:
         achieved = per_unit * units / (avg_ms * 1e-3) / 1e12
-        peak, unit, key = MFMA_F32_PEAK_TF, "TFLOP/s", "alg_flop_per_unit"
+        peak, unit, key = MFMA_PEAK_TF, "TFLOP/s", "alg_flop_per_unit"
     return {"kernel": op, "family": FAMILIES.get(op, op), "bound": bound, "achieved": round(achieved, 3), "peak": peak,
             "unit": unit, "frac": round(achieved / peak, 4),
             # HBM bytes of this entry point are NOT measured inside this process (PMC counters need rocprofv3): see
@@ -180,6 +182,10 @@ def main() -> None:
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays per CPU-baseline step (0 = the method's batch size "
                     "for fruit_nerf, 1024 for fruit_nerf_big)")
     ap.add_argument("--export-n", type=int, default=256, help="lattice side of the volume-export secondary metric")
+    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="arithmetic of the field-MLP GEMMs (include/fruitnerf_hip.h FNR_MLP_*): fp32 = exact fp32 MFMA "
+                         "chains (default, the parity path); bf16x3 = exact 3-way bf16 split on the bf16 matrix pipe "
+                         "(fp32-grade, parity-tested); bf16 = plain bf16 operands (BASELINE config 2; not parity grade)")
     ap.add_argument("--camera-optimizer", default="SO3xR3", choices=["off", "SO3xR3"],
                     help="the method's datamanager default (fruit_nerf_config.py:39-43): pose corrections learned from "
                          "the ray gradients; 'off' skips the input gradient of the hash grids")
@@ -236,7 +242,9 @@ def main() -> None:
     M = METHODS[args.method]
     RAYS_PER_BATCH = M["rays"]
     ALG = alg_table(M["mlp_flop"])
-    model_cfg = FruitNerfModelConfig(**M["model"])
+    global MFMA_PEAK_TF
+    MFMA_PEAK_TF = MFMA_F32_PEAK_TF if args.mlp_precision == "fp32" else MFMA_BF16_PEAK_TF
+    model_cfg = FruitNerfModelConfig(mlp_precision=args.mlp_precision, **M["model"])
     model = FruitModel(model_cfg, apple_metadata(), num_train_data=len(i_train), device=dev)
     model.train()
     opt = FusedAdam(model, algorithm=M["algorithm"], group_lr={k: dict(v) for k, v in M["groups"].items()})
@@ -533,7 +541,9 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        # arithmetic type of the MLP GEMMs; hash grids, samplers, compositing, losses and the optimiser are fp32 in
+        # every mode.  bf16x3 = three bf16 pieces per fp32 operand (fp32-grade results), bf16 = bf16 operands.
+        "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3 split on the bf16 MFMA pipe)", "bf16": "bf16"}[args.mlp_precision],
         "data": "synthetic",
         "config": {"workload": f"{args.method} synthetic apple {HW}x{HW}, {N_CAMERAS} cameras ({len(i_train)} train), "
                                f"{RAYS_PER_BATCH} rays/rank/step, samples {'/'.join(map(str, M['samples']))}, "
@@ -541,7 +551,7 @@ def main() -> None:
                                f"semantic MLP {model_cfg.num_layers_semantic}x{model_cfg.hidden_dim_semantics}, "
                                f"fwd+bwd+{M['algorithm']} over {n_params / 1e6:.1f} M parameters, proposal-net update "
                                f"schedule from step 0, camera optimizer {args.camera_optimizer}",
-                   "method": args.method, "rays_per_rank": RAYS_PER_BATCH, "parallelism": f"dp{world}",
+                   "method": args.method, "mlp_precision": args.mlp_precision, "rays_per_rank": RAYS_PER_BATCH, "parallelism": f"dp{world}",
                    "device": info["arch"], "setup_s": round(setup_s, 1)},
         "roofline": roofline,
         "roofline_other_bound": roofline_other,

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfruitnerf_hip.so")
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 4      # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 5      # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -49,7 +49,8 @@ class fnr_field_net(C.Structure):
                 ("base_w0", C.c_void_p), ("base_b0", C.c_void_p), ("base_w1", C.c_void_p), ("base_b1", C.c_void_p),
                 ("sem_w", C.c_void_p * FNR_MAX_SEM_LAYERS), ("sem_b", C.c_void_p * FNR_MAX_SEM_LAYERS),
                 ("head_w", C.c_void_p), ("head_b", C.c_void_p),
-                ("col_w", C.c_void_p * 3), ("col_b", C.c_void_p * 3), ("embedding", C.c_void_p)]
+                ("col_w", C.c_void_p * 3), ("col_b", C.c_void_p * 3), ("embedding", C.c_void_p),
+                ("mlp_mode", C.c_int32)]
 
 
 class fnr_lattice(C.Structure):

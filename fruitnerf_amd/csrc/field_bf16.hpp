@@ -1,0 +1,246 @@
+// field_bf16.hpp — FruitField's MLP stack (fruit_field.py:132-166) on the gfx950 bf16 matrix pipe
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate), as ONE kernel family with a compile-time split count NS:
+//
+//   NS = 1  "bf16":    operands rounded to bf16 (8 significant bits) — the mode BASELINE config 2 names; NOT parity
+//                      grade (outputs ~1e-2 relative), judged at matched PSNR / IoU.
+//   NS = 3  "bf16x3":  every fp32 operand x is split EXACTLY into three bf16 pieces x = x1 + x2 + x3 (x1 = bf16(x),
+//                      x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); 3 x 8 significant bits cover the 24 of fp32) and the
+//                      product is formed from the six piece products whose weight is above fp32 rounding,
+//                          w x  ~=  w1 x1 + (w1 x2 + w2 x1) + (w1 x3 + w2 x2 + w3 x1)        (dropped terms <= 2^-27 |w x|),
+//                      each exact in the fp32 accumulator.  fp32-grade results (~1e-6, against the 1e-4 bar) at 6 bf16
+//                      MFMAs per fp32-equivalent K-block: the fp32 MFMA runs at 1/16 of the bf16 rate on gfx950
+//                      (MI355X_MICROARCH: 157 vs 2500 TFLOP/s), so this is 16/6 = 2.7x the fp32-MFMA roofline.
+//   NS = 2             three products (w1 x1 + w1 x2 + w2 x1, error 2^-17): used by the bf16x3 mode for the BACKWARD
+//                      pass, whose bar is 5e-4 of max |g|.
+//
+// Formulation (per pair of 16-sample tiles, one wave), transposed like the fp32 path (field_layers.hpp):
+//     Y^T[out][sample] = W[out][in] X^T[in][sample],     A = W fragment (LDS), B = X^T fragment (registers)
+//   A[i][k]: lane l supplies i = l&15 and the 8 K-slots (g = l>>4, e = 0..7);  B[k][j]: same slots, j = l&15;
+//   D[row][col]: lane l holds col = l&15, rows 4 g + r.
+// A K-block covers two 16-wide input blocks; slot (g, e) is input block 2 kb + (e >> 2), element 4 g + (e & 3) of it:
+// exactly the 8 accumulator values lane (g, j) holds for those two blocks, so the accumulator of layer n becomes the
+// B operand of layer n+1 with a conversion and no data movement.  (The hardware's own k numbering inside a lane
+// group is irrelevant: A and B agree on the slot -> k map and the sum over k is order-free.)
+// Both tiles of the pair share every A fragment: one ds_read_b128 feeds 2 NS(NS+1)/2 MFMAs.
+#pragma once
+#include "field_layers.hpp"
+
+namespace fnr {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x8 = __attribute__((ext_vector_type(8))) float;
+
+enum { MLP_FP32 = 0, MLP_BF16 = 1, MLP_BF16X3 = 3 };
+
+// ---- fragment image: [piece][block][64 lanes] x bf16x8 ----------------------------------------------------------
+// forward blocks of layer l: (ob, kb) -> W[16 ob + i][col(2 kb + (e>>2), g, e&3)]
+// transposed blocks of layer l (dX^T = W^T dY^T): (ib, kbT) -> W[16 (2 kbT + (e>>2)) + 4 g + (e&3)][col(ib, i>>2, i&3)]
+template <class Cfg>
+struct BfImage {
+  static constexpr int NL = Cfg::NLAYERS;
+  // mlp_head layer 0 only multiplies the h blocks per sample (per-ray factoring, field_layers.hpp: color_layer0)
+  static constexpr int nib_used(int l) { return l == Cfg::L_COL0 ? Cfg::HB : Cfg::nib(l); }
+  static constexpr int nkb(int l) { return (nib_used(l) + 1) / 2; }
+  static constexpr int nkbT(int l) { return (Cfg::nob(l) + 1) / 2; }
+  static constexpr bool hasT(int l) { return l != Cfg::L_SEM0; }  // mlp_semantics' input is detached: no dX
+  static constexpr int fblocks(int l) { return Cfg::nob(l) * nkb(l); }
+  static constexpr int tblocks(int l) { return hasT(l) ? nib_used(l) * nkbT(l) : 0; }
+  static constexpr int foff(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += fblocks(i);
+    return o;
+  }
+  static constexpr int F_TOTAL = foff(NL);
+  static constexpr int toff(int l) {
+    int o = F_TOTAL;
+    for (int i = 0; i < l; ++i) o += tblocks(i);
+    return o;
+  }
+  static constexpr int BLOCKS = toff(NL);
+  static constexpr size_t piece_elems() { return (size_t)BLOCKS * 64 * 8; }
+  static constexpr size_t bytes(int ns) { return (size_t)ns * piece_elems() * 2; }
+};
+constexpr int BF_MAX_PIECES = 3;
+
+// piece p of the exact bf16 split of w (p < 3)
+__device__ __forceinline__ __bf16 bf_piece(float w, int p) {
+  const __bf16 a = (__bf16)w;
+  if (p == 0) return a;
+  const float r1 = w - (float)a;
+  const __bf16 b = (__bf16)r1;
+  if (p == 1) return b;
+  return (__bf16)(r1 - (float)b);
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_pack_field_weights_bf16(FieldPtrs p, int ns, __bf16* __restrict__ image) {
+  using Img = BfImage<Cfg>;
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (block, lane)
+  if (idx >= Img::BLOCKS * 64) return;
+  const int blk = idx >> 6, lane = idx & 63;
+  const int i = lane & 15, g = lane >> 4;
+  float w[8];
+  if (blk < Img::F_TOTAL) {
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < Cfg::NLAYERS; ++q)
+      if (blk >= Img::foff(q)) l = q;
+    const int local = blk - Img::foff(l);
+    const int nkb = Img::nkb(l), kb = local % nkb, ob = local / nkb;
+    const int out = 16 * ob + i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ib = 2 * kb + (e >> 2);
+      const int col = (ib < Img::nib_used(l)) ? kmap<Cfg>(Cfg::km(l), ib, g, e & 3, Cfg::in_dim(l)) : -1;
+      w[e] = (out < Cfg::out_dim(l) && col >= 0) ? p.w[l][out * Cfg::in_dim(l) + col] : 0.0f;
+    }
+  } else {
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < Cfg::NLAYERS; ++q)
+      if (blk >= Img::toff(q)) l = q;
+    const int local = blk - Img::toff(l);
+    const int nk = Img::nkbT(l), kb = local % nk, ib = local / nk;
+    const int col = kmap<Cfg>(Cfg::km(l), ib, i >> 2, i & 3, Cfg::in_dim(l));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ob = 2 * kb + (e >> 2);
+      const int out = 16 * ob + 4 * g + (e & 3);
+      w[e] = (ob < Cfg::nob(l) && out < Cfg::out_dim(l) && col >= 0) ? p.w[l][out * Cfg::in_dim(l) + col] : 0.0f;
+    }
+  }
+  for (int pc = 0; pc < ns; ++pc) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf_piece(w[e], pc);
+    reinterpret_cast<bf16x8*>(image)[(size_t)pc * Img::BLOCKS * 64 + idx] = v;
+  }
+}
+
+template <class Cfg>
+static inline void launch_pack_field_weights_bf16(const FieldPtrs& p, int ns, __bf16* image, hipStream_t st) {
+  using Img = BfImage<Cfg>;
+  hipLaunchKernelGGL((k_pack_field_weights_bf16<Cfg>), dim3((Img::BLOCKS * 64 + 255) / 256), dim3(256), 0, st, p, ns, image);
+}
+
+// ---- what a kernel keeps in LDS: an ordered list of (layer, forward | transposed) segments, NS pieces each -------
+// Segs: struct with  static constexpr int N;  static constexpr int layer(int i);  static constexpr bool isT(int i);
+template <class Cfg, class Segs, int NS>
+struct BfLds {
+  using Img = BfImage<Cfg>;
+  static constexpr int blocks(int s) { return Segs::isT(s) ? Img::tblocks(Segs::layer(s)) : Img::fblocks(Segs::layer(s)); }
+  static constexpr int off(int s) {  // in fragments of 64 x bf16x8 (1 KiB)
+    int o = 0;
+    for (int i = 0; i < s; ++i) o += blocks(i) * NS;
+    return o;
+  }
+  static constexpr int FRAGS = off(Segs::N);
+  static constexpr int BYTES = FRAGS * 1024;
+  static constexpr int find(int layer, bool isT) {
+    for (int i = 0; i < Segs::N; ++i)
+      if (Segs::layer(i) == layer && Segs::isT(i) == isT) return i;
+    return -1;
+  }
+  // first fragment (piece 0, block 0) of a segment; piece p starts blocks() fragments later
+  template <int LAYER, bool IS_T>
+  __device__ static __forceinline__ const bf16x8* seg(const bf16x8* lds) {
+    constexpr int s = find(LAYER, IS_T);
+    static_assert(s >= 0, "layer not staged by this kernel");
+    return lds + off(s) * 64;
+  }
+  template <int LAYER, bool IS_T>
+  static constexpr int seg_blocks() { return blocks(find(LAYER, IS_T)); }
+  __device__ static __forceinline__ void stage(bf16x8* __restrict__ lds, const __bf16* __restrict__ image) {
+    const bf16x8* img = reinterpret_cast<const bf16x8*>(image);
+#pragma unroll
+    for (int s = 0; s < Segs::N; ++s) {
+      const int nb = blocks(s) * 64;
+      const int src0 = (Segs::isT(s) ? Img::toff(Segs::layer(s)) : Img::foff(Segs::layer(s))) * 64;
+      for (int pc = 0; pc < NS; ++pc)
+        for (int i = threadIdx.x; i < nb; i += blockDim.x)
+          lds[off(s) * 64 + pc * nb + i] = img[(size_t)pc * Img::BLOCKS * 64 + src0 + i];
+    }
+  }
+};
+
+// ---- operands ---------------------------------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void bf_split(const f32x8 v, bf16x8 (&p)[NS]) {
+  p[0] = __builtin_convertvector(v, bf16x8);
+  if constexpr (NS > 1) {
+    const f32x8 r1 = v - __builtin_convertvector(p[0], f32x8);
+    p[1] = __builtin_convertvector(r1, bf16x8);
+    if constexpr (NS > 2) {
+      const f32x8 r2 = r1 - __builtin_convertvector(p[1], f32x8);
+      p[2] = __builtin_convertvector(r2, bf16x8);
+    }
+  }
+}
+
+// B operand pieces of an activation held as NB accumulator blocks (C layout): K-block kb = blocks 2 kb, 2 kb + 1
+template <int NS, int NB>
+__device__ __forceinline__ void bf_operand(const f32x4 (&act)[NB], bf16x8 (&x)[(NB + 1) / 2][NS]) {
+#pragma unroll
+  for (int kb = 0; kb < (NB + 1) / 2; ++kb) {
+    f32x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = act[2 * kb][e];
+      v[4 + e] = (2 * kb + 1 < NB) ? act[(2 * kb + 1 < NB) ? 2 * kb + 1 : 0][e] : 0.0f;
+    }
+    bf_split<NS>(v, x[kb]);
+  }
+}
+
+// out (NOB accumulator blocks, both tiles of the pair) += W * X.  `seg` = the layer's segment in LDS
+// ([piece][NOB * NKB blocks][64]); works for forward (W) and transposed (W^T) segments alike.
+template <int NS, int NOB, int NKB>
+__device__ __forceinline__ void bf_layer_acc(const bf16x8* __restrict__ seg, const bf16x8 (&xa)[NKB][NS],
+                                             const bf16x8 (&xb)[NKB][NS], f32x4 (&oa)[NOB], f32x4 (&ob_)[NOB], int lane) {
+  constexpr int PB = NOB * NKB * 64;  // fragments' stride between pieces
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+      bf16x8 w[NS];
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc) w[pc] = seg[pc * PB + (ob * NKB + kb) * 64 + lane];
+      // smallest terms first
+#pragma unroll
+      for (int s = NS - 1; s >= 0; --s)
+#pragma unroll
+        for (int pw = 0; pw <= s; ++pw) {
+          oa[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[pw], xa[kb][s - pw], oa[ob], 0, 0, 0);
+          ob_[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[pw], xb[kb][s - pw], ob_[ob], 0, 0, 0);
+        }
+    }
+  }
+}
+
+// one layer on the tile pair: out = W in + b (bias from the fp32 fragment image's bias block `B`)
+template <int NS, int NOB, int NIB>
+__device__ __forceinline__ void bf_layer(const bf16x8* __restrict__ seg, const float* __restrict__ B,
+                                         const f32x4 (&ina)[NIB], const f32x4 (&inb)[NIB], f32x4 (&oa)[NOB],
+                                         f32x4 (&ob_)[NOB], int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) oa[ob] = ob_[ob] = *reinterpret_cast<const f32x4*>(B + 16 * ob + 4 * g);
+  bf16x8 xa[(NIB + 1) / 2][NS], xb[(NIB + 1) / 2][NS];
+  bf_operand<NS, NIB>(ina, xa);
+  bf_operand<NS, NIB>(inb, xb);
+  bf_layer_acc<NS, NOB, (NIB + 1) / 2>(seg, xa, xb, oa, ob_, lane);
+}
+
+// out = W^T G (no bias): NIBO input blocks of the layer from its NOB output-gradient blocks
+template <int NS, int NIBO, int NOB>
+__device__ __forceinline__ void bf_layer_T(const bf16x8* __restrict__ segT, const f32x4 (&Ga)[NOB], const f32x4 (&Gb)[NOB],
+                                           f32x4 (&oa)[NIBO], f32x4 (&ob_)[NIBO], int lane) {
+#pragma unroll
+  for (int ib = 0; ib < NIBO; ++ib) oa[ib] = ob_[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 xa[(NOB + 1) / 2][NS], xb[(NOB + 1) / 2][NS];
+  bf_operand<NS, NOB>(Ga, xa);
+  bf_operand<NS, NOB>(Gb, xb);
+  bf_layer_acc<NS, NIBO, (NOB + 1) / 2>(segT, xa, xb, oa, ob_, lane);
+}
+
+}  // namespace fnr

@@ -41,6 +41,16 @@ int field_ptrs(const fnr_field_net* net, FieldPtrs& p, int* cfg_id) {
   return FNR_OK;
 }
 
+// bf16 / bf16x3 modes (field_mlp_bf16.hip)
+int field_mlp_fwd_bf16(int mode, const FieldPtrs& p, const float* packed, void* image_ws, const float* ray_bias,
+                       const RaysDev& rd, int S, long long N, const float2* feats, const uint8_t* selector, float* density,
+                       float* rgb, float* logit, float* geo_out, float* h_buf, hipStream_t st);
+size_t field_bf16_image_bytes();
+// workspace layout of fnr_field_mlp_fwd: [fp32 fragment image | bf16 fragment image (3 pieces) | per-ray colour bias]
+static inline size_t fwd_ws_packed_bytes() { return ((size_t)(FIELD_MAX_PACKED_FLOATS + 64) * sizeof(float) + 255) / 256 * 256; }
+size_t field_fwd_ws_image_offset() { return fwd_ws_packed_bytes(); }
+static inline size_t fwd_ws_fixed_bytes() { return fwd_ws_packed_bytes() + (field_bf16_image_bytes() + 255) / 256 * 256; }
+
 // ---- per-tile pieces shared by the forward and backward kernels ("R" = the LdsRange the kernel staged) ----------
 
 // B operand of base layer 0 from the level-major features: lane group g covers levels {g, 4+g, 8+g, 12+g}
@@ -174,8 +184,9 @@ __global__ void k_embedding_mean(const float* __restrict__ emb, int n, int dim, 
 using namespace fnr;
 
 extern "C" size_t fnr_field_mlp_fwd_workspace_bytes(int64_t n_rays) {
-  // fragment image of the weights (sized for the larger of the two built shapes) + per-ray colour bias [n_rays, 64]
-  return (FIELD_MAX_PACKED_FLOATS + 64) * sizeof(float) + 256 + (size_t)(n_rays > 0 ? n_rays : 0) * 64 * sizeof(float);
+  // fragment images of the weights (fp32, sized for the larger of the two built shapes; bf16 pieces for the
+  // FNR_MLP_BF16* modes) + per-ray colour bias [n_rays, 64]
+  return fwd_ws_fixed_bytes() + 256 + (size_t)(n_rays > 0 ? n_rays : 0) * 64 * sizeof(float);
 }
 
 extern "C" int fnr_field_h_dim(const fnr_field_net* net) {
@@ -197,6 +208,12 @@ int field_mlp_fwd_launch(const FieldPtrs& p, const fnr_field_net* net, const Ray
   FNR_LAUNCH_CHECK();
   const long long n_tiles = (N + 15) / 16;
   const float2* f2 = reinterpret_cast<const float2*>(feats);
+  if (net->mlp_mode != FNR_MLP_FP32) {
+    if constexpr (Cfg::NSEM == 2)
+      return field_mlp_fwd_bf16(net->mlp_mode, p, packed, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),
+                                ray_bias, rd, S, N, f2, selector, density, rgb, logit, geo_out, h_buf, st);
+    FNR_UNSUPPORTED(false, "field_mlp_fwd: mlp_mode %d is built for the `fruit_nerf` shape only", net->mlp_mode);
+  }
   if constexpr (Cfg::NSEM == 2) {
     long long blocks = (n_tiles + 7) / 8;
     const long long max_blocks = 2ll * device_cu_count();
@@ -239,8 +256,11 @@ extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays,
                 "field_mlp_fwd: workspace too small");
   FNR_CHECK_ARG(cfg == 0 || h_save, "field_mlp_fwd: the fruit_nerf_big shape runs as two launches that hand the base MLP's "
                 "output over in h_save [N, fnr_field_h_dim()] — pass that buffer");
+  FNR_CHECK_ARG(net->mlp_mode == FNR_MLP_FP32 || net->mlp_mode == FNR_MLP_BF16 || net->mlp_mode == FNR_MLP_BF16X3,
+                "field_mlp_fwd: mlp_mode %d (FNR_MLP_FP32 0 | FNR_MLP_BF16 1 | FNR_MLP_BF16X3 3)", net->mlp_mode);
   float* packed = reinterpret_cast<float*>(workspace);
-  float* ray_bias = ray_bias_save ? ray_bias_save : packed + (FIELD_MAX_PACKED_FLOATS + 63) / 64 * 64;
+  float* ray_bias = ray_bias_save ? ray_bias_save
+                                  : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + fwd_ws_fixed_bytes());
   const RaysDev rd = make_rays(rays);
   FNR_PROF(OP_MLP_FWD, N);
   if (cfg == 0)

@@ -774,6 +774,13 @@ __global__ __launch_bounds__(1024) void k_embedding_grad(RaysDev rays, const flo
 }
 
 int field_ptrs(const fnr_field_net* net, FieldPtrs& p, int* cfg_id);  // field_mlp.hip
+size_t field_fwd_ws_image_offset();                                     // field_mlp.hip
+size_t field_bf16_image_bytes();                                        // field_mlp_bf16.hip
+int field_mlp_bwd_bf16(int mode, int branch, const FieldPtrs& p, bool pack, const float* packed, void* image_ws,
+                       const float* ray_bias, const RaysDev& rd, int S, long long N, const float2* feats,
+                       const float* h_saved, const uint8_t* selector, const float* d_density, const float* d_rgb,
+                       const float* d_logit, float2* d_feats, float* d_h, float* gsum_tile, float* gsum_extra,
+                       float* partials, long long blocks, hipStream_t st);
 
 }  // namespace fnr
 
@@ -782,6 +789,7 @@ using namespace fnr;
 namespace {
 struct BwdWorkspace {
   float *partials, *d_h, *packed, *ray_bias, *gsum_tile, *g_ray, *gsum_extra;
+  void* bf16_image;
   size_t bytes;
 };
 // carve the workspace: per-workgroup partial weight-gradient images (<= one workgroup per CU), dL/dh [N, 16 HB], the
@@ -803,6 +811,7 @@ BwdWorkspace bwd_workspace(void* base, long long n_rays, int S) {
   w.gsum_tile = take((size_t)n_tiles * 64);
   w.g_ray = take((size_t)n_rays * 64);
   w.gsum_extra = take((size_t)n_rays * 64);
+  w.bf16_image = take((field_bf16_image_bytes() + 3) / 4);
   w.bytes = p - reinterpret_cast<uintptr_t>(base) + 256;
   return w;
 }
@@ -824,8 +833,11 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     const char* e = getenv("FNR_COLOR_WAVES");
     return (e && atoi(e) == 4) ? 4 : 8;
   }();
+  void* bf16_image = ws.bf16_image;
+  const bool bf16_pack = !packed_saved;
   if (packed_saved) {
     packed = const_cast<float*>(packed_saved);  // the forward pass's fragment image of the same weights
+    bf16_image = reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset();  // ... and its bf16 pieces
   } else {
     launch_pack_field_weights<Cfg>(p, packed, st);
     FNR_LAUNCH_CHECK();
@@ -841,7 +853,13 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
   long long blocks = (n_tiles + 3) / 4;
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid((unsigned)blocks);
-  if (color_waves == 4) {
+  const int mode = net->mlp_mode;
+  if (mode != FNR_MLP_FP32) {
+    FNR_UNSUPPORTED(Cfg::NSEM == 2, "field_mlp_bwd: mlp_mode %d is built for the `fruit_nerf` shape only", mode);
+    const int rc = field_mlp_bwd_bf16(mode, 0, p, bf16_pack, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
+                                      d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
+    if (rc) return rc;
+  } else if (color_waves == 4) {
     hipLaunchKernelGGL((k_field_mlp_bwd_color<Cfg, 4>), grid, dim3(256), 0, st, packed, ray_bias, rd, S, N, h_saved, d_rgb,
                        ws.d_h, ws.gsum_tile, gsum_extra, partials);
   } else {
@@ -860,7 +878,13 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                        grads->embedding);
     FNR_LAUNCH_CHECK();
   }
-  if constexpr (Cfg::NSEM == 2) {
+  if (mode != FNR_MLP_FP32) {
+    for (int branch = 1; branch <= 2; ++branch) {
+      const int rc = field_mlp_bwd_bf16(mode, branch, p, false, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
+                                        d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
+      if (rc) return rc;
+    }
+  } else if constexpr (Cfg::NSEM == 2) {
     hipLaunchKernelGGL((k_field_mlp_bwd_sem<Cfg, 8>), grid, dim3(512), 0, st, packed, N, h_saved, d_logit, partials);
     FNR_LAUNCH_CHECK();
   } else {
@@ -871,9 +895,11 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                        partials);
     FNR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL((k_field_mlp_bwd_base<Cfg, 8>), grid, dim3(512), 0, st, packed, N, f2, selector, d_density, ws.d_h,
-                     df2, partials);
-  FNR_LAUNCH_CHECK();
+  if (mode == FNR_MLP_FP32) {
+    hipLaunchKernelGGL((k_field_mlp_bwd_base<Cfg, 8>), grid, dim3(512), 0, st, packed, N, f2, selector, d_density, ws.d_h,
+                       df2, partials);
+    FNR_LAUNCH_CHECK();
+  }
   constexpr int TOT = Cfg::W_TOTAL + Cfg::B_TOTAL;
   hipLaunchKernelGGL((k_reduce_dw<Cfg>), dim3((TOT + 255) / 256, (unsigned)(blocks >= 64 ? 8 : 1)), dim3(256), 0, st,
                      partials, (int)blocks, gp);
@@ -902,6 +928,8 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
   rc = field_ptrs(grads, gp, &gcfg);
   if (rc) return rc;
   FNR_CHECK_ARG(cfg == gcfg, "field_mlp_bwd: net and grads describe different field shapes");
+  FNR_CHECK_ARG(net->mlp_mode == FNR_MLP_FP32 || net->mlp_mode == FNR_MLP_BF16 || net->mlp_mode == FNR_MLP_BF16X3,
+                "field_mlp_bwd: mlp_mode %d (FNR_MLP_FP32 0 | FNR_MLP_BF16 1 | FNR_MLP_BF16X3 3)", net->mlp_mode);
   const long long N = rays->n_rays * (long long)S;
   if (N == 0) return FNR_OK;
   FNR_CHECK_ARG(workspace_bytes >= fnr_field_mlp_bwd_workspace_bytes(rays->n_rays, S),

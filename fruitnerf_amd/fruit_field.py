@@ -9,6 +9,8 @@ from __future__ import annotations
 from enum import Enum
 from typing import Dict, Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor, nn
 
@@ -36,6 +38,11 @@ class SceneContraction(nn.Module):
         self.order = order
 
 
+# FNR_MLP_FP32: exact fp32 MFMA chains; FNR_MLP_BF16: bf16 operands (throughput mode, not parity grade);
+# FNR_MLP_BF16X3: exact three-way bf16 split, fp32-grade results on the bf16 matrix pipe (csrc/field_bf16.hpp)
+MLP_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+
+
 class FruitField(nn.Module):
     aabb: Tensor
 
@@ -46,8 +53,14 @@ class FruitField(nn.Module):
                  hidden_dim_transient: int = 64, appearance_embedding_dim: int = 32, use_semantics: bool = False,
                  test_mode: Optional[str] = None, num_semantic_classes: int = 100,
                  pass_semantic_gradients: bool = False, use_average_appearance_embedding: bool = False,
-                 spatial_distortion: Optional[nn.Module] = None, implementation: str = "hip") -> None:
+                 spatial_distortion: Optional[nn.Module] = None, implementation: str = "hip",
+                 mlp_precision: Optional[str] = None) -> None:
         super().__init__()
+        # arithmetic of the MLP GEMMs (include/fruitnerf_hip.h: FNR_MLP_*); not a reference argument.  None -> the
+        # FNR_MLP_PRECISION environment variable, else fp32 (the parity path)
+        self.mlp_precision = mlp_precision or os.environ.get("FNR_MLP_PRECISION", "fp32")
+        if self.mlp_precision not in MLP_MODES:
+            raise ValueError(f"mlp_precision {self.mlp_precision!r}: one of {sorted(MLP_MODES)}")
         # fruit_field.py:98-113
         self.register_buffer("aabb", aabb.clone().float())
         self.geo_feat_dim = geo_feat_dim
@@ -135,7 +148,7 @@ class FruitField(nn.Module):
         def P(p: nn.Parameter):
             return (p.grad if grads else p.data).data_ptr()
 
-        key = (P(self.mlp_base_grid.hash_table), P(self.mlp_head.layers[2].bias))
+        key = (P(self.mlp_base_grid.hash_table), P(self.mlp_head.layers[2].bias), self.mlp_precision)
         cache = self.__dict__.setdefault("_struct_cache", {})
         hit = cache.get(grads)
         if hit is not None and hit[0] == key and self._net_c is not None:
@@ -163,6 +176,7 @@ class FruitField(nn.Module):
         for i, lyr in enumerate(self.mlp_head.layers):
             net.col_w[i], net.col_b[i] = P(lyr.weight), P(lyr.bias)
         net.embedding = P(self.embedding_appearance.embedding.weight)
+        net.mlp_mode = MLP_MODES[self.mlp_precision]
         cache[grads] = (key, net)
         self._net_c = net  # non-None marks the cache valid (reset by _apply / adopt_arena)
         return net

@@ -60,6 +60,7 @@ class FruitNerfModelConfig:
     disable_scene_contraction: bool = False
     use_gradient_scaling: bool = False
     eval_num_rays_per_chunk: int = 1 << 15
+    mlp_precision: Optional[str] = None   # "fp32" | "bf16" | "bf16x3" (FruitField.mlp_precision; None: env / fp32)
     eval_outputs_on_cpu: bool = False   # True: full-image eval returns CPU tensors like the reference (fruit_nerf.py:245)
     # FruitNerfModelConfig proper
     semantic_loss_weight: float = 1.0
@@ -235,7 +236,8 @@ class FruitModel(nn.Module):
                                 num_images=self.num_train_data, geo_feat_dim=cfg.geo_feat_dim,
                                 use_average_appearance_embedding=cfg.use_average_appearance_embedding,
                                 use_semantics=True, test_mode=self.test_mode, num_semantic_classes=1,
-                                pass_semantic_gradients=cfg.pass_semantic_gradients)
+                                pass_semantic_gradients=cfg.pass_semantic_gradients,
+                                mlp_precision=cfg.mlp_precision)
         self.density_fns = []
         num_prop_nets = cfg.num_proposal_iterations
         self.proposal_networks = nn.ModuleList()

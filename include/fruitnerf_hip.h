@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 4
+#define FNR_ABI_VERSION 5
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -106,7 +106,21 @@ typedef struct fnr_field_net {
   float* head_w; float* head_b;             /* SemanticFieldHead: [1, 64], [1] (components/field_heads.py:29-40) */
   float* col_w[3]; float* col_b[3];         /* mlp_head: [64,16+geo+32],[64,64],[3,64] */
   float* embedding;                         /* embedding_appearance [n_images, 32] */
+  int32_t mlp_mode;                         /* FNR_MLP_*: arithmetic of the MLP GEMMs (fnr_field_mlp_fwd / _bwd) */
 } fnr_field_net;
+
+/* fnr_field_net.mlp_mode.  The reference trains with mixed_precision=True (fp16 autocast on CUDA,
+ * fruit_nerf_config.py:33,69) and runs pure fp32 on the CPU (nerfstudio disables autocast there); parity is judged
+ * against the fp32 CPU path.
+ *   FNR_MLP_FP32    v_mfma_f32_16x16x4_f32: exact fp32 FMA chains (default; the parity path, 157 TFLOP/s roofline)
+ *   FNR_MLP_BF16    v_mfma_f32_16x16x32_bf16 on bf16-rounded operands, fp32 accumulate: throughput mode of BASELINE
+ *                   config 2 (2.5 PFLOP/s roofline); outputs differ from fp32 by ~1e-2 relative — NOT parity grade
+ *   FNR_MLP_BF16X3  the same instruction on an exact three-way bf16 split of every fp32 operand (6 piece products
+ *                   forward, 3 backward): fp32-grade results (~1e-6) at 16/6 resp. 16/3 of the fp32-MFMA rate
+ * The bf16 modes are built for the `fruit_nerf` shape; others return FNR_ERR_UNSUPPORTED. */
+#define FNR_MLP_FP32 0
+#define FNR_MLP_BF16 1
+#define FNR_MLP_BF16X3 3
 
 /* ---- library / device ----------------------------------------------------------------------- */
 int fnr_abi_version(void);

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/fruitnerf_hip.h but not exported"
         assert name in L.SIGNATURES, f"{name} has no ctypes signature in fruitnerf_amd/_lib.py"
     assert set(L.SIGNATURES) == set(declared)
-    assert lib.fnr_abi_version() == 4
+    assert lib.fnr_abi_version() == 5
 
 
 def test_struct_layouts_match_header_sizes():
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(L.fnr_warp) == 4 + 6 * 4
     assert C.sizeof(L.fnr_lattice) == 16 + 3 * 8  # 3 ints padded to 16
     assert C.sizeof(L.fnr_prop_net) == C.sizeof(L.fnr_grid) + 8 + 4 * 8
-    assert C.sizeof(L.fnr_field_net) == C.sizeof(L.fnr_grid) + 8 * 4 + (4 + 8 + 2 + 6 + 1) * 8
+    assert C.sizeof(L.fnr_field_net) == C.sizeof(L.fnr_grid) + 8 * 4 + (4 + 8 + 2 + 6 + 1) * 8 + 8  # + mlp_mode (padded)
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
