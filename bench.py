@@ -443,6 +443,23 @@ def main() -> None:
             torch.cuda.synchronize()
             cam_off = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
             camera = saved
+        # the other arithmetic modes of the field MLPs on the SAME loop (headline mode restored afterwards): bf16x3 is
+        # parity grade (tests/test_gpu_bf16.py), bf16 is BASELINE config 2's throughput mode
+        mlp_modes = None
+        if args.method == "fruit_nerf":
+            mlp_modes = {"note": "train rays/s, 100 steps each after 10 untimed, same model / loop as the headline, "
+                                 f"measured after step {step_idx[0]}"}
+            for mode in ("fp32", "bf16x3", "bf16"):
+                model.field.mlp_precision = mode
+                for _ in range(10):
+                    one_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(100):
+                    one_step()
+                torch.cuda.synchronize()
+                mlp_modes[mode] = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
+            model.field.mlp_precision = args.mlp_precision
         # counting stage front-end on the exported semantic set: radius-outlier removal -> voxel
         # down-sampling -> DBSCAN -> centre-distance merge, all three library calls on the GPU; the scene has 32 fruits
         from fruitnerf_amd.clustering import FruitClustering, PointCloud
@@ -454,7 +471,8 @@ def main() -> None:
                                  remove_outliers_radius=1.8 * spacing, cluster_merge_distance=0.04)
             fruit_count = fc.first_stage_count(PointCloud(pts, None, dev), eps=1.8 * spacing, min_samples=4)
         counting = counting_stage_bench(dev, cpu=not args.no_cpu_baseline)
-        secondary = {"train_rays_per_s_camera_optimizer_off": cam_off,
+        secondary = {"train_rays_per_s_by_mlp_precision": mlp_modes,
+                     "train_rays_per_s_camera_optimizer_off": cam_off,
                      "train_rays_per_s_camera_optimizer_off_note": f"100 steps measured after step {step_idx[0] - 100} "
                      "(proposal nets are updated less often by then than in the headline window)",
                      "eval_rays_per_s": round(HW * HW / eval_s, 1), "eval_image": f"{HW}x{HW}, chunks of 32768 rays",

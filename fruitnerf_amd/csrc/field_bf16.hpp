@@ -150,15 +150,34 @@ struct BfLds {
   }
   template <int LAYER, bool IS_T>
   static constexpr int seg_blocks() { return blocks(find(LAYER, IS_T)); }
+  // global image -> LDS.  The LDS layout is the concatenation of the (segment, piece) chunks, each contiguous in the
+  // global image too: flat LDS vector f comes from global vector f + delta(chunk of f).  All loads of a thread are
+  // issued before its first LDS store (see stage_copy in field_layers.hpp).
+  static constexpr int chunk_begin(int c) { return off(c / NS) * 64 + (c % NS) * blocks(c / NS) * 64; }
+  static constexpr long long chunk_src(int c) {
+    const int s = c / NS, pc = c % NS;
+    return (long long)pc * Img::BLOCKS * 64 + (Segs::isT(s) ? Img::toff(Segs::layer(s)) : Img::foff(Segs::layer(s))) * 64;
+  }
+  template <int THREADS>
   __device__ static __forceinline__ void stage(bf16x8* __restrict__ lds, const __bf16* __restrict__ image) {
-    const bf16x8* img = reinterpret_cast<const bf16x8*>(image);
+    constexpr int T = FRAGS * 64, NCH = Segs::N * NS;
+    constexpr int PER = (T + THREADS - 1) / THREADS;
+    static_assert(PER <= 32, "staging batch too large");
+    const f32x4* img = reinterpret_cast<const f32x4*>(image);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    f32x4 v[PER];
 #pragma unroll
-    for (int s = 0; s < Segs::N; ++s) {
-      const int nb = blocks(s) * 64;
-      const int src0 = (Segs::isT(s) ? Img::toff(Segs::layer(s)) : Img::foff(Segs::layer(s))) * 64;
-      for (int pc = 0; pc < NS; ++pc)
-        for (int i = threadIdx.x; i < nb; i += blockDim.x)
-          lds[off(s) * 64 + pc * nb + i] = img[(size_t)pc * Img::BLOCKS * 64 + src0 + i];
+    for (int u = 0; u < PER; ++u) {
+      const int f = (int)threadIdx.x + u * THREADS;
+      long long delta = chunk_src(0) - chunk_begin(0);
+#pragma unroll
+      for (int c = 1; c < NCH; ++c) delta = (f >= chunk_begin(c)) ? chunk_src(c) - chunk_begin(c) : delta;
+      if (f < T) v[u] = img[f + delta];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int f = (int)threadIdx.x + u * THREADS;
+      if (f < T) dst[f] = v[u];
     }
   }
 };

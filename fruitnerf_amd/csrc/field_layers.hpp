@@ -109,6 +109,31 @@ struct FieldPtrs {
   const float* b[FIELD_MAX_LAYERS];
 };
 
+// Global -> LDS copy of NVEC 16-byte vectors by a workgroup of THREADS threads.  All of a thread's loads are issued
+// before its first LDS store (the trip count is a compile-time constant, batches of <= 12 loads): the plain
+// `for (i = tid; i < n; i += blockDim.x) dst[i] = src[i]` loop exposes one L2/HBM round trip PER ITERATION
+// (~1.5 us each; measured: ~15 us of prologue for the 75 KB image = most of an MLP kernel's FIXED cost, which was a
+// third of the whole MLP backward at 4096 rays).
+template <int THREADS, int NVEC>
+__device__ __forceinline__ void stage_copy(f32x4* __restrict__ dst, const f32x4* __restrict__ src) {
+  constexpr int PER = (NVEC + THREADS - 1) / THREADS;
+  constexpr int BATCH = PER < 12 ? PER : 12;
+#pragma unroll
+  for (int b0 = 0; b0 < PER; b0 += BATCH) {
+    f32x4 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int i = (int)threadIdx.x + (b0 + u) * THREADS;
+      if (b0 + u < PER && i < NVEC) v[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int i = (int)threadIdx.x + (b0 + u) * THREADS;
+      if (b0 + u < PER && i < NVEC) dst[i] = v[u];
+    }
+  }
+}
+
 // The part of the fragment image a kernel keeps in LDS: layers [LA, LB) — weights first, then their biases.
 template <class Cfg, int LA, int LB>
 struct LdsRange {
@@ -118,13 +143,14 @@ struct LdsRange {
   __device__ static __forceinline__ const float* w(const float* lds, int l) { return lds + (Cfg::woff(l) - W0); }
   __device__ static __forceinline__ float* w(float* lds, int l) { return lds + (Cfg::woff(l) - W0); }
   __device__ static __forceinline__ const float* b(const float* lds, int l) { return lds + W_FLOATS + (Cfg::boff(l) - B0); }
-  // fragment image (global, 16-byte aligned) -> LDS
+  // fragment image (global, 16-byte aligned) -> LDS; THREADS = the workgroup size
+  template <int THREADS>
   __device__ static __forceinline__ void stage(float* __restrict__ lds, const float* __restrict__ packed) {
     const f32x4* sw = reinterpret_cast<const f32x4*>(packed + W0);
     const f32x4* sb = reinterpret_cast<const f32x4*>(packed + Cfg::W_TOTAL + B0);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    for (int i = threadIdx.x; i < W_FLOATS / 4; i += blockDim.x) dst[i] = sw[i];
-    for (int i = threadIdx.x; i < B_FLOATS / 4; i += blockDim.x) dst[W_FLOATS / 4 + i] = sb[i];
+    stage_copy<THREADS, W_FLOATS / 4>(dst, sw);
+    stage_copy<THREADS, B_FLOATS / 4>(dst + W_FLOATS / 4, sb);
   }
 };
 

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * WAVES, (PART == PART_SEM) ? WAVES / 4 : 4) voi
   using R = typename FwdRange<Cfg, PART>::type;
   constexpr int HB = Cfg::HB;
   __shared__ __attribute__((aligned(16))) float lds[R::FLOATS];
-  R::stage(lds, packed);
+  R::template stage<64 * WAVES>(lds, packed);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;

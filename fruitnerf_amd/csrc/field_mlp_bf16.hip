@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_fwd_bf16(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
   float* bias = reinterpret_cast<float*>(smem + Lds::BYTES);  // Cfg::B_TOTAL floats, the fp32 image's bias block
-  Lds::stage(lds, image);
+  Lds::template stage<64 * WAVES>(lds, image);
   for (int i = threadIdx.x; i < Cfg::B_TOTAL; i += blockDim.x) bias[i] = packed[Cfg::W_TOTAL + i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_color_bf16(
   float* lds_bias = fbias + NBIAS;
   // the fp32 reduction image re-uses the fragment + scratch area after the tile loop
   static_assert(ACC_FLOATS * 4 <= Lds::BYTES + WAVES * bscr_words<NS>() * 4, "reduction image does not fit");
-  Lds::stage(lds, image);
+  Lds::template stage<64 * WAVES>(lds, image);
   for (int i = threadIdx.x; i < 64; i += blockDim.x) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LC1) + i];
   for (int i = threadIdx.x; i < 16; i += blockDim.x) fbias[64 + i] = packed[Cfg::W_TOTAL + Cfg::boff(LC2) + i];
   for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) lds_bias[i] = 0.0f;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_sem_bf16(
   float* fbias = reinterpret_cast<float*>(scr_all + WAVES * bscr_words<NS>());  // forward biases sem0, sem1
   float* lds_bias = fbias + 128;
   static_assert(ACC_FLOATS * 4 <= Lds::BYTES + WAVES * bscr_words<NS>() * 4, "reduction image does not fit");
-  Lds::stage(lds, image);
+  Lds::template stage<64 * WAVES>(lds, image);
   for (int i = threadIdx.x; i < 128; i += blockDim.x) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LS0) + i];
   for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) lds_bias[i] = 0.0f;
   __syncthreads();
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_base_bf16(
   float* fbias = reinterpret_cast<float*>(scr_all + WAVES * bscr_words<NS>());
   float* lds_bias = fbias + NBIAS;
   static_assert(ACC_FLOATS * 4 <= Lds::BYTES + WAVES * bscr_words<NS>() * 4, "reduction image does not fit");
-  Lds::stage(lds, image);
+  Lds::template stage<64 * WAVES>(lds, image);
   for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LB0) + i];
   for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) lds_bias[i] = 0.0f;
   __syncthreads();

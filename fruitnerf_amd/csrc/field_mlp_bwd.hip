@@ -183,20 +183,20 @@ __device__ __forceinline__ void zero_acc(A& acc) {
     for (auto& v : row) v = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// the layers a branch keeps in LDS (forward recompute + transposed reads); a subset of them are the layers whose
-// gradients it owns (written to the workgroup's partial image)
+// the layers a branch keeps in LDS (forward recompute + transposed reads) = the layers whose gradients it owns: a
+// contiguous range of the fragment image for both shapes (FieldCfgBase used to stage the whole 75 KB image per branch)
 template <class Cfg, int BRANCH>
-struct BwdRange {
-  using type = LdsRange<Cfg, 0, Cfg::NLAYERS>;  // FieldCfgBase: the whole 75 KB image, as in the forward kernel
-};
-template <>
-struct BwdRange<FieldCfgBig, BR_COLOR> { using type = LdsRange<FieldCfgBig, FieldCfgBig::L_COL0, FieldCfgBig::L_COL2 + 1>; };
-template <>
-struct BwdRange<FieldCfgBig, BR_BASE> { using type = LdsRange<FieldCfgBig, FieldCfgBig::L_BASE0, FieldCfgBig::L_BASE1 + 1>; };
-template <>
-struct BwdRange<FieldCfgBig, BR_SEM_A> { using type = LdsRange<FieldCfgBig, FieldCfgBig::L_SEM0, FieldCfgBig::L_HEAD + 1>; };
-template <>
-struct BwdRange<FieldCfgBig, BR_SEM_B> { using type = LdsRange<FieldCfgBig, FieldCfgBig::L_SEM0, FieldCfgBig::L_HEAD + 1>; };
+struct BwdRange;
+template <class Cfg>
+struct BwdRange<Cfg, BR_COLOR> { using type = LdsRange<Cfg, Cfg::L_COL0, Cfg::L_COL2 + 1>; };
+template <class Cfg>
+struct BwdRange<Cfg, BR_BASE> { using type = LdsRange<Cfg, Cfg::L_BASE0, Cfg::L_BASE1 + 1>; };
+template <class Cfg>
+struct BwdRange<Cfg, BR_SEM> { using type = LdsRange<Cfg, Cfg::L_SEM0, Cfg::L_HEAD + 1>; };
+template <class Cfg>
+struct BwdRange<Cfg, BR_SEM_A> { using type = LdsRange<Cfg, Cfg::L_SEM0, Cfg::L_HEAD + 1>; };
+template <class Cfg>
+struct BwdRange<Cfg, BR_SEM_B> { using type = LdsRange<Cfg, Cfg::L_SEM0, Cfg::L_HEAD + 1>; };
 
 // ---- colour branch: mlp_head (fruit_field.py:158-166,270-281) -----------------------------------------------------
 template <class Cfg, int WAVES>
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color(
   __shared__ __attribute__((aligned(16))) float lds[R::FLOATS + WAVES * SCR_FLOATS + 80];
   float* scr_all = lds + R::FLOATS;
   float* lds_bias = scr_all + WAVES * SCR_FLOATS;  // bias-gradient accumulators of col1 (64) and col2 (16)
-  R::stage(lds, packed);
+  R::template stage<64 * WAVES>(lds, packed);
   for (int i = threadIdx.x; i < 80; i += blockDim.x) lds_bias[i] = 0.0f;
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base(
   __shared__ __attribute__((aligned(16))) float lds[R::FLOATS + WAVES * SCR_FLOATS + 64 + 16 * HB];
   float* scr_all = lds + R::FLOATS;
   float* lds_bias = scr_all + WAVES * SCR_FLOATS;
-  R::stage(lds, packed);
+  R::template stage<64 * WAVES>(lds, packed);
   for (int i = threadIdx.x; i < 64 + 16 * HB; i += blockDim.x) lds_bias[i] = 0.0f;
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_sem(
   __shared__ __attribute__((aligned(16))) float lds[R::FLOATS + WAVES * SCR_FLOATS + 144];
   float* scr_all = lds + R::FLOATS;
   float* lds_bias = scr_all + WAVES * SCR_FLOATS;  // sem0 (64), sem1 (64), head (16)
-  R::stage(lds, packed);
+  R::template stage<64 * WAVES>(lds, packed);
   for (int i = threadIdx.x; i < 144; i += blockDim.x) lds_bias[i] = 0.0f;
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_sem_big(
   __shared__ __attribute__((aligned(16))) float lds[R::FLOATS + WAVES * SCR_FLOATS + NBIAS];
   float* scr_all = lds + R::FLOATS;
   float* lds_bias = scr_all + WAVES * SCR_FLOATS;
-  R::stage(lds, packed);
+  R::template stage<64 * WAVES>(lds, packed);
   for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) lds_bias[i] = 0.0f;
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -1,8 +1,10 @@
 import csv, collections, re, sys
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    k=re.sub(r"\(.*","",r["Kernel_Name"]).replace("void ","")[:70]
+    k=re.sub(r"\(.*","",r["Kernel_Name"]).replace("void ","")[:90]
     agg[(k, r["Grid_Size"] if "Grid_Size" in r else "")].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
 rows=sorted(agg.items(), key=lambda kv:-sum(kv[1]))
-for (k,g),v in rows[:40]:
-    v=sorted(v); print(f"{k:72s} grid {g:>9s} n {len(v):4d} total {sum(v)/1e3:8.2f} ms median {v[len(v)//2]:8.1f} us min {v[0]:8.1f}")
+flt=sys.argv[2] if len(sys.argv)>2 else None
+if flt: rows=[r for r in rows if flt in r[0][0]]
+for (k,g),v in (rows if flt else rows[:40]):
+    v=sorted(v); print(f"{k:92s} grid {g:>9s} n {len(v):4d} total {sum(v)/1e3:8.2f} ms median {v[len(v)//2]:8.1f} us min {v[0]:8.1f}")

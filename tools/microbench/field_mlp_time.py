@@ -7,7 +7,9 @@ dev = torch.device('cuda:0')
 m = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=10, device=dev); m.train(); m.arena()
 fld = m.field
 import os
-for R in [int(x) for x in os.environ.get("RS", "16,512,4096").split(",")]:
+for mode, R in [(md, int(x)) for md in os.environ.get("MODES", "fp32,bf16x3,bf16").split(",")
+                for x in os.environ.get("RS", "16,512,4096").split(",")]:
+    fld.mlp_precision = mode
     S = 48; N = R * S
     o = torch.randn(R, 3, device=dev) * 0.3; d = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
     cam = torch.randint(0, 10, (R,), device=dev)
@@ -24,4 +26,4 @@ for R in [int(x) for x in os.environ.get("RS", "16,512,4096").split(",")]:
     import collections
     agg = collections.defaultdict(list)
     for op, u, ms in recs: agg[op].append(ms)
-    print(R, {k: round(sorted(v)[len(v)//2]*1e3, 1) for k, v in agg.items()}, "us")
+    print(mode, R, {k: round(sorted(v)[len(v)//2]*1e3, 1) for k, v in agg.items()}, "us")
