@@ -182,8 +182,9 @@ def main() -> None:
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays per CPU-baseline step (0 = the method's batch size "
                     "for fruit_nerf, 1024 for fruit_nerf_big)")
     ap.add_argument("--export-n", type=int, default=256, help="lattice side of the volume-export secondary metric")
-    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
-                    help="arithmetic of the field-MLP GEMMs (include/fruitnerf_hip.h FNR_MLP_*): fp32 = exact fp32 MFMA "
+    ap.add_argument("--mlp-precision", default="auto", choices=["auto", "fp32", "bf16x3", "bf16"],
+                    help="arithmetic of the field-MLP GEMMs (include/fruitnerf_hip.h FNR_MLP_*): auto = fp32 for fruit_nerf, "
+                         "bf16x3 for fruit_nerf_big (the fastest parity-grade mode per shape); fp32 = exact fp32 MFMA "
                          "chains (default, the parity path); bf16x3 = exact 3-way bf16 split on the bf16 matrix pipe "
                          "(fp32-grade, parity-tested); bf16 = plain bf16 operands (BASELINE config 2; not parity grade)")
     ap.add_argument("--camera-optimizer", default="SO3xR3", choices=["off", "SO3xR3"],
@@ -243,7 +244,11 @@ def main() -> None:
     RAYS_PER_BATCH = M["rays"]
     ALG = alg_table(M["mlp_flop"])
     global MFMA_PEAK_TF
-    MFMA_PEAK_TF = MFMA_F32_PEAK_TF if args.mlp_precision == "fp32" else MFMA_BF16_PEAK_TF
+    if args.mlp_precision == "auto":
+        args.mlp_precision = "fp32" if args.method == "fruit_nerf" else "bf16x3"
+    # fruit_nerf_big in bf16x3 mode: only the semantic branch's backward is on the bf16 pipe; forward, colour and base
+    # are fp32 MFMA, so the fp32 peak stays the yardstick of the MLP entry points there
+    MFMA_PEAK_TF = MFMA_BF16_PEAK_TF if (args.mlp_precision != "fp32" and args.method == "fruit_nerf") else MFMA_F32_PEAK_TF
     model_cfg = FruitNerfModelConfig(mlp_precision=args.mlp_precision, **M["model"])
     model = FruitModel(model_cfg, apple_metadata(), num_train_data=len(i_train), device=dev)
     model.train()
@@ -446,10 +451,10 @@ def main() -> None:
         # the other arithmetic modes of the field MLPs on the SAME loop (headline mode restored afterwards): bf16x3 is
         # parity grade (tests/test_gpu_bf16.py), bf16 is BASELINE config 2's throughput mode
         mlp_modes = None
-        if args.method == "fruit_nerf":
+        if True:
             mlp_modes = {"note": "train rays/s, 100 steps each after 10 untimed, same model / loop as the headline, "
                                  f"measured after step {step_idx[0]}"}
-            for mode in ("fp32", "bf16x3", "bf16"):
+            for mode in (("fp32", "bf16x3", "bf16") if args.method == "fruit_nerf" else ("fp32", "bf16x3")):
                 model.field.mlp_precision = mode
                 for _ in range(10):
                     one_step()
@@ -561,7 +566,10 @@ def main() -> None:
         "vs_baseline": None,
         # arithmetic type of the MLP GEMMs; hash grids, samplers, compositing, losses and the optimiser are fp32 in
         # every mode.  bf16x3 = three bf16 pieces per fp32 operand (fp32-grade results), bf16 = bf16 operands.
-        "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3 split on the bf16 MFMA pipe)", "bf16": "bf16"}[args.mlp_precision],
+        "dtype": {"fp32": "f32", "bf16x3": "f32 (MLP GEMMs: exact bf16x3 split on the bf16 MFMA pipe"
+                                                    + ("" if args.method == "fruit_nerf" else " for the semantic "
+                                                       "branch's backward, fp32 MFMA elsewhere") + ")",
+                  "bf16": "bf16"}[args.mlp_precision],
         "data": "synthetic",
         "config": {"workload": f"{args.method} synthetic apple {HW}x{HW}, {N_CAMERAS} cameras ({len(i_train)} train), "
                                f"{RAYS_PER_BATCH} rays/rank/step, samples {'/'.join(map(str, M['samples']))}, "

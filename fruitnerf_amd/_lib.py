@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfruitnerf_hip.so")
+LIB_PATH = os.environ.get("FNR_LIB_PATH") or os.path.join(_HERE, "lib", "libfruitnerf_hip.so")
 
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4

@@ -262,4 +262,50 @@ __device__ __forceinline__ void bf_layer_T(const bf16x8* __restrict__ segT, cons
   bf_layer_acc<NS, NIBO, (NOB + 1) / 2>(segT, xa, xb, oa, ob_, lane);
 }
 
+// ---- single-tile variants (one 16-sample tile per wave: kernels whose activations are 128 wide) -------------------
+template <int NS, int NOB, int NKB>
+__device__ __forceinline__ void bf_layer_acc1(const bf16x8* __restrict__ seg, const bf16x8 (&x)[NKB][NS], f32x4 (&o)[NOB],
+                                              int lane) {
+  constexpr int PB = NOB * NKB * 64, T = NOB * NKB;
+  // explicit double buffer over the (kb, ob) steps, pinned by scheduling barriers: left alone, the scheduler hoists
+  // the LDS reads of MANY steps above the MFMAs (8 registers per step) and the 128-wide layers spill
+  bf16x8 w[2][NS];
+  auto load = [&](int t, bf16x8 (&dst)[NS]) {
+    const int kb = t / NOB, ob = t % NOB;
+#pragma unroll
+    for (int pc = 0; pc < NS; ++pc) dst[pc] = seg[pc * PB + (ob * NKB + kb) * 64 + lane];
+  };
+  load(0, w[0]);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) load(t + 1, w[(t + 1) & 1]);
+    const int kb = t / NOB, ob = t % NOB;
+#pragma unroll
+    for (int s = NS - 1; s >= 0; --s)
+#pragma unroll
+      for (int pw = 0; pw <= s; ++pw)
+        o[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t & 1][pw], x[kb][s - pw], o[ob], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int NS, int NOB, int NIB>
+__device__ __forceinline__ void bf_layer1(const bf16x8* __restrict__ seg, const float* __restrict__ B,
+                                          const f32x4 (&in)[NIB], f32x4 (&o)[NOB], int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) o[ob] = *reinterpret_cast<const f32x4*>(B + 16 * ob + 4 * g);
+  bf16x8 x[(NIB + 1) / 2][NS];
+  bf_operand<NS, NIB>(in, x);
+  bf_layer_acc1<NS, NOB, (NIB + 1) / 2>(seg, x, o, lane);
+}
+template <int NS, int NIBO, int NOB>
+__device__ __forceinline__ void bf_layer_T1(const bf16x8* __restrict__ segT, const f32x4 (&G)[NOB], f32x4 (&o)[NIBO],
+                                            int lane) {
+#pragma unroll
+  for (int ib = 0; ib < NIBO; ++ib) o[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 x[(NOB + 1) / 2][NS];
+  bf_operand<NS, NOB>(G, x);
+  bf_layer_acc1<NS, NIBO, (NOB + 1) / 2>(segT, x, o, lane);
+}
+
 }  // namespace fnr

@@ -208,11 +208,12 @@ int field_mlp_fwd_launch(const FieldPtrs& p, const fnr_field_net* net, const Ray
   FNR_LAUNCH_CHECK();
   const long long n_tiles = (N + 15) / 16;
   const float2* f2 = reinterpret_cast<const float2*>(feats);
-  if (net->mlp_mode != FNR_MLP_FP32) {
-    if constexpr (Cfg::NSEM == 2)
+  // bf16-pipe modes: the `fruit_nerf` shape; the `fruit_nerf_big` forward stays on fp32 MFMA (its backward runs the
+  // semantic branch on the bf16 pipe, field_mlp_bwd.hip)
+  if constexpr (Cfg::NSEM == 2) {
+    if (net->mlp_mode != FNR_MLP_FP32)
       return field_mlp_fwd_bf16(net->mlp_mode, p, packed, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),
                                 ray_bias, rd, S, N, f2, selector, density, rgb, logit, geo_out, h_buf, st);
-    FNR_UNSUPPORTED(false, "field_mlp_fwd: mlp_mode %d is built for the `fruit_nerf` shape only", net->mlp_mode);
   }
   if constexpr (Cfg::NSEM == 2) {
     long long blocks = (n_tiles + 7) / 8;

@@ -629,6 +629,304 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_base_bf16(
   for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) part[Cfg::W_TOTAL + Cfg::boff(LB0) + i] = lds_bias[i];
 }
 
+// =====================================================================================================================
+// `fruit_nerf_big` semantic branch, backward: mlp_semantics 30 -> 128 -> 128 -> 64 + SemanticFieldHead
+// (fruit_field.py:144-156,263-268 with fruit_nerf_config.py:82-95).  Its 119 KB of fp32 weights, 464 accumulator
+// registers of dW and 128-wide activations made the fp32 path two launches of 4 waves x 512 registers that each repeat
+// the forward and most of the dX chain (field_mlp_bwd.hip: 2.26 ms of a 7.06 ms step at 8192 rays).  Here:
+//   * WEIGHT STREAMING: a workgroup of 8 waves takes a batch of 8 tiles (128 samples) through the branch layer by layer;
+//     the bf16 fragment pieces of the layer(s) in use are re-staged from L2 into the SAME LDS region per phase
+//     (forward sem0+sem1 | transposed head+sem2 | transposed sem1: <= 80 KB at two pieces, 1.4 KB of L2 reads per sample);
+//   * COOPERATIVE dW: dW = dY^T X is not accumulated per wave.  All waves write their tile's dY and X columns (bf16
+//     pieces) into one [feature row][128 samples] LDS scratch (it overlays the weight region between phases), and every
+//     output block (16 x 16 weights) of the layer is owned by ONE wave, which sums it over the batch's 128 samples (four
+//     K = 32 MFMAs per piece product).  116 blocks / 8 waves = 15 accumulator blocks (60 registers) per wave instead of
+//     464, no cross-wave reduction at the end, and the whole branch runs once, at two waves per SIMD;
+//   * the head's dW needs s3 = sem2(s2), which is not recomputed: dW_head = sum_s dlogit_s s3_s = W2 (sum_s dlogit_s s2_s)
+//     + b2 sum_s dlogit_s is linear in a 128-vector that falls out of the sem2 round as one more block per wave.
+// =====================================================================================================================
+template <class Cfg>
+struct SegsBigP1 {  // forward sem0, sem1
+  static constexpr int N = 2;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_SEM0 : Cfg::L_SEM1; }
+  static constexpr bool isT(int) { return false; }
+};
+template <class Cfg>
+struct SegsBigP2 {  // transposed head, sem2
+  static constexpr int N = 2;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_HEAD : Cfg::L_SEM2; }
+  static constexpr bool isT(int) { return true; }
+};
+template <class Cfg>
+struct SegsBigP4 {  // transposed sem1
+  static constexpr int N = 1;
+  static constexpr int layer(int) { return Cfg::L_SEM1; }
+  static constexpr bool isT(int) { return true; }
+};
+
+constexpr int CS_LD = 72;     // words per scratch row: 64 hold the batch's 128 bf16 samples; 72 keeps the b128 reads conflict-free
+constexpr int CS_ROWS = 128;  // feature rows per operand
+template <int NS>
+constexpr int cs_words() { return 2 * NS * CS_ROWS * CS_LD; }  // [G | X][piece][row][CS_LD]
+
+// this wave's tile (NB accumulator blocks) -> rows ROW0.. of operand array `arr`, columns 16 wave + j, as bf16 pieces
+template <int NS, int NB>
+__device__ __forceinline__ void cs_write(uint32_t* __restrict__ arr, int row0, const f32x4 (&a)[NB], int lane, int wave) {
+  const int j = lane & 15, g = lane >> 4;
+  __bf16* base = reinterpret_cast<__bf16*>(arr);
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = a[blk][r];
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc) {
+        const __bf16 pv = (__bf16)v;
+        base[(size_t)((pc * CS_ROWS + row0 + 16 * blk + 4 * g + r) * (2 * CS_LD)) + 16 * wave + j] = pv;
+        if (pc + 1 < NS) v -= (float)pv;
+      }
+    }
+}
+
+// acc[s] += (G rows of block ob0 + s ob_step)^T (X rows of block ib) over the batch's 128 samples
+template <int NS, int NOBW>
+__device__ __forceinline__ void cs_dw(const uint32_t* __restrict__ sG, const uint32_t* __restrict__ sX, int ob0,
+                                      int ob_step, int ib, f32x4 (&acc)[NOBW], int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  // steps (kk, s), K-block outermost (one X fragment set live at a time); explicit double buffer of the G fragments
+  // pinned by scheduling barriers (see bf_layer_acc1)
+  constexpr int T = 4 * NOBW;
+  bf16x8 ga[2][NS], xb[NS];
+  auto load_g = [&](int t, bf16x8 (&dst)[NS]) {
+    const int kk = t / NOBW, ob = ob0 + (t % NOBW) * ob_step;
+#pragma unroll
+    for (int pc = 0; pc < NS; ++pc)
+      dst[pc] = *reinterpret_cast<const bf16x8*>(sG + (pc * CS_ROWS + 16 * ob + i) * CS_LD + 16 * kk + 4 * g);
+  };
+  load_g(0, ga[0]);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int kk = t / NOBW, s = t % NOBW;
+    if (s == 0) {
+#pragma unroll
+      for (int pc = 0; pc < NS; ++pc)
+        xb[pc] = *reinterpret_cast<const bf16x8*>(sX + (pc * CS_ROWS + 16 * ib + i) * CS_LD + 16 * kk + 4 * g);
+    }
+    if (t + 1 < T) load_g(t + 1, ga[(t + 1) & 1]);
+#pragma unroll
+    for (int sp = NS - 1; sp >= 0; --sp)
+#pragma unroll
+      for (int pg = 0; pg <= sp; ++pg)
+        acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[t & 1][pg], xb[sp - pg], acc[s], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// bacc += (G rows of block ob)^T 1: every column of the block ends up with the rows' sums over the batch
+template <int NS>
+__device__ __forceinline__ void cs_bias(const uint32_t* __restrict__ sG, int ob, f32x4& bacc, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int pc = NS - 1; pc >= 0; --pc) {
+      const bf16x8 ga = *reinterpret_cast<const bf16x8*>(sG + (pc * CS_ROWS + 16 * ob + i) * CS_LD + 16 * kk + 4 * g);
+      bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, ones, bacc, 0, 0, 0);
+    }
+}
+// one owned block of dW -> the workgroup's fp32 partial image (index space of field_layers.hpp / flush_dw)
+__device__ __forceinline__ void store_dw_block(float* __restrict__ W, int ob, int ib, int nib_stride, const f32x4& acc,
+                                               int lane) {
+  const int jn = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    W[((ob * nib_stride + ib) * 64 + swz_slot(4 * g + r, jn >> 2)) * 4 + (jn & 3)] = acc[r];
+}
+__device__ __forceinline__ void store_bias_block(float* __restrict__ B, int ob, const f32x4& bacc, int lane) {
+  if ((lane & 15) == 0) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) B[16 * ob + 4 * g + r] = bacc[r];
+  }
+}
+
+// NSF = pieces of the forward recompute, NS = pieces of the dX chain and of dW.  bf16x3 mode: NSF = 3, NS = 2 — the
+// recomputed activations decide the ReLU gates, and a gate that flips against the forward pass (fp32 MFMA for this
+// shape) changes a whole sample's contribution to a dW row: with two pieces (2^-17) that happened ~1000x more often
+// than with three (2^-27) and single flips showed as ~5e-3 of max |g| under random zero-mean upstream gradients.
+template <class Cfg, int NSF, int NS>
+__global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_sem_big_bf16(
+    const float* __restrict__ packed, const __bf16* __restrict__ image, const float* __restrict__ w_sem2,
+    const float* __restrict__ b_sem2, long long N, const float* __restrict__ h_saved, const float* __restrict__ d_logit,
+    float* __restrict__ partials) {
+  static_assert(Cfg::NSEM == 3 && Cfg::HB == 2 && Cfg::SEMB == 8, "fruit_nerf_big semantic shape");
+  constexpr int WAVES = 8, THREADS = 64 * WAVES;
+  constexpr int LS0 = Cfg::L_SEM0, LS1 = Cfg::L_SEM1, LS2 = Cfg::L_SEM2, LH = Cfg::L_HEAD;
+  static_assert(LS1 == LS0 + 1 && LS2 == LS1 + 1 && LH == LS2 + 1, "the branch's layers are adjacent in the fp32 image");
+  using P1 = BfLds<Cfg, SegsBigP1<Cfg>, NSF>;
+  using P2 = BfLds<Cfg, SegsBigP2<Cfg>, NS>;
+  using P4 = BfLds<Cfg, SegsBigP4<Cfg>, NS>;
+  constexpr int REGION = cs_words<NS>() * 4;  // weights of a phase and the dW scratch share this region
+  static_assert(P1::BYTES <= REGION && P2::BYTES <= REGION && P4::BYTES <= REGION, "phase weights exceed the shared region");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smem);
+  uint32_t* sG = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* sX = sG + NS * CS_ROWS * CS_LD;
+  float* fbias = reinterpret_cast<float*>(smem + REGION);  // forward biases: sem0 [128] | sem1 [128]
+  float* vhead = fbias + 256;                              // epilogue: sum_s dlogit_s s2_s [128] and sum_s dlogit_s
+  for (int i = threadIdx.x; i < 256; i += THREADS) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LS0) + i];
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // dW blocks owned by this wave: sem0 (ob = (w>>1) + 4 s, ib = w & 1), sem1 (ob = s, ib = w), sem2 (ob = s, ib = w),
+  // the virtual head block (dlogit^T s2, ib = w); bias blocks: sem0 / sem1 ob = w, sem2 ob = w (waves 0..3), head (wave 4)
+  f32x4 acc0[2], acc1[8], acc2[4], accV[1];
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, b2 = b0;
+  zero_vec_bf(acc0);
+  zero_vec_bf(acc1);
+  zero_vec_bf(acc2);
+  zero_vec_bf(accV);
+
+  const long long n_batches = (N + 127) / 128;
+  for (long long batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+    asm volatile("" ::: "memory");
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int j = lane & 15, g = lane >> 4;
+    const long long n = batch * 128 + 16 * wave + j;
+    const bool valid = n < N;
+    const long long nn = valid ? n : N - 1;
+    f32x4 h[2];
+    h[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * 32 + 4 * g);
+    h[1] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * 32 + 16 + 4 * g);
+    f32x4 Gl[1];
+    Gl[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g == 0 && valid) Gl[0][0] = d_logit[n];
+
+    // phase 1: forward sem0, sem1
+    __syncthreads();  // the previous batch's last scratch reads
+    P1::template stage<THREADS>(wl, image);
+    __syncthreads();
+    f32x4 s1[8], s2[8];
+    bf_layer1<NSF, 8, 2>(P1::template seg<LS0, false>(wl), fbias, h, s1, lane);
+    relu_(s1);
+    bf_layer1<NSF, 8, 8>(P1::template seg<LS1, false>(wl), fbias + 128, s1, s2, lane);
+    relu_(s2);
+    // phase 2: dlogit -> Gs3 (mlp_semantics' output has no activation) -> Gs2.  The transposed head / sem2 fragments are
+    // staged into the X half of the region, so that Gs3 and dlogit can go to the G half of the scratch as soon as they
+    // exist (16 registers less at the kernel's register peak)
+    __syncthreads();
+    bf16x8* wl2 = reinterpret_cast<bf16x8*>(sX);
+    static_assert(P2::BYTES <= NS * CS_ROWS * CS_LD * 4, "phase-2 fragments must fit the X half");
+    P2::template stage<THREADS>(wl2, image);
+    __syncthreads();
+    f32x4 Gs2[8];
+    {
+      f32x4 Gs3[4];
+      bf_layer_T1<NS, 4, 1>(P2::template seg<LH, true>(wl2), Gl, Gs3, lane);
+      // round 1, G side: [Gs3 (blocks 0..3) | dlogit (block 4)]
+      cs_write<NS, 4>(sG, 0, Gs3, lane, wave);
+      cs_write<NS, 1>(sG, 64, Gl, lane, wave);
+      bf_layer_T1<NS, 8, 4>(P2::template seg<LS2, true>(wl2), Gs3, Gs2, lane);
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Gs2[b][r] = (s2[b][r] > 0.0f) ? Gs2[b][r] : 0.0f;
+    // round 1, X side: s2 -> dW sem2, the head's 128-vector, db sem2, db head
+    __syncthreads();  // the fragments of phase 2 are dead
+    cs_write<NS, 8>(sX, 0, s2, lane, wave);
+    __syncthreads();
+    cs_dw<NS, 4>(sG, sX, 0, 1, wave, acc2, lane);
+    cs_dw<NS, 1>(sG, sX, 4, 0, wave, accV, lane);
+    if (wave < 4) cs_bias<NS>(sG, wave, b2, lane);
+    if (wave == 4) cs_bias<NS>(sG, 4, b2, lane);  // wave 4's b2 is the head's bias gradient
+    // round 2: G = Gs2, X = s1 -> dW sem1, db sem1
+    __syncthreads();
+    cs_write<NS, 8>(sG, 0, Gs2, lane, wave);
+    cs_write<NS, 8>(sX, 0, s1, lane, wave);
+    __syncthreads();
+    cs_dw<NS, 8>(sG, sX, 0, 1, wave, acc1, lane);
+    cs_bias<NS>(sG, wave, b1, lane);
+    // phase 4: Gs2 -> Gs1
+    __syncthreads();
+    P4::template stage<THREADS>(wl, image);
+    __syncthreads();
+    f32x4 Gs1[8];
+    bf_layer_T1<NS, 8, 8>(P4::template seg<LS1, true>(wl), Gs2, Gs1, lane);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Gs1[b][r] = (s1[b][r] > 0.0f) ? Gs1[b][r] : 0.0f;
+    // round 3: G = Gs1, X = h -> dW sem0, db sem0 (the input is the detached geo: no dX)
+    __syncthreads();
+    cs_write<NS, 8>(sG, 0, Gs1, lane, wave);
+    {
+      f32x4 hx[2];  // re-read (L2-resident) instead of keeping 8 registers live across the whole batch
+      hx[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * 32 + 4 * g);
+      hx[1] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * 32 + 16 + 4 * g);
+      cs_write<NS, 2>(sX, 0, hx, lane, wave);
+    }
+    __syncthreads();
+    cs_dw<NS, 2>(sG, sX, wave >> 1, 4, wave & 1, acc0, lane);
+    cs_bias<NS>(sG, wave, b0, lane);
+  }
+
+  // ---- this workgroup's partial image: every block of the branch's layers is written by its owner -------------------
+  const int lane = lane0;
+  float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
+  float* pb = part + Cfg::W_TOTAL;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) store_dw_block(part + Cfg::woff(LS0), (wave >> 1) + 4 * s, wave & 1, 2, acc0[s], lane);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) store_dw_block(part + Cfg::woff(LS1), s, wave, 8, acc1[s], lane);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) store_dw_block(part + Cfg::woff(LS2), s, wave, 8, acc2[s], lane);
+  store_bias_block(pb + Cfg::boff(LS0), wave, b0, lane);
+  store_bias_block(pb + Cfg::boff(LS1), wave, b1, lane);
+  if (wave < 4) store_bias_block(pb + Cfg::boff(LS2), wave, b2, lane);
+  // SemanticFieldHead: dW = W2 v + b2 sum(dlogit), v = row 0 of the virtual blocks, sum(dlogit) = row 0 of wave 4's b2
+  __syncthreads();
+  if ((lane >> 4) == 0) vhead[16 * wave + (lane & 15)] = accV[0][0];
+  if (wave == 4 && lane == 0) vhead[128] = b2[0];
+  for (int i = threadIdx.x; i < Cfg::nob(LH) * Cfg::nib(LH) * 256; i += THREADS) part[Cfg::woff(LH) + i] = 0.0f;
+  for (int i = threadIdx.x; i < 16; i += THREADS) pb[Cfg::boff(LH) + i] = 0.0f;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x;  // head input k = output k of mlp_semantics' last layer
+    float dw = b_sem2[k] * vhead[128];
+    for (int m = 0; m < 128; ++m) dw = fmaf(w_sem2[k * 128 + m], vhead[m], dw);
+    const int ib = k >> 4, kk = k & 15;
+    part[Cfg::woff(LH) + (ib * 64 + swz_slot(0, kk >> 2)) * 4 + (kk & 3)] = dw;
+    if (k == 0) pb[Cfg::boff(LH)] = vhead[128];
+  }
+}
+
+int field_mlp_bwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, const float* packed, long long N,
+                               const float* h_saved, const float* d_logit, float* partials, long long blocks,
+                               hipStream_t st) {
+  using Cfg = FieldCfgBig;
+  __bf16* image = reinterpret_cast<__bf16*>(image_ws);
+  const int ns_pack = mode == MLP_BF16 ? 1 : 3;
+  launch_pack_field_weights_bf16<Cfg>(p, ns_pack, image, st);
+  FNR_LAUNCH_CHECK();
+  auto launch = [&](auto kern, int bytes) -> int {
+    FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, p.w[Cfg::L_SEM2], p.b[Cfg::L_SEM2],
+                       N, h_saved, d_logit, partials);
+    FNR_LAUNCH_CHECK();
+    return FNR_OK;
+  };
+  if (mode == MLP_BF16) {
+    constexpr int bytes = cs_words<1>() * 4 + (256 + 144) * 4;
+    return launch(k_field_mlp_bwd_sem_big_bf16<Cfg, 1, 1>, bytes);
+  }
+  constexpr int bytes = cs_words<2>() * 4 + (256 + 144) * 4;
+  static_assert(bytes <= 160 * 1024, "fruit_nerf_big semantic branch exceeds the LDS");
+  return launch(k_field_mlp_bwd_sem_big_bf16<Cfg, 3, 2>, bytes);
+}
+
 // ---- launch helpers (called from field_mlp.hip / field_mlp_bwd.hip when fnr_field_net.mlp_mode != 0) --------------
 template <class K>
 static int set_dyn_lds(K kernel, int bytes) {
@@ -727,6 +1025,9 @@ int field_mlp_bwd_bf16(int mode, int branch, const FieldPtrs& p, bool pack, cons
                             d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
 }
 
-size_t field_bf16_image_bytes() { return BfImage<FieldCfgBase>::bytes(BF_MAX_PIECES) + 256; }
+size_t field_bf16_image_bytes() {
+  const size_t a = BfImage<FieldCfgBase>::bytes(BF_MAX_PIECES), b = BfImage<FieldCfgBig>::bytes(BF_MAX_PIECES);
+  return (a > b ? a : b) + 256;
+}
 
 }  // namespace fnr

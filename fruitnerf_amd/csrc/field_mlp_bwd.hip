@@ -781,6 +781,9 @@ int field_mlp_bwd_bf16(int mode, int branch, const FieldPtrs& p, bool pack, cons
                        const float* h_saved, const uint8_t* selector, const float* d_density, const float* d_rgb,
                        const float* d_logit, float2* d_feats, float* d_h, float* gsum_tile, float* gsum_extra,
                        float* partials, long long blocks, hipStream_t st);
+int field_mlp_bwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, const float* packed, long long N,
+                               const float* h_saved, const float* d_logit, float* partials, long long blocks,
+                               hipStream_t st);
 
 }  // namespace fnr
 
@@ -854,8 +857,11 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid((unsigned)blocks);
   const int mode = net->mlp_mode;
-  if (mode != FNR_MLP_FP32) {
-    FNR_UNSUPPORTED(Cfg::NSEM == 2, "field_mlp_bwd: mlp_mode %d is built for the `fruit_nerf` shape only", mode);
+  // bf16-pipe modes: every branch of the `fruit_nerf` shape; of the `fruit_nerf_big` shape the semantic branch (its
+  // largest kernel by far — weight-streamed, cooperative dW: field_mlp_bf16.hip), colour and base stay on fp32 MFMA
+  const bool bf_all = mode != FNR_MLP_FP32 && Cfg::NSEM == 2;
+  const bool bf_sem_big = mode != FNR_MLP_FP32 && Cfg::NSEM == 3;
+  if (bf_all) {
     const int rc = field_mlp_bwd_bf16(mode, 0, p, bf16_pack, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
                                       d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
     if (rc) return rc;
@@ -878,7 +884,10 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                        grads->embedding);
     FNR_LAUNCH_CHECK();
   }
-  if (mode != FNR_MLP_FP32) {
+  if (bf_sem_big) {
+    const int rc = field_mlp_bwd_sem_big_bf16(mode, p, ws.bf16_image, packed, N, h_saved, d_logit, partials, blocks, st);
+    if (rc) return rc;
+  } else if (bf_all) {
     for (int branch = 1; branch <= 2; ++branch) {
       const int rc = field_mlp_bwd_bf16(mode, branch, p, false, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
                                         d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
@@ -895,7 +904,7 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                        partials);
     FNR_LAUNCH_CHECK();
   }
-  if (mode == FNR_MLP_FP32) {
+  if (!bf_all) {
     hipLaunchKernelGGL((k_field_mlp_bwd_base<Cfg, 8>), grid, dim3(512), 0, st, packed, N, f2, selector, d_density, ws.d_h,
                        df2, partials);
     FNR_LAUNCH_CHECK();

@@ -14,16 +14,23 @@
 // Queue overflow (a pathologically hot bin) falls back to global atomics in step 1, so results never depend on
 // the capacity heuristic.  HBM-bound: 10 B written + read per contribution (value pair + 16-bit row) instead of two
 // serialized atomics.
+#include <stdlib.h>
+#include <string.h>
+
 #include "hash_sources.hpp"
 
 namespace fnr {
 
 constexpr int SC_MAX_ROWS = 8192;       // rows per bin (64 KiB of float2 in LDS)
-constexpr int SC_MAX_BINS = 512;        // per level (LDS histogram size)
-constexpr int SC_CHUNK = 512;           // samples per emit workgroup (512 x 8 records x 16 B = 64 KiB of LDS)
+constexpr int SC_MAX_BINS = 256;        // per level (LDS histogram size): T = 2^21 (fruit_nerf_big) has 256 bins of 8192 rows
+// samples per emit workgroup: 512 x 8 records x 12 B (value pair + packed row|bin) = 48 KiB of LDS, + 3 KiB of bin
+// tables = 3 workgroups (24 waves) per CU; with 16-byte records it was 2, and the kernel spends half its wave-cycles
+// waiting (reservation atomics, barriers between its phases) with only the other workgroup to fill in
+constexpr int SC_CHUNK = 512;
 constexpr int SC_EMIT_THREADS = 512;    // 8 waves, one sample per thread
 constexpr int SC_PER_THREAD = SC_CHUNK / SC_EMIT_THREADS;
-constexpr int SC_BINS_PER_THREAD = SC_MAX_BINS / SC_EMIT_THREADS;
+constexpr int SC_BINS_PER_THREAD = 1;    // thread t < bins owns bin t in the scan / reservation step
+static_assert(SC_MAX_BINS <= SC_EMIT_THREADS, "one bin per thread");
 // Every bin's queue counter (and its max-|v| word) sits in its own 128-byte line: all workgroups of a level hit the
 // same 64 counters, and atomics to one L2 line serialise (~12 ns each) — packed 4 bytes apart, 64 counters shared
 // two lines and the reservation step alone cost ~150 us per call.
@@ -97,6 +104,7 @@ __device__ __forceinline__ float dpp_f32(float old, float v) {
 // corner and made this kernel VALU-bound).
 struct RunMasks {
   bool m1, m2, m4, m8, tail;
+  bool any_run;  // wave-uniform: some lane continues its left neighbour's run
 };
 __device__ __forceinline__ RunMasks run_structure(uint32_t key_a, uint32_t key_b, int lane) {
   const int j = lane & 15;
@@ -112,6 +120,7 @@ __device__ __forceinline__ RunMasks run_structure(uint32_t key_a, uint32_t key_b
   m.m4 = dist >= 4;
   m.m8 = dist >= 8;
   m.tail = (j == 15) || ((row >> (j + 1)) & 1u);
+  m.any_run = ~heads != 0ull;
   return m;
 }
 __device__ __forceinline__ float run_sum(float v, const RunMasks& m) {
@@ -129,18 +138,38 @@ __device__ __forceinline__ float run_sum(float v, const RunMasks& m) {
   return v;
 }
 
+// Debug build only (make EXTRA=-DFNR_EMIT_TIMING): wave 0 of every emit workgroup adds the shader-clock length of
+// each phase to g_emit_phase_clk[] (tools/microbench/scatter_phases.py reads it through fnr_debug_emit_phases).
+#ifdef FNR_EMIT_TIMING
+constexpr int EMIT_T_SLOTS = 1 << 16;
+__device__ unsigned g_emit_phase_clk[EMIT_T_SLOTS][8];   // per workgroup (plain stores: atomics would serialise)
+#define EMIT_T(k)                                                                              \
+  do {                                                                                         \
+    const unsigned long long now__ = __builtin_readcyclecounter();                             \
+    t_acc__[k] = (unsigned)(now__ - t_phase__);                                                \
+    t_phase__ = now__;                                                                         \
+  } while (0)
+#else
+#define EMIT_T(k) do { } while (0)
+#endif
+
 template <class Source>
 __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, Warp warp, Source src, long long N,
                                                       const float2* __restrict__ d_feats, float2* __restrict__ queue_v,
                                                       unsigned short* __restrict__ queue_r, unsigned* __restrict__ qcount, unsigned* __restrict__ qmax,
                                                       long long cap, int log2_rows, int level0) {
   // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs
-  __shared__ float4 s_rec[SC_CHUNK * 8];
+  __shared__ float2 s_val[SC_CHUNK * 8];    // value pair of a record
+  __shared__ unsigned s_key[SC_CHUNK * 8];  // row inside the bin | bin << 16
   __shared__ unsigned s_cnt[SC_MAX_BINS];   // per-bin count, then running cursor
-  __shared__ unsigned s_off[SC_MAX_BINS];   // per-bin start inside s_rec
+  __shared__ unsigned s_off[SC_MAX_BINS];   // per-bin start inside s_val / s_key
   __shared__ unsigned s_base[SC_MAX_BINS];  // per-bin start inside the global queue
   __shared__ unsigned s_max;                // max |value| emitted by this workgroup (float bits; order-preserving for >= 0)
   __shared__ unsigned s_wsum[SC_EMIT_THREADS / 64];
+#ifdef FNR_EMIT_TIMING
+  unsigned long long t_phase__ = __builtin_readcyclecounter();
+  unsigned t_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   const int lrel = blockIdx.y;           // level inside this call's range: indexes the counters and queues
   const int level = level0 + lrel;       // level of the grid: indexes scalings, d_feats and the gradient table
   const int bins = 1 << (grid.log2_T - log2_rows);
@@ -150,6 +179,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   if (threadIdx.x == 0) s_max = 0;
   __syncthreads();
+  EMIT_T(0);
   const uint32_t mask = (1u << grid.log2_T) - 1u;
   const uint32_t row_mask = (1u << log2_rows) - 1u;
   const int scaling = grid.scalings[level];
@@ -173,6 +203,14 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       src.position(n, px, py, pz);
       warp_position(warp, px, py, pz, x);
     }
+#ifdef FNR_EMIT_TIMING
+    {  // x and gf are in registers once this dependent dummy has been consumed
+      asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(gf.x), "v"(gf.y));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long now__ = __builtin_readcyclecounter();
+      t_acc__[6] = (unsigned)(now__ - t_phase__);
+    }
+#endif
     float wgt[8];
     const GridLevel g = corner_weights(x, scaling, mask, hk[q], wgt);
     const bool valid = n < N;
@@ -183,10 +221,29 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
                                  : (0x80000000u | (uint32_t)lane);
     const RunMasks rm = run_structure(key_a, key_b, lane);
     emit_mask[q] = 0;
+    // fine levels: every sample of the wave sits in its own cell — no run to sum (wave-uniform branch around the
+    // 16 x 4 DPP steps, a quarter of this kernel's VALU instructions)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      vxk[q][k] = run_sum(valid ? wgt[k] * gf.x : 0.0f, rm);
-      vyk[q][k] = run_sum(valid ? wgt[k] * gf.y : 0.0f, rm);
+      vxk[q][k] = valid ? wgt[k] * gf.x : 0.0f;
+      vyk[q][k] = valid ? wgt[k] * gf.y : 0.0f;
+    }
+    if (rm.any_run) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        vxk[q][k] = run_sum(vxk[q][k], rm);
+        vyk[q][k] = run_sum(vyk[q][k], rm);
+      }
+    }
+#ifdef FNR_EMIT_TIMING
+    {
+      asm volatile("" ::"v"(vxk[q][0]), "v"(vyk[q][7]));
+      const unsigned long long now__ = __builtin_readcyclecounter();
+      t_acc__[7] = (unsigned)(now__ - t_phase__);
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
       if (rm.tail && (vxk[q][k] != 0.0f || vyk[q][k] != 0.0f)) {
         emit_mask[q] |= 1u << k;
         const int bin = hk[q][k] >> log2_rows;
@@ -202,6 +259,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   for (int dsh = 32; dsh >= 1; dsh >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, dsh, 64));
   if (lane == 0 && tmax > 0.0f) atomicMax(&s_max, __float_as_uint(tmax));
   __syncthreads();
+  EMIT_T(1);
   if (threadIdx.x == 0 && s_max != 0u) atomicMax(&qmax[(size_t)lrel * SC_CNT_STRIDE], s_max);
   // exclusive scan of the per-bin counts (bins <= 1024 = 4 per thread) + one global reservation per non-empty bin
   unsigned c4[SC_BINS_PER_THREAD], tsum = 0;
@@ -219,6 +277,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   if (lane == 63) s_wsum[wave] = incl;
   __syncthreads();
+  EMIT_T(2);
   unsigned woff = 0;
   for (int w = 0; w < wave; ++w) woff += s_wsum[w];
   unsigned total = 0;
@@ -236,6 +295,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     }
   }
   __syncthreads();
+  EMIT_T(3);
   // place the records bin by bin in LDS
 #pragma unroll
   for (int q = 0; q < SC_PER_THREAD; ++q) {
@@ -244,27 +304,37 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       if ((emit_mask[q] >> k) & 1u) {
         const int bin = hk[q][k] >> log2_rows;
         const unsigned pos = s_off[bin] + atomicAdd(&s_cnt[bin], 1u);
-        s_rec[pos] = make_float4(__uint_as_float(hk[q][k] & row_mask), vxk[q][k], vyk[q][k], __uint_as_float((unsigned)bin));
+        s_val[pos] = make_float2(vxk[q][k], vyk[q][k]);
+        s_key[pos] = (hk[q][k] & row_mask) | ((unsigned)bin << 16);
       }
     }
   }
   __syncthreads();
+  EMIT_T(4);
   // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 8-byte + 2-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
   for (unsigned i = threadIdx.x; i < total; i += SC_EMIT_THREADS) {
-    const float4 r = s_rec[i];
-    const unsigned bin = __float_as_uint(r.w);
+    const float2 v = s_val[i];
+    const unsigned key = s_key[i];
+    const unsigned bin = key >> 16, row_in_bin = key & 0xffffu;
     const unsigned slot = s_base[bin] + (i - s_off[bin]);
     if ((long long)slot < cap) {
       const size_t q = ((size_t)lrel * bins + bin) * cap + slot;
-      queue_v[q] = make_float2(r.y, r.z);
-      queue_r[q] = (unsigned short)__float_as_uint(r.x);
+      queue_v[q] = v;
+      queue_r[q] = (unsigned short)row_in_bin;
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
-      const size_t row = ((size_t)bin << log2_rows) + __float_as_uint(r.x);
-      atomicAdd(table + 2 * row, r.y);
-      atomicAdd(table + 2 * row + 1, r.z);
+      const size_t row = ((size_t)bin << log2_rows) + row_in_bin;
+      atomicAdd(table + 2 * row, v.x);
+      atomicAdd(table + 2 * row + 1, v.y);
     }
   }
+  EMIT_T(5);
+#ifdef FNR_EMIT_TIMING
+  {
+    const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) & (EMIT_T_SLOTS - 1);
+    if (threadIdx.x < 8) g_emit_phase_clk[slot][threadIdx.x] += t_acc__[threadIdx.x];
+  }
+#endif
 }
 
 // LDS fp32 atomics (ds_add_f32) retire ~1 lane every 3 clocks per CU on gfx950 (measured: 200 G/s chip-wide,
@@ -319,19 +389,34 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   __syncthreads();
   const float2* qv = queue_v + (size_t)gbin * cap;
   const unsigned short* qr = queue_r + (size_t)gbin * cap;
+  // records in PAIRS: one 16-byte + one 4-byte load per two records (a bin's queue starts at a multiple of `cap`, a
+  // multiple of 1024 records).  8-byte + 2-byte loads ran at ~0.6x the bytes per clock of a CU (MI355X_MICROARCH: narrow
+  // accesses), and this kernel is bound by exactly that: one workgroup per CU streaming its queue.
+  const float4* qv2 = reinterpret_cast<const float4*>(qv);
+  const ushort2* qr2 = reinterpret_cast<const ushort2*>(qr);
+  const long long np = n >> 1;  // full pairs
   long long i = threadIdx.x;
-  for (; i + 3 * (long long)blockDim.x < n; i += 4 * (long long)blockDim.x) {  // 8 loads in flight per thread
-    float2 v[4];
-    unsigned row[4];
+  for (; i + 3 * (long long)blockDim.x < np; i += 4 * (long long)blockDim.x) {  // 8 loads (8 records) in flight per thread
+    float4 v[4];
+    ushort2 row[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      v[u] = qv[i + u * (long long)blockDim.x];
-      row[u] = qr[i + u * (long long)blockDim.x];
+      v[u] = qv2[i + u * (long long)blockDim.x];
+      row[u] = qr2[i + u * (long long)blockDim.x];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc_record(s_acc, row[u], v[u], scale);
+    for (int u = 0; u < 4; ++u) {
+      acc_record(s_acc, row[u].x, make_float2(v[u].x, v[u].y), scale);
+      acc_record(s_acc, row[u].y, make_float2(v[u].z, v[u].w), scale);
+    }
   }
-  for (; i < n; i += blockDim.x) acc_record(s_acc, qr[i], qv[i], scale);
+  for (; i < np; i += blockDim.x) {
+    const float4 v = qv2[i];
+    const ushort2 row = qr2[i];
+    acc_record(s_acc, row.x, make_float2(v.x, v.y), scale);
+    acc_record(s_acc, row.y, make_float2(v.z, v.w), scale);
+  }
+  if ((n & 1) && threadIdx.x == 0) acc_record(s_acc, qr[n - 1], qv[n - 1], scale);
   __syncthreads();
   float2* dst = grid.table + ((size_t)level << grid.log2_T) + (size_t)bin * rows;
   for (int e2 = threadIdx.x; e2 < rows; e2 += blockDim.x) {
@@ -566,6 +651,22 @@ __global__ __launch_bounds__(64) void k_prop_reduce(const float* __restrict__ pa
 }  // namespace fnr
 
 using namespace fnr;
+
+#ifdef FNR_EMIT_TIMING
+extern "C" int fnr_debug_emit_phases(unsigned long long* out_host, int reset) {
+  static unsigned* host = nullptr;
+  if (!host) host = (unsigned*)malloc(sizeof(unsigned) * EMIT_T_SLOTS * 8);
+  FNR_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_emit_phase_clk), sizeof(unsigned) * EMIT_T_SLOTS * 8));
+  for (int k = 0; k < 8; ++k) out_host[k] = 0;
+  for (int i = 0; i < EMIT_T_SLOTS; ++i)
+    for (int k = 0; k < 8; ++k) out_host[k] += host[i * 8 + k];
+  if (reset) {
+    memset(host, 0, sizeof(unsigned) * EMIT_T_SLOTS * 8);
+    FNR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_emit_phase_clk), host, sizeof(unsigned) * EMIT_T_SLOTS * 8));
+  }
+  return FNR_OK;
+}
+#endif
 
 extern "C" size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
   const ScatterPlan p = scatter_plan(n_samples, n_levels, log2_hashmap_size);

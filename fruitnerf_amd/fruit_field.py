@@ -41,6 +41,10 @@ class SceneContraction(nn.Module):
 # FNR_MLP_FP32: exact fp32 MFMA chains; FNR_MLP_BF16: bf16 operands (throughput mode, not parity grade);
 # FNR_MLP_BF16X3: exact three-way bf16 split, fp32-grade results on the bf16 matrix pipe (csrc/field_bf16.hpp)
 MLP_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+# "auto": the fastest PARITY-GRADE arithmetic per field shape, as measured on MI355X:
+#   `fruit_nerf`      fp32 (its bf16x3 kernels are only ~3 % faster per step and the fp32 chain is bit-for-bit an fmaf chain)
+#   `fruit_nerf_big`  bf16x3: the semantic branch's backward (30 -> 128 -> 128 -> 64 -> head) runs weight-streamed on the
+#                     bf16 pipe, 2.26 -> 0.72 ms per 8192-ray step; forward, colour and base stay on fp32 MFMA
 
 
 class FruitField(nn.Module):
@@ -58,9 +62,9 @@ class FruitField(nn.Module):
         super().__init__()
         # arithmetic of the MLP GEMMs (include/fruitnerf_hip.h: FNR_MLP_*); not a reference argument.  None -> the
         # FNR_MLP_PRECISION environment variable, else fp32 (the parity path)
-        self.mlp_precision = mlp_precision or os.environ.get("FNR_MLP_PRECISION", "fp32")
-        if self.mlp_precision not in MLP_MODES:
-            raise ValueError(f"mlp_precision {self.mlp_precision!r}: one of {sorted(MLP_MODES)}")
+        self.mlp_precision = mlp_precision or os.environ.get("FNR_MLP_PRECISION", "auto")
+        if self.mlp_precision not in MLP_MODES and self.mlp_precision != "auto":
+            raise ValueError(f"mlp_precision {self.mlp_precision!r}: one of {sorted(MLP_MODES) + ['auto']}")
         # fruit_field.py:98-113
         self.register_buffer("aabb", aabb.clone().float())
         self.geo_feat_dim = geo_feat_dim
@@ -176,10 +180,15 @@ class FruitField(nn.Module):
         for i, lyr in enumerate(self.mlp_head.layers):
             net.col_w[i], net.col_b[i] = P(lyr.weight), P(lyr.bias)
         net.embedding = P(self.embedding_appearance.embedding.weight)
-        net.mlp_mode = MLP_MODES[self.mlp_precision]
+        net.mlp_mode = MLP_MODES[self.resolved_mlp_precision()]
         cache[grads] = (key, net)
         self._net_c = net  # non-None marks the cache valid (reset by _apply / adopt_arena)
         return net
+
+    def resolved_mlp_precision(self) -> str:
+        if self.mlp_precision != "auto":
+            return self.mlp_precision
+        return "fp32" if self.geo_feat_dim == 15 else "bf16x3"
 
     def warp_struct(self) -> L.fnr_warp:
         # fruit_field.py:169-175: contraction + (x+2)/4, or aabb normalisation when spatial_distortion is None

@@ -60,7 +60,7 @@ class FruitNerfModelConfig:
     disable_scene_contraction: bool = False
     use_gradient_scaling: bool = False
     eval_num_rays_per_chunk: int = 1 << 15
-    mlp_precision: Optional[str] = None   # "fp32" | "bf16" | "bf16x3" (FruitField.mlp_precision; None: env / fp32)
+    mlp_precision: Optional[str] = None   # "auto" | "fp32" | "bf16x3" | "bf16" (FruitField.mlp_precision; None: env / auto)
     eval_outputs_on_cpu: bool = False   # True: full-image eval returns CPU tensors like the reference (fruit_nerf.py:245)
     # FruitNerfModelConfig proper
     semantic_loss_weight: float = 1.0

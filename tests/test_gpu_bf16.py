@@ -35,6 +35,19 @@ def test_bf16x3_losses_and_all_gradients(dev, monkeypatch, step, n_samples):
     _rerun(monkeypatch, t.test_losses_and_all_gradients, dev, step, n_samples, "fruit_nerf")
 
 
+@pytest.mark.parametrize("step,n_samples", [(0, 128), (12, 40)])
+def test_bf16x3_big_shape_losses_and_all_gradients(dev, monkeypatch, step, n_samples):
+    """fruit_nerf_big: the bf16x3 mode runs the semantic branch's backward (30 -> 128 -> 128 -> 64 -> head) as the
+    weight-streamed cooperative-dW kernel on the bf16 pipe; forward, colour and base stay on fp32 MFMA."""
+    from tests import test_gpu_training_parity as t
+    _rerun(monkeypatch, t.test_losses_and_all_gradients, dev, step, n_samples, "fruit_nerf_big")
+
+
+def test_bf16x3_big_shape_fused_step_matches_the_autograd_step(dev, monkeypatch):
+    from tests import test_gpu_training_parity as t
+    _rerun(monkeypatch, t.test_fused_step_matches_the_autograd_step, dev, "fruit_nerf_big")
+
+
 def test_bf16x3_three_training_steps_track_the_oracle(dev, monkeypatch):
     from tests import test_gpu_training_parity as t
     _rerun(monkeypatch, t.test_three_training_steps_track_the_oracle, dev)
@@ -60,12 +73,12 @@ def test_bf16x3_model_matches_the_reference_model(dev, monkeypatch):
     _rerun(monkeypatch, t.test_hip_model_matches_the_reference_model, dev)
 
 
-def _field_pair(dev, precision, seed=2):
-    cfg = util.small_config(log2=16)
+def _field_pair(dev, precision, seed=2, shape="fruit_nerf"):
+    cfg = util.small_config(log2=16) if shape == "fruit_nerf" else util.big_config(log2=16)
     om = util.make_oracle(cfg, seed=seed)
     ref = util.make_hip_like(om, dev)
     alt = util.make_hip_like(om, dev)
-    assert ref.field.mlp_precision == "fp32"
+    ref.field.mlp_precision = "fp32"
     alt.field.mlp_precision = precision
     return ref, alt
 
@@ -101,15 +114,15 @@ def test_bf16_modes_vs_the_fp32_kernels_forward(dev, precision, tol_rgb, tol_log
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-4), ("bf16", 0.2)])
-@pytest.mark.parametrize("S", [48, 40])
-def test_bf16_modes_vs_the_fp32_kernels_backward(dev, precision, tol, S):
+@pytest.mark.parametrize("S,shape", [(48, "fruit_nerf"), (40, "fruit_nerf"), (48, "fruit_nerf_big"), (37, "fruit_nerf_big")])
+def test_bf16_modes_vs_the_fp32_kernels_backward(dev, precision, tol, S, shape):
     """d_feats and every MLP / embedding gradient of fnr_field_mlp_bwd in the bf16-pipe modes vs the fp32 kernels
     (S = 40: tiles straddle rays).  bf16x3 (three piece products in the backward pass): max error relative to each
     tensor's max |g| within the 5e-4 bar of the oracle tests (measured 5e-6 .. 2e-4).  Plain bf16: L2-relative error —
     the random zero-mean upstream gradients of this test make the weight gradients sums with ~100x cancellation and
     bf16-sized pre-activation errors flip ReLU gates, so max-norm errors of single elements reach 10-25 %."""
     from fruitnerf_amd import _kernels as K
-    ref, alt = _field_pair(dev, precision, seed=4)
+    ref, alt = _field_pair(dev, precision, seed=4, shape=shape)
     R = 96
     N = R * S
     o, d, pa, cam = util.random_rays(R, 7, seed=9)
