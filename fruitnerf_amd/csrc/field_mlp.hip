@@ -46,6 +46,8 @@ int field_mlp_fwd_bf16(int mode, const FieldPtrs& p, const float* packed, void* 
                        const RaysDev& rd, int S, long long N, const float2* feats, const uint8_t* selector, float* density,
                        float* rgb, float* logit, float* geo_out, float* h_buf, hipStream_t st);
 size_t field_bf16_image_bytes();
+int field_mlp_fwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, const float* packed, long long N,
+                               const float* h_buf, float* logit, hipStream_t st);
 // workspace layout of fnr_field_mlp_fwd: [fp32 fragment image | bf16 fragment image (3 pieces) | per-ray colour bias]
 static inline size_t fwd_ws_packed_bytes() { return ((size_t)(FIELD_MAX_PACKED_FLOATS + 64) * sizeof(float) + 255) / 256 * 256; }
 size_t field_fwd_ws_image_offset() { return fwd_ws_packed_bytes(); }
@@ -208,8 +210,8 @@ int field_mlp_fwd_launch(const FieldPtrs& p, const fnr_field_net* net, const Ray
   FNR_LAUNCH_CHECK();
   const long long n_tiles = (N + 15) / 16;
   const float2* f2 = reinterpret_cast<const float2*>(feats);
-  // bf16-pipe modes: the `fruit_nerf` shape; the `fruit_nerf_big` forward stays on fp32 MFMA (its backward runs the
-  // semantic branch on the bf16 pipe, field_mlp_bwd.hip)
+  // bf16-pipe modes: every layer of the `fruit_nerf` shape; of the `fruit_nerf_big` shape the semantic branch (below and
+  // in field_mlp_bwd.hip), base and colour MLPs stay on fp32 MFMA
   if constexpr (Cfg::NSEM == 2) {
     if (net->mlp_mode != FNR_MLP_FP32)
       return field_mlp_fwd_bf16(net->mlp_mode, p, packed, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),
@@ -228,6 +230,9 @@ int field_mlp_fwd_launch(const FieldPtrs& p, const fnr_field_net* net, const Ray
     hipLaunchKernelGGL((k_field_mlp_fwd<Cfg, PART_BASE_COLOR, 8>), dim3((unsigned)blocks), dim3(512), 0, st, packed,
                        ray_bias, rd, S, N, f2, selector, density, rgb, logit, geo_out, h_buf);
     FNR_LAUNCH_CHECK();
+    if (net->mlp_mode != FNR_MLP_FP32)  // semantic branch on the bf16 pipe, weight-streamed (field_mlp_bf16.hip)
+      return field_mlp_fwd_sem_big_bf16(net->mlp_mode, p, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),
+                                        packed, N, h_buf, logit, st);
     blocks = (n_tiles + 15) / 16;   // 120 KB of semantic weights: one 16-wave workgroup per CU
     if (blocks > (long long)device_cu_count()) blocks = device_cu_count();
     hipLaunchKernelGGL((k_field_mlp_fwd<Cfg, PART_SEM, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, packed, ray_bias,

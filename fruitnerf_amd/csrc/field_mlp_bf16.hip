@@ -7,6 +7,8 @@
 // the per-ray colour bias, the per-ray / per-camera finish of mlp_head layer 0 and k_reduce_dw are shared.
 // Replaces the same reference code: fruit_field.py:132-166,187-281 and its autograd.
 // Built shape: `fruit_nerf` (FieldCfgBase).  One wave = one PAIR of 16-sample tiles per iteration.
+#include <stdlib.h>
+
 #include "field_bf16.hpp"
 
 namespace fnr {
@@ -666,11 +668,11 @@ struct SegsBigP4 {  // transposed sem1
 
 constexpr int CS_LD = 72;     // words per scratch row: 64 hold the batch's 128 bf16 samples; 72 keeps the b128 reads conflict-free
 constexpr int CS_ROWS = 128;  // feature rows per operand
-template <int NS>
-constexpr int cs_words() { return 2 * NS * CS_ROWS * CS_LD; }  // [G | X][piece][row][CS_LD]
+template <int NS, int ROWS = CS_ROWS>
+constexpr int cs_words() { return 2 * NS * ROWS * CS_LD; }  // [G | X][piece][row][CS_LD]
 
 // this wave's tile (NB accumulator blocks) -> rows ROW0.. of operand array `arr`, columns 16 wave + j, as bf16 pieces
-template <int NS, int NB>
+template <int NS, int NB, int ROWS = CS_ROWS>
 __device__ __forceinline__ void cs_write(uint32_t* __restrict__ arr, int row0, const f32x4 (&a)[NB], int lane, int wave) {
   const int j = lane & 15, g = lane >> 4;
   __bf16* base = reinterpret_cast<__bf16*>(arr);
@@ -682,14 +684,14 @@ __device__ __forceinline__ void cs_write(uint32_t* __restrict__ arr, int row0, c
 #pragma unroll
       for (int pc = 0; pc < NS; ++pc) {
         const __bf16 pv = (__bf16)v;
-        base[(size_t)((pc * CS_ROWS + row0 + 16 * blk + 4 * g + r) * (2 * CS_LD)) + 16 * wave + j] = pv;
+        base[(size_t)((pc * ROWS + row0 + 16 * blk + 4 * g + r) * (2 * CS_LD)) + 16 * wave + j] = pv;
         if (pc + 1 < NS) v -= (float)pv;
       }
     }
 }
 
 // acc[s] += (G rows of block ob0 + s ob_step)^T (X rows of block ib) over the batch's 128 samples
-template <int NS, int NOBW>
+template <int NS, int NOBW, int ROWS = CS_ROWS>
 __device__ __forceinline__ void cs_dw(const uint32_t* __restrict__ sG, const uint32_t* __restrict__ sX, int ob0,
                                       int ob_step, int ib, f32x4 (&acc)[NOBW], int lane) {
   const int i = lane & 15, g = lane >> 4;
@@ -701,7 +703,7 @@ __device__ __forceinline__ void cs_dw(const uint32_t* __restrict__ sG, const uin
     const int kk = t / NOBW, ob = ob0 + (t % NOBW) * ob_step;
 #pragma unroll
     for (int pc = 0; pc < NS; ++pc)
-      dst[pc] = *reinterpret_cast<const bf16x8*>(sG + (pc * CS_ROWS + 16 * ob + i) * CS_LD + 16 * kk + 4 * g);
+      dst[pc] = *reinterpret_cast<const bf16x8*>(sG + (pc * ROWS + 16 * ob + i) * CS_LD + 16 * kk + 4 * g);
   };
   load_g(0, ga[0]);
 #pragma unroll
@@ -710,7 +712,7 @@ __device__ __forceinline__ void cs_dw(const uint32_t* __restrict__ sG, const uin
     if (s == 0) {
 #pragma unroll
       for (int pc = 0; pc < NS; ++pc)
-        xb[pc] = *reinterpret_cast<const bf16x8*>(sX + (pc * CS_ROWS + 16 * ib + i) * CS_LD + 16 * kk + 4 * g);
+        xb[pc] = *reinterpret_cast<const bf16x8*>(sX + (pc * ROWS + 16 * ib + i) * CS_LD + 16 * kk + 4 * g);
     }
     if (t + 1 < T) load_g(t + 1, ga[(t + 1) & 1]);
 #pragma unroll
@@ -722,7 +724,7 @@ __device__ __forceinline__ void cs_dw(const uint32_t* __restrict__ sG, const uin
   }
 }
 // bacc += (G rows of block ob)^T 1: every column of the block ends up with the rows' sums over the batch
-template <int NS>
+template <int NS, int ROWS = CS_ROWS>
 __device__ __forceinline__ void cs_bias(const uint32_t* __restrict__ sG, int ob, f32x4& bacc, int lane) {
   const int i = lane & 15, g = lane >> 4;
   bf16x8 ones;
@@ -732,7 +734,7 @@ __device__ __forceinline__ void cs_bias(const uint32_t* __restrict__ sG, int ob,
   for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
     for (int pc = NS - 1; pc >= 0; --pc) {
-      const bf16x8 ga = *reinterpret_cast<const bf16x8*>(sG + (pc * CS_ROWS + 16 * ob + i) * CS_LD + 16 * kk + 4 * g);
+      const bf16x8 ga = *reinterpret_cast<const bf16x8*>(sG + (pc * ROWS + 16 * ob + i) * CS_LD + 16 * kk + 4 * g);
       bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, ones, bacc, 0, 0, 0);
     }
 }
@@ -903,6 +905,83 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_sem_big_bf16(
   }
 }
 
+// ---- `fruit_nerf_big` semantic branch, forward (h [N,32] -> logit): the same weight streaming in two phases ------------
+template <class Cfg>
+struct SegsBigF2 {  // forward sem2, head
+  static constexpr int N = 2;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_SEM2 : Cfg::L_HEAD; }
+  static constexpr bool isT(int) { return false; }
+};
+
+template <class Cfg, int NS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_fwd_sem_big_bf16(
+    const float* __restrict__ packed, const __bf16* __restrict__ image, long long N, const float* __restrict__ h_buf,
+    float* __restrict__ logit) {
+  static_assert(Cfg::NSEM == 3 && Cfg::HB == 2 && Cfg::SEMB == 8, "fruit_nerf_big semantic shape");
+  constexpr int THREADS = 64 * WAVES;
+  constexpr int LS0 = Cfg::L_SEM0, LS1 = Cfg::L_SEM1, LS2 = Cfg::L_SEM2, LH = Cfg::L_HEAD;
+  using F1 = BfLds<Cfg, SegsBigP1<Cfg>, NS>;
+  using F2 = BfLds<Cfg, SegsBigF2<Cfg>, NS>;
+  constexpr int REGION = F1::BYTES > F2::BYTES ? F1::BYTES : F2::BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smem);
+  float* fbias = reinterpret_cast<float*>(smem + REGION);  // sem0 [128] | sem1 [128] | sem2 [64] | head [16]
+  for (int i = threadIdx.x; i < 336; i += THREADS) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LS0) + i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const long long per_batch = 16 * WAVES;
+  const long long n_batches = (N + per_batch - 1) / per_batch;
+  for (long long batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+    asm volatile("" ::: "memory");
+    const long long n = batch * per_batch + 16 * wave + j;
+    const bool valid = n < N;
+    const long long nn = valid ? n : N - 1;
+    f32x4 h[2];
+    h[0] = *reinterpret_cast<const f32x4*>(h_buf + (size_t)nn * 32 + 4 * g);
+    h[1] = *reinterpret_cast<const f32x4*>(h_buf + (size_t)nn * 32 + 16 + 4 * g);
+    __syncthreads();
+    F1::template stage<THREADS>(wl, image);
+    __syncthreads();
+    f32x4 s1[8], s2[8];
+    bf_layer1<NS, 8, 2>(F1::template seg<LS0, false>(wl), fbias, h, s1, lane);
+    relu_(s1);
+    bf_layer1<NS, 8, 8>(F1::template seg<LS1, false>(wl), fbias + 128, s1, s2, lane);
+    relu_(s2);
+    __syncthreads();
+    F2::template stage<THREADS>(wl, image);
+    __syncthreads();
+    f32x4 s3[4], hd[1];
+    bf_layer1<NS, 4, 8>(F2::template seg<LS2, false>(wl), fbias + 256, s2, s3, lane);
+    bf_layer1<NS, 1, 4>(F2::template seg<LH, false>(wl), fbias + 320, s3, hd, lane);
+    if (g == 0 && valid) logit[n] = hd[0][0];
+  }
+}
+
+int field_mlp_fwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, const float* packed, long long N,
+                               const float* h_buf, float* logit, hipStream_t st) {
+  using Cfg = FieldCfgBig;
+  __bf16* image = reinterpret_cast<__bf16*>(image_ws);
+  launch_pack_field_weights_bf16<Cfg>(p, mode == MLP_BF16 ? 1 : 3, image, st);
+  FNR_LAUNCH_CHECK();
+  constexpr int WAVES = 8;
+  const long long n_batches = (N + 16 * WAVES - 1) / (16 * WAVES);
+  long long blocks = n_batches;
+  if (blocks > (long long)device_cu_count()) blocks = device_cu_count();
+  auto launch = [&](auto kern, int bytes) -> int {
+    FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), bytes, st, packed, image, N, h_buf, logit);
+    FNR_LAUNCH_CHECK();
+    return FNR_OK;
+  };
+  if (mode == MLP_BF16) {
+    constexpr int bytes = BfLds<Cfg, SegsBigP1<Cfg>, 1>::BYTES + 336 * 4;
+    return launch(k_field_mlp_fwd_sem_big_bf16<Cfg, 1, WAVES>, bytes);
+  }
+  constexpr int bytes = BfLds<Cfg, SegsBigP1<Cfg>, 3>::BYTES + 336 * 4;
+  static_assert(bytes <= 160 * 1024, "fruit_nerf_big forward fragments exceed the LDS");
+  return launch(k_field_mlp_fwd_sem_big_bf16<Cfg, 3, WAVES>, bytes);
+}
+
 int field_mlp_bwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, const float* packed, long long N,
                                const float* h_saved, const float* d_logit, float* partials, long long blocks,
                                hipStream_t st) {
@@ -925,6 +1004,423 @@ int field_mlp_bwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, con
   constexpr int bytes = cs_words<2>() * 4 + (256 + 144) * 4;
   static_assert(bytes <= 160 * 1024, "fruit_nerf_big semantic branch exceeds the LDS");
   return launch(k_field_mlp_bwd_sem_big_bf16<Cfg, 3, 2>, bytes);
+}
+
+// =====================================================================================================================
+// `fruit_nerf` shape, backward, COOPERATIVE form (the kernels the bf16 modes launch).  Same building blocks as the
+// fruit_nerf_big semantic kernel above: one 16-sample tile per wave, 8 waves = a 128-sample batch per workgroup, dW
+// blocks owned by single waves over the batch (<= 6 accumulator blocks per wave instead of 144-164 registers), two waves
+// per SIMD.  The branch's forward (NSF pieces) and transposed (NS pieces) fragments stay resident next to the scratch
+// (no streaming at these sizes).  NSF = 3 / NS = 2 in the bf16x3 mode: the recomputed activations gate the ReLUs and
+// must reproduce the forward pass's signs.
+// =====================================================================================================================
+constexpr int CB_ROWS = 64;  // feature rows per scratch operand: layers are <= 64 wide
+template <int NS>
+constexpr int cb_words() { return cs_words<NS, CB_ROWS>(); }
+
+template <class Cfg, class SegsF, class SegsT, int NSF, int NS>
+struct CoopLds {
+  using F = BfLds<Cfg, SegsF, NSF>;
+  using T = BfLds<Cfg, SegsT, NS>;
+  static constexpr int SCR_OFF = F::BYTES + T::BYTES;
+  static constexpr int FB_OFF = SCR_OFF + cb_words<NS>() * 4;  // floats after the scratch
+};
+template <class Cfg>
+struct SegsColF {
+  static constexpr int N = 3;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_COL0 : i == 1 ? Cfg::L_COL1 : Cfg::L_COL2; }
+  static constexpr bool isT(int) { return false; }
+};
+template <class Cfg>
+struct SegsColT {
+  static constexpr int N = 3;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_COL0 : i == 1 ? Cfg::L_COL1 : Cfg::L_COL2; }
+  static constexpr bool isT(int) { return true; }
+};
+template <class Cfg>
+struct SegsSemF {
+  static constexpr int N = 2;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_SEM0 : Cfg::L_SEM1; }
+  static constexpr bool isT(int) { return false; }
+};
+template <class Cfg>
+struct SegsSemT {
+  static constexpr int N = 2;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_SEM1 : Cfg::L_HEAD; }
+  static constexpr bool isT(int) { return true; }
+};
+template <class Cfg>
+struct SegsBaseF {
+  static constexpr int N = 2;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_BASE0 : Cfg::L_BASE1; }
+  static constexpr bool isT(int) { return false; }
+};
+template <class Cfg>
+struct SegsBaseT {
+  static constexpr int N = 2;
+  static constexpr int layer(int i) { return i == 0 ? Cfg::L_BASE0 : Cfg::L_BASE1; }
+  static constexpr bool isT(int) { return true; }
+};
+
+template <int N>
+__device__ __forceinline__ void relu_mask1_(f32x4 (&G)[N], const f32x4 (&act)[N]) {
+#pragma unroll
+  for (int b = 0; b < N; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[b][r] = (act[b][r] > 0.0f) ? G[b][r] : 0.0f;
+}
+__device__ __forceinline__ void zero_blocks(float* __restrict__ dst, int floats, int threads) {
+  for (int i = threadIdx.x; i < floats; i += threads) dst[i] = 0.0f;
+}
+
+// ---- colour branch ---------------------------------------------------------------------------------------------------
+template <class Cfg, int NSF, int NS>
+__global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_color_coop(
+    const float* __restrict__ packed, const __bf16* __restrict__ image, const float* __restrict__ ray_bias, RaysDev rays,
+    int S, long long N, const float* __restrict__ h_saved, const float* __restrict__ d_rgb, float* __restrict__ d_h,
+    float* __restrict__ gsum_tile, float* __restrict__ gsum_extra, float* __restrict__ partials) {
+  static_assert(Cfg::HB == 1, "`fruit_nerf` shape");
+  constexpr int WAVES = 8, THREADS = 512;
+  constexpr int LC0 = Cfg::L_COL0, LC1 = Cfg::L_COL1, LC2 = Cfg::L_COL2;
+  using CL = CoopLds<Cfg, SegsColF<Cfg>, SegsColT<Cfg>, NSF, NS>;
+  using F = typename CL::F;
+  using T = typename CL::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* wf = reinterpret_cast<bf16x8*>(smem);
+  bf16x8* wt = reinterpret_cast<bf16x8*>(smem + F::BYTES);
+  uint32_t* sG = reinterpret_cast<uint32_t*>(smem + CL::SCR_OFF);
+  uint32_t* sX = sG + NS * CB_ROWS * CS_LD;
+  float* fbias = reinterpret_cast<float*>(smem + CL::FB_OFF);  // col1 [64] | col2 [16]
+  F::template stage<THREADS>(wf, image);
+  T::template stage<THREADS>(wt, image);
+  for (int i = threadIdx.x; i < 64; i += THREADS) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LC1) + i];
+  for (int i = threadIdx.x; i < 16; i += THREADS) fbias[64 + i] = packed[Cfg::W_TOTAL + Cfg::boff(LC2) + i];
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // owned blocks: col2 (ob 0, ib = w; waves 0..3), col1 (ob = (w >> 2) + 2 s, ib = w & 3), col0's h block (ob = w; waves 0..3);
+  // bias blocks: col1 ob = w (waves 0..3), col2 (wave 4)
+  f32x4 accC[1], accB[2], accA[1];
+  f32x4 bB = {0.f, 0.f, 0.f, 0.f}, bC = bB;
+  zero_vec_bf(accC);
+  zero_vec_bf(accB);
+  zero_vec_bf(accA);
+
+  const long long n_batches = (N + 127) / 128, n_tiles = (N + 15) / 16;
+  for (long long batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+    asm volatile("" ::: "memory");
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int j = lane & 15, g = lane >> 4;
+    const long long tile = batch * 8 + wave;
+    const long long n = tile * 16 + j;
+    const bool valid = n < N;
+    const long long nn = valid ? n : N - 1;
+    const long long ray = nn / S;
+    f32x4 h[1], c1[4], c2[4], c3[1];
+    h[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * 16 + 4 * g);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) c1[ob] = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)ray * 64 + 16 * ob + 4 * g);
+    __syncthreads();  // fragments staged (first batch) / the previous batch's last scratch reads
+    {
+      bf16x8 x[1][NSF];
+      bf_operand<NSF, 1>(h, x);
+      bf_layer_acc1<NSF, 4, 1>(F::template seg<LC0, false>(wf), x, c1, lane);
+    }
+    relu_(c1);
+    bf_layer1<NSF, 4, 4>(F::template seg<LC1, false>(wf), fbias, c1, c2, lane);
+    relu_(c2);
+    bf_layer1<NSF, 1, 4>(F::template seg<LC2, false>(wf), fbias + 64, c2, c3, lane);
+    f32x4 G3[1];
+    G3[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g == 0 && valid) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float sg = 1.0f / (1.0f + expf(-c3[0][r]));
+        G3[0][r] = d_rgb[3 * n + r] * sg * (1.0f - sg);
+      }
+    }
+    // round 1: G = G3, X = c2 -> dW / db of col2
+    cs_write<NS, 1, CB_ROWS>(sG, 0, G3, lane, wave);
+    cs_write<NS, 4, CB_ROWS>(sX, 0, c2, lane, wave);
+    __syncthreads();
+    if (wave < 4) cs_dw<NS, 1, CB_ROWS>(sG, sX, 0, 0, wave, accC, lane);
+    if (wave == 4) cs_bias<NS, CB_ROWS>(sG, 0, bC, lane);
+    f32x4 G2[4];
+    bf_layer_T1<NS, 4, 1>(T::template seg<LC2, true>(wt), G3, G2, lane);
+    relu_mask1_(G2, c2);
+    // round 2: G = G2, X = c1 -> col1
+    __syncthreads();
+    cs_write<NS, 4, CB_ROWS>(sG, 0, G2, lane, wave);
+    cs_write<NS, 4, CB_ROWS>(sX, 0, c1, lane, wave);
+    __syncthreads();
+    cs_dw<NS, 2, CB_ROWS>(sG, sX, wave >> 2, 2, wave & 3, accB, lane);
+    if (wave < 4) cs_bias<NS, CB_ROWS>(sG, wave, bB, lane);
+    f32x4 G1[4];
+    bf_layer_T1<NS, 4, 4>(T::template seg<LC1, true>(wt), G2, G1, lane);
+    relu_mask1_(G1, c1);
+    // round 3: G = G1, X = h -> the h block of col0; the 48 ray-constant inputs and the bias are finished per ray by
+    // k_color_ray_grads from the tiles' 64 row sums of G1 (exact fp32 DPP sums)
+    __syncthreads();
+    cs_write<NS, 4, CB_ROWS>(sG, 0, G1, lane, wave);
+    cs_write<NS, 1, CB_ROWS>(sX, 0, h, lane, wave);
+    __syncthreads();
+    if (wave < 4) cs_dw<NS, 1, CB_ROWS>(sG, sX, wave, 0, 0, accA, lane);
+    if (tile < n_tiles) {
+      const long long ray0 = __shfl(ray, lane & 48, 64);
+      const bool uniform = __all(ray == ray0);  // invalid lanes were clamped to the last sample's ray
+      if (uniform) {
+        float mine = 0.0f;  // lane (g, j) keeps feature 16 (j >> 2) + 4 g + (j & 3)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float t = row16_sum_bf(G1[ob][r]);
+            mine = (j == 4 * ob + r) ? t : mine;
+          }
+        gsum_tile[(size_t)tile * 64 + 16 * (j >> 2) + 4 * g + (j & 3)] = mine;
+      } else if (valid) {  // tile straddles rays (S % 16 != 0): per-sample contributions
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(&gsum_extra[(size_t)ray * 64 + 16 * ob + 4 * g + r], G1[ob][r]);
+      }
+    }
+    f32x4 Gh[1];
+    bf_layer_T1<NS, 1, 4>(T::template seg<LC0, true>(wt), G1, Gh, lane);
+    if (valid) *reinterpret_cast<f32x4*>(d_h + (size_t)n * 16 + 4 * g) = Gh[0];
+  }
+  const int lane = lane0;
+  float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
+  float* pb = part + Cfg::W_TOTAL;
+  // col0: this kernel owns input block 0 (h); blocks 1..3 (ray-constant inputs) and the bias belong to
+  // k_color_ray_grads, which only overwrites SOME workgroups' images: zero them here
+  constexpr int NIB0 = Cfg::HB + 3;
+  for (int i = threadIdx.x; i < 4 * 3 * 256; i += THREADS) {
+    const int blk = i >> 8, ob = blk / 3, ib = 1 + blk % 3;
+    part[Cfg::woff(LC0) + (ob * NIB0 + ib) * 256 + (i & 255)] = 0.0f;
+  }
+  for (int i = threadIdx.x; i < 64; i += THREADS) pb[Cfg::boff(LC0) + i] = 0.0f;
+  if (wave < 4) {
+    store_dw_block(part + Cfg::woff(LC0), wave, 0, NIB0, accA[0], lane);
+    store_dw_block(part + Cfg::woff(LC2), 0, wave, 4, accC[0], lane);
+    store_bias_block(pb + Cfg::boff(LC1), wave, bB, lane);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) store_dw_block(part + Cfg::woff(LC1), (wave >> 2) + 2 * s, wave & 3, 4, accB[s], lane);
+  if (wave == 4) store_bias_block(pb + Cfg::boff(LC2), 0, bC, lane);
+}
+
+// ---- semantic branch -------------------------------------------------------------------------------------------------
+template <class Cfg, int NSF, int NS>
+__global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_sem_coop(
+    const float* __restrict__ packed, const __bf16* __restrict__ image, long long N, const float* __restrict__ h_saved,
+    const float* __restrict__ d_logit, float* __restrict__ partials) {
+  static_assert(Cfg::NSEM == 2 && Cfg::HB == 1, "`fruit_nerf` shape");
+  constexpr int WAVES = 8, THREADS = 512;
+  constexpr int LS0 = Cfg::L_SEM0, LS1 = Cfg::L_SEM1, LH = Cfg::L_HEAD;
+  using CL = CoopLds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS>;
+  using F = typename CL::F;
+  using T = typename CL::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* wf = reinterpret_cast<bf16x8*>(smem);
+  bf16x8* wt = reinterpret_cast<bf16x8*>(smem + F::BYTES);
+  uint32_t* sG = reinterpret_cast<uint32_t*>(smem + CL::SCR_OFF);
+  uint32_t* sX = sG + NS * CB_ROWS * CS_LD;
+  float* fbias = reinterpret_cast<float*>(smem + CL::FB_OFF);  // sem0 [64] | sem1 [64]
+  F::template stage<THREADS>(wf, image);
+  T::template stage<THREADS>(wt, image);
+  for (int i = threadIdx.x; i < 128; i += THREADS) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LS0) + i];
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // owned blocks: head (ob 0, ib = w; waves 0..3), sem1 (ob = (w >> 2) + 2 s, ib = w & 3), sem0 (ob = w, ib 0; waves 0..3);
+  // bias blocks: sem1 ob = w (waves 0..3), head (wave 4), sem0 ob = w - 4 (waves 4..7)
+  f32x4 accH[1], accB[2], accA[1];
+  f32x4 bB = {0.f, 0.f, 0.f, 0.f}, bX = bB, bA = bB;  // bX: head's bias on wave 4
+  zero_vec_bf(accH);
+  zero_vec_bf(accB);
+  zero_vec_bf(accA);
+  const long long n_batches = (N + 127) / 128;
+  for (long long batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+    asm volatile("" ::: "memory");
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int j = lane & 15, g = lane >> 4;
+    const long long n = (batch * 8 + wave) * 16 + j;
+    const bool valid = n < N;
+    const long long nn = valid ? n : N - 1;
+    f32x4 h[1], s1[4], s2[4];
+    h[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * 16 + 4 * g);
+    __syncthreads();
+    bf_layer1<NSF, 4, 1>(F::template seg<LS0, false>(wf), fbias, h, s1, lane);
+    relu_(s1);
+    bf_layer1<NSF, 4, 4>(F::template seg<LS1, false>(wf), fbias + 64, s1, s2, lane);
+    f32x4 Gl[1];
+    Gl[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g == 0 && valid) Gl[0][0] = d_logit[n];
+    // round 1: G = dlogit, X = s2 -> SemanticFieldHead
+    cs_write<NS, 1, CB_ROWS>(sG, 0, Gl, lane, wave);
+    cs_write<NS, 4, CB_ROWS>(sX, 0, s2, lane, wave);
+    __syncthreads();
+    if (wave < 4) cs_dw<NS, 1, CB_ROWS>(sG, sX, 0, 0, wave, accH, lane);
+    if (wave == 4) cs_bias<NS, CB_ROWS>(sG, 0, bX, lane);
+    f32x4 Gs2[4];
+    bf_layer_T1<NS, 4, 1>(T::template seg<LH, true>(wt), Gl, Gs2, lane);  // no activation on mlp_semantics' last layer
+    // round 2: G = Gs2, X = s1 -> sem1
+    __syncthreads();
+    cs_write<NS, 4, CB_ROWS>(sG, 0, Gs2, lane, wave);
+    cs_write<NS, 4, CB_ROWS>(sX, 0, s1, lane, wave);
+    __syncthreads();
+    cs_dw<NS, 2, CB_ROWS>(sG, sX, wave >> 2, 2, wave & 3, accB, lane);
+    if (wave < 4) cs_bias<NS, CB_ROWS>(sG, wave, bB, lane);
+    f32x4 Gs1[4];
+    bf_layer_T1<NS, 4, 4>(T::template seg<LS1, true>(wt), Gs2, Gs1, lane);
+    relu_mask1_(Gs1, s1);
+    // round 3: G = Gs1, X = h -> sem0 (input = detached geo: no dX)
+    __syncthreads();
+    cs_write<NS, 4, CB_ROWS>(sG, 0, Gs1, lane, wave);
+    cs_write<NS, 1, CB_ROWS>(sX, 0, h, lane, wave);
+    __syncthreads();
+    if (wave < 4) cs_dw<NS, 1, CB_ROWS>(sG, sX, wave, 0, 0, accA, lane);
+    if (wave >= 4) cs_bias<NS, CB_ROWS>(sG, wave - 4, bA, lane);
+  }
+  const int lane = lane0;
+  float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
+  float* pb = part + Cfg::W_TOTAL;
+  if (wave < 4) {
+    store_dw_block(part + Cfg::woff(LH), 0, wave, 4, accH[0], lane);
+    store_dw_block(part + Cfg::woff(LS0), wave, 0, 1, accA[0], lane);
+    store_bias_block(pb + Cfg::boff(LS1), wave, bB, lane);
+  } else {
+    store_bias_block(pb + Cfg::boff(LS0), wave - 4, bA, lane);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) store_dw_block(part + Cfg::woff(LS1), (wave >> 2) + 2 * s, wave & 3, 4, accB[s], lane);
+  if (wave == 4) store_bias_block(pb + Cfg::boff(LH), 0, bX, lane);
+}
+
+// ---- base branch -----------------------------------------------------------------------------------------------------
+template <class Cfg, int NSF, int NS>
+__global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
+    const float* __restrict__ packed, const __bf16* __restrict__ image, long long N, const float2* __restrict__ feats,
+    const uint8_t* __restrict__ selector, const float* __restrict__ d_density, const float* __restrict__ d_h,
+    float2* __restrict__ d_feats, float* __restrict__ partials) {
+  static_assert(Cfg::HB == 1, "`fruit_nerf` shape");
+  constexpr int WAVES = 8, THREADS = 512;
+  constexpr int LB0 = Cfg::L_BASE0, LB1 = Cfg::L_BASE1;
+  using CL = CoopLds<Cfg, SegsBaseF<Cfg>, SegsBaseT<Cfg>, NSF, NS>;
+  using F = typename CL::F;
+  using T = typename CL::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* wf = reinterpret_cast<bf16x8*>(smem);
+  bf16x8* wt = reinterpret_cast<bf16x8*>(smem + F::BYTES);
+  uint32_t* sG = reinterpret_cast<uint32_t*>(smem + CL::SCR_OFF);
+  uint32_t* sX = sG + NS * CB_ROWS * CS_LD;
+  float* fbias = reinterpret_cast<float*>(smem + CL::FB_OFF);  // base0 [64] | base1 [16]
+  F::template stage<THREADS>(wf, image);
+  T::template stage<THREADS>(wt, image);
+  for (int i = threadIdx.x; i < 80; i += THREADS) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LB0) + i];
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // owned blocks: base1 (ob 0, ib = w; waves 0..3), base0 (ob = w >> 1, ib = w & 1); bias: base1 (wave 4), base0 ob = w - 4 (waves 4..7)
+  f32x4 accB[1], accA[1];
+  f32x4 bB = {0.f, 0.f, 0.f, 0.f}, bA = bB;
+  zero_vec_bf(accB);
+  zero_vec_bf(accA);
+  const long long n_batches = (N + 127) / 128;
+  for (long long batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+    asm volatile("" ::: "memory");
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int j = lane & 15, g = lane >> 4;
+    const long long n = (batch * 8 + wave) * 16 + j;
+    const bool valid = n < N;
+    const long long nn = valid ? n : N - 1;
+    f32x4 x0[2], a1[4], h[1];
+    load_hash_block(feats, N, nn, g, x0);
+    f32x4 Gh[1];
+    Gh[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (valid) Gh[0] = *reinterpret_cast<const f32x4*>(d_h + (size_t)n * 16 + 4 * g);
+    __syncthreads();
+    bf_layer1<NSF, 4, 2>(F::template seg<LB0, false>(wf), fbias, x0, a1, lane);
+    relu_(a1);
+    bf_layer1<NSF, 1, 4>(F::template seg<LB1, false>(wf), fbias + 64, a1, h, lane);
+    if (valid && g == 0) {
+      const bool sel = selector ? (selector[n] != 0) : true;
+      const float te = expf(fminf(fmaxf(h[0][0], -15.0f), 15.0f));  // trunc_exp backward (fruit_field.py:191)
+      Gh[0][0] = sel ? d_density[n] * te : 0.0f;                   // colour block has a zero row 0
+    }
+    // round 1: G = Gh, X = a1 -> base1
+    cs_write<NS, 1, CB_ROWS>(sG, 0, Gh, lane, wave);
+    cs_write<NS, 4, CB_ROWS>(sX, 0, a1, lane, wave);
+    __syncthreads();
+    if (wave < 4) cs_dw<NS, 1, CB_ROWS>(sG, sX, 0, 0, wave, accB, lane);
+    if (wave == 4) cs_bias<NS, CB_ROWS>(sG, 0, bB, lane);
+    f32x4 Ga[4];
+    bf_layer_T1<NS, 4, 1>(T::template seg<LB1, true>(wt), Gh, Ga, lane);
+    relu_mask1_(Ga, a1);
+    // round 2: G = Ga, X = hash features -> base0
+    __syncthreads();
+    cs_write<NS, 4, CB_ROWS>(sG, 0, Ga, lane, wave);
+    cs_write<NS, 2, CB_ROWS>(sX, 0, x0, lane, wave);
+    __syncthreads();
+    cs_dw<NS, 1, CB_ROWS>(sG, sX, wave >> 1, 0, wave & 1, accA, lane);
+    if (wave >= 4) cs_bias<NS, CB_ROWS>(sG, wave - 4, bA, lane);
+    f32x4 Gx[2];
+    bf_layer_T1<NS, 2, 4>(T::template seg<LB0, true>(wt), Ga, Gx, lane);
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        d_feats[(size_t)(4 * m + g) * N + n] = make_float2(Gx[m >> 1][2 * (m & 1)], Gx[m >> 1][2 * (m & 1) + 1]);
+    }
+  }
+  const int lane = lane0;
+  float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
+  float* pb = part + Cfg::W_TOTAL;
+  if (wave < 4) store_dw_block(part + Cfg::woff(LB1), 0, wave, 4, accB[0], lane);
+  store_dw_block(part + Cfg::woff(LB0), wave >> 1, wave & 1, 2, accA[0], lane);
+  if (wave == 4) store_bias_block(pb + Cfg::boff(LB1), 0, bB, lane);
+  if (wave >= 4) store_bias_block(pb + Cfg::boff(LB0), wave - 4, bA, lane);
+}
+
+template <int NSF, int NS>
+static int bwd_launch_coop(const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd, int S,
+                           long long N, const float2* feats, const float* h_saved, const uint8_t* selector,
+                           const float* d_density, const float* d_rgb, const float* d_logit, float2* d_feats, float* d_h,
+                           float* gsum_tile, float* gsum_extra, float* partials, long long blocks, int branch,
+                           hipStream_t st) {
+  using Cfg = FieldCfgBase;
+  // exactly `blocks` workgroups: every one of the caller's partial images must receive this branch's blocks (a
+  // workgroup without a batch stores zeros)
+  auto attr = [](auto kern, int bytes) -> int {
+    FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return FNR_OK;
+  };
+  if (branch == 0) {
+    using CL = CoopLds<Cfg, SegsColF<Cfg>, SegsColT<Cfg>, NSF, NS>;
+    constexpr int bytes = CL::FB_OFF + 80 * 4;
+    static_assert(bytes <= 160 * 1024, "colour branch exceeds the LDS");
+    auto kern = k_field_mlp_bwd_color_coop<Cfg, NSF, NS>;
+    static int once = attr(kern, bytes);
+    if (once) return once;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, ray_bias, rd, S, N, h_saved, d_rgb,
+                       d_h, gsum_tile, gsum_extra, partials);
+  } else if (branch == 1) {
+    using CL = CoopLds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS>;
+    constexpr int bytes = CL::FB_OFF + 128 * 4;
+    static_assert(bytes <= 160 * 1024, "semantic branch exceeds the LDS");
+    auto kern = k_field_mlp_bwd_sem_coop<Cfg, NSF, NS>;
+    static int once = attr(kern, bytes);
+    if (once) return once;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, h_saved, d_logit, partials);
+  } else {
+    using CL = CoopLds<Cfg, SegsBaseF<Cfg>, SegsBaseT<Cfg>, NSF, NS>;
+    constexpr int bytes = CL::FB_OFF + 80 * 4;
+    static_assert(bytes <= 160 * 1024, "base branch exceeds the LDS");
+    auto kern = k_field_mlp_bwd_base_coop<Cfg, NSF, NS>;
+    static int once = attr(kern, bytes);
+    if (once) return once;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, feats, selector, d_density, d_h,
+                       d_feats, partials);
+  }
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
 }
 
 // ---- launch helpers (called from field_mlp.hip / field_mlp_bwd.hip when fnr_field_net.mlp_mode != 0) --------------
@@ -1017,6 +1513,17 @@ int field_mlp_bwd_bf16(int mode, int branch, const FieldPtrs& p, bool pack, cons
   if (pack) {
     launch_pack_field_weights_bf16<FieldCfgBase>(p, mode == MLP_BF16 ? 1 : 3, image, st);
     FNR_LAUNCH_CHECK();
+  }
+  static const bool per_wave = [] {
+    const char* e = getenv("FNR_BF16_BWD");
+    return e && e[0] == 'w';
+  }();
+  if (!per_wave) {
+    if (mode == MLP_BF16)
+      return bwd_launch_coop<1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit,
+                                   d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+    return bwd_launch_coop<3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit,
+                                 d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
   }
   if (mode == MLP_BF16)
     return bwd_launch_bf16<1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit, d_feats,

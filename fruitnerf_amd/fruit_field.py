@@ -41,10 +41,12 @@ class SceneContraction(nn.Module):
 # FNR_MLP_FP32: exact fp32 MFMA chains; FNR_MLP_BF16: bf16 operands (throughput mode, not parity grade);
 # FNR_MLP_BF16X3: exact three-way bf16 split, fp32-grade results on the bf16 matrix pipe (csrc/field_bf16.hpp)
 MLP_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
-# "auto": the fastest PARITY-GRADE arithmetic per field shape, as measured on MI355X:
-#   `fruit_nerf`      fp32 (its bf16x3 kernels are only ~3 % faster per step and the fp32 chain is bit-for-bit an fmaf chain)
-#   `fruit_nerf_big`  bf16x3: the semantic branch's backward (30 -> 128 -> 128 -> 64 -> head) runs weight-streamed on the
-#                     bf16 pipe, 2.26 -> 0.72 ms per 8192-ray step; forward, colour and base stay on fp32 MFMA
+# "auto" = "bf16x3", the fastest PARITY-GRADE arithmetic on MI355X for both built shapes (the fp32
+# MFMA runs at 1/16 of the bf16 rate on gfx950, the exact three-way split costs 6 / 3 bf16 products per fp32 product):
+#   `fruit_nerf`      every MLP kernel, 1.065 -> 0.987 ms per 4096-ray step
+#   `fruit_nerf_big`  the semantic branch (30 -> 128 -> 128 -> 64 -> head) forward and backward, weight-streamed,
+#                     7.06 -> 5.30 ms per 8192-ray step; its base and colour MLPs stay on fp32 MFMA
+# "fp32" keeps the exact fmaf-chain kernels (v_mfma_f32_16x16x4_f32); both pass the same oracle-parity tests.
 
 
 class FruitField(nn.Module):
@@ -188,7 +190,7 @@ class FruitField(nn.Module):
     def resolved_mlp_precision(self) -> str:
         if self.mlp_precision != "auto":
             return self.mlp_precision
-        return "fp32" if self.geo_feat_dim == 15 else "bf16x3"
+        return "bf16x3"
 
     def warp_struct(self) -> L.fnr_warp:
         # fruit_field.py:169-175: contraction + (x+2)/4, or aabb normalisation when spatial_distortion is None

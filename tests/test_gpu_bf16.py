@@ -1,8 +1,9 @@
 """The bf16 matrix-pipe modes of the field MLPs (include/fruitnerf_hip.h: FNR_MLP_BF16X3 / FNR_MLP_BF16,
 csrc/field_bf16.hpp) on the GPU.
 
-bf16x3 is parity grade: the SAME oracle-parity tests the fp32 path passes are re-run with the field switched to the
-exact three-way bf16 split (FNR_MLP_PRECISION=bf16x3 is read by FruitField at construction), at the SAME tolerances.
+bf16x3 is parity grade and FruitField's default ("auto"): the oracle-parity tests of the default path are re-run
+here with the field switched explicitly to fp32 (exact fmaf chains) and to bf16x3 (FNR_MLP_PRECISION is read by
+FruitField at construction), at the SAME tolerances.
 bf16 (plain) is a throughput mode: it is compared with the fp32 HIP path at bf16-sized tolerances."""
 import pytest
 import torch
@@ -13,8 +14,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _rerun(monkeypatch, fn, *args):
-    monkeypatch.setenv("FNR_MLP_PRECISION", "bf16x3")
-    fn(*args)
+    """Re-run an oracle-parity test of the default path with the field MLPs in BOTH parity-grade arithmetics: whichever
+    of them is FruitField's default ("auto"), the other one's kernels are covered here at the same tolerances."""
+    for precision in ("fp32", "bf16x3"):
+        monkeypatch.setenv("FNR_MLP_PRECISION", precision)
+        fn(*args)
 
 
 @pytest.mark.parametrize("training", [False, True])
