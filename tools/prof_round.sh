@@ -1,0 +1,25 @@
+#!/bin/bash
+# on the GPU box: everything profiles/r02_* is made from.  bench lines (both methods, default arithmetic + fp32),
+# rocprofv3 kernel trace + the three PMC passes of the default bench command, kernel trace of fruit_nerf_big.
+mkdir -p /root/repo/gpurun_out/r02
+OUT=/root/repo/gpurun_out/r02
+cd /tmp && export TMPDIR=/tmp
+python /root/repo/bench.py > $OUT/bench_fruit_nerf.log 2>&1
+python /root/repo/bench.py --mlp-precision fp32 --no-cpu-baseline > $OUT/bench_fruit_nerf_fp32.log 2>&1
+python /root/repo/bench.py --method fruit_nerf_big > $OUT/bench_fruit_nerf_big.log 2>&1
+python /root/repo/bench.py --method fruit_nerf_big --mlp-precision fp32 --no-cpu-baseline --no-quality > $OUT/bench_fruit_nerf_big_fp32.log 2>&1
+CMD="python /root/repo/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_kt -o p -- $CMD > $OUT/prof_bench.json 2>/tmp/pf_kt.err
+python /root/repo/tools/kt_agg.py /tmp/pf_kt/p_kernel_trace.csv > $OUT/prof_kernel_trace_top40.txt
+python /root/repo/tools/kt_agg.py /tmp/pf_kt/p_kernel_trace.csv fnr > $OUT/prof_kernel_trace.txt
+python /root/repo/tools/kt_step.py /tmp/pf_kt/p_kernel_trace.csv > $OUT/prof_step_timeline.txt
+head -60 /tmp/pf_kt/p_kernel_stats.csv > $OUT/prof_kernel_stats_head.csv 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf_f -o p -- $CMD > /dev/null 2>&1
+python /root/repo/tools/pmc_agg.py /tmp/pf_f/p_counter_collection.csv fnr > $OUT/prof_fetch.txt
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pf_w -o p -- $CMD > /dev/null 2>&1
+python /root/repo/tools/pmc_agg.py /tmp/pf_w/p_counter_collection.csv fnr > $OUT/prof_write.txt
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/pf_s -o p -- $CMD > /dev/null 2>&1
+python /root/repo/tools/pmc_agg.py /tmp/pf_s/p_counter_collection.csv fnr > $OUT/prof_sq.txt
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pf_big -o p -- python /root/repo/bench.py --method fruit_nerf_big --steps 40 --warmup 10 --no-cpu-baseline --no-quality > $OUT/prof_bench_big.json 2>/dev/null
+python /root/repo/tools/kt_agg.py /tmp/pf_big/p_kernel_trace.csv fnr > $OUT/prof_kernel_trace_big.txt
+ls -la $OUT
