@@ -146,7 +146,7 @@ __device__ unsigned g_emit_phase_clk[EMIT_T_SLOTS][8];   // per workgroup (plain
 #define EMIT_T(k)                                                                              \
   do {                                                                                         \
     const unsigned long long now__ = __builtin_readcyclecounter();                             \
-    t_acc__[k] = (unsigned)(now__ - t_phase__);                                                \
+    t_acc__[k] += (unsigned)(now__ - t_phase__);                                               \
     t_phase__ = now__;                                                                         \
   } while (0)
 #else
@@ -161,8 +161,11 @@ template <class Source, bool PAIRS>
 __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, Warp warp, Source src, long long N,
                                                       const float2* __restrict__ d_feats, float2* __restrict__ queue_v,
                                                       unsigned short* __restrict__ queue_r, unsigned* __restrict__ qcount, unsigned* __restrict__ qmax,
-                                                      long long cap, int log2_rows, int level0) {
-  // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs
+                                                      long long cap, int log2_rows, int level0, int level_count, int lpb) {
+  // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs.
+  // A workgroup takes its 512 samples through `lpb` consecutive levels: the sample position and its warp are computed
+  // once, and the next level's feature gradient is loaded while the current level is processed (the wait for the first
+  // loads + the warp was 22 % of a one-level workgroup's time).
   __shared__ float2 s_val[SC_CHUNK * 8];    // value pair of a record
   __shared__ unsigned s_key[SC_CHUNK * 8];  // row inside the bin | bin << 16
   __shared__ unsigned s_cnt[SC_MAX_BINS];   // per-bin count, then running cursor
@@ -174,21 +177,35 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   unsigned long long t_phase__ = __builtin_readcyclecounter();
   unsigned t_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  const int lrel = blockIdx.y;           // level inside this call's range: indexes the counters and queues
-  const int level = level0 + lrel;       // level of the grid: indexes scalings, d_feats and the gradient table
   const int bins = 1 << (grid.log2_T - log2_rows);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t mask = (1u << grid.log2_T) - 1u;
+  const uint32_t row_mask = (1u << log2_rows) - 1u;
+  const long long n0 = (long long)blockIdx.x * SC_CHUNK;
+  static_assert(SC_PER_THREAD == 1, "one sample per thread");
+  const long long n = n0 + threadIdx.x;
+  const bool valid = n < N;
+  float x[3] = {0.f, 0.f, 0.f};
+  float2 gf_next = make_float2(0.f, 0.f);
+  const int lrel0 = blockIdx.y * lpb;
+  if (valid) {
+    gf_next = d_feats[(size_t)(level0 + lrel0) * N + n];
+    float px, py, pz;
+    src.position(n, px, py, pz);
+    warp_position(warp, px, py, pz, x);
+  }
+  for (int li = 0; li < lpb && lrel0 + li < level_count; ++li) {
+  const int lrel = lrel0 + li;           // level inside this call's range: indexes the counters and queues
+  const int level = level0 + lrel;       // level of the grid: indexes scalings, d_feats and the gradient table
   for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) {
     s_cnt[i] = 0;
   }
   if (threadIdx.x == 0) s_max = 0;
   __syncthreads();
   EMIT_T(0);
-  const uint32_t mask = (1u << grid.log2_T) - 1u;
-  const uint32_t row_mask = (1u << log2_rows) - 1u;
   const int scaling = grid.scalings[level];
-  const long long n0 = (long long)blockIdx.x * SC_CHUNK;
-  const float2* gl = d_feats + (size_t)level * N;
+  const float2 gf = gf_next;
+  if (valid && li + 1 < lpb && lrel + 1 < level_count) gf_next = d_feats[(size_t)(level + 1) * N + n];
 
   // contributions of this thread's samples; equal rows in adjacent lanes (consecutive samples of a ray share
   // cells at coarse levels) are pre-summed so only the last lane of a run emits a record
@@ -198,26 +215,15 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   unsigned emit_mask[SC_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < SC_PER_THREAD; ++q) {
-    const long long n = n0 + q * SC_EMIT_THREADS + threadIdx.x;
-    float2 gf = make_float2(0.f, 0.f);
-    float x[3] = {0.f, 0.f, 0.f};
-    if (n < N) {
-      gf = gl[n];
-      float px, py, pz;
-      src.position(n, px, py, pz);
-      warp_position(warp, px, py, pz, x);
-    }
 #ifdef FNR_EMIT_TIMING
     {  // x and gf are in registers once this dependent dummy has been consumed
       asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(gf.x), "v"(gf.y));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long now__ = __builtin_readcyclecounter();
-      t_acc__[6] = (unsigned)(now__ - t_phase__);
+      t_acc__[6] += (unsigned)(now__ - t_phase__);
     }
 #endif
     float wgt[8];
     const GridLevel g = corner_weights(x, scaling, mask, hk[q], wgt);
-    const bool valid = n < N;
     // exact cell identity: floor coordinates + whether ceil differs (coordinates < 2^16, checked on the host)
     const uint32_t key_a = valid ? (g.f[0] | (g.f[1] << 16)) : 0xffffffffu;
     const uint32_t key_b = valid ? (g.f[2] | ((g.c[0] - g.f[0]) << 16) | ((g.c[1] - g.f[1]) << 17) |
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     {
       asm volatile("" ::"v"(vxk[q][0]), "v"(vyk[q][7]));
       const unsigned long long now__ = __builtin_readcyclecounter();
-      t_acc__[7] = (unsigned)(now__ - t_phase__);
+      t_acc__[7] += (unsigned)(now__ - t_phase__);
     }
 #endif
 #pragma unroll
@@ -363,6 +369,8 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     }
   }
   EMIT_T(5);
+  __syncthreads();  // the next level re-uses the bin tables and the record staging
+  }  // levels of this workgroup
 #ifdef FNR_EMIT_TIMING
   {
     const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) & (EMIT_T_SLOTS - 1);
@@ -486,14 +494,27 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
     FNR_CHECK_ARG(gd.scalings[l] > 0 && gd.scalings[l] < 65535, "hash scatter: level resolution %d out of range", gd.scalings[l]);
   bool pairs = true;  // every level's resolution below the bin size: x-neighbours share their bin (see k_scatter_emit)
   for (int l = level0; l < level0 + level_count; ++l) pairs = pairs && gd.scalings[l] < (1 << p.log2_rows);
+  // levels per workgroup: as many as leaves >= 4 workgroups per CU-slot (3 workgroups per CU) in flight
+  int lpb = 1;
+  {
+    static const int forced = [] {
+      const char* e = getenv("FNR_EMIT_LPB");
+      return e ? atoi(e) : 0;
+    }();
+    const long long slots = 3ll * device_cu_count();
+    while (lpb < level_count && lpb < 8 && chunks * ((level_count + 2 * lpb - 1) / (2 * lpb)) >= 2 * slots) lpb *= 2;
+    if (forced > 0) lpb = forced;
+    if (lpb > level_count) lpb = level_count;
+  }
+  const unsigned gy = (unsigned)((level_count + lpb - 1) / lpb);
   if (pairs)
-    hipLaunchKernelGGL((k_scatter_emit<Source, true>), dim3((unsigned)chunks, (unsigned)level_count), dim3(SC_EMIT_THREADS),
+    hipLaunchKernelGGL((k_scatter_emit<Source, true>), dim3((unsigned)chunks, gy), dim3(SC_EMIT_THREADS),
                        0, st, gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap,
-                       p.log2_rows, level0);
+                       p.log2_rows, level0, level_count, lpb);
   else
-    hipLaunchKernelGGL((k_scatter_emit<Source, false>), dim3((unsigned)chunks, (unsigned)level_count), dim3(SC_EMIT_THREADS),
+    hipLaunchKernelGGL((k_scatter_emit<Source, false>), dim3((unsigned)chunks, gy), dim3(SC_EMIT_THREADS),
                        0, st, gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap,
-                       p.log2_rows, level0);
+                       p.log2_rows, level0, level_count, lpb);
   FNR_LAUNCH_CHECK();
   const unsigned nbins = (unsigned)(level_count * p.bins_per_level);
   hipLaunchKernelGGL(k_scatter_accumulate, dim3(nbins), dim3(1024), 0, st, gd,
