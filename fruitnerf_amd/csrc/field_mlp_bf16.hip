@@ -986,10 +986,7 @@ int field_mlp_bwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, con
                                const float* h_saved, const float* d_logit, float* partials, long long blocks,
                                hipStream_t st) {
   using Cfg = FieldCfgBig;
-  __bf16* image = reinterpret_cast<__bf16*>(image_ws);
-  const int ns_pack = mode == MLP_BF16 ? 1 : 3;
-  launch_pack_field_weights_bf16<Cfg>(p, ns_pack, image, st);
-  FNR_LAUNCH_CHECK();
+  __bf16* image = reinterpret_cast<__bf16*>(image_ws);  // packed by the colour branch's call (or the forward pass)
   auto launch = [&](auto kern, int bytes) -> int {
     FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, p.w[Cfg::L_SEM2], p.b[Cfg::L_SEM2],
@@ -1079,7 +1076,8 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_color_coop(
     const float* __restrict__ packed, const __bf16* __restrict__ image, const float* __restrict__ ray_bias, RaysDev rays,
     int S, long long N, const float* __restrict__ h_saved, const float* __restrict__ d_rgb, float* __restrict__ d_h,
     float* __restrict__ gsum_tile, float* __restrict__ gsum_extra, float* __restrict__ partials) {
-  static_assert(Cfg::HB == 1, "`fruit_nerf` shape");
+  constexpr int HB = Cfg::HB;  // 16-wide blocks of h: 1 (`fruit_nerf`) or 2 (`fruit_nerf_big`)
+  static_assert(HB == 1 || HB == 2, "built shapes");
   constexpr int WAVES = 8, THREADS = 512;
   constexpr int LC0 = Cfg::L_COL0, LC1 = Cfg::L_COL1, LC2 = Cfg::L_COL2;
   using CL = CoopLds<Cfg, SegsColF<Cfg>, SegsColT<Cfg>, NSF, NS>;
@@ -1096,8 +1094,10 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_color_coop(
   for (int i = threadIdx.x; i < 64; i += THREADS) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LC1) + i];
   for (int i = threadIdx.x; i < 16; i += THREADS) fbias[64 + i] = packed[Cfg::W_TOTAL + Cfg::boff(LC2) + i];
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // owned blocks: col2 (ob 0, ib = w; waves 0..3), col1 (ob = (w >> 2) + 2 s, ib = w & 3), col0's h block (ob = w; waves 0..3);
-  // bias blocks: col1 ob = w (waves 0..3), col2 (wave 4)
+  // owned blocks: col2 (ob 0, ib = w; waves 0..3), col1 (ob = (w >> 2) + 2 s, ib = w & 3), col0's h blocks (HB = 1: ob = w on
+  // waves 0..3; HB = 2: ob = w >> 1, ib = w & 1 on all waves); bias blocks: col1 ob = w (waves 0..3), col2 (wave 4)
+  const bool ownA = HB == 2 || wave < 4;
+  const int obA = HB == 2 ? (wave >> 1) : wave, ibA = HB == 2 ? (wave & 1) : 0;
   f32x4 accC[1], accB[2], accA[1];
   f32x4 bB = {0.f, 0.f, 0.f, 0.f}, bC = bB;
   zero_vec_bf(accC);
@@ -1115,14 +1115,15 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_color_coop(
     const bool valid = n < N;
     const long long nn = valid ? n : N - 1;
     const long long ray = nn / S;
-    f32x4 h[1], c1[4], c2[4], c3[1];
-    h[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * 16 + 4 * g);
+    f32x4 h[HB], c1[4], c2[4], c3[1];
+#pragma unroll
+    for (int b = 0; b < HB; ++b) h[b] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nn * (16 * HB) + 16 * b + 4 * g);
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) c1[ob] = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)ray * 64 + 16 * ob + 4 * g);
     __syncthreads();  // fragments staged (first batch) / the previous batch's last scratch reads
     {
       bf16x8 x[1][NSF];
-      bf_operand<NSF, 1>(h, x);
+      bf_operand<NSF, HB>(h, x);
       bf_layer_acc1<NSF, 4, 1>(F::template seg<LC0, false>(wf), x, c1, lane);
     }
     relu_(c1);
@@ -1161,9 +1162,9 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_color_coop(
     // k_color_ray_grads from the tiles' 64 row sums of G1 (exact fp32 DPP sums)
     __syncthreads();
     cs_write<NS, 4, CB_ROWS>(sG, 0, G1, lane, wave);
-    cs_write<NS, 1, CB_ROWS>(sX, 0, h, lane, wave);
+    cs_write<NS, HB, CB_ROWS>(sX, 0, h, lane, wave);
     __syncthreads();
-    if (wave < 4) cs_dw<NS, 1, CB_ROWS>(sG, sX, wave, 0, 0, accA, lane);
+    if (ownA) cs_dw<NS, 1, CB_ROWS>(sG, sX, obA, 0, ibA, accA, lane);
     if (tile < n_tiles) {
       const long long ray0 = __shfl(ray, lane & 48, 64);
       const bool uniform = __all(ray == ray0);  // invalid lanes were clamped to the last sample's ray
@@ -1184,23 +1185,26 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_color_coop(
           for (int r = 0; r < 4; ++r) atomicAdd(&gsum_extra[(size_t)ray * 64 + 16 * ob + 4 * g + r], G1[ob][r]);
       }
     }
-    f32x4 Gh[1];
-    bf_layer_T1<NS, 1, 4>(T::template seg<LC0, true>(wt), G1, Gh, lane);
-    if (valid) *reinterpret_cast<f32x4*>(d_h + (size_t)n * 16 + 4 * g) = Gh[0];
+    f32x4 Gh[HB];
+    bf_layer_T1<NS, HB, 4>(T::template seg<LC0, true>(wt), G1, Gh, lane);
+    if (valid) {
+#pragma unroll
+      for (int b = 0; b < HB; ++b) *reinterpret_cast<f32x4*>(d_h + (size_t)n * (16 * HB) + 16 * b + 4 * g) = Gh[b];
+    }
   }
   const int lane = lane0;
   float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
   float* pb = part + Cfg::W_TOTAL;
-  // col0: this kernel owns input block 0 (h); blocks 1..3 (ray-constant inputs) and the bias belong to
+  // col0: this kernel owns the h input blocks; the three blocks of ray-constant inputs and the bias belong to
   // k_color_ray_grads, which only overwrites SOME workgroups' images: zero them here
-  constexpr int NIB0 = Cfg::HB + 3;
+  constexpr int NIB0 = HB + 3;
   for (int i = threadIdx.x; i < 4 * 3 * 256; i += THREADS) {
-    const int blk = i >> 8, ob = blk / 3, ib = 1 + blk % 3;
+    const int blk = i >> 8, ob = blk / 3, ib = HB + blk % 3;
     part[Cfg::woff(LC0) + (ob * NIB0 + ib) * 256 + (i & 255)] = 0.0f;
   }
   for (int i = threadIdx.x; i < 64; i += THREADS) pb[Cfg::boff(LC0) + i] = 0.0f;
+  if (ownA) store_dw_block(part + Cfg::woff(LC0), obA, ibA, NIB0, accA[0], lane);
   if (wave < 4) {
-    store_dw_block(part + Cfg::woff(LC0), wave, 0, NIB0, accA[0], lane);
     store_dw_block(part + Cfg::woff(LC2), 0, wave, 4, accC[0], lane);
     store_bias_block(pb + Cfg::boff(LC1), wave, bB, lane);
   }
@@ -1302,7 +1306,8 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
     const float* __restrict__ packed, const __bf16* __restrict__ image, long long N, const float2* __restrict__ feats,
     const uint8_t* __restrict__ selector, const float* __restrict__ d_density, const float* __restrict__ d_h,
     float2* __restrict__ d_feats, float* __restrict__ partials) {
-  static_assert(Cfg::HB == 1, "`fruit_nerf` shape");
+  constexpr int HB = Cfg::HB;
+  static_assert(HB == 1 || HB == 2, "built shapes");
   constexpr int WAVES = 8, THREADS = 512;
   constexpr int LB0 = Cfg::L_BASE0, LB1 = Cfg::L_BASE1;
   using CL = CoopLds<Cfg, SegsBaseF<Cfg>, SegsBaseT<Cfg>, NSF, NS>;
@@ -1313,12 +1318,15 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
   bf16x8* wt = reinterpret_cast<bf16x8*>(smem + F::BYTES);
   uint32_t* sG = reinterpret_cast<uint32_t*>(smem + CL::SCR_OFF);
   uint32_t* sX = sG + NS * CB_ROWS * CS_LD;
-  float* fbias = reinterpret_cast<float*>(smem + CL::FB_OFF);  // base0 [64] | base1 [16]
+  float* fbias = reinterpret_cast<float*>(smem + CL::FB_OFF);  // base0 [64] | base1 [16 HB]
   F::template stage<THREADS>(wf, image);
   T::template stage<THREADS>(wt, image);
-  for (int i = threadIdx.x; i < 80; i += THREADS) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LB0) + i];
+  for (int i = threadIdx.x; i < 64 + 16 * HB; i += THREADS) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LB0) + i];
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // owned blocks: base1 (ob 0, ib = w; waves 0..3), base0 (ob = w >> 1, ib = w & 1); bias: base1 (wave 4), base0 ob = w - 4 (waves 4..7)
+  // owned blocks: base1 (HB = 1: ob 0, ib = w on waves 0..3; HB = 2: ob = w >> 2, ib = w & 3 on all waves), base0 (ob = w >> 1,
+  // ib = w & 1); bias: base1 ob = w - 4 (waves 4..4+HB-1), base0 ob = w - 4 (waves 4..7)
+  const bool ownB = HB == 2 || wave < 4;
+  const int obB = HB == 2 ? (wave >> 2) : 0, ibB = wave & 3;
   f32x4 accB[1], accA[1];
   f32x4 bB = {0.f, 0.f, 0.f, 0.f}, bA = bB;
   zero_vec_bf(accB);
@@ -1332,28 +1340,31 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
     const long long n = (batch * 8 + wave) * 16 + j;
     const bool valid = n < N;
     const long long nn = valid ? n : N - 1;
-    f32x4 x0[2], a1[4], h[1];
+    f32x4 x0[2], a1[4], h[HB];
     load_hash_block(feats, N, nn, g, x0);
-    f32x4 Gh[1];
-    Gh[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (valid) Gh[0] = *reinterpret_cast<const f32x4*>(d_h + (size_t)n * 16 + 4 * g);
+    f32x4 Gh[HB];
+#pragma unroll
+    for (int b = 0; b < HB; ++b) {
+      Gh[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (valid) Gh[b] = *reinterpret_cast<const f32x4*>(d_h + (size_t)n * (16 * HB) + 16 * b + 4 * g);
+    }
     __syncthreads();
     bf_layer1<NSF, 4, 2>(F::template seg<LB0, false>(wf), fbias, x0, a1, lane);
     relu_(a1);
-    bf_layer1<NSF, 1, 4>(F::template seg<LB1, false>(wf), fbias + 64, a1, h, lane);
+    bf_layer1<NSF, HB, 4>(F::template seg<LB1, false>(wf), fbias + 64, a1, h, lane);
     if (valid && g == 0) {
       const bool sel = selector ? (selector[n] != 0) : true;
       const float te = expf(fminf(fmaxf(h[0][0], -15.0f), 15.0f));  // trunc_exp backward (fruit_field.py:191)
       Gh[0][0] = sel ? d_density[n] * te : 0.0f;                   // colour block has a zero row 0
     }
     // round 1: G = Gh, X = a1 -> base1
-    cs_write<NS, 1, CB_ROWS>(sG, 0, Gh, lane, wave);
+    cs_write<NS, HB, CB_ROWS>(sG, 0, Gh, lane, wave);
     cs_write<NS, 4, CB_ROWS>(sX, 0, a1, lane, wave);
     __syncthreads();
-    if (wave < 4) cs_dw<NS, 1, CB_ROWS>(sG, sX, 0, 0, wave, accB, lane);
-    if (wave == 4) cs_bias<NS, CB_ROWS>(sG, 0, bB, lane);
+    if (ownB) cs_dw<NS, 1, CB_ROWS>(sG, sX, obB, 0, ibB, accB, lane);
+    if (wave >= 4 && wave < 4 + HB) cs_bias<NS, CB_ROWS>(sG, wave - 4, bB, lane);
     f32x4 Ga[4];
-    bf_layer_T1<NS, 4, 1>(T::template seg<LB1, true>(wt), Gh, Ga, lane);
+    bf_layer_T1<NS, 4, HB>(T::template seg<LB1, true>(wt), Gh, Ga, lane);
     relu_mask1_(Ga, a1);
     // round 2: G = Ga, X = hash features -> base0
     __syncthreads();
@@ -1373,19 +1384,18 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
   const int lane = lane0;
   float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
   float* pb = part + Cfg::W_TOTAL;
-  if (wave < 4) store_dw_block(part + Cfg::woff(LB1), 0, wave, 4, accB[0], lane);
+  if (ownB) store_dw_block(part + Cfg::woff(LB1), obB, ibB, 4, accB[0], lane);
   store_dw_block(part + Cfg::woff(LB0), wave >> 1, wave & 1, 2, accA[0], lane);
-  if (wave == 4) store_bias_block(pb + Cfg::boff(LB1), 0, bB, lane);
+  if (wave >= 4 && wave < 4 + HB) store_bias_block(pb + Cfg::boff(LB1), wave - 4, bB, lane);
   if (wave >= 4) store_bias_block(pb + Cfg::boff(LB0), wave - 4, bA, lane);
 }
 
-template <int NSF, int NS>
+template <class Cfg, int NSF, int NS>
 static int bwd_launch_coop(const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd, int S,
                            long long N, const float2* feats, const float* h_saved, const uint8_t* selector,
                            const float* d_density, const float* d_rgb, const float* d_logit, float2* d_feats, float* d_h,
                            float* gsum_tile, float* gsum_extra, float* partials, long long blocks, int branch,
                            hipStream_t st) {
-  using Cfg = FieldCfgBase;
   // exactly `blocks` workgroups: every one of the caller's partial images must receive this branch's blocks (a
   // workgroup without a batch stores zeros)
   auto attr = [](auto kern, int bytes) -> int {
@@ -1402,16 +1412,20 @@ static int bwd_launch_coop(const float* packed, const __bf16* image, const float
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, ray_bias, rd, S, N, h_saved, d_rgb,
                        d_h, gsum_tile, gsum_extra, partials);
   } else if (branch == 1) {
-    using CL = CoopLds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS>;
-    constexpr int bytes = CL::FB_OFF + 128 * 4;
-    static_assert(bytes <= 160 * 1024, "semantic branch exceeds the LDS");
-    auto kern = k_field_mlp_bwd_sem_coop<Cfg, NSF, NS>;
-    static int once = attr(kern, bytes);
-    if (once) return once;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, h_saved, d_logit, partials);
+    if constexpr (Cfg::NSEM == 2) {
+      using CL = CoopLds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS>;
+      constexpr int bytes = CL::FB_OFF + 128 * 4;
+      static_assert(bytes <= 160 * 1024, "semantic branch exceeds the LDS");
+      auto kern = k_field_mlp_bwd_sem_coop<Cfg, NSF, NS>;
+      static int once = attr(kern, bytes);
+      if (once) return once;
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, h_saved, d_logit, partials);
+    } else {
+      FNR_CHECK_ARG(false, "the fruit_nerf_big semantic branch has its own kernel");
+    }
   } else {
     using CL = CoopLds<Cfg, SegsBaseF<Cfg>, SegsBaseT<Cfg>, NSF, NS>;
-    constexpr int bytes = CL::FB_OFF + 80 * 4;
+    constexpr int bytes = CL::FB_OFF + (64 + 16 * Cfg::HB) * 4;
     static_assert(bytes <= 160 * 1024, "base branch exceeds the LDS");
     auto kern = k_field_mlp_bwd_base_coop<Cfg, NSF, NS>;
     static int once = attr(kern, bytes);
@@ -1503,27 +1517,38 @@ static int bwd_launch_bf16(const float* packed, const __bf16* image, const float
   return FNR_OK;
 }
 
-// branch: 0 colour, 1 semantic, 2 base.  The bf16x3 mode runs its backward with two pieces (three products).
-int field_mlp_bwd_bf16(int mode, int branch, const FieldPtrs& p, bool pack, const float* packed, void* image_ws,
+// branch: 0 colour, 1 semantic, 2 base; cfg: 0 `fruit_nerf`, 1 `fruit_nerf_big` (its semantic branch is
+// field_mlp_bwd_sem_big_bf16).  The bf16x3 mode runs dX / dW with two pieces (three products), the forward recompute with three.
+int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool pack, const float* packed, void* image_ws,
                        const float* ray_bias, const RaysDev& rd, int S, long long N, const float2* feats,
                        const float* h_saved, const uint8_t* selector, const float* d_density, const float* d_rgb,
                        const float* d_logit, float2* d_feats, float* d_h, float* gsum_tile, float* gsum_extra,
                        float* partials, long long blocks, hipStream_t st) {
   __bf16* image = reinterpret_cast<__bf16*>(image_ws);
   if (pack) {
-    launch_pack_field_weights_bf16<FieldCfgBase>(p, mode == MLP_BF16 ? 1 : 3, image, st);
+    if (cfg == 0)
+      launch_pack_field_weights_bf16<FieldCfgBase>(p, mode == MLP_BF16 ? 1 : 3, image, st);
+    else
+      launch_pack_field_weights_bf16<FieldCfgBig>(p, mode == MLP_BF16 ? 1 : 3, image, st);
     FNR_LAUNCH_CHECK();
   }
-  static const bool per_wave = [] {
+  if (cfg == 1) {
+    if (mode == MLP_BF16)
+      return bwd_launch_coop<FieldCfgBig, 1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
+                                                d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+    return bwd_launch_coop<FieldCfgBig, 3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
+                                              d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+  }
+  static const bool per_wave = [] {  // FNR_BF16_BWD=wave: the first-generation per-wave-dW kernels (A/B runs)
     const char* e = getenv("FNR_BF16_BWD");
     return e && e[0] == 'w';
   }();
   if (!per_wave) {
     if (mode == MLP_BF16)
-      return bwd_launch_coop<1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit,
-                                   d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
-    return bwd_launch_coop<3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit,
-                                 d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+      return bwd_launch_coop<FieldCfgBase, 1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
+                                                 d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+    return bwd_launch_coop<FieldCfgBase, 3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
+                                               d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
   }
   if (mode == MLP_BF16)
     return bwd_launch_bf16<1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit, d_feats,

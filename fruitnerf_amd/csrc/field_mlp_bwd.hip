@@ -776,7 +776,7 @@ __global__ __launch_bounds__(1024) void k_embedding_grad(RaysDev rays, const flo
 int field_ptrs(const fnr_field_net* net, FieldPtrs& p, int* cfg_id);  // field_mlp.hip
 size_t field_fwd_ws_image_offset();                                     // field_mlp.hip
 size_t field_bf16_image_bytes();                                        // field_mlp_bf16.hip
-int field_mlp_bwd_bf16(int mode, int branch, const FieldPtrs& p, bool pack, const float* packed, void* image_ws,
+int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool pack, const float* packed, void* image_ws,
                        const float* ray_bias, const RaysDev& rd, int S, long long N, const float2* feats,
                        const float* h_saved, const uint8_t* selector, const float* d_density, const float* d_rgb,
                        const float* d_logit, float2* d_feats, float* d_h, float* gsum_tile, float* gsum_extra,
@@ -857,12 +857,13 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid((unsigned)blocks);
   const int mode = net->mlp_mode;
-  // bf16-pipe modes: every branch of the `fruit_nerf` shape; of the `fruit_nerf_big` shape the semantic branch (its
-  // largest kernel by far — weight-streamed, cooperative dW: field_mlp_bf16.hip), colour and base stay on fp32 MFMA
-  const bool bf_all = mode != FNR_MLP_FP32 && Cfg::NSEM == 2;
+  // bf16-pipe modes: every branch of both shapes (field_mlp_bf16.hip: cooperative dW; the `fruit_nerf_big` semantic
+  // branch additionally weight-streamed)
+  constexpr int cfg_id = Cfg::NSEM == 2 ? 0 : 1;
+  const bool bf_all = mode != FNR_MLP_FP32;
   const bool bf_sem_big = mode != FNR_MLP_FP32 && Cfg::NSEM == 3;
   if (bf_all) {
-    const int rc = field_mlp_bwd_bf16(mode, 0, p, bf16_pack, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
+    const int rc = field_mlp_bwd_bf16(cfg_id, mode, 0, p, bf16_pack, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
                                       d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
     if (rc) return rc;
   } else if (color_waves == 4) {
@@ -885,11 +886,14 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     FNR_LAUNCH_CHECK();
   }
   if (bf_sem_big) {
-    const int rc = field_mlp_bwd_sem_big_bf16(mode, p, ws.bf16_image, packed, N, h_saved, d_logit, partials, blocks, st);
+    int rc = field_mlp_bwd_sem_big_bf16(mode, p, bf16_image, packed, N, h_saved, d_logit, partials, blocks, st);
+    if (rc) return rc;
+    rc = field_mlp_bwd_bf16(cfg_id, mode, 2, p, false, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector, d_density,
+                            d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
     if (rc) return rc;
   } else if (bf_all) {
     for (int branch = 1; branch <= 2; ++branch) {
-      const int rc = field_mlp_bwd_bf16(mode, branch, p, false, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
+      const int rc = field_mlp_bwd_bf16(cfg_id, mode, branch, p, false, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
                                         d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
       if (rc) return rc;
     }
