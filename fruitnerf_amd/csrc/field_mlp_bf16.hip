@@ -6,7 +6,10 @@
 // Same entry points, buffers and partial-gradient image as the fp32 kernels (field_mlp.hip, field_mlp_bwd.hip):
 // the per-ray colour bias, the per-ray / per-camera finish of mlp_head layer 0 and k_reduce_dw are shared.
 // Replaces the same reference code: fruit_field.py:132-166,187-281 and its autograd.
-// Built shape: `fruit_nerf` (FieldCfgBase).  One wave = one PAIR of 16-sample tiles per iteration.
+// Forward (`fruit_nerf`): one wave = one PAIR of 16-sample tiles sharing every LDS fragment.  Backward (both shapes)
+// and the `fruit_nerf_big` semantic branch: one tile per wave, 8 waves = a 128-sample batch, COOPERATIVE dW (every
+// 16 x 16 block of a layer's weight gradient owned by one wave over the batch), weight streaming where the fragments
+// exceed the LDS.
 #include <stdlib.h>
 
 #include "field_bf16.hpp"
@@ -19,33 +22,6 @@ struct SegsFwdAll {  // every layer, forward only
   static constexpr int N = Cfg::NLAYERS;
   static constexpr int layer(int i) { return i; }
   static constexpr bool isT(int) { return false; }
-};
-template <class Cfg>
-struct SegsBwdColor {
-  static constexpr int N = 6;
-  static constexpr int layer(int i) {
-    constexpr int a[N] = {Cfg::L_COL0, Cfg::L_COL1, Cfg::L_COL2, Cfg::L_COL2, Cfg::L_COL1, Cfg::L_COL0};
-    return a[i];
-  }
-  static constexpr bool isT(int i) { return i >= 3; }
-};
-template <class Cfg>
-struct SegsBwdSem {
-  static constexpr int N = 4;
-  static constexpr int layer(int i) {
-    constexpr int a[N] = {Cfg::L_SEM0, Cfg::L_SEM1, Cfg::L_HEAD, Cfg::L_SEM1};
-    return a[i];
-  }
-  static constexpr bool isT(int i) { return i >= 2; }
-};
-template <class Cfg>
-struct SegsBwdBase {
-  static constexpr int N = 4;
-  static constexpr int layer(int i) {
-    constexpr int a[N] = {Cfg::L_BASE0, Cfg::L_BASE1, Cfg::L_BASE1, Cfg::L_BASE0};
-    return a[i];
-  }
-  static constexpr bool isT(int i) { return i >= 2; }
 };
 
 // the 16 x 2 hash features of sample nn as the single K-block of mlp_base layer 0 (slot (g, e): level 4 (e>>1) + g,
@@ -152,108 +128,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_fwd_bf16(
   }
 }
 
-// =====================================================================================================================
-// backward.  dW = dY^T X has the SAMPLES on the K axis: the pair's 32 samples are one K-block.  Both operands go
-// through a per-wave LDS scratch as bf16 pieces, one 32-bit word per (feature row, sample j) holding tile A's value in
-// the low and tile B's in the high half (K-slot of a sample = its position in the row, the same for both operands);
-// rows are 24 words apart: the b128 fragment reads are conflict-free, the b32 writes 2-way (free on ds_write_b32).
-// =====================================================================================================================
-constexpr int BSCR_LD = 24;                      // words per feature row (16 used)
-constexpr int BSCR_ROWS = 64;                    // feature rows per operand
-constexpr int BSCR_ARRAY = BSCR_ROWS * BSCR_LD;  // words per (operand, piece)
-template <int NS>
-constexpr int bscr_words() { return 2 * NS * BSCR_ARRAY; }
-
-__device__ __forceinline__ void wave_lds_fence_bf() {
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ uint32_t pack_bf16x2(__bf16 lo, __bf16 hi) {
-  return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
-}
-
-// write NB accumulator blocks of the tile pair as bf16 pieces into `arr` ([piece][row][BSCR_LD] words)
-template <int NS, int NB>
-__device__ __forceinline__ void bscr_write(uint32_t* __restrict__ arr, const f32x4* __restrict__ a,
-                                           const f32x4* __restrict__ b, int lane) {
-  const int j = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float ra = a[blk][r], rb = b[blk][r];
-#pragma unroll
-      for (int pc = 0; pc < NS; ++pc) {
-        const __bf16 pa = (__bf16)ra, pb = (__bf16)rb;
-        arr[pc * BSCR_ARRAY + (16 * blk + 4 * g + r) * BSCR_LD + j] = pack_bf16x2(pa, pb);
-        if (pc + 1 < NS) {
-          ra -= (float)pa;
-          rb -= (float)pb;
-        }
-      }
-    }
-}
-
-// acc[OB0 + ob][IB0 + ib] += G^T X over the pair's 32 samples (NOB, NIB <= 4 blocks staged at a time);
-// BIAS: bacc[OB0 + ob] += G^T 1 (every column of the block holds the row sums)
-template <int NS, int NOB, int NIB, int NOBT, int NIBT, int OB0, int IB0, bool BIAS>
-__device__ __forceinline__ void dw_accumulate_bf(uint32_t* __restrict__ scr, const f32x4* __restrict__ Ga,
-                                                 const f32x4* __restrict__ Gb, const f32x4* __restrict__ Xa,
-                                                 const f32x4* __restrict__ Xb, f32x4 (&acc)[NOBT][NIBT],
-                                                 f32x4 (&bacc)[NOBT], int lane) {
-  static_assert(NOB <= 4 && NIB <= 4 && OB0 + NOB <= NOBT && IB0 + NIB <= NIBT, "block group out of range");
-  uint32_t* sG = scr;
-  uint32_t* sX = scr + NS * BSCR_ARRAY;
-  bscr_write<NS, NOB>(sG, Ga, Gb, lane);
-  bscr_write<NS, NIB>(sX, Xa, Xb, lane);
-  wave_lds_fence_bf();
-  const int i = lane & 15, g = lane >> 4;
-  bf16x8 xb[NIB][NS];
-#pragma unroll
-  for (int ib = 0; ib < NIB; ++ib)
-#pragma unroll
-    for (int pc = 0; pc < NS; ++pc)
-      xb[ib][pc] = *reinterpret_cast<const bf16x8*>(sX + pc * BSCR_ARRAY + (16 * ib + i) * BSCR_LD + 4 * g);
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) {
-    bf16x8 ga[NS];
-#pragma unroll
-    for (int pc = 0; pc < NS; ++pc)
-      ga[pc] = *reinterpret_cast<const bf16x8*>(sG + pc * BSCR_ARRAY + (16 * ob + i) * BSCR_LD + 4 * g);
-#pragma unroll
-    for (int s = NS - 1; s >= 0; --s)
-#pragma unroll
-      for (int pg = 0; pg <= s; ++pg)
-#pragma unroll
-        for (int ib = 0; ib < NIB; ++ib)
-          acc[OB0 + ob][IB0 + ib] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[pg], xb[ib][s - pg], acc[OB0 + ob][IB0 + ib], 0, 0, 0);
-    if constexpr (BIAS) {
-#pragma unroll
-      for (int pc = NS - 1; pc >= 0; --pc)
-        bacc[OB0 + ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[pc], ones, bacc[OB0 + ob], 0, 0, 0);
-    }
-  }
-  wave_lds_fence_bf();
-}
-
-template <int N>
-__device__ __forceinline__ void relu_mask2_(f32x4 (&Ga)[N], const f32x4 (&acta)[N], f32x4 (&Gb)[N], const f32x4 (&actb)[N]) {
-#pragma unroll
-  for (int b = 0; b < N; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      Ga[b][r] = (acta[b][r] > 0.0f) ? Ga[b][r] : 0.0f;
-      Gb[b][r] = (actb[b][r] > 0.0f) ? Gb[b][r] : 0.0f;
-    }
-}
-
+// ---- helpers of the backward kernels ---------------------------------------------------------------------------------
 // sum over the 16 lanes of a DPP row (= the 16 samples of a tile); every lane ends up with the total
 __device__ __forceinline__ float row16_sum_bf(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
@@ -262,373 +137,10 @@ __device__ __forceinline__ float row16_sum_bf(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
   return v;
 }
-
-// wave's dW accumulators of a layer += into the workgroup's fp32 partial image (same index space as the fp32 kernels'
-// flush_dw: field_mlp_bwd.hip); the caller serialises the waves
-template <int NOB, int NIB, int NIB_STRIDE = NIB>
-__device__ __forceinline__ void flush_dw_bf(float* __restrict__ W, const f32x4 (&acc)[NOB][NIB], int lane) {
-  const int jn = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-    for (int ib = 0; ib < NIB; ++ib)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int slot = swz_slot(4 * g + r, jn >> 2);
-        W[((ob * NIB_STRIDE + ib) * 64 + slot) * 4 + (jn & 3)] += acc[ob][ib][r];
-      }
-}
-// bias accumulators (every column holds the row sums): column 0 adds them to `B` [16 NOB]
-template <int NOB>
-__device__ __forceinline__ void flush_bias_bf(float* __restrict__ B, const f32x4 (&bacc)[NOB], int lane) {
-  if ((lane & 15) == 0) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) B[16 * ob + 4 * g + r] += bacc[ob][r];
-  }
-}
-
-template <class A>
-__device__ __forceinline__ void zero_acc_bf(A& acc) {
-#pragma unroll
-  for (auto& row : acc)
-#pragma unroll
-    for (auto& v : row) v = f32x4{0.f, 0.f, 0.f, 0.f};
-}
 template <int N>
 __device__ __forceinline__ void zero_vec_bf(f32x4 (&a)[N]) {
 #pragma unroll
   for (int b = 0; b < N; ++b) a[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-
-// ---- colour branch: mlp_head (fruit_field.py:158-166,270-281) -------------------------------------------------------
-template <class Cfg, int NS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_color_bf16(
-    const float* __restrict__ packed, const __bf16* __restrict__ image, const float* __restrict__ ray_bias, RaysDev rays,
-    int S, long long N, const float* __restrict__ h_saved, const float* __restrict__ d_rgb, float* __restrict__ d_h,
-    float* __restrict__ gsum_tile, float* __restrict__ gsum_extra, float* __restrict__ partials) {
-  static_assert(Cfg::HB == 1, "bf16 kernels: `fruit_nerf` shape");
-  using Lds = BfLds<Cfg, SegsBwdColor<Cfg>, NS>;
-  constexpr int LC0 = Cfg::L_COL0, LC1 = Cfg::L_COL1, LC2 = Cfg::L_COL2;
-  constexpr int ACC_FLOATS = Cfg::woff(LC2 + 1) - Cfg::woff(LC0);  // fp32 partial image of the branch's layers
-  constexpr int NBIAS = 80;                                        // col1 (64) + col2 (16)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
-  uint32_t* scr_all = reinterpret_cast<uint32_t*>(smem + Lds::BYTES);
-  float* fbias = reinterpret_cast<float*>(scr_all + WAVES * bscr_words<NS>());  // forward biases of col1, col2
-  float* lds_bias = fbias + NBIAS;
-  // the fp32 reduction image re-uses the fragment + scratch area after the tile loop
-  static_assert(ACC_FLOATS * 4 <= Lds::BYTES + WAVES * bscr_words<NS>() * 4, "reduction image does not fit");
-  Lds::template stage<64 * WAVES>(lds, image);
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LC1) + i];
-  for (int i = threadIdx.x; i < 16; i += blockDim.x) fbias[64 + i] = packed[Cfg::W_TOTAL + Cfg::boff(LC2) + i];
-  for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) lds_bias[i] = 0.0f;
-  __syncthreads();
-  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* scr = scr_all + wave * bscr_words<NS>();
-
-  f32x4 accA[4][1], accB[4][4], accC[1][4];
-  f32x4 bA[4], bB[4], bC[1];  // bA unused (col0's bias comes from the per-ray finish)
-  zero_acc_bf(accA);
-  zero_acc_bf(accB);
-  zero_acc_bf(accC);
-  zero_vec_bf(bA);
-  zero_vec_bf(bB);
-  zero_vec_bf(bC);
-
-  const long long n_pairs = (N + 31) / 32;
-  for (long long pr = (long long)blockIdx.x * WAVES + wave; pr < n_pairs; pr += (long long)gridDim.x * WAVES) {
-    asm volatile("" ::: "memory");
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int j = lane & 15, g = lane >> 4;
-    const long long na = pr * 32 + j, nb = na + 16;
-    const bool va = na < N, vb = nb < N;
-    const long long nna = va ? na : N - 1, nnb = vb ? nb : N - 1;
-    const long long raya = nna / S, rayb = nnb / S;
-
-    f32x4 ha[1], hb[1];
-    ha[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nna * 16 + 4 * g);
-    hb[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nnb * 16 + 4 * g);
-    f32x4 c1a[4], c1b[4], c2a[4], c2b[4], c3a[1], c3b[1];
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-      c1a[ob] = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)raya * 64 + 16 * ob + 4 * g);
-      c1b[ob] = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)rayb * 64 + 16 * ob + 4 * g);
-    }
-    {
-      bf16x8 xa[1][NS], xb[1][NS];
-      bf_operand<NS, 1>(ha, xa);
-      bf_operand<NS, 1>(hb, xb);
-      bf_layer_acc<NS, 4, 1>(Lds::template seg<LC0, false>(lds), xa, xb, c1a, c1b, lane);
-    }
-    relu2_(c1a, c1b);
-    bf_layer<NS, 4, 4>(Lds::template seg<LC1, false>(lds), fbias, c1a, c1b, c2a, c2b, lane);
-    relu2_(c2a, c2b);
-    bf_layer<NS, 1, 4>(Lds::template seg<LC2, false>(lds), fbias + 64, c2a, c2b, c3a, c3b, lane);
-    // d(pre-sigmoid) = d_rgb * rgb * (1 - rgb) on rows 0..2 (lane group 0), zero elsewhere
-    f32x4 G3a[1], G3b[1];
-    G3a[0] = G3b[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (g == 0) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (va) {
-          const float s = 1.0f / (1.0f + expf(-c3a[0][r]));
-          G3a[0][r] = d_rgb[3 * na + r] * s * (1.0f - s);
-        }
-        if (vb) {
-          const float s = 1.0f / (1.0f + expf(-c3b[0][r]));
-          G3b[0][r] = d_rgb[3 * nb + r] * s * (1.0f - s);
-        }
-      }
-    }
-    dw_accumulate_bf<NS, 1, 4, 1, 4, 0, 0, true>(scr, G3a, G3b, c2a, c2b, accC, bC, lane);
-    f32x4 G2a[4], G2b[4];
-    bf_layer_T<NS, 4, 1>(Lds::template seg<LC2, true>(lds), G3a, G3b, G2a, G2b, lane);
-    relu_mask2_(G2a, c2a, G2b, c2b);
-    dw_accumulate_bf<NS, 4, 4, 4, 4, 0, 0, true>(scr, G2a, G2b, c1a, c1b, accB, bB, lane);
-    f32x4 G1a[4], G1b[4];
-    bf_layer_T<NS, 4, 4>(Lds::template seg<LC1, true>(lds), G2a, G2b, G1a, G1b, lane);
-    relu_mask2_(G1a, c1a, G1b, c1b);
-    // layer 0: dW of the h block here; the 48 ray-constant inputs and the bias are finished per ray by
-    // k_color_ray_grads from the tiles' 64 row sums of G1 (exact fp32 DPP sums)
-    dw_accumulate_bf<NS, 4, 1, 4, 1, 0, 0, false>(scr, G1a, G1b, ha, hb, accA, bA, lane);
-    auto row_sums = [&](const f32x4 (&G1)[4], long long tile, long long ray, bool valid) {
-      const long long ray0 = __shfl(ray, lane & 48, 64);
-      const bool uniform = __all(ray == ray0);  // invalid lanes were clamped to the last sample's ray
-      if (uniform) {
-        float mine = 0.0f;  // lane (g, j) keeps feature 16 (j >> 2) + 4 g + (j & 3)
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float t = row16_sum_bf(G1[ob][r]);
-            mine = (j == 4 * ob + r) ? t : mine;
-          }
-        gsum_tile[(size_t)tile * 64 + 16 * (j >> 2) + 4 * g + (j & 3)] = mine;
-      } else if (valid) {  // tile straddles rays (S % 16 != 0): per-sample contributions
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(&gsum_extra[(size_t)ray * 64 + 16 * ob + 4 * g + r], G1[ob][r]);
-      }
-    };
-    const long long n_tiles = (N + 15) / 16;
-    row_sums(G1a, 2 * pr, raya, va);
-    if (2 * pr + 1 < n_tiles) row_sums(G1b, 2 * pr + 1, rayb, vb);
-    f32x4 Gha[1], Ghb[1];
-    bf_layer_T<NS, 1, 4>(Lds::template seg<LC0, true>(lds), G1a, G1b, Gha, Ghb, lane);
-    if (va) *reinterpret_cast<f32x4*>(d_h + (size_t)na * 16 + 4 * g) = Gha[0];
-    if (vb) *reinterpret_cast<f32x4*>(d_h + (size_t)nb * 16 + 4 * g) = Ghb[0];
-  }
-
-  // ---- workgroup reduction of the weight gradients into this workgroup's fp32 partial image --------------------------
-  const int lane = lane0;
-  __syncthreads();  // every wave is done with the fragments and its scratch
-  float* acc_lds = reinterpret_cast<float*>(smem);
-  for (int i = threadIdx.x; i < ACC_FLOATS; i += blockDim.x) acc_lds[i] = 0.0f;
-  __syncthreads();
-  for (int turn = 0; turn < WAVES; ++turn) {
-    if (wave == turn) {
-      flush_dw_bf<4, 1, Cfg::HB + 3>(acc_lds + (Cfg::woff(LC0) - Cfg::woff(LC0)), accA, lane);
-      flush_dw_bf<4, 4>(acc_lds + (Cfg::woff(LC1) - Cfg::woff(LC0)), accB, lane);
-      flush_dw_bf<1, 4>(acc_lds + (Cfg::woff(LC2) - Cfg::woff(LC0)), accC, lane);
-      flush_bias_bf<4>(lds_bias, bB, lane);
-      flush_bias_bf<1>(lds_bias + 64, bC, lane);
-    }
-    __syncthreads();
-  }
-  float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
-  for (int i = threadIdx.x; i < ACC_FLOATS; i += blockDim.x) part[Cfg::woff(LC0) + i] = acc_lds[i];
-  // col0's bias slot belongs to k_color_ray_grads (which owns some workgroups' images only): zero it here
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) part[Cfg::W_TOTAL + Cfg::boff(LC0) + i] = 0.0f;
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) part[Cfg::W_TOTAL + Cfg::boff(LC1) + i] = lds_bias[i];
-  for (int i = threadIdx.x; i < 16; i += blockDim.x) part[Cfg::W_TOTAL + Cfg::boff(LC2) + i] = lds_bias[64 + i];
-}
-
-// ---- semantic branch: mlp_semantics 15 -> 64 -> 64 + SemanticFieldHead (fruit_field.py:144-156,263-268) ---------------
-template <class Cfg, int NS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_sem_bf16(
-    const float* __restrict__ packed, const __bf16* __restrict__ image, long long N, const float* __restrict__ h_saved,
-    const float* __restrict__ d_logit, float* __restrict__ partials) {
-  static_assert(Cfg::NSEM == 2 && Cfg::HB == 1, "bf16 kernels: `fruit_nerf` shape");
-  using Lds = BfLds<Cfg, SegsBwdSem<Cfg>, NS>;
-  constexpr int LS0 = Cfg::L_SEM0, LS1 = Cfg::L_SEM1, LH = Cfg::L_HEAD;
-  static_assert(LS1 == LS0 + 1 && LH == LS1 + 1, "the branch's layers are adjacent in the fp32 image");
-  constexpr int ACC_FLOATS = Cfg::woff(LH + 1) - Cfg::woff(LS0);
-  constexpr int NBIAS = 144;  // sem0 (64), sem1 (64), head (16)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
-  uint32_t* scr_all = reinterpret_cast<uint32_t*>(smem + Lds::BYTES);
-  float* fbias = reinterpret_cast<float*>(scr_all + WAVES * bscr_words<NS>());  // forward biases sem0, sem1
-  float* lds_bias = fbias + 128;
-  static_assert(ACC_FLOATS * 4 <= Lds::BYTES + WAVES * bscr_words<NS>() * 4, "reduction image does not fit");
-  Lds::template stage<64 * WAVES>(lds, image);
-  for (int i = threadIdx.x; i < 128; i += blockDim.x) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LS0) + i];
-  for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) lds_bias[i] = 0.0f;
-  __syncthreads();
-  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* scr = scr_all + wave * bscr_words<NS>();
-
-  f32x4 accA[4][1], accB[4][4], accC[1][4];
-  f32x4 bA[4], bB[4], bC[1];
-  zero_acc_bf(accA);
-  zero_acc_bf(accB);
-  zero_acc_bf(accC);
-  zero_vec_bf(bA);
-  zero_vec_bf(bB);
-  zero_vec_bf(bC);
-
-  const long long n_pairs = (N + 31) / 32;
-  for (long long pr = (long long)blockIdx.x * WAVES + wave; pr < n_pairs; pr += (long long)gridDim.x * WAVES) {
-    asm volatile("" ::: "memory");
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int j = lane & 15, g = lane >> 4;
-    const long long na = pr * 32 + j, nb = na + 16;
-    const bool va = na < N, vb = nb < N;
-    const long long nna = va ? na : N - 1, nnb = vb ? nb : N - 1;
-    f32x4 ha[1], hb[1];
-    ha[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nna * 16 + 4 * g);
-    hb[0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)nnb * 16 + 4 * g);
-    f32x4 s1a[4], s1b[4], s2a[4], s2b[4];
-    bf_layer<NS, 4, 1>(Lds::template seg<LS0, false>(lds), fbias, ha, hb, s1a, s1b, lane);
-    relu2_(s1a, s1b);
-    bf_layer<NS, 4, 4>(Lds::template seg<LS1, false>(lds), fbias + 64, s1a, s1b, s2a, s2b, lane);
-    f32x4 Gla[1], Glb[1];
-    Gla[0] = Glb[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (g == 0 && va) Gla[0][0] = d_logit[na];
-    if (g == 0 && vb) Glb[0][0] = d_logit[nb];
-    dw_accumulate_bf<NS, 1, 4, 1, 4, 0, 0, true>(scr, Gla, Glb, s2a, s2b, accC, bC, lane);  // SemanticFieldHead
-    f32x4 Gs2a[4], Gs2b[4];
-    bf_layer_T<NS, 4, 1>(Lds::template seg<LH, true>(lds), Gla, Glb, Gs2a, Gs2b, lane);  // no activation on the last layer
-    dw_accumulate_bf<NS, 4, 4, 4, 4, 0, 0, true>(scr, Gs2a, Gs2b, s1a, s1b, accB, bB, lane);
-    f32x4 Gs1a[4], Gs1b[4];
-    bf_layer_T<NS, 4, 4>(Lds::template seg<LS1, true>(lds), Gs2a, Gs2b, Gs1a, Gs1b, lane);
-    relu_mask2_(Gs1a, s1a, Gs1b, s1b);
-    dw_accumulate_bf<NS, 4, 1, 4, 1, 0, 0, true>(scr, Gs1a, Gs1b, ha, hb, accA, bA, lane);  // input = detached geo: no dX
-  }
-
-  const int lane = lane0;
-  __syncthreads();
-  float* acc_lds = reinterpret_cast<float*>(smem);
-  for (int i = threadIdx.x; i < ACC_FLOATS; i += blockDim.x) acc_lds[i] = 0.0f;
-  __syncthreads();
-  for (int turn = 0; turn < WAVES; ++turn) {
-    if (wave == turn) {
-      flush_dw_bf<4, 1>(acc_lds, accA, lane);
-      flush_dw_bf<4, 4>(acc_lds + (Cfg::woff(LS1) - Cfg::woff(LS0)), accB, lane);
-      flush_dw_bf<1, 4>(acc_lds + (Cfg::woff(LH) - Cfg::woff(LS0)), accC, lane);
-      flush_bias_bf<4>(lds_bias, bA, lane);
-      flush_bias_bf<4>(lds_bias + 64, bB, lane);
-      flush_bias_bf<1>(lds_bias + 128, bC, lane);
-    }
-    __syncthreads();
-  }
-  float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
-  for (int i = threadIdx.x; i < ACC_FLOATS; i += blockDim.x) part[Cfg::woff(LS0) + i] = acc_lds[i];
-  for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) part[Cfg::W_TOTAL + Cfg::boff(LS0) + i] = lds_bias[i];
-}
-
-// ---- base branch: mlp_base_mlp (fruit_field.py:132-140,187-193) ------------------------------------------------------
-template <class Cfg, int NS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_base_bf16(
-    const float* __restrict__ packed, const __bf16* __restrict__ image, long long N, const float2* __restrict__ feats,
-    const uint8_t* __restrict__ selector, const float* __restrict__ d_density, const float* __restrict__ d_h,
-    float2* __restrict__ d_feats, float* __restrict__ partials) {
-  static_assert(Cfg::HB == 1, "bf16 kernels: `fruit_nerf` shape");
-  using Lds = BfLds<Cfg, SegsBwdBase<Cfg>, NS>;
-  constexpr int LB0 = Cfg::L_BASE0, LB1 = Cfg::L_BASE1;
-  constexpr int ACC_FLOATS = Cfg::woff(LB1 + 1) - Cfg::woff(LB0);
-  constexpr int NBIAS = 80;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
-  uint32_t* scr_all = reinterpret_cast<uint32_t*>(smem + Lds::BYTES);
-  float* fbias = reinterpret_cast<float*>(scr_all + WAVES * bscr_words<NS>());
-  float* lds_bias = fbias + NBIAS;
-  static_assert(ACC_FLOATS * 4 <= Lds::BYTES + WAVES * bscr_words<NS>() * 4, "reduction image does not fit");
-  Lds::template stage<64 * WAVES>(lds, image);
-  for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) fbias[i] = packed[Cfg::W_TOTAL + Cfg::boff(LB0) + i];
-  for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) lds_bias[i] = 0.0f;
-  __syncthreads();
-  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* scr = scr_all + wave * bscr_words<NS>();
-
-  f32x4 accA[4][2], accB[1][4];
-  f32x4 bA[4], bB[1];
-  zero_acc_bf(accA);
-  zero_acc_bf(accB);
-  zero_vec_bf(bA);
-  zero_vec_bf(bB);
-
-  const long long n_pairs = (N + 31) / 32;
-  for (long long pr = (long long)blockIdx.x * WAVES + wave; pr < n_pairs; pr += (long long)gridDim.x * WAVES) {
-    asm volatile("" ::: "memory");
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int j = lane & 15, g = lane >> 4;
-    const long long na = pr * 32 + j, nb = na + 16;
-    const bool va = na < N, vb = nb < N;
-    const long long nna = va ? na : N - 1, nnb = vb ? nb : N - 1;
-
-    // the hidden layer is recomputed from the hash features
-    f32x4 x0a[2], x0b[2], a1a[4], a1b[4], ha[1], hb[1];
-    load_hash_block(feats, N, nna, g, x0a);
-    load_hash_block(feats, N, nnb, g, x0b);
-    bf_layer<NS, 4, 2>(Lds::template seg<LB0, false>(lds), fbias, x0a, x0b, a1a, a1b, lane);
-    relu2_(a1a, a1b);
-    bf_layer<NS, 1, 4>(Lds::template seg<LB1, false>(lds), fbias + 64, a1a, a1b, ha, hb, lane);
-
-    // dL/dh = colour-branch gradient (+ density through trunc_exp on row 0)
-    f32x4 Gha[1], Ghb[1];
-    Gha[0] = Ghb[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto load_gh = [&](long long n, bool valid, const f32x4 (&h)[1], f32x4 (&Gh)[1]) {
-      if (!valid) return;
-      Gh[0] = *reinterpret_cast<const f32x4*>(d_h + (size_t)n * 16 + 4 * g);
-      if (g == 0) {
-        const bool sel = selector ? (selector[n] != 0) : true;
-        const float te = expf(fminf(fmaxf(h[0][0], -15.0f), 15.0f));  // trunc_exp backward (fruit_field.py:191)
-        Gh[0][0] = sel ? d_density[n] * te : 0.0f;                   // colour block has a zero row 0
-      }
-    };
-    load_gh(na, va, ha, Gha);
-    load_gh(nb, vb, hb, Ghb);
-    dw_accumulate_bf<NS, 1, 4, 1, 4, 0, 0, true>(scr, Gha, Ghb, a1a, a1b, accB, bB, lane);
-    f32x4 Gaa[4], Gab[4];
-    bf_layer_T<NS, 4, 1>(Lds::template seg<LB1, true>(lds), Gha, Ghb, Gaa, Gab, lane);
-    relu_mask2_(Gaa, a1a, Gab, a1b);
-    dw_accumulate_bf<NS, 4, 2, 4, 2, 0, 0, true>(scr, Gaa, Gab, x0a, x0b, accA, bA, lane);
-    f32x4 Gxa[2], Gxb[2];
-    bf_layer_T<NS, 2, 4>(Lds::template seg<LB0, true>(lds), Gaa, Gab, Gxa, Gxb, lane);
-    auto store_gx = [&](long long n, bool valid, const f32x4 (&Gx)[2]) {
-      if (!valid) return;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        d_feats[(size_t)(4 * m + g) * N + n] = make_float2(Gx[m >> 1][2 * (m & 1)], Gx[m >> 1][2 * (m & 1) + 1]);
-    };
-    store_gx(na, va, Gxa);
-    store_gx(nb, vb, Gxb);
-  }
-
-  const int lane = lane0;
-  __syncthreads();
-  float* acc_lds = reinterpret_cast<float*>(smem);
-  for (int i = threadIdx.x; i < ACC_FLOATS; i += blockDim.x) acc_lds[i] = 0.0f;
-  __syncthreads();
-  for (int turn = 0; turn < WAVES; ++turn) {
-    if (wave == turn) {
-      flush_dw_bf<4, 2>(acc_lds, accA, lane);
-      flush_dw_bf<1, 4>(acc_lds + (Cfg::woff(LB1) - Cfg::woff(LB0)), accB, lane);
-      flush_bias_bf<4>(lds_bias, bA, lane);
-      flush_bias_bf<1>(lds_bias + 64, bB, lane);
-    }
-    __syncthreads();
-  }
-  float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
-  for (int i = threadIdx.x; i < ACC_FLOATS; i += blockDim.x) part[Cfg::woff(LB0) + i] = acc_lds[i];
-  for (int i = threadIdx.x; i < NBIAS; i += blockDim.x) part[Cfg::W_TOTAL + Cfg::boff(LB0) + i] = lds_bias[i];
 }
 
 // =====================================================================================================================
@@ -1078,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_color_coop(
     float* __restrict__ gsum_tile, float* __restrict__ gsum_extra, float* __restrict__ partials) {
   constexpr int HB = Cfg::HB;  // 16-wide blocks of h: 1 (`fruit_nerf`) or 2 (`fruit_nerf_big`)
   static_assert(HB == 1 || HB == 2, "built shapes");
-  constexpr int WAVES = 8, THREADS = 512;
+  constexpr int THREADS = 512;  // 8 waves
   constexpr int LC0 = Cfg::L_COL0, LC1 = Cfg::L_COL1, LC2 = Cfg::L_COL2;
   using CL = CoopLds<Cfg, SegsColF<Cfg>, SegsColT<Cfg>, NSF, NS>;
   using F = typename CL::F;
@@ -1219,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_sem_coop(
     const float* __restrict__ packed, const __bf16* __restrict__ image, long long N, const float* __restrict__ h_saved,
     const float* __restrict__ d_logit, float* __restrict__ partials) {
   static_assert(Cfg::NSEM == 2 && Cfg::HB == 1, "`fruit_nerf` shape");
-  constexpr int WAVES = 8, THREADS = 512;
+  constexpr int THREADS = 512;  // 8 waves
   constexpr int LS0 = Cfg::L_SEM0, LS1 = Cfg::L_SEM1, LH = Cfg::L_HEAD;
   using CL = CoopLds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS>;
   using F = typename CL::F;
@@ -1308,7 +820,7 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
     float2* __restrict__ d_feats, float* __restrict__ partials) {
   constexpr int HB = Cfg::HB;
   static_assert(HB == 1 || HB == 2, "built shapes");
-  constexpr int WAVES = 8, THREADS = 512;
+  constexpr int THREADS = 512;  // 8 waves
   constexpr int LB0 = Cfg::L_BASE0, LB1 = Cfg::L_BASE1;
   using CL = CoopLds<Cfg, SegsBaseF<Cfg>, SegsBaseT<Cfg>, NSF, NS>;
   using F = typename CL::F;
@@ -1477,46 +989,6 @@ int field_mlp_fwd_bf16(int mode, const FieldPtrs& p, const float* packed, void* 
   return fwd_launch_bf16<3>(packed, image, ray_bias, rd, S, N, feats, selector, density, rgb, logit, geo_out, h_buf, st);
 }
 
-template <int NS>
-static int bwd_launch_bf16(const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd, int S,
-                           long long N, const float2* feats, const float* h_saved, const uint8_t* selector,
-                           const float* d_density, const float* d_rgb, const float* d_logit, float2* d_feats, float* d_h,
-                           float* gsum_tile, float* gsum_extra, float* partials, long long blocks, int branch,
-                           hipStream_t st) {
-  using Cfg = FieldCfgBase;
-  constexpr int WAVES = 4;
-  constexpr int SCR = WAVES * bscr_words<NS>() * 4;
-  if (branch == 0) {
-    using Lds = BfLds<Cfg, SegsBwdColor<Cfg>, NS>;
-    constexpr int bytes = Lds::BYTES + SCR + 2 * 80 * 4;
-    static_assert(bytes <= 160 * 1024, "colour branch exceeds the LDS");
-    auto kern = k_field_mlp_bwd_color_bf16<Cfg, NS, WAVES>;
-    static int once = set_dyn_lds(kern, bytes);
-    if (once) return once;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), bytes, st, packed, image, ray_bias, rd, S, N, h_saved,
-                       d_rgb, d_h, gsum_tile, gsum_extra, partials);
-  } else if (branch == 1) {
-    using Lds = BfLds<Cfg, SegsBwdSem<Cfg>, NS>;
-    constexpr int bytes = Lds::BYTES + SCR + (128 + 144) * 4;
-    static_assert(bytes <= 160 * 1024, "semantic branch exceeds the LDS");
-    auto kern = k_field_mlp_bwd_sem_bf16<Cfg, NS, WAVES>;
-    static int once = set_dyn_lds(kern, bytes);
-    if (once) return once;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), bytes, st, packed, image, N, h_saved, d_logit, partials);
-  } else {
-    using Lds = BfLds<Cfg, SegsBwdBase<Cfg>, NS>;
-    constexpr int bytes = Lds::BYTES + SCR + 2 * 80 * 4;
-    static_assert(bytes <= 160 * 1024, "base branch exceeds the LDS");
-    auto kern = k_field_mlp_bwd_base_bf16<Cfg, NS, WAVES>;
-    static int once = set_dyn_lds(kern, bytes);
-    if (once) return once;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), bytes, st, packed, image, N, feats, selector, d_density,
-                       d_h, d_feats, partials);
-  }
-  FNR_LAUNCH_CHECK();
-  return FNR_OK;
-}
-
 // branch: 0 colour, 1 semantic, 2 base; cfg: 0 `fruit_nerf`, 1 `fruit_nerf_big` (its semantic branch is
 // field_mlp_bwd_sem_big_bf16).  The bf16x3 mode runs dX / dW with two pieces (three products), the forward recompute with three.
 int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool pack, const float* packed, void* image_ws,
@@ -1539,22 +1011,11 @@ int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool p
     return bwd_launch_coop<FieldCfgBig, 3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
                                               d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
   }
-  static const bool per_wave = [] {  // FNR_BF16_BWD=wave: the first-generation per-wave-dW kernels (A/B runs)
-    const char* e = getenv("FNR_BF16_BWD");
-    return e && e[0] == 'w';
-  }();
-  if (!per_wave) {
-    if (mode == MLP_BF16)
-      return bwd_launch_coop<FieldCfgBase, 1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
-                                                 d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
-    return bwd_launch_coop<FieldCfgBase, 3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
-                                               d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
-  }
   if (mode == MLP_BF16)
-    return bwd_launch_bf16<1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit, d_feats,
-                              d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
-  return bwd_launch_bf16<2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit, d_feats,
-                            d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+    return bwd_launch_coop<FieldCfgBase, 1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
+                                               d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+  return bwd_launch_coop<FieldCfgBase, 3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
+                                             d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
 }
 
 size_t field_bf16_image_bytes() {

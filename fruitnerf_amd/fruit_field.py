@@ -44,8 +44,8 @@ MLP_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 3}
 # "auto" = "bf16x3", the fastest PARITY-GRADE arithmetic on MI355X for both built shapes (the fp32
 # MFMA runs at 1/16 of the bf16 rate on gfx950, the exact three-way split costs 6 / 3 bf16 products per fp32 product):
 #   `fruit_nerf`      every MLP kernel, 1.065 -> 0.987 ms per 4096-ray step
-#   `fruit_nerf_big`  the semantic branch (30 -> 128 -> 128 -> 64 -> head) forward and backward, weight-streamed,
-#                     7.06 -> 5.30 ms per 8192-ray step; its base and colour MLPs stay on fp32 MFMA
+#   `fruit_nerf_big`  the semantic branch (30 -> 128 -> 128 -> 64 -> head) forward and backward, weight-streamed, and the
+#                     colour / base backward, 6.96 -> 5.01 ms per 8192-ray step; its base + colour FORWARD stays on fp32 MFMA
 # "fp32" keeps the exact fmaf-chain kernels (v_mfma_f32_16x16x4_f32); both pass the same oracle-parity tests.
 
 

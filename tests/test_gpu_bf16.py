@@ -97,12 +97,12 @@ def _samples(dev, R=128, S=48, seed=7):
 
 
 @pytest.mark.parametrize("precision,tol_rgb,tol_logit,tol_dens", [("bf16x3", 5e-6, 2e-5, 2e-5), ("bf16", 3e-2, 2e-1, 1e-1)])
-@pytest.mark.parametrize("training", [False, True])
-def test_bf16_modes_vs_the_fp32_kernels_forward(dev, precision, tol_rgb, tol_logit, tol_dens, training):
+@pytest.mark.parametrize("training,shape", [(False, "fruit_nerf"), (True, "fruit_nerf"), (True, "fruit_nerf_big")])
+def test_bf16_modes_vs_the_fp32_kernels_forward(dev, precision, tol_rgb, tol_logit, tol_dens, training, shape):
     """Same weights, same samples: per-sample rgb / logit / density of the bf16-pipe kernels vs the exact fp32 MFMA
     kernels.  bf16x3 agrees to fp32 rounding; plain bf16 to ~2^-8 of the activations."""
     from fruitnerf_amd.fruit_field import FieldHeadNames as H
-    ref, alt = _field_pair(dev, precision)
+    ref, alt = _field_pair(dev, precision, shape=shape)
     ref.train(training)
     alt.train(training)
     rs = _samples(dev)
@@ -113,8 +113,8 @@ def test_bf16_modes_vs_the_fp32_kernels_forward(dev, precision, tol_rgb, tol_log
     print(f"[{precision} train={training}] rgb {e_rgb:.3e} logit {e_log:.3e} density(rel) {e_den:.3e} "
           f"(|logit| max {float(a[H.SEMANTICS].abs().max()):.2f})")
     assert e_rgb <= tol_rgb and e_log <= tol_logit and e_den <= tol_dens
-    if precision == "bf16":
-        assert e_rgb > 1e-6   # the mode really is a different arithmetic
+    if precision == "bf16":   # the mode really is a different arithmetic (fruit_nerf_big: only its semantic branch)
+        assert (e_rgb if shape == "fruit_nerf" else e_log) > 1e-6
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-4), ("bf16", 0.2)])
