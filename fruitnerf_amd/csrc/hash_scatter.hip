@@ -497,10 +497,8 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
   // levels per workgroup: as many as leaves >= 4 workgroups per CU-slot (3 workgroups per CU) in flight
   int lpb = 1;
   {
-    static const int forced = [] {
-      const char* e = getenv("FNR_EMIT_LPB");
-      return e ? atoi(e) : 0;
-    }();
+    const char* e = getenv("FNR_EMIT_LPB");  // tests force the multi-level path at small sizes
+    const int forced = e ? atoi(e) : 0;
     const long long slots = 3ll * device_cu_count();
     while (lpb < level_count && lpb < 8 && chunks * ((level_count + 2 * lpb - 1) / (2 * lpb)) >= 2 * slots) lpb *= 2;
     if (forced > 0) lpb = forced;

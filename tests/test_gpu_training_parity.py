@@ -409,6 +409,38 @@ def test_level_group_scatter_matches_single_scatter(dev, monkeypatch):
     assert int((grads[0] != 0).sum()) == int((grads[1] != 0).sum())
 
 
+@pytest.mark.parametrize("log2,prop_log2", [(15, 13), (19, 17)])
+def test_scatter_is_invariant_to_the_levels_per_workgroup(dev, monkeypatch, log2, prop_log2):
+    """k_scatter_emit takes a workgroup's 512 samples through `lpb` consecutive levels (hash_scatter.hip); the launch
+    heuristic only picks lpb > 1 at bench-sized calls, so the test forces it (FNR_EMIT_LPB).  The table gradients are
+    sums in 64-bit block fixed point, i.e. order-independent: bit-equal across lpb = 1, 2, 3 (ragged: 16 = 5 x 3 + 1 and
+    5 = 3 + 2 levels), 5.  Small tables take the per-corner path, full-size tables the corner-PAIR path."""
+    from fruitnerf_amd.rays import RayBundle
+    import fruitnerf_amd.training as T
+    cfg = util.small_config(log2=log2, prop_log2=prop_log2)
+    om = util.make_oracle(cfg, seed=9)
+    R = 96
+    o, d, pa, cam = util.random_rays(R, 7, seed=4)
+    jit = [torch.rand(R, 1).to(dev) for _ in range(3)]
+    hb = {k: v.to(dev) for k, v in _batch(R, 8).items()}
+    grads = []
+    for lpb in ("1", "1", "2", "3", "5"):
+        monkeypatch.setenv("FNR_EMIT_LPB", lpb)
+        hm = util.make_hip_like(om, dev)
+        hm.train()
+        hm.set_anneal(0)
+        T.fused_forward_backward(hm, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), hb, jitter=jit)
+        torch.cuda.synchronize()
+        # the hash tables only: the MLP weight gradients meet in float atomics (k_reduce_dw), whose order is not fixed
+        tables = [hm.field.mlp_base_grid.hash_table.grad] + [p.encoding.hash_table.grad for p in hm.proposal_networks]
+        grads.append([t.detach().clone() for t in tables])
+    assert all(float(t.abs().max()) > 0 for t in grads[0])
+    for which, g in enumerate(grads[1:]):
+        for t, ref in zip(g, grads[0]):
+            diff = (t - ref).abs().max().item()
+            assert torch.equal(t, ref), (which, diff, float(ref.abs().max()))
+
+
 def test_ray_gradient_paths_agree(dev):
     """The saved-Jacobian path (forward encode stores d feats / d x) and the gather path (backward re-reads the table)
     of the hash grid's input gradient give the same ray gradients."""
