@@ -37,7 +37,6 @@ TRAIN_SPLIT = 0.9              # fruitnerf_dataparser.py:62
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA (the roofline of --mlp-precision bf16 / bf16x3)
-MFMA_PEAK_TF = MFMA_F32_PEAK_TF  # set in main() from --mlp-precision
 # issued bf16 products per algorithmic fp32 product (set in main(): bf16x3 -> fwd 6, bwd (6 + 3 + 3) / 2 per its three
 # equal thirds recompute / dX / dW measured against the algorithmic dX + dW; plain bf16 -> 1 and 1.5)
 ISSUED_BF16 = {}
@@ -98,9 +97,11 @@ def roofline_entry(op, units, avg_ms, launches, alg):
         peak, unit, key = HBM_PEAK_GBS, "GB/s", "alg_bytes_per_unit"
     else:
         achieved = per_unit * units / (avg_ms * 1e-3) / 1e12
-        peak, unit, key = MFMA_PEAK_TF, "TFLOP/s", "alg_flop_per_unit"
+        peak, unit, key = MFMA_F32_PEAK_TF, "TFLOP/s", "alg_flop_per_unit"
     extra = {}
-    if bound == "mfma" and MFMA_PEAK_TF != MFMA_F32_PEAK_TF:
+    if bound == "mfma":
+        peak = MFMA_BF16_PEAK_TF if op in ISSUED_BF16 else MFMA_F32_PEAK_TF
+    if bound == "mfma" and op in ISSUED_BF16:
         # bf16x3 / bf16: `achieved` stays the ALGORITHMIC (fp32-equivalent) FLOP rate; the pipe executes ISSUED_BF16[op]
         # bf16 products per algorithmic product (exact three-way split: 6 forward; backward = 6 for the forward
         # recompute it repeats, 3 for dX and dW), which is what loads the 2.5 PFLOP/s bf16 pipe
@@ -256,16 +257,19 @@ def main() -> None:
     M = METHODS[args.method]
     RAYS_PER_BATCH = M["rays"]
     ALG = alg_table(M["mlp_flop"])
-    global MFMA_PEAK_TF
     if args.mlp_precision == "auto":
         args.mlp_precision = "bf16x3"
-    # fruit_nerf_big in bf16x3 mode: only the semantic branch's backward is on the bf16 pipe; forward, colour and base
-    # are fp32 MFMA, so the fp32 peak stays the yardstick of the MLP entry points there
-    MFMA_PEAK_TF = MFMA_BF16_PEAK_TF if (args.mlp_precision != "fp32" and args.method == "fruit_nerf") else MFMA_F32_PEAK_TF
+    # entry points that run on the bf16 pipe (their roofline peak is the dense bf16 MFMA peak) and the bf16 piece
+    # products they issue per algorithmic fp32 product.  fruit_nerf_big: the whole backward and the forward's semantic
+    # branch; its base + colour forward is fp32 MFMA, so field_mlp_fwd keeps the fp32 peak there.
     if args.mlp_precision == "bf16x3":
-        ISSUED_BF16.update({"field_mlp_fwd": 6.0, "field_mlp_bwd": 6.0})   # (6 recompute + 3 dX + 3 dW) per (dX + dW)
+        ISSUED_BF16.update({"field_mlp_bwd": 6.0})                          # (6 recompute + 3 dX + 3 dW) per (dX + dW)
+        if args.method == "fruit_nerf":
+            ISSUED_BF16.update({"field_mlp_fwd": 6.0})
     elif args.mlp_precision == "bf16":
-        ISSUED_BF16.update({"field_mlp_fwd": 1.0, "field_mlp_bwd": 1.5})
+        ISSUED_BF16.update({"field_mlp_bwd": 1.5})
+        if args.method == "fruit_nerf":
+            ISSUED_BF16.update({"field_mlp_fwd": 1.0})
     model_cfg = FruitNerfModelConfig(mlp_precision=args.mlp_precision, **M["model"])
     model = FruitModel(model_cfg, apple_metadata(), num_train_data=len(i_train), device=dev)
     model.train()
@@ -584,8 +588,8 @@ def main() -> None:
         # arithmetic type of the MLP GEMMs; hash grids, samplers, compositing, losses and the optimiser are fp32 in
         # every mode.  bf16x3 = three bf16 pieces per fp32 operand (fp32-grade results), bf16 = bf16 operands.
         "dtype": {"fp32": "f32", "bf16x3": "f32 (MLP GEMMs: exact bf16x3 split on the bf16 MFMA pipe"
-                                                    + ("" if args.method == "fruit_nerf" else " for the semantic "
-                                                       "branch's backward, fp32 MFMA elsewhere") + ")",
+                                                    + ("" if args.method == "fruit_nerf" else "; the base + colour "
+                                                       "forward on fp32 MFMA") + ")",
                   "bf16": "bf16"}[args.mlp_precision],
         "data": "synthetic",
         "config": {"workload": f"{args.method} synthetic apple {HW}x{HW}, {N_CAMERAS} cameras ({len(i_train)} train), "
