@@ -231,7 +231,8 @@ def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, se
                                   L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
             "field_mlp_fwd")
     if want_h:
-        return density, rgb, logit, geo, (h, ray_bias, ws)
+        # the workspace holds the fragment images of THIS call's weights in THIS call's arithmetic (fnr_field_net.mlp_mode)
+        return density, rgb, logit, geo, (h, ray_bias, ws, int(net.mlp_mode))
     return density, rgb, logit, geo
 
 
@@ -348,7 +349,10 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
     """h_saved: what field_mlp_fwd(want_h=True) returned — (h [N,16], ray_bias [R,64], packed weights); a bare h tensor
     is accepted too (the per-ray bias and the fragment image are then recomputed)."""
     lib = L.load()
+    fwd_mode = h_saved[3] if isinstance(h_saved, tuple) and len(h_saved) > 3 else None
     h_saved, ray_bias, packed = (tuple(h_saved) + (None, None))[:3] if isinstance(h_saved, tuple) else (h_saved, None, None)
+    if fwd_mode is not None and fwd_mode != int(net.mlp_mode):
+        packed = None   # the forward ran in another arithmetic: its workspace lacks this mode's fragment images — repack
     dev = rays.device
     N = rays.n * S
     d_feats = torch.empty_like(feats)
