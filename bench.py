@@ -61,6 +61,21 @@ METHODS = {
                 "fields": dict(lr=1e-2, lr_final=1e-4, max_steps=50000)},
         camera=dict(lr=6e-4, eps=1e-8, weight_decay=1e-3, lr_final=None, max_steps=None, algorithm="radam"),
         samples=(512, 256, 128), mlp_flop=83584.0, flop_per_ray_train=32.9e6, bytes_per_ray_train=3 * 376832.0),
+    # fruit_nerf_config.py:113-164: the big field at max_res 8192, proposal nets 5 levels -> 512 and 7 levels -> 2048
+    "fruit_nerf_huge": dict(
+        rays=16384,
+        model=dict(num_nerf_samples_per_ray=64, num_proposal_samples_per_ray=(512, 512), geo_feat_dim=30,
+                   hidden_dim_semantics=128, num_layers_semantic=3, max_res=8192,
+                   proposal_weights_anneal_max_num_iters=5000, log2_hashmap_size=21,
+                   proposal_net_args_list=[
+                       {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 512, "use_linear": False},
+                       {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 7, "max_res": 2048, "use_linear": False}]),
+        algorithm="radam",
+        groups={"proposal_networks": dict(lr=1e-2, lr_final=None, max_steps=None),
+                "fields": dict(lr=1e-2, lr_final=1e-4, max_steps=50000)},
+        camera=dict(lr=6e-4, eps=1e-8, weight_decay=1e-3, lr_final=6e-5, max_steps=50000, algorithm="radam"),
+        samples=(512, 512, 64), mlp_flop=83584.0, flop_per_ray_train=3 * 5.775e6,
+        bytes_per_ray_train=3 * (64 * 1024.0 + 512 * 5 * 64.0 + 512 * 7 * 64.0)),
 }
 
 
@@ -594,7 +609,9 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": f"{args.method} synthetic apple {HW}x{HW}, {N_CAMERAS} cameras ({len(i_train)} train), "
                                f"{RAYS_PER_BATCH} rays/rank/step, samples {'/'.join(map(str, M['samples']))}, "
-                               f"hash 16x2^{model_cfg.log2_hashmap_size}x2 + 2x(5x2^17x2), geo {model_cfg.geo_feat_dim}, "
+                               f"hash 16x2^{model_cfg.log2_hashmap_size}x2 + proposal grids "
+                               f"{'+'.join(str(a['num_levels']) + 'x2^' + str(a['log2_hashmap_size']) + 'x2' for a in model_cfg.proposal_net_args_list)}"
+                               f", geo {model_cfg.geo_feat_dim}, "
                                f"semantic MLP {model_cfg.num_layers_semantic}x{model_cfg.hidden_dim_semantics}, "
                                f"fwd+bwd+{M['algorithm']} over {n_params / 1e6:.1f} M parameters, proposal-net update "
                                f"schedule from step 0, camera optimizer {args.camera_optimizer}",

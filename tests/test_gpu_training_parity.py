@@ -53,14 +53,17 @@ def _grad_report(om, hm, tag="", with_aggregate=False):
 
 
 @pytest.mark.parametrize("step,n_samples,shape", [(0, 48, "fruit_nerf"), (12, 48, "fruit_nerf"), (0, 40, "fruit_nerf"),
+                                                  (0, 64, "fruit_nerf_huge"),
                                                   (0, 128, "fruit_nerf_big"), (12, 40, "fruit_nerf_big")])
 def test_losses_and_all_gradients(dev, step, n_samples, shape):
     """step 0: proposal nets are 'updated' (interlevel gradient flows); step 12 with a fresh sampler
     state: not updated -> proposal-network gradients must be exactly zero on both sides.
     40 samples per ray: 16-sample MFMA tiles straddle rays (per-ray colour terms take their slow path).
-    fruit_nerf_big: the second built MLP shape (geo 30, semantic 30 -> 128 -> 128 -> 64; FieldCfgBig)."""
+    fruit_nerf_big: the second built MLP shape (geo 30, semantic 30 -> 128 -> 128 -> 64; FieldCfgBig).
+    fruit_nerf_huge: that field with the huge method's proposal networks (5 levels -> 512, 7 levels -> 2048)."""
     from fruitnerf_amd.rays import RayBundle
-    cfg = (util.small_config if shape == "fruit_nerf" else util.big_config)(log2=15, prop_log2=13)
+    cfg = {"fruit_nerf": util.small_config, "fruit_nerf_big": util.big_config,
+           "fruit_nerf_huge": util.huge_config}[shape](log2=15, prop_log2=13)
     cfg.num_nerf_samples_per_ray = n_samples
     # this test is about the MLP shape: keep the sampler in the regime of the fruit_nerf cases (an anneal exponent of
     # 0.02 at step 12 of 5000 makes the PDF sampler's inverse CDF ill-conditioned, and max_res 4096 on a RANDOM table

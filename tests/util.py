@@ -28,6 +28,17 @@ def big_config(log2=14, prop_log2=12, max_res=4096):
     return cfg
 
 
+def huge_config(log2=14, prop_log2=12):
+    """`fruit_nerf_huge` (fruit_nerf_config.py:113-164) on small tables: the field of `fruit_nerf_big` at max_res 8192 and
+    ITS proposal networks — 5 levels up to 512 and 7 levels up to 2048 (the only config with a 7-level proposal grid)."""
+    cfg = big_config(log2=log2, prop_log2=prop_log2, max_res=8192)
+    cfg.proposal_net_args_list = [
+        {"hidden_dim": 16, "log2_hashmap_size": prop_log2, "num_levels": 5, "max_res": 512, "use_linear": False},
+        {"hidden_dim": 16, "log2_hashmap_size": prop_log2, "num_levels": 7, "max_res": 2048, "use_linear": False},
+    ]
+    return cfg
+
+
 def fruit_nerf_big_config():
     """The model part of the `fruit_nerf_big` method at its real sizes (fruit_nerf_config.py:82-95)."""
     cfg = fo.FruitNerfModelConfig(log2_hashmap_size=21, max_res=4096)
