@@ -1,8 +1,9 @@
 // field_mlp_bf16.hip — FruitField's MLP stack, forward and backward, on the bf16 matrix pipe of gfx950
-// (v_mfma_f32_16x16x32_bf16).  Two opt-in modes of fnr_field_net.mlp_mode, see field_bf16.hpp:
-//   FNR_MLP_BF16   (1)  plain bf16 operands, fp32 accumulate — throughput mode, not parity grade;
-//   FNR_MLP_BF16X3 (3)  exact 3-way bf16 split of every fp32 operand, 6 products forward / 3 products backward —
-//                       fp32-grade results at 16/6 (forward) and 16/3 (backward) of the fp32-MFMA issue rate.
+// (v_mfma_f32_16x16x32_bf16).  Two modes of fnr_field_net.mlp_mode, see field_bf16.hpp:
+//   FNR_MLP_BF16X3 (3)  exact 3-way bf16 split of every fp32 operand (FruitField's default): 6 piece products per
+//                       product in the forward pass and in the backward's forward recompute, 3 in dX / dW — fp32-grade
+//                       results at 16/6 resp. 16/3 of the fp32-MFMA issue rate;
+//   FNR_MLP_BF16   (1)  plain bf16 operands, fp32 accumulate — throughput mode, not parity grade.
 // Same entry points, buffers and partial-gradient image as the fp32 kernels (field_mlp.hip, field_mlp_bwd.hip):
 // the per-ray colour bias, the per-ray / per-camera finish of mlp_head layer 0 and k_reduce_dw are shared.
 // Replaces the same reference code: fruit_field.py:132-166,187-281 and its autograd.
@@ -150,7 +151,7 @@ __device__ __forceinline__ void zero_vec_bf(f32x4 (&a)[N]) {
 // the forward and most of the dX chain (field_mlp_bwd.hip: 2.26 ms of a 7.06 ms step at 8192 rays).  Here:
 //   * WEIGHT STREAMING: a workgroup of 8 waves takes a batch of 8 tiles (128 samples) through the branch layer by layer;
 //     the bf16 fragment pieces of the layer(s) in use are re-staged from L2 into the SAME LDS region per phase
-//     (forward sem0+sem1 | transposed head+sem2 | transposed sem1: <= 80 KB at two pieces, 1.4 KB of L2 reads per sample);
+//     (forward sem0+sem1 at three pieces, 120 KB | transposed head+sem2 | transposed sem1 at two: ~1.8 KB of L2 reads per sample);
 //   * COOPERATIVE dW: dW = dY^T X is not accumulated per wave.  All waves write their tile's dY and X columns (bf16
 //     pieces) into one [feature row][128 samples] LDS scratch (it overlays the weight region between phases), and every
 //     output block (16 x 16 weights) of the layer is owned by ONE wave, which sums it over the batch's 128 samples (four
