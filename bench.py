@@ -86,7 +86,9 @@ def alg_table(mlp_flop: float):
     issued work, not useful work, and is not counted."""
     return {
         "hash_encode_fwd": ("hbm", 1024.0 + 128.0),          # 16 lvl x 8 corners x 8 B + 128 B features written
-        "hash_encode_bwd": ("hbm", 2 * 1024.0 + 128.0),      # gradient read-modify-write + d_feats read
+        # gradient read-modify-write + d_feats read.  (At N=1 the launch also carries the table's Adam step, 24 B per
+        # table parameter that are NOT added here: `achieved` understates that launch.)
+        "hash_encode_bwd": ("hbm", 2 * 1024.0 + 128.0),
         "prop_density_fwd": ("hbm", 320.0 + 4.0),            # 5 lvl x 8 corners x 8 B + density
         "prop_density_bwd": ("hbm", 2 * 320.0 + 40.0 + 4.0),
         "field_mlp_fwd": ("mfma", mlp_flop),                 # useful FLOP / sample
@@ -616,6 +618,9 @@ def main() -> None:
                                f"fwd+bwd+{M['algorithm']} over {n_params / 1e6:.1f} M parameters, proposal-net update "
                                f"schedule from step 0, camera optimizer {args.camera_optimizer}",
                    "method": args.method, "mlp_precision": args.mlp_precision, "rays_per_rank": RAYS_PER_BATCH, "parallelism": f"dp{world}",
+                   # N=1: the main table's optimiser step runs inside the scatter's accumulate kernel (its launches are
+                   # the hash_encode_bwd entry; no gradient table is written or re-read); N>1: separate step after RCCL
+                   "table_optimizer": "fused into hash_encode_bwd" if not dist_on else "separate (after the exchange)",
                    "device": info["arch"], "setup_s": round(setup_s, 1)},
         "roofline": roofline,
         "roofline_other_bound": roofline_other,

@@ -394,6 +394,18 @@ def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, eucl
             "hash_encode_bwd")
 
 
+def hash_encode_bwd_adam(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
+                         d_feats: Tensor, adam: L.fnr_table_adam) -> None:
+    """hash_encode_bwd over all levels with the table's optimiser step fused into the accumulate kernel (the gradient
+    table is not written; `adam` points at the table's parameter / moment slices)."""
+    lib = L.load()
+    nbytes = lib.fnr_hash_scatter_workspace_bytes(rays.n * S, grid_grad.n_levels, grid_grad.log2_hashmap_size)
+    ws, clean = _scatter_workspace(rays.device, nbytes, "field")
+    L.check(lib.fnr_hash_encode_bwd_adam(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
+                                         L.ptr(ws), nbytes, clean, C.byref(adam), L.stream_ptr(rays.device)),
+            "hash_encode_bwd_adam")
+
+
 def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor,
                      S: int, feats: Tensor, d_density: Tensor, want_position_grad: bool = False) -> Optional[Tensor]:
     """want_position_grad: also return d(loss)/d(unit-cube position) [N,4] for position_grad_reduce(n_levels=1)."""

@@ -53,6 +53,12 @@ class fnr_field_net(C.Structure):
                 ("mlp_mode", C.c_int32)]
 
 
+class fnr_table_adam(C.Structure):
+    _fields_ = [("algorithm", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("step", C.c_int64), ("grad_scale", C.c_float), ("weight_decay", C.c_float),
+                ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p)]
+
+
 class fnr_lattice(C.Structure):
     _fields_ = [("n_x", C.c_int32), ("n_y", C.c_int32), ("n_z", C.c_int32),
                 ("xs", C.c_void_p), ("ys", C.c_void_p), ("zs", C.c_void_p)]
@@ -100,6 +106,8 @@ SIGNATURES = {
                                _vp, _vp, _vp, C.c_size_t, _vp]),
     "fnr_hash_scatter_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "fnr_hash_encode_bwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _i, _vp]),
+    "fnr_hash_encode_bwd_adam": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, C.c_size_t, _i,
+                                      P(fnr_table_adam), _vp]),
     "fnr_prop_density_bwd_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "fnr_prop_density_bwd": (_i, [P(fnr_prop_net), P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp,
                                   _vp, C.c_size_t, _i, _vp]),

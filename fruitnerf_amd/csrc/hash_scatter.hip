@@ -363,6 +363,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       queue_v[q] = v;
       queue_r[q] = (unsigned short)row_in_bin;
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
+      qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;  // tells the accumulate kernel that the table holds part of the sum
       const size_t row = ((size_t)bin << log2_rows) + row_in_bin;
       atomicAdd(table + 2 * row, v.x);
       atomicAdd(table + 2 * row + 1, v.y);
@@ -392,12 +393,43 @@ __device__ __forceinline__ void acc_record(unsigned long long* __restrict__ s_ac
   atomicAdd(&s_acc[2 * row + 1], (unsigned long long)iy);
 }
 
+// Optimiser step fused into the accumulate kernel (single-process training): the workgroup that owns a bin has the
+// bin's summed gradient in LDS, so it applies torch.optim.Adam / RAdam to those rows right there.  The gradient table
+// is then neither read-modify-written here nor read and zeroed by the optimiser pass: 40 -> 24 bytes of HBM traffic
+// per table parameter and step.  Same operations in the same order as k_adam / k_radam (train.hip): bit-identical
+// parameters and moments.
+struct TableAdam {
+  float2 *p, *m, *v;  // the table's slices of the parameter / exp_avg / exp_avg_sq arenas, [L << log2_T] rows
+  float lr, b1, b2, eps, bc1, bc2_sqrt, rect, grad_scale, weight_decay;
+  int radam;
+};
+__device__ __forceinline__ void table_adam_update(const TableAdam& a, float g, float& P, float& M, float& V) {
+  float gr = g * a.grad_scale;
+  if (a.weight_decay != 0.0f) gr = gr + a.weight_decay * P;
+  M = M + (gr - M) * (1.0f - a.b1);
+  V = V * a.b2 + (1.0f - a.b2) * gr * gr;
+  if (!a.radam) {
+    const float step_size = a.lr / a.bc1;
+    const float denom = sqrtf(V) / a.bc2_sqrt + a.eps;
+    P = P - step_size * (M / denom);
+  } else {
+    const float mhat = M / a.bc1;
+    if (a.rect >= 0.0f) {
+      const float adaptive = a.bc2_sqrt / (sqrtf(V) + a.eps);
+      P = P - a.lr * (mhat * a.rect * adaptive);
+    } else {
+      P = P - a.lr * mhat;
+    }
+  }
+}
+
+template <bool ADAM>
 __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float2* __restrict__ queue_v,
                                                              const unsigned short* __restrict__ queue_r,
                                                              unsigned* __restrict__ qcount,
                                                              unsigned* __restrict__ qmax,
                                                              unsigned* __restrict__ qdone, long long cap,
-                                                             int log2_rows, int level0) {
+                                                             int log2_rows, int level0, TableAdam adam) {
   __shared__ unsigned long long s_acc[2 * SC_MAX_ROWS];  // [rows][2] two's-complement fixed point, 128 KiB
   const int rows = 1 << log2_rows;
   const int bins = 1 << (grid.log2_T - log2_rows);
@@ -407,6 +439,8 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   const int level = level0 + lrel;
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
   const float vmax = __uint_as_float(qmax[(size_t)lrel * SC_CNT_STRIDE]);  // largest |value| of the whole level
+  // some emit workgroup overflowed a queue of this level and added records to the gradient table with atomics
+  const bool overflowed = qmax[(size_t)lrel * SC_CNT_STRIDE + 1] != 0u;
   // every thread has its copy: put the counters back to zero, so the NEXT call on this workspace needs no memset
   // launch (the caller says so with workspace_clean = 1).  The level's max is shared by its `bins` workgroups: the
   // last of them to have read it clears it.
@@ -415,11 +449,14 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
     qcount[(size_t)gbin * SC_CNT_STRIDE] = 0u;
     if (atomicAdd(&qdone[(size_t)lrel * SC_CNT_STRIDE], 1u) == (unsigned)bins - 1u) {
       qmax[(size_t)lrel * SC_CNT_STRIDE] = 0u;
+      qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 0u;
       qdone[(size_t)lrel * SC_CNT_STRIDE] = 0u;
     }
   }
-  if (n == 0 || !(vmax > 0.0f)) return;
+  const bool have = n != 0 && vmax > 0.0f;
+  if (!ADAM && !have) return;  // (with the fused optimiser every row still takes its moment-decay step)
   if (n > cap) n = cap;
+  if (n < 1) n = 1;
   // |v| < 2^e ; n < 2^nb  =>  |sum * 2^S| < 2^62 with S = 62 - nb - e
   int e;
   (void)frexpf(vmax, &e);
@@ -429,6 +466,7 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   const double scale = ldexp(1.0, S), inv = ldexp(1.0, -S);
   for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0ull;
   __syncthreads();
+  if (!have) n = 0;
   const float2* qv = queue_v + (size_t)gbin * cap;
   const unsigned short* qr = queue_r + (size_t)gbin * cap;
   // records in PAIRS: one 16-byte + one 4-byte load per two records (a bin's queue starts at a multiple of `cap`, a
@@ -461,13 +499,37 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   if ((n & 1) && threadIdx.x == 0) acc_record(s_acc, qr[n - 1], qv[n - 1], scale);
   __syncthreads();
   float2* dst = grid.table + ((size_t)level << grid.log2_T) + (size_t)bin * rows;
-  for (int e2 = threadIdx.x; e2 < rows; e2 += blockDim.x) {
-    const long long ax = (long long)s_acc[2 * e2], ay = (long long)s_acc[2 * e2 + 1];
-    if (ax != 0 || ay != 0) {
-      float2 t = dst[e2];
-      t.x += (float)((double)ax * inv);
-      t.y += (float)((double)ay * inv);
-      dst[e2] = t;
+  if constexpr (ADAM) {
+    const size_t row0 = ((size_t)level << grid.log2_T) + (size_t)bin * rows;
+    for (int e2 = threadIdx.x; e2 < rows; e2 += blockDim.x) {
+      const long long ax = (long long)s_acc[2 * e2], ay = (long long)s_acc[2 * e2 + 1];
+      // the gradient exactly as the unfused path leaves it in the table: existing entry (zero, or what overflowed
+      // queues added with atomics) + this bin's sum
+      float2 g = make_float2(0.0f, 0.0f);
+      if (overflowed) {
+        g = dst[e2];
+        if (g.x != 0.0f || g.y != 0.0f) dst[e2] = make_float2(0.0f, 0.0f);
+      }
+      if (ax != 0 || ay != 0) {
+        g.x += (float)((double)ax * inv);
+        g.y += (float)((double)ay * inv);
+      }
+      float2 P = adam.p[row0 + e2], M = adam.m[row0 + e2], V = adam.v[row0 + e2];
+      table_adam_update(adam, g.x, P.x, M.x, V.x);
+      table_adam_update(adam, g.y, P.y, M.y, V.y);
+      adam.p[row0 + e2] = P;
+      adam.m[row0 + e2] = M;
+      adam.v[row0 + e2] = V;
+    }
+  } else {
+    for (int e2 = threadIdx.x; e2 < rows; e2 += blockDim.x) {
+      const long long ax = (long long)s_acc[2 * e2], ay = (long long)s_acc[2 * e2 + 1];
+      if (ax != 0 || ay != 0) {
+        float2 t = dst[e2];
+        t.x += (float)((double)ax * inv);
+        t.y += (float)((double)ay * inv);
+        dst[e2] = t;
+      }
     }
   }
 }
@@ -475,7 +537,7 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
 template <class Source>
 static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Source& src, long long N,
                           const float2* d_feats, int level0, int level_count, void* workspace, size_t workspace_bytes,
-                          int workspace_clean, hipStream_t st) {
+                          int workspace_clean, hipStream_t st, const TableAdam* adam = nullptr) {
   FNR_CHECK_ARG(level0 >= 0 && level_count >= 1 && level0 + level_count <= grid_grad->n_levels,
                 "hash scatter: level range [%d,+%d) outside the %d levels", level0, level_count, grid_grad->n_levels);
   const ScatterPlan p = scatter_plan(N, level_count, grid_grad->log2_hashmap_size);
@@ -505,7 +567,9 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
     if (lpb > level_count) lpb = level_count;
   }
   const unsigned gy = (unsigned)((level_count + lpb - 1) / lpb);
-  if (pairs)
+  if (chunks == 0) {
+    // nothing to emit (the fused-optimiser call still runs the accumulate kernel: every row takes its step)
+  } else if (pairs)
     hipLaunchKernelGGL((k_scatter_emit<Source, true>), dim3((unsigned)chunks, gy), dim3(SC_EMIT_THREADS),
                        0, st, gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap,
                        p.log2_rows, level0, level_count, lpb);
@@ -515,9 +579,14 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
                        p.log2_rows, level0, level_count, lpb);
   FNR_LAUNCH_CHECK();
   const unsigned nbins = (unsigned)(level_count * p.bins_per_level);
-  hipLaunchKernelGGL(k_scatter_accumulate, dim3(nbins), dim3(1024), 0, st, gd,
-                     queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE,
-                     qcount + (nbins_all + level_count) * SC_CNT_STRIDE, p.cap, p.log2_rows, level0);
+  if (adam)
+    hipLaunchKernelGGL(k_scatter_accumulate<true>, dim3(nbins), dim3(1024), 0, st, gd, queue_v, queue_r, qcount,
+                       qcount + nbins_all * SC_CNT_STRIDE, qcount + (nbins_all + level_count) * SC_CNT_STRIDE, p.cap,
+                       p.log2_rows, level0, *adam);
+  else
+    hipLaunchKernelGGL(k_scatter_accumulate<false>, dim3(nbins), dim3(1024), 0, st, gd, queue_v, queue_r, qcount,
+                       qcount + nbins_all * SC_CNT_STRIDE, qcount + (nbins_all + level_count) * SC_CNT_STRIDE, p.cap,
+                       p.log2_rows, level0, TableAdam{});
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }
@@ -745,6 +814,51 @@ extern "C" int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* wa
   FNR_PROF(OP_ENCODE_BWD, N);
   return binned_scatter(grid_grad, make_warp(warp), src, N, reinterpret_cast<const float2*>(d_feats), level_begin,
                         level_count, workspace, workspace_bytes, workspace_clean, as_stream(stream));
+}
+
+namespace {
+// host side of TableAdam: the step-dependent scalars exactly as fnr_adam_step / fnr_radam_step compute them (double)
+int make_table_adam(const fnr_table_adam* a, const fnr_grid* grid_grad, TableAdam& t) {
+  FNR_CHECK_ARG(a && a->params && a->exp_avg && a->exp_avg_sq, "table adam: null argument");
+  FNR_CHECK_ARG(a->algorithm == 0 || a->algorithm == 1, "table adam: algorithm %d (0 = Adam, 1 = RAdam)", a->algorithm);
+  FNR_CHECK_ARG(a->step >= 1, "table adam: step must be >= 1");
+  t.p = reinterpret_cast<float2*>(a->params);
+  t.m = reinterpret_cast<float2*>(a->exp_avg);
+  t.v = reinterpret_cast<float2*>(a->exp_avg_sq);
+  t.lr = a->lr, t.b1 = a->beta1, t.b2 = a->beta2, t.eps = a->eps, t.grad_scale = a->grad_scale, t.weight_decay = a->weight_decay;
+  t.radam = a->algorithm;
+  const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step);
+  const double b2t = pow((double)a->beta2, (double)a->step);
+  const double bc2 = 1.0 - b2t;
+  t.bc1 = (float)bc1;
+  t.bc2_sqrt = (float)sqrt(bc2);
+  t.rect = -1.0f;
+  if (a->algorithm == 1) {
+    const double rho_inf = 2.0 / (1.0 - (double)a->beta2) - 1.0;
+    const double rho_t = rho_inf - 2.0 * (double)a->step * b2t / bc2;
+    if (rho_t > 5.0)
+      t.rect = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+  }
+  (void)grid_grad;
+  return FNR_OK;
+}
+}  // namespace
+
+extern "C" int fnr_hash_encode_bwd_adam(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
+                                        const float* euclid_bins, int S, const float* d_feats, void* workspace,
+                                        size_t workspace_bytes, int workspace_clean, const fnr_table_adam* adam,
+                                        void* stream) {
+  FNR_CHECK_ARG(grid_grad && warp && rays && euclid_bins && d_feats && S > 0, "hash_encode_bwd_adam: null argument");
+  FNR_CHECK_ARG(grid_grad->n_levels >= 1 && grid_grad->n_levels <= FNR_MAX_LEVELS, "hash_encode_bwd_adam: n_levels");
+  TableAdam t;
+  const int rc = make_table_adam(adam, grid_grad, t);
+  if (rc) return rc;
+  const long long N = rays->n_rays * (long long)S;
+  RaySource src{make_rays(rays), euclid_bins, S};
+  FNR_PROF(OP_ENCODE_BWD, N);
+  // N == 0 still takes the optimiser step (every row decays its moments): the scatter runs with empty queues
+  return binned_scatter(grid_grad, make_warp(warp), src, N, reinterpret_cast<const float2*>(d_feats), 0,
+                        grid_grad->n_levels, workspace, workspace_bytes, workspace_clean, as_stream(stream), &t);
 }
 
 extern "C" size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {

@@ -299,6 +299,24 @@ class FusedAdam:
         return {name: (exponential_decay_lr(self.step_count - 1, g["lr"], g["lr_final"], g["max_steps"])
                        if g.get("lr_final") is not None else g["lr"]) for name, g in self.groups.items()}
 
+    def table_adam_args(self, table: Tensor, group: str = "fields", grad_scale: float = 1.0):
+        """fnr_table_adam for the NEXT update of `table` (a parameter of `group` that lives in the arena): learning
+        rate and step count as begin_step() will set them — the fused scatter (fnr_hash_encode_bwd_adam) runs before
+        the optimiser's own step and takes this parameter's update with it.  -> (struct, (a, b) arena span)."""
+        from . import _lib as L
+        hit = [(off, n) for _, p, off, n in self.arena.entries if p is table]
+        if len(hit) != 1:
+            raise RuntimeError("parameter not found in the arena")
+        a, n = hit[0]
+        g = self.groups[group]
+        lr = (exponential_decay_lr(self.step_count, g["lr"], g["lr_final"], g["max_steps"])
+              if g.get("lr_final") is not None else g["lr"])
+        args = L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], self.eps,
+                                self.group_steps[group] + 1, grad_scale, self.weight_decay,
+                                L.ptr(self.arena.params[a:a + n]), L.ptr(self.exp_avg[a:a + n]),
+                                L.ptr(self.exp_avg_sq[a:a + n]))
+        return args, (a, a + n)
+
     def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0, group: Optional[str] = None) -> None:
         """Adam update (+ zero_grad) of arena elements [a, b); begin_step() must have been called for this step.
         group: whose step counter feeds the bias corrections (default: the group that contains a)."""
@@ -310,9 +328,10 @@ class FusedAdam:
                self.betas[0], self.betas[1], self.eps, self.group_steps[group], grad_scale, True,
                weight_decay=self.weight_decay)
 
-    def step(self, grad_scale: float = 1.0, skip=()) -> None:
+    def step(self, grad_scale: float = 1.0, skip=(), done=()) -> None:
         """One optimiser step over every group except `skip` (see begin_step).  Adjacent groups whose learning rate AND
-        step count coincide share one launch."""
+        step count coincide share one launch.  done: arena spans whose update a fused kernel already applied for this
+        step (table_adam_args) — they are cut out of the launches."""
         lrs = self.begin_step(skip)
         runs = []   # [a, b, lr, group]
         for name, (a, b) in self.arena.group_ranges.items():
@@ -323,6 +342,17 @@ class FusedAdam:
                 runs[-1][1] = b
             else:
                 runs.append([a, b, lrs[name], name])
+        for da, db in sorted(done):
+            cut = []
+            for a, b, lr, name in runs:
+                if db <= a or da >= b:
+                    cut.append([a, b, lr, name])
+                else:
+                    if a < da:
+                        cut.append([a, da, lr, name])
+                    if db < b:
+                        cut.append([db, b, lr, name])
+            runs = cut
         for a, b, lr, name in runs:
             self.step_span(a, b, lr, grad_scale, group=name)
 
@@ -423,7 +453,8 @@ class _FieldGradientExchange:
 
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
-                           ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False):
+                           ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False,
+                           table_adam=None):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -432,7 +463,9 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
     launches; per step that removes ~20 elementwise/fill/reduce launches and the engine's start-up gap that
     autograd put between them.  Gradients land in the model's arena exactly as with loss.backward().
     ray_grads: pass a dict to also receive d(loss)/d(origins) and d(loss)/d(directions) [R,3] under the keys
-    "origins" / "directions" (what a camera-pose optimiser back-propagates further)."""
+    "origins" / "directions" (what a camera-pose optimiser back-propagates further).
+    table_adam: fnr_table_adam of the main hash table (FusedAdam.table_adam_args): its gradient is not materialised,
+    the scatter's accumulate kernel applies the optimiser step to the table (single process only)."""
     from . import _lib as L
     cfg = model.config
     dev = model.device
@@ -482,7 +515,9 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         net, gnet = fld.net_struct(), fld.net_struct(grads=True)
         d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
                                   d_rgb_s, d_logit)
-        if exchange is None:
+        if exchange is None and table_adam is not None:
+            K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, table_adam)
+        elif exchange is None:
             K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
         else:
             n_lv = int(gnet.grid.n_levels)
@@ -524,8 +559,12 @@ def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: 
     camera_adam.step(grad_scale=scale)
 
 
+FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter
+
+
 def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, world_size: int = 1,
-                          jitter: Optional[List[Tensor]] = None, want_metrics: bool = True, camera=None):
+                          jitter: Optional[List[Tensor]] = None, want_metrics: bool = True, camera=None,
+                          fuse_table_optimizer: Optional[bool] = None):
     """train_iteration() on fused_forward_backward(); returns the same (loss_dict, metrics_dict) tensors.
 
     world_size > 1 (DDP semantics, fruit_pipeline.py:116-118): the field's gradient (67 MB of the 78 MB arena) is
@@ -537,13 +576,21 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
     spans = arena.group_ranges
     exchange = _FieldGradientExchange(model, world_size) if world_size >= EXCHANGE_MIN_WORLD else None
     ray_grads = {} if camera is not None else None   # camera = (CameraOptimizer, CameraAdam, PixelBatcher)
+    # Without a gradient exchange the main table's optimiser step is fused into the scatter's accumulate kernel (its
+    # 16.8 M parameters are 86 % of the arena: 40 -> 24 bytes of HBM traffic per parameter and step, bit-identical
+    # results); the table's gradient stays zero.
+    fuse = FUSE_TABLE_OPTIMIZER if fuse_table_optimizer is None else fuse_table_optimizer
+    table_adam, done = None, ()
+    if exchange is None and fuse:
+        table_adam, span = optimizer.table_adam_args(model.field.mlp_base_grid.hash_table, "fields")
+        done = (span,)
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
-                                                     ray_grads)
+                                                     ray_grads, table_adam=table_adam)
     with torch.no_grad():
         if exchange is None:
             if camera is not None:
                 camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
-            optimizer.step(skip=skipped_groups(model))
+            optimizer.step(skip=skipped_groups(model), done=done)
         else:
             pending = list(exchange.pending)
             # the update schedule is a function of the step, identical on every rank: on steps that did not train the

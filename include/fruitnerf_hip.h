@@ -310,6 +310,26 @@ int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const f
                         const float* euclid_bins, int S, const float* d_feats, int level_begin, int level_count,
                         void* workspace, size_t workspace_bytes, int workspace_clean, void* stream);
 
+/* fnr_hash_encode_bwd over ALL levels with the optimiser step of the table fused in (single-process training: with
+ * several ranks the gradient has to exist for the all-reduce).  The workgroup that owns a bin of rows holds their summed
+ * gradient in LDS and applies torch.optim.Adam (algorithm 0) / RAdam (1) to those rows — parameters, exp_avg and
+ * exp_avg_sq are the TABLE's slices [n_levels << log2_hashmap_size, 2] of the caller's arenas, `step` is the
+ * optimiser's step count of this update (>= 1), grad_scale / weight_decay as in fnr_adam_step.  The gradient table
+ * (grid_grad->table) is left as it was (zero): it is only read where an overflowed queue spilled into it.  Results are
+ * bit-identical to fnr_hash_encode_bwd followed by fnr_adam_step / fnr_radam_step on the table's span. */
+typedef struct fnr_table_adam {
+  int32_t algorithm;
+  float lr, beta1, beta2, eps;
+  int64_t step;
+  float grad_scale, weight_decay;
+  float* params;
+  float* exp_avg;
+  float* exp_avg_sq;
+} fnr_table_adam;
+int fnr_hash_encode_bwd_adam(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
+                             const float* euclid_bins, int S, const float* d_feats, void* workspace,
+                             size_t workspace_bytes, int workspace_clean, const fnr_table_adam* adam, void* stream);
+
 /* Backward of fnr_prop_density_fwd: d_density [R,S] -> += into grads (table, w0, b0, w1, b1).
  * d_position (optional) [N,4]: gradient w.r.t. each sample's unit-cube position (xyz, w = 0) for
  * fnr_position_grad_reduce(n_levels = 1) — only needed when the rays carry gradients (camera-pose optimiser).

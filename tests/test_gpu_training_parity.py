@@ -444,6 +444,53 @@ def test_scatter_is_invariant_to_the_levels_per_workgroup(dev, monkeypatch, log2
             assert torch.equal(t, ref), (which, diff, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape,algorithm,log2", [("fruit_nerf", "adam", 15), ("fruit_nerf", "adam", 19),
+                                                  ("fruit_nerf_big", "radam", 15)])
+def test_fused_table_optimizer_matches_the_separate_step(dev, shape, algorithm, log2):
+    """fnr_hash_encode_bwd_adam: the main hash table's Adam / RAdam step applied inside the scatter's accumulate kernel
+    (single-process training; the gradient table is never written) vs scatter + fnr_adam_step / fnr_radam_step.
+    First step from identical states: the table's parameters and both moments are BIT-identical (same fixed-point
+    sums, same operation order), every row took its step (moment decay of untouched rows included), the table's
+    gradient stays zero.  Then 11 more steps across step 10 (proposal nets no longer updated every step): the fused
+    run is no further from a separate-step run than a second separate-step run is (the MLP weight gradients meet in
+    float atomics, so later steps are not bit-reproducible even within one path, and Adam's m / sqrt(v) turns last-bit
+    gradient differences of near-zero entries into O(lr) moves)."""
+    from fruitnerf_amd.rays import RayBundle
+    from fruitnerf_amd.training import FusedAdam, fused_train_iteration
+    cfg = {"fruit_nerf": util.small_config, "fruit_nerf_big": util.big_config}[shape](log2=log2, prop_log2=13)
+    om = util.make_oracle(cfg, seed=3)
+    R = 128
+    o, d, pa, cam = util.random_rays(R, 7, seed=2)
+    hb = {k: v.to(dev) for k, v in _batch(R, 5).items()}
+    g = torch.Generator().manual_seed(0)
+    jits = [[torch.rand(R, 1, generator=g).to(dev) for _ in range(3)] for _ in range(12)]
+    runs = []
+    for fuse in (False, True, False):
+        hm = util.make_hip_like(om, dev)
+        hm.train()
+        opt = FusedAdam(hm, algorithm=algorithm)
+        snaps = []
+        for step in range(12):
+            fused_train_iteration(hm, opt, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), hb, step,
+                                  jitter=jits[step], fuse_table_optimizer=fuse)
+            if step in (0, 11):
+                torch.cuda.synchronize()
+                snaps.append((hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
+        table = hm.field.mlp_base_grid.hash_table
+        a, n = [(off, k) for _, p, off, k in hm.arena().entries if p is table][0]
+        assert float(hm.arena().grads.abs().max()) == 0.0          # zero_grad everywhere, the table never written
+        runs.append((snaps, (a, a + n)))
+    (s0, (a, b)), (s1, _), (s2, _) = runs
+    for x, y in zip(s0[0], s1[0]):                                  # after the first step
+        assert torch.equal(x[a:b], y[a:b])
+        assert float((x - y).abs().max()) <= 1e-7
+    p0 = s0[0][0][a:b]
+    assert int((p0 != runs[0][0][1][0][a:b]).sum()) > 0            # the table did move between step 1 and step 12
+    for x, y, z in zip(s0[1], s1[1], s2[1]):                        # after 12 steps: within the path's own spread
+        spread = float((x - z).abs().mean())                        # two runs of the separate-step path
+        assert float((x - y).abs().mean()) <= 3.0 * spread + 1e-6 * float(x.abs().mean()), spread
+
+
 def test_ray_gradient_paths_agree(dev):
     """The saved-Jacobian path (forward encode stores d feats / d x) and the gather path (backward re-reads the table)
     of the hash grid's input gradient give the same ray gradients."""
