@@ -211,6 +211,62 @@ __device__ __forceinline__ float2 grid_interp(const float2 (&v)[8], const float 
   }
   return r;
 }
+// ---- corner gathers by lane PAIRS ----------------------------------------------------------------
+// A wave-wide 8-byte gather costs the texture path one tag lookup per distinct 128-byte line, and that (not HBM or L2
+// bandwidth) bounds the encode kernels: with one sample per lane every instruction touches 64 lines.  The two
+// x-neighbours of a cell edge — corners (0,3), (1,2), (4,7), (5,6) — sit in the same line 15 times out of 16 (dense
+// levels: consecutive rows; hashed levels: x enters the hash with multiplier 1, so x -> x + 1 only changes low row
+// bits).  So lanes 2i and 2i+1 gather TOGETHER: first the four pairs of the even lane's sample, then the four pairs of
+// the odd lane's, each lane taking one side — 64 lanes, ~34 lines per instruction — and swap what belongs to the
+// other (DPP quad_perm, no LDS).  Values and blend order are unchanged (bit-identical features).  Measured: k_hash_encode
+// alone on spread-out samples 84 -> 71 us; in the training step nothing at initialisation (the table arrives cold from
+// HBM there) and +2.6 % rays/s at a trained state, eval +3 %, 256^3 export +10 %.  The proposal networks' gathers
+// (coarse levels, 256 closely spaced samples per ray: neighbouring lanes already share lines) got 5-10 % SLOWER with it
+// and keep one sample per lane.  Needs every lane of the wave active (no early return before it).
+__device__ __forceinline__ uint32_t lane_swap1(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float2 lane_swap1(float2 v) {
+  return make_float2(__uint_as_float(lane_swap1(__float_as_uint(v.x))), __uint_as_float(lane_swap1(__float_as_uint(v.y))));
+}
+struct PairedRows {
+  uint32_t a[4], b[4];  // rows this lane reads for the even lane's sample / for the odd lane's sample
+};
+__device__ __forceinline__ PairedRows paired_rows(const uint32_t (&h)[8], bool odd) {
+  constexpr int KA[4] = {0, 1, 4, 5}, KB[4] = {3, 2, 7, 6};
+  PairedRows r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t recv = lane_swap1(odd ? h[KA[j]] : h[KB[j]]);
+    r.a[j] = odd ? recv : h[KA[j]];
+    r.b[j] = odd ? h[KB[j]] : recv;
+  }
+  return r;
+}
+__device__ __forceinline__ void paired_values(const float2 (&va)[4], const float2 (&vb)[4], bool odd, float2 (&v)[8]) {
+  constexpr int KA[4] = {0, 1, 4, 5}, KB[4] = {3, 2, 7, 6};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float2 recv = lane_swap1(odd ? va[j] : vb[j]);
+    v[KA[j]] = odd ? recv : va[j];
+    v[KB[j]] = odd ? vb[j] : recv;
+  }
+}
+// one level, all lanes of the wave active: gather 8 corners (lane pairs) and blend
+__device__ __forceinline__ float2 grid_lookup_paired(const float2* __restrict__ level_table, const float (&x)[3],
+                                                     int scaling, uint32_t mask, bool odd) {
+  GridLevel g = grid_cell(x, scaling);
+  uint32_t h[8];
+  grid_corners(g, mask, h);
+  const PairedRows r = paired_rows(h, odd);
+  float2 va[4], vb[4], v[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) va[j] = level_table[r.a[j]];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vb[j] = level_table[r.b[j]];
+  paired_values(va, vb, odd, v);
+  return grid_interp(v, g.o);
+}
 // one level: gather 8 corners and blend
 __device__ __forceinline__ float2 grid_lookup(const float2* __restrict__ level_table, const float (&x)[3], int scaling,
                                               uint32_t mask) {

@@ -18,7 +18,7 @@ namespace fnr {
 // ------------------------------------------------------------------------------------------------
 // main-field encode: one thread per (sample, level)
 // ------------------------------------------------------------------------------------------------
-constexpr int ENC_SPT = 2;  // samples per thread: 16 independent 8-byte gathers in flight hide the L2-miss latency
+constexpr int ENC_SPT = 2;  // samples per thread: 16 independent 8-byte gathers in flight hide the L2-hit latency
 
 template <class Source>
 __global__ __launch_bounds__(256) void k_hash_encode(GridDev grid, Warp warp, Source src, long long N,
@@ -46,11 +46,22 @@ __global__ __launch_bounds__(256) void k_hash_encode(GridDev grid, Warp warp, So
     grid_corners(g, mask, h[u]);
     o[u][0] = g.o[0], o[u][1] = g.o[1], o[u][2] = g.o[2];
   }
+  // lane pairs gather the x-neighbour corners side by side (common.hpp: corner gathers by lane pairs)
+  const bool odd = threadIdx.x & 1;
+  PairedRows rows[ENC_SPT];
+#pragma unroll
+  for (int u = 0; u < ENC_SPT; ++u) rows[u] = paired_rows(h[u], odd);
+  float2 va[ENC_SPT][4], vb[ENC_SPT][4];
+#pragma unroll
+  for (int u = 0; u < ENC_SPT; ++u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) va[u][j] = lt[rows[u].a[j]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[u][j] = lt[rows[u].b[j]];
+  }
   float2 v[ENC_SPT][8];
 #pragma unroll
-  for (int u = 0; u < ENC_SPT; ++u)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[u][k] = lt[h[u][k]];
+  for (int u = 0; u < ENC_SPT; ++u) paired_values(va[u], vb[u], odd, v[u]);
 #pragma unroll
   for (int u = 0; u < ENC_SPT; ++u) {
     if (n[u] >= N) continue;

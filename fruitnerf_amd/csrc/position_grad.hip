@@ -46,11 +46,21 @@ __global__ __launch_bounds__(256) void k_hash_input_grad(GridDev grid, Warp warp
     o[u][0] = g.o[0], o[u][1] = g.o[1], o[u][2] = g.o[2];
     gf[u] = d_feats[(size_t)level * N + nn];
   }
+  const bool odd = threadIdx.x & 1;  // gathers by lane pairs (common.hpp)
+  PairedRows rows[PG_SPT];
+#pragma unroll
+  for (int u = 0; u < PG_SPT; ++u) rows[u] = paired_rows(h[u], odd);
+  float2 va[PG_SPT][4], vb[PG_SPT][4];
+#pragma unroll
+  for (int u = 0; u < PG_SPT; ++u) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) va[u][q] = lt[rows[u].a[q]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vb[u][q] = lt[rows[u].b[q]];
+  }
   float2 v[PG_SPT][8];
 #pragma unroll
-  for (int u = 0; u < PG_SPT; ++u)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[u][k] = lt[h[u][k]];
+  for (int u = 0; u < PG_SPT; ++u) paired_values(va[u], vb[u], odd, v[u]);
 #pragma unroll
   for (int u = 0; u < PG_SPT; ++u) {
     if (n[u] >= N) continue;
