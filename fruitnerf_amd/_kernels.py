@@ -468,6 +468,20 @@ def radam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tenso
                                float(weight_decay), 1 if zero_grad else 0, L.stream_ptr(params.device)), "radam_step")
 
 
+def adam_step_spans(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, spans, algorithm: str,
+                    beta1: float, beta2: float, eps: float, grad_scale: float = 1.0, zero_grad: bool = True,
+                    weight_decay: float = 0.0) -> None:
+    """One launch over several spans of one arena: spans = [(offset, count, lr, step), ...] (<= FNR_MAX_ADAM_SPANS),
+    each updated exactly as adam_step / radam_step would with its own learning rate and step count."""
+    lib = L.load()
+    arr = (L.fnr_adam_span * len(spans))(*[L.fnr_adam_span(int(a), int(n), int(step), float(lr), 0)
+                                           for a, n, lr, step in spans])
+    L.check(lib.fnr_adam_step_spans(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), len(spans), arr,
+                                    0 if algorithm == "adam" else 1, float(beta1), float(beta2), float(eps),
+                                    float(grad_scale), float(weight_decay), 1 if zero_grad else 0,
+                                    L.stream_ptr(params.device)), "adam_step_spans")
+
+
 # ---- point-cloud front-end of the counting stage ------------------------------------------------------
 
 

@@ -59,6 +59,14 @@ class fnr_table_adam(C.Structure):
                 ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p)]
 
 
+class fnr_adam_span(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("step", C.c_int64), ("lr", C.c_float),
+                ("reserved", C.c_int32)]
+
+
+FNR_MAX_ADAM_SPANS = 8
+
+
 class fnr_lattice(C.Structure):
     _fields_ = [("n_x", C.c_int32), ("n_y", C.c_int32), ("n_z", C.c_int32),
                 ("xs", C.c_void_p), ("ys", C.c_void_p), ("zs", C.c_void_p)]
@@ -115,6 +123,7 @@ SIGNATURES = {
     "fnr_position_grad_reduce": (_i, [P(fnr_warp), P(fnr_rays), _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fnr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
     "fnr_radam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
+    "fnr_adam_step_spans": (_i, [_vp, _vp, _vp, _vp, _i, P(fnr_adam_span), _i, _f, _f, _f, _f, _f, _i, _vp]),
     "fnr_cloud_workspace_bytes": (C.c_size_t, [_i64]),
     "fnr_cloud_bounds": (_i, [_vp, _i64, _vp, _vp, C.c_size_t, _vp]),
     "fnr_cloud_radius_count": (_i, [_vp, _i64, P(C.c_double), P(C.c_double), C.c_double, _i, _vp, _vp, C.c_size_t,

@@ -330,6 +330,60 @@ __global__ __launch_bounds__(256) void k_radam(float4* __restrict__ p, float4* _
   }
 }
 
+// Adam / RAdam over several spans of one arena in one launch (fnr_adam_step_spans): the spans' float4 chunks are
+// numbered consecutively, a thread finds its span by scanning the (<= 8) cumulative counts.  Per element the same
+// operations in the same order as k_adam / k_radam.
+struct AdamSpansDev {
+  int n;
+  long long cum4[FNR_MAX_ADAM_SPANS + 1];  // chunk index at which span k starts; cum4[n] = total
+  long long off4[FNR_MAX_ADAM_SPANS];      // first float4 of span k in the arena
+  float lr[FNR_MAX_ADAM_SPANS], bc1[FNR_MAX_ADAM_SPANS], bc2_sqrt[FNR_MAX_ADAM_SPANS], rect[FNR_MAX_ADAM_SPANS];
+};
+template <bool RADAM>
+__global__ __launch_bounds__(256) void k_adam_spans(float4* __restrict__ p, float4* __restrict__ g,
+                                                    float4* __restrict__ m, float4* __restrict__ v, AdamSpansDev sp,
+                                                    float b1, float b2, float eps, float grad_scale,
+                                                    float weight_decay, int zero_grad) {
+  const long long total = sp.cum4[sp.n];
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < total; c += (long long)gridDim.x * 256) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < FNR_MAX_ADAM_SPANS; ++q)
+      if (q < sp.n && c >= sp.cum4[q]) k = q;
+    const long long i = sp.off4[k] + (c - sp.cum4[k]);
+    const float lr = sp.lr[k], bc1 = sp.bc1[k], bc2_sqrt = sp.bc2_sqrt[k], rect = sp.rect[k];
+    const float step_size = lr / bc1;
+    float4 P = p[i], G = g[i], M = m[i], V = v[i];
+    float* pp = reinterpret_cast<float*>(&P);
+    float* gp = reinterpret_cast<float*>(&G);
+    float* mp = reinterpret_cast<float*>(&M);
+    float* vp = reinterpret_cast<float*>(&V);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gr = gp[e] * grad_scale;
+      if (weight_decay != 0.0f) gr = gr + weight_decay * pp[e];
+      mp[e] = mp[e] + (gr - mp[e]) * (1.0f - b1);
+      vp[e] = vp[e] * b2 + (1.0f - b2) * gr * gr;
+      if (!RADAM) {
+        const float denom = sqrtf(vp[e]) / bc2_sqrt + eps;
+        pp[e] = pp[e] - step_size * (mp[e] / denom);
+      } else {
+        const float mhat = mp[e] / bc1;
+        if (rect >= 0.0f) {
+          const float adaptive = bc2_sqrt / (sqrtf(vp[e]) + eps);
+          pp[e] = pp[e] - lr * (mhat * rect * adaptive);
+        } else {
+          pp[e] = pp[e] - lr * mhat;
+        }
+      }
+    }
+    p[i] = P;
+    m[i] = M;
+    v[i] = V;
+    if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 }  // namespace fnr
 
 using namespace fnr;
@@ -442,6 +496,60 @@ extern "C" int fnr_radam_step(float* params, float* grads, float* exp_avg, float
                      reinterpret_cast<float4*>(grads), reinterpret_cast<float4*>(exp_avg),
                      reinterpret_cast<float4*>(exp_avg_sq), n4, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
                      (float)rect, grad_scale, weight_decay, zero_grad);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_adam_step_spans(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_spans,
+                                   const fnr_adam_span* spans, int algorithm, float beta1, float beta2, float eps,
+                                   float grad_scale, float weight_decay, int zero_grad, void* stream) {
+  FNR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && spans, "adam_step_spans: null argument");
+  FNR_CHECK_ARG(n_spans >= 1 && n_spans <= FNR_MAX_ADAM_SPANS, "adam_step_spans: %d spans (1..%d)", n_spans,
+                FNR_MAX_ADAM_SPANS);
+  FNR_CHECK_ARG(algorithm == 0 || algorithm == 1, "adam_step_spans: algorithm %d (0 = Adam, 1 = RAdam)", algorithm);
+  AdamSpansDev sp;
+  sp.n = n_spans;
+  sp.cum4[0] = 0;
+  long long total_floats = 0;
+  for (int k = 0; k < FNR_MAX_ADAM_SPANS; ++k) {
+    if (k >= n_spans) {
+      sp.cum4[k + 1] = sp.cum4[k];
+      sp.off4[k] = 0;
+      sp.lr[k] = 0.0f, sp.bc1[k] = 1.0f, sp.bc2_sqrt[k] = 1.0f, sp.rect[k] = -1.0f;
+      continue;
+    }
+    const fnr_adam_span& s = spans[k];
+    FNR_CHECK_ARG(s.offset >= 0 && s.count >= 0 && s.offset % 4 == 0 && s.count % 4 == 0 && s.step >= 1,
+                  "adam_step_spans: span %d: offset / count must be multiples of 4, step >= 1", k);
+    // the step-dependent scalars exactly as fnr_adam_step / fnr_radam_step compute them (double)
+    const double bc1 = 1.0 - pow((double)beta1, (double)s.step);
+    const double b2t = pow((double)beta2, (double)s.step);
+    const double bc2 = 1.0 - b2t;
+    double rect = -1.0;
+    if (algorithm == 1) {
+      const double rho_inf = 2.0 / (1.0 - (double)beta2) - 1.0;
+      const double rho_t = rho_inf - 2.0 * (double)s.step * b2t / bc2;
+      if (rho_t > 5.0)
+        rect = sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+    }
+    sp.off4[k] = s.offset / 4;
+    sp.cum4[k + 1] = sp.cum4[k] + s.count / 4;
+    sp.lr[k] = s.lr, sp.bc1[k] = (float)bc1, sp.bc2_sqrt[k] = (float)sqrt(bc2), sp.rect[k] = (float)rect;
+    total_floats += s.count;
+  }
+  const long long total4 = sp.cum4[n_spans];
+  if (total4 == 0) return FNR_OK;
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  FNR_PROF(OP_ADAM, total_floats);
+  float4 *p4 = reinterpret_cast<float4*>(params), *g4 = reinterpret_cast<float4*>(grads);
+  float4 *m4 = reinterpret_cast<float4*>(exp_avg), *v4 = reinterpret_cast<float4*>(exp_avg_sq);
+  if (algorithm == 0)
+    hipLaunchKernelGGL(k_adam_spans<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p4, g4, m4, v4, sp,
+                       beta1, beta2, eps, grad_scale, weight_decay, zero_grad);
+  else
+    hipLaunchKernelGGL(k_adam_spans<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p4, g4, m4, v4, sp,
+                       beta1, beta2, eps, grad_scale, weight_decay, zero_grad);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

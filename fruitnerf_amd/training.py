@@ -253,6 +253,9 @@ def exponential_decay_lr(step: int, lr_init: float, lr_final: float, max_steps: 
     return float(np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
 
 
+L_MAX_ADAM_SPANS = 8   # include/fruitnerf_hip.h: FNR_MAX_ADAM_SPANS
+
+
 class FusedAdam:
     """torch.optim.Adam semantics for both parameter groups of the `fruit_nerf` method
     (AdamOptimizerConfig(lr=1e-2, eps=1e-15) + ExponentialDecay to 1e-4 over 200k steps,
@@ -353,8 +356,14 @@ class FusedAdam:
                     if db < b:
                         cut.append([db, b, lr, name])
             runs = cut
-        for a, b, lr, name in runs:
-            self.step_span(a, b, lr, grad_scale, group=name)
+        runs = [r for r in runs if r[1] > r[0]]
+        if len(runs) <= 1 or len(runs) > L_MAX_ADAM_SPANS:
+            for a, b, lr, name in runs:
+                self.step_span(a, b, lr, grad_scale, group=name)
+        else:   # one launch for all of them (the groups' MLP weights are a few thousand floats each)
+            K.adam_step_spans(self.arena.params, self.arena.grads, self.exp_avg, self.exp_avg_sq,
+                              [(a, b - a, lr, self.group_steps[name]) for a, b, lr, name in runs], self.algorithm,
+                              self.betas[0], self.betas[1], self.eps, grad_scale, True, weight_decay=self.weight_decay)
 
 
 def skipped_groups(model) -> tuple:
@@ -476,7 +485,11 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         S = fin["S"]
         image, mask = batch["image"].to(dev), batch["fruit_mask"].to(dev)
         losses, d_rgb, d_sem = K.losses_fwd(outputs["rgb"], image, outputs["semantics"], mask, cfg.semantic_loss_weight)
-        slots = torch.zeros(2, L.FNR_LOSS_SLOTS, device=dev)   # [interlevel | distortion] accumulators: one fill
+        # one fill for everything this step accumulates into: [interlevel | distortion] loss slots and, with a camera
+        # optimiser, the ray gradients d(loss)/d(origins | directions)
+        n_slots = 2 * L.FNR_LOSS_SLOTS
+        zeros = torch.zeros(n_slots + (6 * rays.n if ray_grads is not None else 0), device=dev)
+        slots = zeros[:n_slots].view(2, L.FNR_LOSS_SLOTS)
         d_wps = [K.interlevel_fwd(S, fin["spacing"], fin["weights"], lv["S"], lv["spacing"], lv["weights"],
                                   cfg.interlevel_loss_mult, slots[0]) for lv in rctx.levels[:-1]]
         if want_metrics:
@@ -490,8 +503,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         arena.reattach_grads()
         d_o = d_d = None
         if ray_grads is not None:
-            d_o = ray_grads["origins"] = torch.zeros(rays.n, 3, device=dev)
-            d_d = ray_grads["directions"] = torch.zeros(rays.n, 3, device=dev)
+            d_o = ray_grads["origins"] = zeros[n_slots:n_slots + 3 * rays.n].view(rays.n, 3)
+            d_d = ray_grads["directions"] = zeros[n_slots + 3 * rays.n:].view(rays.n, 3)
         # The proposal-network backward (interlevel loss) and the field backward (rgb + semantic losses) share no
         # buffers.  overlap_proposal_backward=True runs the former on a second HIP stream so that its ~14 small/medium
         # launches fill the gaps and tails of the field kernels (measured: -2 % step time); off by default because

@@ -373,6 +373,21 @@ int fnr_radam_step(float* params, float* grads, float* exp_avg, float* exp_avg_s
                    float beta2, float eps, int64_t step, float grad_scale, float weight_decay, int zero_grad,
                    void* stream);
 
+/* Several spans of ONE arena in one launch (the parameter groups of a method differ in learning rate and step count;
+ * each is a few thousand to a few million floats and a launch of its own cost more than its traffic).  Span k updates
+ * elements [offset, offset + count) (both multiples of 4) exactly as fnr_adam_step (algorithm 0) / fnr_radam_step (1)
+ * with its own lr / step would.  n_spans <= FNR_MAX_ADAM_SPANS; `spans` is host memory. */
+#define FNR_MAX_ADAM_SPANS 8
+typedef struct fnr_adam_span {
+  int64_t offset, count;
+  int64_t step;
+  float lr;
+  int32_t reserved;
+} fnr_adam_span;
+int fnr_adam_step_spans(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_spans,
+                        const fnr_adam_span* spans, int algorithm, float beta1, float beta2, float eps,
+                        float grad_scale, float weight_decay, int zero_grad, void* stream);
+
 /* ---- export --------------------------------------------------------------------------------- */
 /* sample_volume's masks + gathers (export/exporter_utils.py:111-153) as an order-preserving stream
  * compaction.  Sets: 0 = semantic_colormap (sigmoid(logit) > 0.9 and density >= 70),

@@ -798,3 +798,39 @@ def test_radam_matches_torch(dev):
             assert float(gd.abs().max()) == 0.0
             err = (p.cpu() - p_ref.detach()).abs().max().item()
             assert err <= 5e-6, (wd, step, err)
+
+
+@pytest.mark.parametrize("algorithm", ["adam", "radam"])
+def test_adam_step_spans_is_the_separate_launches(dev, algorithm):
+    """fnr_adam_step_spans: three spans of one arena (own learning rate and step count each, gaps between them) in one
+    launch vs one fnr_adam_step / fnr_radam_step launch per span — bit-identical parameters and moments, gradients
+    zeroed inside the spans only, nothing touched outside."""
+    from fruitnerf_amd import _kernels as K
+    g0 = torch.Generator().manual_seed(11)
+    n = 1 << 16
+    spans = [(0, 540, 6e-4, 3), (1024, 16856 // 4 * 4, 1e-2, 9), (40000, 20000, 3e-3, 1)]
+    state = [torch.randn(n, generator=g0), torch.randn(n, generator=g0), torch.randn(n, generator=g0) * 0.1,
+             torch.rand(n, generator=g0) * 0.01]
+    outs = []
+    for fused in (False, True):
+        p, g, m, v = [t.clone().to(dev) for t in state]
+        if fused:
+            K.adam_step_spans(p, g, m, v, spans, algorithm, 0.9, 0.999, 1e-15, grad_scale=0.5, zero_grad=True,
+                              weight_decay=1e-3)
+        else:
+            fn = K.adam_step if algorithm == "adam" else K.radam_step
+            for a, cnt, lr, step in spans:
+                fn(p[a:a + cnt], g[a:a + cnt], m[a:a + cnt], v[a:a + cnt], lr, 0.9, 0.999, 1e-15, step,
+                   grad_scale=0.5, zero_grad=True, weight_decay=1e-3)
+        outs.append((p, g, m, v))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    p, g, m, v = outs[1]
+    inside = torch.zeros(n, dtype=torch.bool)
+    for a, cnt, _, _ in spans:
+        inside[a:a + cnt] = True
+    assert float(g.cpu()[inside].abs().max()) == 0.0
+    for t, t0 in zip((p, g, m, v), state):
+        assert torch.equal(t.cpu()[~inside], t0[~inside])
+    assert not torch.equal(p.cpu()[inside], state[0][inside])
+
