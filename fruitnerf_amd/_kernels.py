@@ -319,6 +319,33 @@ def distortion(S: int, spacing: Tensor, weights: Tensor, out: Optional[Tensor] =
     return slots.sum() if out is None else None
 
 
+def train_losses(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tensor, semantic_loss_weight: float,
+                 S_f: int, spacing_f: Tensor, weights_f: Tensor, levels, interlevel_mult: float, want_distortion: bool,
+                 accum: Tensor):
+    """losses_fwd + interlevel_fwd per proposal level + distortion + the slot sums in one launch.
+    levels: [(S_p, spacing_p, weights_p), ...]; accum: ZEROED float buffer of FNR_TRAIN_LOSSES_ACCUM_FLOATS.
+    -> losses [5] (rgb_loss, semantics_loss, psnr, interlevel_loss, distortion), d_rgb [R,3], d_semantics [R],
+       [d_weights_p per level]."""
+    lib = L.load()
+    dev = rgb.device
+    R = rgb.shape[0]
+    rgb, image = _f32c(rgb), _f32c(image.reshape(R, 3))
+    semantics, fruit_mask = _f32c(semantics.reshape(R)), _f32c(fruit_mask.reshape(R))
+    losses = torch.empty(5, device=dev)
+    d_rgb = torch.empty(R, 3, device=dev)
+    d_sem = torch.empty(R, device=dev)
+    n = len(levels)
+    d_wps = [torch.empty(R, S_p, device=dev) for S_p, _, _ in levels]
+    sp = (C.c_int * max(n, 1))(*[int(S_p) for S_p, _, _ in levels])
+    vps = lambda ts: (C.c_void_p * max(n, 1))(*[L.ptr(t) for t in ts])   # noqa: E731
+    L.check(lib.fnr_train_losses(R, L.ptr(rgb), L.ptr(image), L.ptr(semantics), L.ptr(fruit_mask),
+                                 float(semantic_loss_weight), L.ptr(d_rgb), L.ptr(d_sem), S_f, L.ptr(spacing_f),
+                                 L.ptr(weights_f), n, sp, vps([t for _, t, _ in levels]), vps([t for _, _, t in levels]),
+                                 vps(d_wps), float(interlevel_mult), 1 if want_distortion else 0, L.ptr(accum),
+                                 L.ptr(losses), L.stream_ptr(dev)), "train_losses")
+    return losses, d_rgb, d_sem, d_wps
+
+
 def composite_bwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, weights: Tensor, g_rgb: Tensor,
                   g_sem: Tensor):
     lib = L.load()

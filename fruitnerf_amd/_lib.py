@@ -65,6 +65,8 @@ class fnr_adam_span(C.Structure):
 
 
 FNR_MAX_ADAM_SPANS = 8
+FNR_MAX_PROPOSAL_LEVELS = 4
+FNR_TRAIN_LOSSES_ACCUM_FLOATS = 4 * FNR_LOSS_SLOTS + 33 * 32
 
 
 class fnr_lattice(C.Structure):
@@ -121,6 +123,8 @@ SIGNATURES = {
                                   _vp, C.c_size_t, _i, _vp]),
     "fnr_hash_encode_input_grad": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
     "fnr_position_grad_reduce": (_i, [P(fnr_warp), P(fnr_rays), _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "fnr_train_losses": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _i, P(C.c_int), P(C.c_void_p),
+                              P(C.c_void_p), P(C.c_void_p), _f, _i, _vp, _vp, _vp]),
     "fnr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
     "fnr_radam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
     "fnr_adam_step_spans": (_i, [_vp, _vp, _vp, _vp, _i, P(fnr_adam_span), _i, _f, _f, _f, _f, _f, _i, _vp]),

@@ -73,9 +73,10 @@ __device__ __forceinline__ __bf16 bf_piece(float w, int p) {
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(256) void k_pack_field_weights_bf16(FieldPtrs p, int ns, __bf16* __restrict__ image) {
+__device__ __forceinline__ void pack_field_weights_bf16_block(const FieldPtrs& p, int ns, __bf16* __restrict__ image,
+                                                              int block) {
   using Img = BfImage<Cfg>;
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // (block, lane)
+  const int idx = block * 256 + threadIdx.x;  // (block, lane)
   if (idx >= Img::BLOCKS * 64) return;
   const int blk = idx >> 6, lane = idx & 63;
   const int i = lane & 15, g = lane >> 4;
@@ -118,9 +119,51 @@ __global__ __launch_bounds__(256) void k_pack_field_weights_bf16(FieldPtrs p, in
 }
 
 template <class Cfg>
+__global__ __launch_bounds__(256) void k_pack_field_weights_bf16(FieldPtrs p, int ns, __bf16* __restrict__ image) {
+  pack_field_weights_bf16_block<Cfg>(p, ns, image, blockIdx.x);
+}
+template <class Cfg>
+constexpr int pack_field_weights_bf16_blocks() { return (BfImage<Cfg>::BLOCKS * 64 + 255) / 256; }
+
+template <class Cfg>
 static inline void launch_pack_field_weights_bf16(const FieldPtrs& p, int ns, __bf16* image, hipStream_t st) {
-  using Img = BfImage<Cfg>;
-  hipLaunchKernelGGL((k_pack_field_weights_bf16<Cfg>), dim3((Img::BLOCKS * 64 + 255) / 256), dim3(256), 0, st, p, ns, image);
+  hipLaunchKernelGGL((k_pack_field_weights_bf16<Cfg>), dim3(pack_field_weights_bf16_blocks<Cfg>()), dim3(256), 0, st, p, ns,
+                     image);
+}
+
+// Everything a forward call prepares from the weights, ONE launch (three dependent ~5 us launches before): workgroups
+// [0, nb_pack) write the fp32 fragment image, [nb_pack, nb_pack + nb_pack16) the bf16 pieces (none in fp32 mode), the
+// rest the per-ray colour bias — read from the raw weights, so no role waits for another.
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_prepare_field(FieldPtrs p, float* __restrict__ packed, int ns,
+                                                       __bf16* __restrict__ image, RaysDev rays,
+                                                       const float* __restrict__ embedding,
+                                                       const float* __restrict__ mean_embedding,
+                                                       float* __restrict__ ray_bias, int nb_pack, int nb_pack16) {
+  int b = blockIdx.x;
+  if (b < nb_pack) {
+    pack_field_weights_block<Cfg>(p, packed, b);
+    return;
+  }
+  b -= nb_pack;
+  if (b < nb_pack16) {
+    pack_field_weights_bf16_block<Cfg>(p, ns, image, b);
+    return;
+  }
+  b -= nb_pack16;
+  color_ray_bias_block<Cfg, true>(p, nullptr, rays, embedding, mean_embedding, ray_bias, b,
+                                  (int)gridDim.x - nb_pack - nb_pack16);
+}
+// ns = 0: fp32 mode (no bf16 pieces)
+template <class Cfg>
+static inline void launch_prepare_field(const FieldPtrs& p, float* packed, int ns, __bf16* image, const RaysDev& rays,
+                                        const float* embedding, const float* mean_embedding, float* ray_bias,
+                                        hipStream_t st) {
+  const int nb_pack = pack_field_weights_blocks<Cfg>();
+  const int nb_pack16 = ns > 0 ? pack_field_weights_bf16_blocks<Cfg>() : 0;
+  const long long nb_bias = color_ray_bias_blocks(rays);
+  hipLaunchKernelGGL((k_prepare_field<Cfg>), dim3((unsigned)(nb_pack + nb_pack16 + nb_bias)), dim3(256), 0, st, p, packed, ns,
+                     image, rays, embedding, mean_embedding, ray_bias, nb_pack, nb_pack16);
 }
 
 // ---- what a kernel keeps in LDS: an ordered list of (layer, forward | transposed) segments, NS pieces each -------

@@ -221,8 +221,8 @@ __device__ __forceinline__ float packed_value(int idx, const FieldPtrs& p) {
 // Packing inside every workgroup's prologue cost ~40 us per launch (18.8k scattered 4-byte loads + index math
 // per workgroup); a 74-workgroup pack launch + linear float4 copies cost ~3 us.
 template <class Cfg>
-__global__ __launch_bounds__(256) void k_pack_field_weights(FieldPtrs p, float* __restrict__ packed) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_field_weights_block(const FieldPtrs& p, float* __restrict__ packed, int block) {
+  const int idx = block * 256 + threadIdx.x;
   if (idx < Cfg::LDS_FLOATS) {
     packed[idx] = packed_value<Cfg>(idx, p);
   } else if (idx < Cfg::PACKED_FLOATS) {
@@ -230,6 +230,12 @@ __global__ __launch_bounds__(256) void k_pack_field_weights(FieldPtrs p, float* 
     packed[idx] = p.w[Cfg::L_COL0][o * Cfg::in_dim(Cfg::L_COL0) + color_const_col<Cfg>(k)];
   }
 }
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_pack_field_weights(FieldPtrs p, float* __restrict__ packed) {
+  pack_field_weights_block<Cfg>(p, packed, blockIdx.x);
+}
+template <class Cfg>
+constexpr int pack_field_weights_blocks() { return (Cfg::PACKED_FLOATS + 255) / 256; }
 
 template <class Cfg>
 static inline void launch_pack_field_weights(const FieldPtrs& p, float* packed, hipStream_t st) {
@@ -317,21 +323,31 @@ __device__ __forceinline__ void sh16_all(const float* __restrict__ dir, float (&
 // lane = output feature; the 48 x 64 weight slice (packed buffer, already transposed) is copied to LDS.
 // Two rays per wave and many small workgroups: the per-ray chain camera -> embedding row -> 48 FMAs is pure
 // latency, so it is hidden by occupancy rather than by a long loop.
-template <class Cfg>
-__global__ __launch_bounds__(256) void k_color_ray_bias(const float* __restrict__ packed, RaysDev rays,
-                                                        const float* __restrict__ embedding,
-                                                        const float* __restrict__ mean_embedding,
-                                                        float* __restrict__ ray_bias) {
-  __shared__ __attribute__((aligned(16))) float Wt[COLOR_CONST_K][64];
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(packed + Cfg::LDS_FLOATS);
-    f32x4* dst = reinterpret_cast<f32x4*>(&Wt[0][0]);
-    for (int i = threadIdx.x; i < COLOR_CONST_K * 64 / 4; i += 256) dst[i] = src[i];
-  }
+// FROM_RAW: the weight slice and the bias come straight from the nn.Linear tensors (same values as the packed image
+// holds) so that the kernel does not depend on the pack launch and can share a launch with it (k_prepare_field).
+template <class Cfg, bool FROM_RAW>
+__device__ __forceinline__ void color_ray_bias_block(const FieldPtrs& p, const float* __restrict__ packed,
+                                                     const RaysDev& rays, const float* __restrict__ embedding,
+                                                     const float* __restrict__ mean_embedding,
+                                                     float* __restrict__ ray_bias, int block, int n_blocks) {
+  // row stride 65: the FROM_RAW fill walks k fastest (consecutive words of a weight row), reads walk the lane
+  __shared__ __attribute__((aligned(16))) float Wt[COLOR_CONST_K][65];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float b = packed[Cfg::W_TOTAL + Cfg::boff(Cfg::L_COL0) + lane];
+  float b;
+  if constexpr (FROM_RAW) {
+    constexpr int IN = Cfg::in_dim(Cfg::L_COL0);
+    for (int i = threadIdx.x; i < COLOR_CONST_K * 64; i += 256) {
+      const int o = i / COLOR_CONST_K, k = i - o * COLOR_CONST_K;
+      Wt[k][o] = p.w[Cfg::L_COL0][o * IN + color_const_col<Cfg>(k)];
+    }
+    b = p.b[Cfg::L_COL0][lane];
+  } else {
+    const float* src = packed + Cfg::LDS_FLOATS;
+    for (int i = threadIdx.x; i < COLOR_CONST_K * 64; i += 256) Wt[i >> 6][i & 63] = src[i];
+    b = packed[Cfg::W_TOTAL + Cfg::boff(Cfg::L_COL0) + lane];
+  }
   __syncthreads();
-  for (long long ray = (long long)blockIdx.x * 4 + wave; ray < rays.n_rays; ray += (long long)gridDim.x * 4) {
+  for (long long ray = (long long)block * 4 + wave; ray < rays.n_rays; ray += (long long)n_blocks * 4) {
     float c[16];
     sh16_all(rays.directions + 3 * ray, c);
     const float* emb = mean_embedding ? mean_embedding : embedding + (size_t)rays.cam[ray] * 32;
@@ -349,15 +365,25 @@ __global__ __launch_bounds__(256) void k_color_ray_bias(const float* __restrict_
     ray_bias[(size_t)ray * 64 + lane] = acc;
   }
 }
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_color_ray_bias(const float* __restrict__ packed, RaysDev rays,
+                                                        const float* __restrict__ embedding,
+                                                        const float* __restrict__ mean_embedding,
+                                                        float* __restrict__ ray_bias) {
+  FieldPtrs none{};
+  color_ray_bias_block<Cfg, false>(none, packed, rays, embedding, mean_embedding, ray_bias, blockIdx.x, gridDim.x);
+}
+static inline long long color_ray_bias_blocks(const RaysDev& rays) {
+  long long blocks = (rays.n_rays + 7) / 8;
+  if (blocks > 8ll * device_cu_count()) blocks = 8ll * device_cu_count();
+  return blocks < 1 ? 1 : blocks;
+}
 
 template <class Cfg>
 static inline void launch_color_ray_bias(const float* packed, const RaysDev& rays, const float* embedding,
                                          const float* mean_embedding, float* ray_bias, hipStream_t st) {
-  long long blocks = (rays.n_rays + 7) / 8;
-  if (blocks > 8ll * device_cu_count()) blocks = 8ll * device_cu_count();
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_color_ray_bias<Cfg>), dim3((unsigned)blocks), dim3(256), 0, st, packed, rays, embedding,
-                     mean_embedding, ray_bias);
+  hipLaunchKernelGGL((k_color_ray_bias<Cfg>), dim3((unsigned)color_ray_bias_blocks(rays)), dim3(256), 0, st, packed, rays,
+                     embedding, mean_embedding, ray_bias);
 }
 
 }  // namespace fnr

@@ -6,6 +6,7 @@
 // (see field_layers.hpp); weights live in LDS for the whole (persistent) workgroup.
 // Roofline: MFMA fp32 (157.3 TF peak): 33 024 useful FLOP/sample, 36 864 issued (padding).
 #include "field_layers.hpp"
+#include "field_bf16.hpp"
 
 namespace fnr {
 
@@ -204,9 +205,10 @@ int field_mlp_fwd_launch(const FieldPtrs& p, const fnr_field_net* net, const Ray
                          const float* feats, const uint8_t* selector, const float* mean_embedding, float* density,
                          float* rgb, float* logit, float* geo_out, float* h_buf, float* packed, float* ray_bias,
                          hipStream_t st) {
-  launch_pack_field_weights<Cfg>(p, packed, st);
-  FNR_LAUNCH_CHECK();
-  launch_color_ray_bias<Cfg>(packed, rd, net->embedding, mean_embedding, ray_bias, st);
+  // fp32 fragment image + (bf16-pipe modes) the bf16 pieces + per-ray colour bias: one launch
+  launch_prepare_field<Cfg>(p, packed, net->mlp_mode == FNR_MLP_FP32 ? 0 : (net->mlp_mode == FNR_MLP_BF16 ? 1 : 3),
+                            reinterpret_cast<__bf16*>(reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset()), rd,
+                            net->embedding, mean_embedding, ray_bias, st);
   FNR_LAUNCH_CHECK();
   const long long n_tiles = (N + 15) / 16;
   const float2* f2 = reinterpret_cast<const float2*>(feats);

@@ -473,9 +473,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_fwd_sem_big
 int field_mlp_fwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, const float* packed, long long N,
                                const float* h_buf, float* logit, hipStream_t st) {
   using Cfg = FieldCfgBig;
-  __bf16* image = reinterpret_cast<__bf16*>(image_ws);
-  launch_pack_field_weights_bf16<Cfg>(p, mode == MLP_BF16 ? 1 : 3, image, st);
-  FNR_LAUNCH_CHECK();
+  __bf16* image = reinterpret_cast<__bf16*>(image_ws);  // packed by the caller (k_prepare_field)
   constexpr int WAVES = 8;
   const long long n_batches = (N + 16 * WAVES - 1) / (16 * WAVES);
   long long blocks = n_batches;
@@ -982,9 +980,7 @@ static int fwd_launch_bf16(const float* packed, const __bf16* image, const float
 int field_mlp_fwd_bf16(int mode, const FieldPtrs& p, const float* packed, void* image_ws, const float* ray_bias,
                        const RaysDev& rd, int S, long long N, const float2* feats, const uint8_t* selector, float* density,
                        float* rgb, float* logit, float* geo_out, float* h_buf, hipStream_t st) {
-  __bf16* image = reinterpret_cast<__bf16*>(image_ws);
-  launch_pack_field_weights_bf16<FieldCfgBase>(p, mode == MLP_BF16 ? 1 : 3, image, st);
-  FNR_LAUNCH_CHECK();
+  __bf16* image = reinterpret_cast<__bf16*>(image_ws);  // packed by the caller (k_prepare_field)
   if (mode == MLP_BF16)
     return fwd_launch_bf16<1>(packed, image, ray_bias, rd, S, N, feats, selector, density, rgb, logit, geo_out, h_buf, st);
   return fwd_launch_bf16<3>(packed, image, ray_bias, rd, S, N, feats, selector, density, rgb, logit, geo_out, h_buf, st);

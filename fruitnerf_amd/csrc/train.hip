@@ -13,15 +13,16 @@ namespace fnr {
 // ---------------------------------------------------------------------------------------------------
 // One workgroup: a training batch is a few thousand rays, and finishing inside the kernel (block reduction, PSNR)
 // saves the memset, the atomics and three follow-up elementwise launches per step.
-__global__ __launch_bounds__(1024) void k_losses(long long R, const float* __restrict__ rgb,
-                                                 const float* __restrict__ image, const float* __restrict__ sem,
-                                                 const float* __restrict__ mask, float sem_weight,
-                                                 float* __restrict__ losses, float* __restrict__ d_rgb,
-                                                 float* __restrict__ d_sem) {
+template <int THREADS>
+__device__ __forceinline__ void losses_block(long long R, const float* __restrict__ rgb,
+                                             const float* __restrict__ image, const float* __restrict__ sem,
+                                             const float* __restrict__ mask, float sem_weight,
+                                             float* __restrict__ losses, float* __restrict__ d_rgb,
+                                             float* __restrict__ d_sem) {
   __shared__ float red[2][16];
   float l_rgb = 0.0f, l_sem = 0.0f;
   const float inv3r = 1.0f / (float)(3 * R), invr = 1.0f / (float)R;
-  for (long long r = threadIdx.x; r < R; r += 1024) {
+  for (long long r = threadIdx.x; r < R; r += THREADS) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float d = rgb[3 * r + c] - image[3 * r + c];
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(1024) void k_losses(long long R, const float* __res
   __syncthreads();
   if (threadIdx.x == 0) {
     float a = 0.0f, b = 0.0f;
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < THREADS / 64; ++w) {
       a += red[0][w];
       b += red[1][w];
     }
@@ -53,12 +54,20 @@ __global__ __launch_bounds__(1024) void k_losses(long long R, const float* __res
     losses[2] = -10.0f * log10f(mse);  // PeakSignalNoiseRatio(data_range=1.0) of the same batch (fruit_nerf.py:398)
   }
 }
+__global__ __launch_bounds__(1024) void k_losses(long long R, const float* __restrict__ rgb,
+                                                 const float* __restrict__ image, const float* __restrict__ sem,
+                                                 const float* __restrict__ mask, float sem_weight,
+                                                 float* __restrict__ losses, float* __restrict__ d_rgb,
+                                                 float* __restrict__ d_sem) {
+  losses_block<1024>(R, rgb, image, sem, mask, sem_weight, losses, d_rgb, d_sem);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // interlevel loss of one proposal level against the final level (nerfstudio losses.interlevel_loss):
 // value (accumulated) + unit gradient w.r.t. the proposal weights.
 // ---------------------------------------------------------------------------------------------------
 constexpr int IL_MAX_P = 512;
+constexpr int IL_LDS_FLOATS = 4 * (3 * IL_MAX_P + 4);   // per wave: cp [P+1], cy [P+1], dd [P+2]
 
 __device__ __forceinline__ int searchsorted_right(const float* a, int n, float v) {
   int lo = 0, hi = n;
@@ -70,20 +79,17 @@ __device__ __forceinline__ int searchsorted_right(const float* a, int n, float v
   return lo;
 }
 
-__global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const float* __restrict__ spacing_f,
-                                                    const float* __restrict__ w_f, int S_p,
-                                                    const float* __restrict__ spacing_p,
-                                                    const float* __restrict__ w_p, float mult,
-                                                    float* __restrict__ loss, float* __restrict__ d_wp) {
-  __shared__ float s_cp[4][IL_MAX_P + 1];
-  __shared__ float s_cy[4][IL_MAX_P + 1];
-  __shared__ float s_d[4][IL_MAX_P + 2];
+__device__ __forceinline__ void interlevel_block(long long R, int S_f, const float* __restrict__ spacing_f,
+                                                 const float* __restrict__ w_f, int S_p,
+                                                 const float* __restrict__ spacing_p, const float* __restrict__ w_p,
+                                                 float mult, float* __restrict__ loss, float* __restrict__ d_wp,
+                                                 int block, float* lds) {  // lds: IL_LDS_FLOATS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long r = (long long)blockIdx.x * 4 + wave;
+  const long long r = (long long)block * 4 + wave;
   if (r >= R) return;
-  float* cp = s_cp[wave];
-  float* cy = s_cy[wave];
-  float* dd = s_d[wave];
+  float* cp = lds + wave * (3 * IL_MAX_P + 4);
+  float* cy = cp + IL_MAX_P + 1;
+  float* dd = cy + IL_MAX_P + 1;
   const float* sp = spacing_p + r * (S_p + 1);
   const float* wp = w_p + r * S_p;
   // cy1 = [0, cumsum(wp)] : lane-chunked scan
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const 
   }
   lsum = wave_sum(lsum);
   // atomics to one L2 line serialise at ~12 ns each (4096 rays = ~35-50 us): 32 lines, 4 words (waves) per line
-  if (lane == 0) atomicAdd(&loss[(blockIdx.x & 31) * 32 + wave], lsum * scale);
+  if (lane == 0) atomicAdd(&loss[(block & 31) * 32 + wave], lsum * scale);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   // d_wp = inclusive scan of the difference array
@@ -147,14 +153,23 @@ __global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const 
     }
   }
 }
+__global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const float* __restrict__ spacing_f,
+                                                    const float* __restrict__ w_f, int S_p,
+                                                    const float* __restrict__ spacing_p,
+                                                    const float* __restrict__ w_p, float mult,
+                                                    float* __restrict__ loss, float* __restrict__ d_wp) {
+  __shared__ float lds[IL_LDS_FLOATS];
+  interlevel_block(R, S_f, spacing_f, w_f, S_p, spacing_p, w_p, mult, loss, d_wp, blockIdx.x, lds);
+}
 
 // distortion_loss (metric, fruit_nerf.py:400): mean over rays of sum_ij w_i w_j |m_i - m_j| + sum_i w_i^2 ds_i / 3
-__global__ __launch_bounds__(256) void k_distortion(long long R, int S, const float* __restrict__ spacing,
-                                                    const float* __restrict__ weights, float* __restrict__ out) {
-  __shared__ float s_m[4][512];
-  __shared__ float s_w[4][512];
+__device__ __forceinline__ void distortion_block(long long R, int S, const float* __restrict__ spacing,
+                                                 const float* __restrict__ weights, float* __restrict__ out,
+                                                 int block, float* lds) {  // lds: 4096 floats
+  float(*s_m)[512] = reinterpret_cast<float(*)[512]>(lds);
+  float(*s_w)[512] = reinterpret_cast<float(*)[512]>(lds + 2048);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long r = (long long)blockIdx.x * 4 + wave;
+  const long long r = (long long)block * 4 + wave;
   if (r >= R) return;
   const float* t = spacing + r * (S + 1);
   const float* w = weights + r * S;
@@ -172,7 +187,117 @@ __global__ __launch_bounds__(256) void k_distortion(long long R, int S, const fl
     acc += wi * inner + wi * wi * (t[i + 1] - t[i]) / 3.0f;
   }
   acc = wave_sum(acc);
-  if (lane == 0) atomicAdd(&out[(blockIdx.x & 31) * 32 + wave], acc / (float)R);
+  if (lane == 0) atomicAdd(&out[(block & 31) * 32 + wave], acc / (float)R);
+}
+__global__ __launch_bounds__(256) void k_distortion(long long R, int S, const float* __restrict__ spacing,
+                                                    const float* __restrict__ weights, float* __restrict__ out) {
+  __shared__ float lds[4096];
+  distortion_block(R, S, spacing, weights, out, blockIdx.x, lds);
+}
+
+// Every loss of a training step in ONE launch (fnr_train_losses; five dependent 4-10 us launches before): workgroups
+// [0, nbl) = rgb + semantic losses and their gradients (256 rays each), then (R + 3) / 4 workgroups per proposal level
+// = interlevel loss, then as many for the distortion metric.  Sums go to accumulator slots in 32 different 128-byte
+// lines (same-line atomics serialise at ~12 ns each); the last workgroup to finish — found with a two-level
+// completion count for the same reason — adds the slots up and writes the five scalars.
+struct LevelLossArgs {
+  int n_levels;
+  int S_p[FNR_MAX_PROPOSAL_LEVELS];
+  const float* spacing_p[FNR_MAX_PROPOSAL_LEVELS];
+  const float* w_p[FNR_MAX_PROPOSAL_LEVELS];
+  float* d_wp[FNR_MAX_PROPOSAL_LEVELS];
+};
+constexpr int TL_ROWS = 4;                                       // slot rows: interlevel, distortion, rgb, semantic
+constexpr int TL_ACCUM_FLOATS = TL_ROWS * FNR_LOSS_SLOTS + 33 * 32;  // + 32 group counters and the top one, a line each
+static_assert(TL_ACCUM_FLOATS == FNR_TRAIN_LOSSES_ACCUM_FLOATS, "fruitnerf_hip.h: FNR_TRAIN_LOSSES_ACCUM_FLOATS");
+__global__ __launch_bounds__(256) void k_train_losses(long long R, const float* __restrict__ rgb,
+                                                      const float* __restrict__ image, const float* __restrict__ sem,
+                                                      const float* __restrict__ mask, float sem_weight,
+                                                      float* __restrict__ d_rgb, float* __restrict__ d_sem, int S_f,
+                                                      const float* __restrict__ spacing_f,
+                                                      const float* __restrict__ w_f, LevelLossArgs lv, float mult,
+                                                      int want_distortion, float* __restrict__ accum,
+                                                      float* __restrict__ losses) {
+  static_assert(IL_LDS_FLOATS >= 4096, "one buffer for both roles");
+  __shared__ float lds[IL_LDS_FLOATS];
+  __shared__ bool s_last;
+  __shared__ float s_red[TL_ROWS][4];
+  float* il_slots = accum;
+  float* di_slots = accum + FNR_LOSS_SLOTS;
+  float* rgb_slots = accum + 2 * FNR_LOSS_SLOTS;
+  float* sem_slots = accum + 3 * FNR_LOSS_SLOTS;
+  unsigned* cnt = reinterpret_cast<unsigned*>(accum + TL_ROWS * FNR_LOSS_SLOTS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbl = (int)((R + 255) / 256);
+  const int per = (int)((R + 3) / 4);
+  const float inv3r = 1.0f / (float)(3 * R), invr = 1.0f / (float)R;
+  if ((int)blockIdx.x < nbl) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    float l_rgb = 0.0f, l_sem = 0.0f;
+    if (r < R) {  // per ray exactly what losses_block does
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = rgb[3 * r + c] - image[3 * r + c];
+        l_rgb += d * d;
+        d_rgb[3 * r + c] = 2.0f * d * inv3r;
+      }
+      const float x = sem[r], y = mask[r];
+      l_sem = fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
+      const float sg = 1.0f / (1.0f + expf(-x));
+      d_sem[r] = sem_weight * (sg - y) * invr;
+    }
+    l_rgb = wave_sum(l_rgb);
+    l_sem = wave_sum(l_sem);
+    if (lane == 0) {
+      atomicAdd(&rgb_slots[(blockIdx.x & 31) * 32 + wave], l_rgb);
+      atomicAdd(&sem_slots[(blockIdx.x & 31) * 32 + wave], l_sem);
+    }
+  } else {
+    const int b = (int)blockIdx.x - nbl;
+    const int role = b / per, local = b - role * per;
+    if (role < lv.n_levels)
+      interlevel_block(R, S_f, spacing_f, w_f, lv.S_p[role], lv.spacing_p[role], lv.w_p[role], mult, il_slots,
+                       lv.d_wp[role], local, lds);
+    else
+      distortion_block(R, S_f, spacing_f, w_f, di_slots, local, lds);
+  }
+  // Completion count WITHOUT __threadfence(): an agent-scope release fence writes the XCD's L2 back (this kernel's
+  // outputs are dirty there) and 3000 workgroups doing that cost 100 us.  The slot sums are agent-scope atomics, performed
+  // at the memory side; every wave waits until its own have been acknowledged (vmcnt(0)) before the workgroup's barrier,
+  // then one thread counts the workgroup in, and the last workgroup reads the slots back with agent-scope loads.
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned g = blockIdx.x & 31u;
+    const unsigned gsize = (gridDim.x - g + 31u) / 32u, ngroups = gridDim.x < 32u ? gridDim.x : 32u;
+    bool last = false;
+    if (atomicAdd(&cnt[g * 32], 1u) == gsize - 1u) last = atomicAdd(&cnt[32 * 32], 1u) == ngroups - 1u;
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float acc[TL_ROWS] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = threadIdx.x; i < FNR_LOSS_SLOTS; i += 256)
+#pragma unroll
+    for (int q = 0; q < TL_ROWS; ++q)
+      acc[q] += __hip_atomic_load(accum + q * FNR_LOSS_SLOTS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int q = 0; q < TL_ROWS; ++q) {
+    acc[q] = wave_sum(acc[q]);
+    if (lane == 0) s_red[q][wave] = acc[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[TL_ROWS];
+#pragma unroll
+    for (int q = 0; q < TL_ROWS; ++q) t[q] = (s_red[q][0] + s_red[q][1]) + (s_red[q][2] + s_red[q][3]);
+    const float mse = t[2] * inv3r;
+    losses[0] = mse;
+    losses[1] = sem_weight * t[3] * invr;
+    losses[2] = -10.0f * log10f(mse);  // PeakSignalNoiseRatio(data_range=1.0) of the same batch (fruit_nerf.py:398)
+    losses[3] = t[0];
+    losses[4] = want_distortion ? t[1] : 0.0f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -550,6 +675,36 @@ extern "C" int fnr_adam_step_spans(float* params, float* grads, float* exp_avg, 
   else
     hipLaunchKernelGGL(k_adam_spans<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p4, g4, m4, v4, sp,
                        beta1, beta2, eps, grad_scale, weight_decay, zero_grad);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_train_losses(int64_t n_rays, const float* rgb, const float* image, const float* semantics,
+                                const float* fruit_mask, float semantic_loss_weight, float* d_rgb, float* d_semantics,
+                                int S_f, const float* spacing_f, const float* weights_f, int n_levels, const int* S_p,
+                                const float* const* spacing_p, const float* const* weights_p, float* const* d_weights_p,
+                                float interlevel_mult, int want_distortion, float* accum, float* losses, void* stream) {
+  FNR_CHECK_ARG(rgb && image && semantics && fruit_mask && d_rgb && d_semantics && spacing_f && weights_f && accum &&
+                    losses && n_rays > 0,
+                "train_losses: null argument");
+  FNR_CHECK_ARG(n_levels >= 0 && n_levels <= FNR_MAX_PROPOSAL_LEVELS, "train_losses: %d proposal levels (0..%d)",
+                n_levels, FNR_MAX_PROPOSAL_LEVELS);
+  FNR_CHECK_ARG(S_f > 0 && (!want_distortion || S_f <= 512), "train_losses: S_f %d out of range", S_f);
+  LevelLossArgs lv{};
+  lv.n_levels = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    FNR_CHECK_ARG(S_p && spacing_p && weights_p && d_weights_p && spacing_p[l] && weights_p[l] && d_weights_p[l],
+                  "train_losses: null proposal level %d", l);
+    FNR_CHECK_ARG(S_p[l] > 0 && S_p[l] <= IL_MAX_P, "train_losses: S_p %d out of range", S_p[l]);
+    lv.S_p[l] = S_p[l], lv.spacing_p[l] = spacing_p[l], lv.w_p[l] = weights_p[l], lv.d_wp[l] = d_weights_p[l];
+  }
+  const long long per = (n_rays + 3) / 4;
+  const long long blocks = (n_rays + 255) / 256 + per * (n_levels + (want_distortion ? 1 : 0));
+  FNR_CHECK_ARG(blocks < (1ll << 31), "train_losses: too many rays");
+  FNR_PROF(OP_LOSSES, n_rays);
+  hipLaunchKernelGGL(k_train_losses, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (long long)n_rays, rgb, image,
+                     semantics, fruit_mask, semantic_loss_weight, d_rgb, d_semantics, S_f, spacing_f, weights_f, lv,
+                     interlevel_mult, want_distortion, accum, losses);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -484,19 +484,17 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         rays, fin = rctx.rays, rctx.levels[-1]
         S = fin["S"]
         image, mask = batch["image"].to(dev), batch["fruit_mask"].to(dev)
-        losses, d_rgb, d_sem = K.losses_fwd(outputs["rgb"], image, outputs["semantics"], mask, cfg.semantic_loss_weight)
-        # one fill for everything this step accumulates into: [interlevel | distortion] loss slots and, with a camera
-        # optimiser, the ray gradients d(loss)/d(origins | directions)
-        n_slots = 2 * L.FNR_LOSS_SLOTS
+        # one fill for everything this step accumulates into: the loss slots (+ completion counter) and, with a camera
+        # optimiser, the ray gradients d(loss)/d(origins | directions); one launch for every loss and metric
+        n_slots = L.FNR_TRAIN_LOSSES_ACCUM_FLOATS
         zeros = torch.zeros(n_slots + (6 * rays.n if ray_grads is not None else 0), device=dev)
-        slots = zeros[:n_slots].view(2, L.FNR_LOSS_SLOTS)
-        d_wps = [K.interlevel_fwd(S, fin["spacing"], fin["weights"], lv["S"], lv["spacing"], lv["weights"],
-                                  cfg.interlevel_loss_mult, slots[0]) for lv in rctx.levels[:-1]]
-        if want_metrics:
-            K.distortion(S, fin["spacing"], fin["weights"], out=slots[1])
-        sums = slots.sum(dim=1)                                # one reduce
-        loss_dict = {"rgb_loss": losses[0], "semantics_loss": losses[1], "interlevel_loss": sums[0]}
-        metrics_dict = {"psnr": losses[2], "distortion": sums[1]} if want_metrics else {}
+        prop_levels = [(lv["S"], lv["spacing"], lv["weights"]) for lv in rctx.levels[:-1]]
+        losses, d_rgb, d_sem, d_wps = K.train_losses(outputs["rgb"], image, outputs["semantics"], mask,
+                                                     cfg.semantic_loss_weight, S, fin["spacing"], fin["weights"],
+                                                     prop_levels, cfg.interlevel_loss_mult, want_metrics,
+                                                     zeros[:n_slots])
+        loss_dict = {"rgb_loss": losses[0], "semantics_loss": losses[1], "interlevel_loss": losses[3]}
+        metrics_dict = {"psnr": losses[2], "distortion": losses[4]} if want_metrics else {}
 
         # ---- backward (what loss.backward() runs through _LossFn, _RenderFn, _InterlevelFn) ----
         arena = model.arena()

@@ -340,6 +340,20 @@ int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, con
                          const float* d_density, float* d_position, void* workspace, size_t workspace_bytes,
                          int workspace_clean, void* stream);
 
+/* All of get_loss_dict / get_metrics_dict for one training batch in ONE launch: fnr_losses_fwd + fnr_interlevel_fwd for
+ * each of the n_levels (<= FNR_MAX_PROPOSAL_LEVELS) proposal levels against the final level + (want_distortion)
+ * fnr_distortion, and the sum of the accumulator slots.  losses [5] = rgb_loss, semantics_loss, psnr,
+ * interlevel_loss, distortion (0 when not wanted); d_rgb [R,3], d_semantics [R], d_weights_p[l] [R,S_p[l]] as the
+ * single calls give them.  accum: FNR_TRAIN_LOSSES_ACCUM_FLOATS floats, ZEROED by the caller (loss slots + completion
+ * counters).  S_p / spacing_p / weights_p / d_weights_p are host arrays of n_levels entries. */
+#define FNR_MAX_PROPOSAL_LEVELS 4
+#define FNR_TRAIN_LOSSES_ACCUM_FLOATS (4 * FNR_LOSS_SLOTS + 33 * 32)
+int fnr_train_losses(int64_t n_rays, const float* rgb, const float* image, const float* semantics,
+                     const float* fruit_mask, float semantic_loss_weight, float* d_rgb, float* d_semantics, int S_f,
+                     const float* spacing_f, const float* weights_f, int n_levels, const int* S_p,
+                     const float* const* spacing_p, const float* const* weights_p, float* const* d_weights_p,
+                     float interlevel_mult, int want_distortion, float* accum, float* losses, void* stream);
+
 /* ---- gradient of the rays (camera-pose optimisation, fruit_nerf_config.py:39-43) ----------------- */
 /* Input gradient of fnr_hash_encode_fwd: partial [L][N][4] = per level d(loss)/d(unit-cube position) of every
  * sample, from d_feats [L][N][2] and the PARAMETER table (autograd of HashEncoding w.r.t. its input through the
