@@ -321,11 +321,13 @@ def distortion(S: int, spacing: Tensor, weights: Tensor, out: Optional[Tensor] =
 
 def train_losses(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tensor, semantic_loss_weight: float,
                  S_f: int, spacing_f: Tensor, weights_f: Tensor, levels, interlevel_mult: float, want_distortion: bool,
-                 accum: Tensor):
+                 accum: Tensor, fuse_weights_bwd: bool = False):
     """losses_fwd + interlevel_fwd per proposal level + distortion + the slot sums in one launch.
     levels: [(S_p, spacing_p, weights_p), ...]; accum: ZEROED float buffer of FNR_TRAIN_LOSSES_ACCUM_FLOATS.
     -> losses [5] (rgb_loss, semantics_loss, psnr, interlevel_loss, distortion), d_rgb [R,3], d_semantics [R],
-       [d_weights_p per level]."""
+       [d_weights_p per level].
+    fuse_weights_bwd: levels are (S_p, spacing_p, weights_p, euclid_p, density_p) and the last list holds each level's
+    d(loss)/d(density) [R,S_p] (= weights_bwd of the level, unit upstream) instead of d_weights_p."""
     lib = L.load()
     dev = rgb.device
     R = rgb.shape[0]
@@ -335,15 +337,19 @@ def train_losses(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tens
     d_rgb = torch.empty(R, 3, device=dev)
     d_sem = torch.empty(R, device=dev)
     n = len(levels)
-    d_wps = [torch.empty(R, S_p, device=dev) for S_p, _, _ in levels]
-    sp = (C.c_int * max(n, 1))(*[int(S_p) for S_p, _, _ in levels])
+    outs = [torch.empty(R, lv[0], device=dev) for lv in levels]
+    sp = (C.c_int * max(n, 1))(*[int(lv[0]) for lv in levels])
     vps = lambda ts: (C.c_void_p * max(n, 1))(*[L.ptr(t) for t in ts])   # noqa: E731
+    if fuse_weights_bwd:
+        d_wp, eu, dn, d_dn = None, vps([lv[3] for lv in levels]), vps([lv[4] for lv in levels]), vps(outs)
+    else:
+        d_wp, eu, dn, d_dn = vps(outs), None, None, None
     L.check(lib.fnr_train_losses(R, L.ptr(rgb), L.ptr(image), L.ptr(semantics), L.ptr(fruit_mask),
                                  float(semantic_loss_weight), L.ptr(d_rgb), L.ptr(d_sem), S_f, L.ptr(spacing_f),
-                                 L.ptr(weights_f), n, sp, vps([t for _, t, _ in levels]), vps([t for _, _, t in levels]),
-                                 vps(d_wps), float(interlevel_mult), 1 if want_distortion else 0, L.ptr(accum),
+                                 L.ptr(weights_f), n, sp, vps([lv[1] for lv in levels]), vps([lv[2] for lv in levels]),
+                                 d_wp, eu, dn, d_dn, float(interlevel_mult), 1 if want_distortion else 0, L.ptr(accum),
                                  L.ptr(losses), L.stream_ptr(dev)), "train_losses")
-    return losses, d_rgb, d_sem, d_wps
+    return losses, d_rgb, d_sem, outs
 
 
 def composite_bwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, weights: Tensor, g_rgb: Tensor,

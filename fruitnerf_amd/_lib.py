@@ -124,7 +124,8 @@ SIGNATURES = {
     "fnr_hash_encode_input_grad": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
     "fnr_position_grad_reduce": (_i, [P(fnr_warp), P(fnr_rays), _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fnr_train_losses": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _i, P(C.c_int), P(C.c_void_p),
-                              P(C.c_void_p), P(C.c_void_p), _f, _i, _vp, _vp, _vp]),
+                              P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), _f, _i, _vp,
+                              _vp, _vp]),
     "fnr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
     "fnr_radam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _f, _i, _vp]),
     "fnr_adam_step_spans": (_i, [_vp, _vp, _vp, _vp, _i, P(fnr_adam_span), _i, _f, _f, _f, _f, _f, _i, _vp]),

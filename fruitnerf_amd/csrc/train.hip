@@ -67,6 +67,50 @@ __global__ __launch_bounds__(1024) void k_losses(long long R, const float* __res
 // value (accumulated) + unit gradient w.r.t. the proposal weights.
 // ---------------------------------------------------------------------------------------------------
 constexpr int IL_MAX_P = 512;
+constexpr int WB_MAXE = 8;   // samples per lane in the per-ray weight kernels (S <= 512)
+
+// k_weights_bwd<false> for one ray with the upstream gradient d(loss)/d(w_k) already in registers (gw[e] belongs to
+// sample lane * E + e, zero beyond S): same operations in the same order -> bit-identical d_density.
+__device__ __forceinline__ void weights_bwd_ray_from_regs(long long r, int S, int lane, const float* __restrict__ euclid,
+                                                          const float* __restrict__ density,
+                                                          const float* __restrict__ weights,
+                                                          const float (&gw)[WB_MAXE], float* __restrict__ d_density) {
+  const int E = (S + 63) >> 6;
+  const float* eb = euclid + r * (S + 1);
+  const float* dn = density + r * S;
+  const float* w = weights + r * S;
+  float delta[WB_MAXE], wk[WB_MAXE];
+  float dd_local = 0.0f, gww_local = 0.0f;
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    delta[e] = 0.0f;
+    wk[e] = 0.0f;
+    if (e < E && k < S) {
+      delta[e] = eb[k + 1] - eb[k];
+      wk[e] = w[k];
+      dd_local += delta[e] * dn[k];
+      gww_local += gw[e] * wk[e];
+    }
+  }
+  float cum_dd = wave_excl_scan(dd_local, lane);
+  float suffix = wave_bcast_lane(wave_excl_scan(wave_bcast_lane(gww_local, 63 - lane), lane), 63 - lane);
+  float suf[WB_MAXE];
+#pragma unroll
+  for (int e = WB_MAXE - 1; e >= 0; --e) {
+    suf[e] = suffix;
+    suffix += gw[e] * wk[e];
+  }
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    if (e < E && k < S) {
+      cum_dd += delta[e] * dn[k];
+      const float T_next = expf(-cum_dd);
+      d_density[r * S + k] = delta[e] * (gw[e] * T_next - suf[e]);
+    }
+  }
+}
 constexpr int IL_LDS_FLOATS = 4 * (3 * IL_MAX_P + 4);   // per wave: cp [P+1], cy [P+1], dd [P+2]
 
 __device__ __forceinline__ int searchsorted_right(const float* a, int n, float v) {
@@ -83,7 +127,10 @@ __device__ __forceinline__ void interlevel_block(long long R, int S_f, const flo
                                                  const float* __restrict__ w_f, int S_p,
                                                  const float* __restrict__ spacing_p, const float* __restrict__ w_p,
                                                  float mult, float* __restrict__ loss, float* __restrict__ d_wp,
-                                                 int block, float* lds) {  // lds: IL_LDS_FLOATS
+                                                 int block, float* lds,  // lds: IL_LDS_FLOATS
+                                                 const float* __restrict__ euclid_p = nullptr,
+                                                 const float* __restrict__ density_p = nullptr,
+                                                 float* __restrict__ d_density_p = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r = (long long)block * 4 + wave;
   if (r >= R) return;
@@ -145,13 +192,29 @@ __device__ __forceinline__ void interlevel_block(long long R, int S_f, const flo
     if (k < S_p) l2 += dd[k];
   }
   float run2 = wave_excl_scan(l2, lane);
-  for (int e = 0; e < E; ++e) {
+  if (!d_density_p) {
+    for (int e = 0; e < E; ++e) {
+      const int k = lane * E + e;
+      if (k < S_p) {
+        run2 += dd[k];
+        d_wp[r * S_p + k] = run2;
+      }
+    }
+    return;
+  }
+  // the proposal level's weights backward right here (the ray is in this wave's hands; d_wp stays in registers)
+  float gw[WB_MAXE];
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
     const int k = lane * E + e;
-    if (k < S_p) {
+    gw[e] = 0.0f;
+    if (e < E && k < S_p) {
       run2 += dd[k];
-      d_wp[r * S_p + k] = run2;
+      gw[e] = run2;
+      if (d_wp) d_wp[r * S_p + k] = run2;
     }
   }
+  weights_bwd_ray_from_regs(r, S_p, lane, euclid_p, density_p, w_p, gw, d_density_p);
 }
 __global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const float* __restrict__ spacing_f,
                                                     const float* __restrict__ w_f, int S_p,
@@ -206,6 +269,9 @@ struct LevelLossArgs {
   const float* spacing_p[FNR_MAX_PROPOSAL_LEVELS];
   const float* w_p[FNR_MAX_PROPOSAL_LEVELS];
   float* d_wp[FNR_MAX_PROPOSAL_LEVELS];
+  const float* euclid_p[FNR_MAX_PROPOSAL_LEVELS];   // with d_density_p: the level's weights backward is fused in
+  const float* density_p[FNR_MAX_PROPOSAL_LEVELS];
+  float* d_density_p[FNR_MAX_PROPOSAL_LEVELS];
 };
 constexpr int TL_ROWS = 4;                                       // slot rows: interlevel, distortion, rgb, semantic
 constexpr int TL_ACCUM_FLOATS = TL_ROWS * FNR_LOSS_SLOTS + 33 * 32;  // + 32 group counters and the top one, a line each
@@ -257,7 +323,7 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
     const int role = b / per, local = b - role * per;
     if (role < lv.n_levels)
       interlevel_block(R, S_f, spacing_f, w_f, lv.S_p[role], lv.spacing_p[role], lv.w_p[role], mult, il_slots,
-                       lv.d_wp[role], local, lds);
+                       lv.d_wp[role], local, lds, lv.euclid_p[role], lv.density_p[role], lv.d_density_p[role]);
     else
       distortion_block(R, S_f, spacing_f, w_f, di_slots, local, lds);
   }
@@ -304,8 +370,6 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
 // backward of w_i = (1 - exp(-d_i s_i)) exp(-sum_{j<i} d_j s_j):
 //   dL/ds_k = d_k [ g_k T_{k+1} - sum_{i>k} g_i w_i ],  T_{k+1} = exp(-sum_{j<=k} d_j s_j)
 // ---------------------------------------------------------------------------------------------------
-constexpr int WB_MAXE = 8;
-
 template <bool COMPOSITE>
 __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const float* __restrict__ euclid,
                                                      const float* __restrict__ density,
@@ -683,7 +747,9 @@ extern "C" int fnr_train_losses(int64_t n_rays, const float* rgb, const float* i
                                 const float* fruit_mask, float semantic_loss_weight, float* d_rgb, float* d_semantics,
                                 int S_f, const float* spacing_f, const float* weights_f, int n_levels, const int* S_p,
                                 const float* const* spacing_p, const float* const* weights_p, float* const* d_weights_p,
-                                float interlevel_mult, int want_distortion, float* accum, float* losses, void* stream) {
+                                const float* const* euclid_p, const float* const* density_p,
+                                float* const* d_density_p, float interlevel_mult, int want_distortion, float* accum,
+                                float* losses, void* stream) {
   FNR_CHECK_ARG(rgb && image && semantics && fruit_mask && d_rgb && d_semantics && spacing_f && weights_f && accum &&
                     losses && n_rays > 0,
                 "train_losses: null argument");
@@ -693,10 +759,18 @@ extern "C" int fnr_train_losses(int64_t n_rays, const float* rgb, const float* i
   LevelLossArgs lv{};
   lv.n_levels = n_levels;
   for (int l = 0; l < n_levels; ++l) {
-    FNR_CHECK_ARG(S_p && spacing_p && weights_p && d_weights_p && spacing_p[l] && weights_p[l] && d_weights_p[l],
-                  "train_losses: null proposal level %d", l);
+    FNR_CHECK_ARG(S_p && spacing_p && weights_p && spacing_p[l] && weights_p[l], "train_losses: null proposal level %d", l);
     FNR_CHECK_ARG(S_p[l] > 0 && S_p[l] <= IL_MAX_P, "train_losses: S_p %d out of range", S_p[l]);
-    lv.S_p[l] = S_p[l], lv.spacing_p[l] = spacing_p[l], lv.w_p[l] = weights_p[l], lv.d_wp[l] = d_weights_p[l];
+    lv.S_p[l] = S_p[l], lv.spacing_p[l] = spacing_p[l], lv.w_p[l] = weights_p[l];
+    lv.d_wp[l] = d_weights_p ? d_weights_p[l] : nullptr;
+    lv.d_density_p[l] = d_density_p ? d_density_p[l] : nullptr;
+    if (lv.d_density_p[l]) {
+      FNR_CHECK_ARG(euclid_p && density_p && euclid_p[l] && density_p[l],
+                    "train_losses: level %d: d_density_p needs euclid_p and density_p", l);
+      lv.euclid_p[l] = euclid_p[l], lv.density_p[l] = density_p[l];
+    } else {
+      FNR_CHECK_ARG(lv.d_wp[l], "train_losses: level %d: neither d_weights_p nor d_density_p", l);
+    }
   }
   const long long per = (n_rays + 3) / 4;
   const long long blocks = (n_rays + 255) / 256 + per * (n_levels + (want_distortion ? 1 : 0));

@@ -166,13 +166,15 @@ class _InterlevelFn(torch.autograd.Function):
         return None, d_o, d_d, None, None, None
 
 
-def _proposal_backward(model, rctx, d_wps, upstream: Tensor, d_origins: Optional[Tensor],
+def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins: Optional[Tensor],
                        d_directions: Optional[Tensor]) -> None:
-    """Backward of the interlevel loss into the proposal networks (and, when asked, into the rays)."""
+    """Backward of the interlevel loss into the proposal networks (and, when asked, into the rays).
+    upstream None: d_wps already holds d(loss)/d(density) per level (train_losses(fuse_weights_bwd=True))."""
     cfg = model.config
     rays = rctx.rays
     for i, (lv, d_wp) in enumerate(zip(rctx.levels[:-1], d_wps)):
-        d_density = K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, upstream)
+        d_density = d_wp if upstream is None else \
+            K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, upstream)
         net = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
         d_pos = K.prop_density_bwd(net.prop_struct(), net.prop_struct(grads=True), net.warp_struct(), rays,
                                    lv["euclid"], lv["S"], lv["feats"], d_density,
@@ -488,11 +490,15 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         # optimiser, the ray gradients d(loss)/d(origins | directions); one launch for every loss and metric
         n_slots = L.FNR_TRAIN_LOSSES_ACCUM_FLOATS
         zeros = torch.zeros(n_slots + (6 * rays.n if ray_grads is not None else 0), device=dev)
-        prop_levels = [(lv["S"], lv["spacing"], lv["weights"]) for lv in rctx.levels[:-1]]
+        # on steps that train the proposal networks their weights backward (unit upstream) rides along: the list
+        # then holds d(loss)/d(density) per level instead of d(loss)/d(weights)
+        prop_bwd = bool(rctx.training and rctx.updated)
+        prop_levels = [(lv["S"], lv["spacing"], lv["weights"]) + ((lv["euclid"], lv["density"]) if prop_bwd else ())
+                       for lv in rctx.levels[:-1]]
         losses, d_rgb, d_sem, d_wps = K.train_losses(outputs["rgb"], image, outputs["semantics"], mask,
                                                      cfg.semantic_loss_weight, S, fin["spacing"], fin["weights"],
                                                      prop_levels, cfg.interlevel_loss_mult, want_metrics,
-                                                     zeros[:n_slots])
+                                                     zeros[:n_slots], fuse_weights_bwd=prop_bwd)
         loss_dict = {"rgb_loss": losses[0], "semantics_loss": losses[1], "interlevel_loss": losses[3]}
         metrics_dict = {"psnr": losses[2], "distortion": losses[4]} if want_metrics else {}
 
@@ -509,10 +515,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         # the per-kernel HIP-event timings bench.py reports would then include the other stream's kernels.
         main = torch.cuda.current_stream(dev)
         side = None
-        if rctx.training and rctx.updated:
-            up = model.__dict__.get("_unit_upstream")
-            if up is None or up.device != dev:
-                up = model.__dict__["_unit_upstream"] = torch.ones(1, device=dev)
+        up = None   # d_wps is d(loss)/d(density) already (fuse_weights_bwd above)
+        if prop_bwd:
             if overlap_proposal_backward:
                 side = model.__dict__.get("_side_stream")
                 if side is None or side.device != dev:
@@ -540,7 +544,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             exchange.field_done()
         if side is not None:
             main.wait_stream(side)                 # proposal gradients (and their share of the ray gradients) are final
-        elif rctx.training and rctx.updated:
+        elif prop_bwd:
             _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
         if ray_grads is not None:
             _field_ray_grads(model, rctx, d_feats, d_o, d_d)   # after the join: both chains add into d_o / d_d

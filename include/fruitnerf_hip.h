@@ -345,13 +345,17 @@ int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, con
  * fnr_distortion, and the sum of the accumulator slots.  losses [5] = rgb_loss, semantics_loss, psnr,
  * interlevel_loss, distortion (0 when not wanted); d_rgb [R,3], d_semantics [R], d_weights_p[l] [R,S_p[l]] as the
  * single calls give them.  accum: FNR_TRAIN_LOSSES_ACCUM_FLOATS floats, ZEROED by the caller (loss slots + completion
- * counters).  S_p / spacing_p / weights_p / d_weights_p are host arrays of n_levels entries. */
+ * counters).  S_p / spacing_p / weights_p / d_weights_p are host arrays of n_levels entries.
+ * d_density_p (optional, with euclid_p [R,S_p+1] and density_p [R,S_p]): level l's d(loss)/d(density) [R,S_p[l]] =
+ * fnr_weights_bwd of that level with d_weights_p[l] as upstream, computed in the same pass (bit-identical); then
+ * d_weights_p / d_weights_p[l] may be NULL. */
 #define FNR_MAX_PROPOSAL_LEVELS 4
 #define FNR_TRAIN_LOSSES_ACCUM_FLOATS (4 * FNR_LOSS_SLOTS + 33 * 32)
 int fnr_train_losses(int64_t n_rays, const float* rgb, const float* image, const float* semantics,
                      const float* fruit_mask, float semantic_loss_weight, float* d_rgb, float* d_semantics, int S_f,
                      const float* spacing_f, const float* weights_f, int n_levels, const int* S_p,
                      const float* const* spacing_p, const float* const* weights_p, float* const* d_weights_p,
+                     const float* const* euclid_p, const float* const* density_p, float* const* d_density_p,
                      float interlevel_mult, int want_distortion, float* accum, float* losses, void* stream);
 
 /* ---- gradient of the rays (camera-pose optimisation, fruit_nerf_config.py:39-43) ----------------- */

@@ -869,4 +869,20 @@ def test_train_losses_is_the_separate_launches(dev, R, n_levels, want_distortion
         want = torch.stack([ref_l[0], ref_l[1], ref_l[2], ref_sums[0], ref_sums[1]])
         err = ((losses - want).abs() / want.abs().clamp_min(1e-3)).max().item()
         assert err <= 1e-6 * 5, (losses.tolist(), want.tolist())
+    # the proposal levels' weights backward fused in: d(loss)/d(density) bit-identical to fnr_weights_bwd(d_wp, 1)
+    if n_levels:
+        full = []
+        for S, sp, w in props:
+            eu = torch.cumsum(torch.rand(R, S + 1, generator=g0) * 0.05, dim=-1).to(dev)
+            dens = (torch.rand(R, S, generator=g0) * 30.0).to(dev)
+            full.append((S, sp, w, eu, dens))
+        accum = torch.zeros(L.FNR_TRAIN_LOSSES_ACCUM_FLOATS, device=dev)
+        losses2, d_rgb2, d_sem2, d_dens = K.train_losses(rgb, img, sem, msk, 2.0, S_f, sp_f, w_f, full, 1.0,
+                                                         want_distortion, accum, fuse_weights_bwd=True)
+        assert torch.equal(d_rgb2, ref_drgb) and torch.equal(d_sem2, ref_dsem)
+        one = torch.ones(1, device=dev)
+        for (S, sp, w, eu, dens), dwp, got in zip(full, ref_dwp, d_dens):
+            ref = K.weights_bwd(S, eu, dens, w, dwp, one)
+            assert float(ref.abs().max()) > 0
+            assert torch.equal(got, ref)
 
