@@ -618,6 +618,18 @@ def camera_pose_grad(image_set: ImageSetArg, train_ids: Tensor, u: Tensor, cam: 
                                      L.ptr(d_directions), L.ptr(pose_grad), L.stream_ptr(u.device)), "camera_pose_grad")
 
 
+def camera_pose_grad_adam(image_set: ImageSetArg, train_ids: Tensor, u: Tensor, cam: Tensor, c2w_adjusted: Tensor,
+                          d_origins: Tensor, d_directions: Tensor, pose_grad: Tensor, adam: L.fnr_table_adam) -> None:
+    """camera_pose_grad + the pose table's Adam / RAdam step (adam.params = pose_adjustment) in one launch; pose_grad
+    is consumed and left zero."""
+    lib = L.load()
+    ids = train_ids.to(torch.int64).contiguous()
+    L.check(lib.fnr_camera_pose_grad_adam(C.byref(image_set.c), L.ptr(ids), ids.numel(), u.shape[0], L.ptr(_f32c(u)),
+                                          L.ptr(cam), L.ptr(c2w_adjusted), L.ptr(d_origins), L.ptr(d_directions),
+                                          L.ptr(pose_grad), C.byref(adam), L.stream_ptr(u.device)),
+            "camera_pose_grad_adam")
+
+
 def sample_pixels(image_set: ImageSetArg, train_ids: Tensor, u: Tensor, c2w_adjusted: Optional[Tensor] = None):
     lib = L.load()
     dev = u.device

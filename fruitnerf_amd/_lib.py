@@ -139,6 +139,8 @@ SIGNATURES = {
                                          C.c_size_t, _vp]),
     "fnr_camera_adjust": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "fnr_camera_pose_grad": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_camera_pose_grad_adam": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, P(fnr_table_adam),
+                                       _vp]),
     "fnr_export_workspace_bytes": (C.c_size_t, [_i64]),
     "fnr_export_compact": (_i, [P(fnr_lattice), _i64, _i64, _vp, _i64, _vp, _vp, _vp, P(_vp), P(_vp), _i64, _vp, _vp,
                                 _vp]),

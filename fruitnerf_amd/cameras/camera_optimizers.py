@@ -95,6 +95,19 @@ class CameraAdam:
         self.exp_avg = torch.zeros_like(p.data)
         self.exp_avg_sq = torch.zeros_like(p.data)
 
+    def fused_step_args(self, grad_scale: float = 1.0):
+        """Advance the step count and return the fnr_table_adam of THIS update for a kernel that applies it itself
+        (fnr_camera_pose_grad_adam) — same learning rate / step as step() would use."""
+        from ..training import exponential_decay_lr
+        from .. import _lib as L
+        self.step_count += 1
+        c = self.cfg
+        lr = c.lr if c.lr_final is None else exponential_decay_lr(self.step_count - 1, c.lr, c.lr_final, c.max_steps)
+        p = self.opt.pose_adjustment
+        return L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], c.eps,
+                                self.step_count, grad_scale, c.weight_decay, L.ptr(p.data), L.ptr(self.exp_avg),
+                                L.ptr(self.exp_avg_sq))
+
     def step(self, grad_scale: float = 1.0) -> None:
         from ..training import exponential_decay_lr
         self.step_count += 1

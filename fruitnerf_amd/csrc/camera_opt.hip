@@ -59,7 +59,11 @@ struct PinholeDev {
   float fx, fy, cx, cy;
 };
 
-// pose_grad[k] += d(loss)/d(tangent[k]) from the ray gradients of camera k's rays
+// pose_grad[k] += d(loss)/d(tangent[k]) from the ray gradients of camera k's rays.  ADAM (single process): the
+// camera's workgroup then takes the optimiser step of its 6 pose parameters itself (the gradient it has just finished
+// + whatever pose_grad held) and leaves pose_grad zero — fnr_camera_pose_grad + fnr_adam_step / fnr_radam_step with
+// zero_grad, one launch less per step.
+template <bool ADAM>
 __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const float* __restrict__ c2w,
                                                           const long long* __restrict__ train_ids, long long n_rays,
                                                           const float* __restrict__ u, const int* __restrict__ cam_idx,
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const 
                                                           const float* __restrict__ c2w_adj,
                                                           const float* __restrict__ d_origins,
                                                           const float* __restrict__ d_directions,
-                                                          float* __restrict__ pose_grad) {
+                                                          float* __restrict__ pose_grad, TableAdam adam) {
   __shared__ float red[4][12];
   const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* Ma = c2w_adj + 12 * k;  // adjusted camera: R' = rows of Ma[:, :3]
@@ -157,8 +161,19 @@ __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const 
     const float wi = (i == 0) ? x : (i == 1) ? y : z;
     const float dth = above ? wi / th : 0.0f;
     const float g = s.f1 * gK[i] + s.f2 * (Sw[i] - 2.0f * wi * tr) + dth * (df1 * gk + df2 * gk2);
-    out[3 + i] += g;
-    out[i] += gtt[i];
+    if constexpr (!ADAM) {
+      out[3 + i] += g;
+      out[i] += gtt[i];
+    } else {
+      float* P = reinterpret_cast<float*>(adam.p) + 6 * k;
+      float* M = reinterpret_cast<float*>(adam.m) + 6 * k;
+      float* V = reinterpret_cast<float*>(adam.v) + 6 * k;
+      const float gr = out[3 + i] + g, gtr = out[i] + gtt[i];
+      table_adam_update(adam, gr, P[3 + i], M[3 + i], V[3 + i]);
+      table_adam_update(adam, gtr, P[i], M[i], V[i]);
+      out[3 + i] = 0.0f;
+      out[i] = 0.0f;
+    }
   }
 }
 
@@ -184,9 +199,28 @@ extern "C" int fnr_camera_pose_grad(const fnr_image_set* set, const int64_t* tra
                 "camera_pose_grad: null argument");
   if (n_rays == 0) return FNR_OK;
   PinholeDev cam{set->H, set->W, set->fx, set->fy, set->cx, set->cy};
-  hipLaunchKernelGGL(k_camera_pose_grad, dim3((unsigned)n_train), dim3(256), 0, as_stream(stream), cam, set->c2w,
+  hipLaunchKernelGGL(k_camera_pose_grad<false>, dim3((unsigned)n_train), dim3(256), 0, as_stream(stream), cam, set->c2w,
                      reinterpret_cast<const long long*>(train_ids), (long long)n_rays, u, camera_indices, pose_adjustment,
-                     c2w_adjusted, d_origins, d_directions, pose_grad);
+                     c2w_adjusted, d_origins, d_directions, pose_grad, TableAdam{});
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_camera_pose_grad_adam(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays,
+                                         const float* u, const int32_t* camera_indices, const float* c2w_adjusted,
+                                         const float* d_origins, const float* d_directions, float* pose_grad,
+                                         const fnr_table_adam* adam, void* stream) {
+  FNR_CHECK_ARG(set && set->c2w && train_ids && u && camera_indices && c2w_adjusted && d_origins && d_directions &&
+                    pose_grad && adam && n_train > 0,
+                "camera_pose_grad_adam: null argument");
+  TableAdam t;
+  const int rc = make_table_adam(adam, t);
+  if (rc) return rc;
+  PinholeDev cam{set->H, set->W, set->fx, set->fy, set->cx, set->cy};
+  // n_rays == 0 still takes the step (every pose parameter decays its moments)
+  hipLaunchKernelGGL(k_camera_pose_grad<true>, dim3((unsigned)n_train), dim3(256), 0, as_stream(stream), cam, set->c2w,
+                     reinterpret_cast<const long long*>(train_ids), (long long)n_rays, u, camera_indices, adam->params,
+                     c2w_adjusted, d_origins, d_directions, pose_grad, t);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -393,36 +393,7 @@ __device__ __forceinline__ void acc_record(unsigned long long* __restrict__ s_ac
   atomicAdd(&s_acc[2 * row + 1], (unsigned long long)iy);
 }
 
-// Optimiser step fused into the accumulate kernel (single-process training): the workgroup that owns a bin has the
-// bin's summed gradient in LDS, so it applies torch.optim.Adam / RAdam to those rows right there.  The gradient table
-// is then neither read-modify-written here nor read and zeroed by the optimiser pass: 40 -> 24 bytes of HBM traffic
-// per table parameter and step.  Same operations in the same order as k_adam / k_radam (train.hip): bit-identical
-// parameters and moments.
-struct TableAdam {
-  float2 *p, *m, *v;  // the table's slices of the parameter / exp_avg / exp_avg_sq arenas, [L << log2_T] rows
-  float lr, b1, b2, eps, bc1, bc2_sqrt, rect, grad_scale, weight_decay;
-  int radam;
-};
-__device__ __forceinline__ void table_adam_update(const TableAdam& a, float g, float& P, float& M, float& V) {
-  float gr = g * a.grad_scale;
-  if (a.weight_decay != 0.0f) gr = gr + a.weight_decay * P;
-  M = M + (gr - M) * (1.0f - a.b1);
-  V = V * a.b2 + (1.0f - a.b2) * gr * gr;
-  if (!a.radam) {
-    const float step_size = a.lr / a.bc1;
-    const float denom = sqrtf(V) / a.bc2_sqrt + a.eps;
-    P = P - step_size * (M / denom);
-  } else {
-    const float mhat = M / a.bc1;
-    if (a.rect >= 0.0f) {
-      const float adaptive = a.bc2_sqrt / (sqrtf(V) + a.eps);
-      P = P - a.lr * (mhat * a.rect * adaptive);
-    } else {
-      P = P - a.lr * mhat;
-    }
-  }
-}
-
+// (TableAdam / table_adam_update: common.hpp — the optimiser step fused into the accumulate kernel)
 template <bool ADAM>
 __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float2* __restrict__ queue_v,
                                                              const unsigned short* __restrict__ queue_r,
@@ -816,34 +787,6 @@ extern "C" int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* wa
                         level_count, workspace, workspace_bytes, workspace_clean, as_stream(stream));
 }
 
-namespace {
-// host side of TableAdam: the step-dependent scalars exactly as fnr_adam_step / fnr_radam_step compute them (double)
-int make_table_adam(const fnr_table_adam* a, const fnr_grid* grid_grad, TableAdam& t) {
-  FNR_CHECK_ARG(a && a->params && a->exp_avg && a->exp_avg_sq, "table adam: null argument");
-  FNR_CHECK_ARG(a->algorithm == 0 || a->algorithm == 1, "table adam: algorithm %d (0 = Adam, 1 = RAdam)", a->algorithm);
-  FNR_CHECK_ARG(a->step >= 1, "table adam: step must be >= 1");
-  t.p = reinterpret_cast<float2*>(a->params);
-  t.m = reinterpret_cast<float2*>(a->exp_avg);
-  t.v = reinterpret_cast<float2*>(a->exp_avg_sq);
-  t.lr = a->lr, t.b1 = a->beta1, t.b2 = a->beta2, t.eps = a->eps, t.grad_scale = a->grad_scale, t.weight_decay = a->weight_decay;
-  t.radam = a->algorithm;
-  const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step);
-  const double b2t = pow((double)a->beta2, (double)a->step);
-  const double bc2 = 1.0 - b2t;
-  t.bc1 = (float)bc1;
-  t.bc2_sqrt = (float)sqrt(bc2);
-  t.rect = -1.0f;
-  if (a->algorithm == 1) {
-    const double rho_inf = 2.0 / (1.0 - (double)a->beta2) - 1.0;
-    const double rho_t = rho_inf - 2.0 * (double)a->step * b2t / bc2;
-    if (rho_t > 5.0)
-      t.rect = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
-  }
-  (void)grid_grad;
-  return FNR_OK;
-}
-}  // namespace
-
 extern "C" int fnr_hash_encode_bwd_adam(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
                                         const float* euclid_bins, int S, const float* d_feats, void* workspace,
                                         size_t workspace_bytes, int workspace_clean, const fnr_table_adam* adam,
@@ -851,7 +794,7 @@ extern "C" int fnr_hash_encode_bwd_adam(const fnr_grid* grid_grad, const fnr_war
   FNR_CHECK_ARG(grid_grad && warp && rays && euclid_bins && d_feats && S > 0, "hash_encode_bwd_adam: null argument");
   FNR_CHECK_ARG(grid_grad->n_levels >= 1 && grid_grad->n_levels <= FNR_MAX_LEVELS, "hash_encode_bwd_adam: n_levels");
   TableAdam t;
-  const int rc = make_table_adam(adam, grid_grad, t);
+  const int rc = make_table_adam(adam, t);
   if (rc) return rc;
   const long long N = rays->n_rays * (long long)S;
   RaySource src{make_rays(rays), euclid_bins, S};

@@ -567,13 +567,20 @@ def camera_backward(camera_optimizer, batcher, ray_grads: dict, world_size: int 
 
 
 def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: dict, world_size: int = 1) -> None:
-    """camera_backward() + the camera optimiser's Adam step."""
+    """camera_backward() + the camera optimiser's Adam step (one launch in a single process)."""
+    if world_size < EXCHANGE_MIN_WORLD and FUSE_CAMERA_OPTIMIZER:
+        d = batcher.last_draw
+        pose = camera_optimizer.pose_adjustment
+        K.camera_pose_grad_adam(batcher._set, batcher.image_ids, d["u"], d["cam"], d["c2w_adjusted"],
+                                ray_grads["origins"], ray_grads["directions"], pose.grad, camera_adam.fused_step_args())
+        return
     work, scale = camera_backward(camera_optimizer, batcher, ray_grads, world_size)
     if work is not None:
         work.wait()
     camera_adam.step(grad_scale=scale)
 
 
+FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter
 
 

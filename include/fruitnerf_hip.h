@@ -330,6 +330,15 @@ int fnr_hash_encode_bwd_adam(const fnr_grid* grid_grad, const fnr_warp* warp, co
                              const float* euclid_bins, int S, const float* d_feats, void* workspace,
                              size_t workspace_bytes, int workspace_clean, const fnr_table_adam* adam, void* stream);
 
+/* fnr_camera_pose_grad with the pose table's optimiser step fused in (single-process training): adam->params is
+ * pose_adjustment [n_train,6] (read for the gradient, then updated), exp_avg / exp_avg_sq its moments; pose_grad is
+ * added to the new gradient and left ZERO.  Bit-identical to fnr_camera_pose_grad followed by fnr_adam_step /
+ * fnr_radam_step(zero_grad = 1) over the 6 n_train floats. */
+int fnr_camera_pose_grad_adam(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays,
+                              const float* u, const int32_t* camera_indices, const float* c2w_adjusted,
+                              const float* d_origins, const float* d_directions, float* pose_grad,
+                              const fnr_table_adam* adam, void* stream);
+
 /* Backward of fnr_prop_density_fwd: d_density [R,S] -> += into grads (table, w0, b0, w1, b1).
  * d_position (optional) [N,4]: gradient w.r.t. each sample's unit-cube position (xyz, w = 0) for
  * fnr_position_grad_reduce(n_levels = 1) — only needed when the rays carry gradients (camera-pose optimiser).

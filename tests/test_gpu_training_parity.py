@@ -644,6 +644,18 @@ def test_camera_optimizer_pose_gradients_and_step(dev):
     torch.cuda.synchronize()
     assert util.report("camera.pose_after_adam", hcam.pose_adjustment.data, ocam.pose_adjustment.data)[0] <= 2e-6
     assert float(hcam.pose_adjustment.grad.abs().max()) == 0.0
+    # fnr_camera_pose_grad_adam (gradient + optimiser step in one launch, the single-process training path) from the
+    # same state: pose and both moments bit-identical to the two launches above, gradient left zero
+    from fruitnerf_amd.training import camera_backward_and_step
+    hcam2 = CameraOptimizerConfig(mode="SO3xR3").setup(n_cam, dev)
+    with torch.no_grad():
+        hcam2.pose_adjustment.copy_(pose0.to(dev))
+    hadam2 = CameraAdam(hcam2)
+    camera_backward_and_step(hcam2, hadam2, batcher, got, world_size=1)
+    torch.cuda.synchronize()
+    assert torch.equal(hcam2.pose_adjustment.data, hcam.pose_adjustment.data)
+    assert torch.equal(hadam2.exp_avg, hadam.exp_avg) and torch.equal(hadam2.exp_avg_sq, hadam.exp_avg_sq)
+    assert float(hcam2.pose_adjustment.grad.abs().max()) == 0.0 and hadam2.step_count == hadam.step_count == 1
 
 
 def test_step_at_a_trained_state_matches_the_oracle(dev):
