@@ -1,0 +1,104 @@
+"""The multi-rank training path on the one GPU a test box has: a ONE-rank RCCL process group with the gradient exchange
+forced on (training.EXCHANGE_MIN_WORLD = 1).  The all-reduces move no bytes, but everything else is the N > 1 code:
+bucketed asynchronous collectives on RCCL's stream issued per scatter level group, per-bucket waits, the separate
+optimiser launches, the pose-gradient exchange.  (Two ranks: tests/test_distributed_cpu.py over gloo.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from . import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def test_bench_runs_over_a_one_rank_rccl_group(dev):
+    env = dict(os.environ, FNR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-quality"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["value"] > 0
+    assert d["config"]["table_optimizer"].startswith("separate")
+
+
+def test_exchange_path_step_is_the_single_process_step(dev):
+    """Training steps (camera optimiser included) from identical states: the exchange path — scatter in level
+    groups with an all-reduce per group, separate optimiser launches per bucket, pose gradient all-reduced — against
+    the single-process path (optimiser steps fused into the scatter / pose-gradient kernels).  After the first step the
+    hash table, its moments and the poses are bit-identical (fixed-point scatter sums, same optimiser arithmetic); the
+    MLP weights meet in float atomics and agree to 1e-6.  A second step stays together on average."""
+    import torch.distributed as dist
+    import fruitnerf_amd.training as T
+    from fruitnerf_amd import _kernels as K
+    from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+    from fruitnerf_amd.data import synthetic_apple as sa
+    from fruitnerf_amd.rays import RayBundle
+    n_cam, HW, focal, R = 8, 64, 90.0, 256
+    cfg = util.small_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, num_images=n_cam, seed=21)
+    scene = sa.make_scene(seed=0)
+    c2w = sa.make_cameras(n_cam, seed=0)
+    data = {k: (v.to(dev) if torch.is_tensor(v) else v)
+            for k, v in sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal).items()}
+    g = torch.Generator().manual_seed(1)
+    us = [torch.rand(R, 3, generator=g).to(dev) for _ in range(2)]
+    jits = [[torch.rand(R, 1, generator=g).to(dev) for _ in range(3)] for _ in range(2)]
+
+    def run(world_arg):
+        hm = util.make_hip_like(om, dev)
+        hm.train()
+        opt = T.FusedAdam(hm)
+        cam = CameraOptimizerConfig(mode="SO3xR3").setup(n_cam, dev)
+        cadam = CameraAdam(cam)
+        batcher = sa.PixelBatcher(data, torch.arange(n_cam, device=dev), seed=0)
+        batcher._set = K.ImageSetArg(data["images"], data["masks"], data["c2w"], focal, focal, HW / 2.0, HW / 2.0)
+        snaps = []
+        for step in range(2):
+            c2w_adj = cam.adjusted_cameras(batcher._set, batcher.image_ids)
+            o, d, ci, image, mask = K.sample_pixels(batcher._set, batcher.image_ids, us[step], c2w_adj)
+            batcher.last_draw = {"u": us[step], "cam": ci, "c2w_adjusted": c2w_adj}
+            T.fused_train_iteration(hm, opt, RayBundle(o, d, None, ci[:, None]), {"image": image, "fruit_mask": mask[:, None]},
+                                    step, world_size=world_arg, jitter=jits[step], camera=(cam, cadam, batcher))
+            torch.cuda.synchronize()
+            snaps.append((hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                          cam.pose_adjustment.data.clone()))
+        table = hm.field.mlp_base_grid.hash_table
+        a, n = [(off, k) for _, p, off, k in hm.arena().entries if p is table][0]
+        return snaps, (a, a + n)
+
+    single = run(1)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29641", rank=0, world_size=1, device_id=dev)
+    old = T.EXCHANGE_MIN_WORLD
+    T.EXCHANGE_MIN_WORLD = 1
+    try:
+        exch = run(1)
+    finally:
+        T.EXCHANGE_MIN_WORLD = old
+        if created:
+            dist.destroy_process_group()
+    (s1, s2), (a, b) = single
+    (e1, e2), _ = exch
+    for x, y in zip(s1[:3], e1[:3]):                     # after the first step
+        assert torch.equal(x[a:b], y[a:b])
+        assert float((x - y).abs().max()) <= 1e-6 * max(1.0, float(x.abs().max()))
+    assert torch.equal(s1[3], e1[3])
+    assert int((s1[0][a:b] != util.make_hip_like(om, dev).arena().params[a:b]).sum()) > 0   # the table did move
+    # second step: its inputs (the MLP weights) already differ in the last bits between ANY two runs
+    for x, y in zip(s2, e2):
+        assert float((x - y).abs().mean()) <= 1e-4 * float(x.abs().mean()) + 1e-9
