@@ -86,8 +86,8 @@ def alg_table(mlp_flop: float):
     issued work, not useful work, and is not counted."""
     return {
         "hash_encode_fwd": ("hbm", 1024.0 + 128.0),          # 16 lvl x 8 corners x 8 B + 128 B features written
-        # gradient read-modify-write + d_feats read.  (At N=1 the launch also carries the table's Adam step, 24 B per
-        # table parameter that are NOT added here: `achieved` understates that launch.)
+        # gradient read-modify-write + d_feats read.  (At N=1 the launch also carries the table's optimiser step: its
+        # 28 B per table parameter are added per launch, see roofline_entry(fixed_bytes).)
         "hash_encode_bwd": ("hbm", 2 * 1024.0 + 128.0),
         "prop_density_fwd": ("hbm", 320.0 + 4.0),            # 5 lvl x 8 corners x 8 B + density
         "prop_density_bwd": ("hbm", 2 * 320.0 + 40.0 + 4.0),
@@ -107,10 +107,12 @@ FAMILIES = {
 }
 
 
-def roofline_entry(op, units, avg_ms, launches, alg):
+def roofline_entry(op, units, avg_ms, launches, alg, fixed_bytes=0.0, fixed_note=None):
+    """fixed_bytes: algorithmic bytes of the launch that do not scale with `units` (the table optimiser's step when it
+    runs inside hash_encode_bwd: torch.optim's 28 B per table parameter, the same figure adam_step is priced with)."""
     bound, per_unit = alg[op]
     if bound == "hbm":
-        achieved = per_unit * units / (avg_ms * 1e-3) / 1e9
+        achieved = (per_unit * units + fixed_bytes) / (avg_ms * 1e-3) / 1e9
         peak, unit, key = HBM_PEAK_GBS, "GB/s", "alg_bytes_per_unit"
     else:
         achieved = per_unit * units / (avg_ms * 1e-3) / 1e12
@@ -127,6 +129,9 @@ def roofline_entry(op, units, avg_ms, launches, alg):
                  "issued_bf16_tflops": round(issued, 1), "issued_frac_of_bf16_peak": round(issued / MFMA_BF16_PEAK_TF, 4),
                  "peak_note": "peak = dense bf16 MFMA (the pipe these kernels run on); the arithmetic they replace is "
                               "fp32, whose MFMA peak on gfx950 is 157.3 TFLOP/s (1/16 of bf16)"}
+    if bound == "hbm" and fixed_bytes:
+        extra = {"alg_bytes_per_launch_fixed": fixed_bytes, "alg_bytes_fixed_note": fixed_note,
+                 "achieved_without_fixed_bytes": round(per_unit * units / (avg_ms * 1e-3) / 1e9, 3)}
     return {"kernel": op, "family": FAMILIES.get(op, op), "bound": bound, "achieved": round(achieved, 3), "peak": peak,
             "unit": unit, "frac": round(achieved / peak, 4), **extra,
             # HBM bytes of this entry point are NOT measured inside this process (PMC counters need rocprofv3): see
@@ -376,7 +381,13 @@ def main() -> None:
         sel = [(u, ms) for o, u, ms in recs if o == op and (want_units is None or u == want_units)]
         if not sel:
             return None
-        return roofline_entry(op, sel[0][0], float(np.mean([ms for _, ms in sel])), len(sel), ALG)
+        fixed, note = 0.0, None
+        if op == "hash_encode_bwd" and not dist_on and sel[0][0] == RAYS_PER_BATCH * M["samples"][2]:
+            # single process: this entry point also takes the main table's optimiser step (fnr_hash_encode_bwd_adam)
+            fixed = ALG["adam_step"][1] * float(model.field.mlp_base_grid.hash_table.numel())
+            note = (f"main hash table's {M['algorithm']} step fused into this launch: {ALG['adam_step'][1]:.0f} B x "
+                    f"{model.field.mlp_base_grid.hash_table.numel()} table parameters (what adam_step is priced with)")
+        return roofline_entry(op, sel[0][0], float(np.mean([ms for _, ms in sel])), len(sel), ALG, fixed, note)
 
     roofline = _roof(roof_op, roof_units)
     roofline_other = _roof(roof2_op, roof2_units) if roof2_op else None

@@ -48,6 +48,9 @@ def rf(x):
     if 'frac_of_fp32_mfma_peak' in x:
         s += " (%.2f of the fp32-MFMA peak; issued %s TF = %.2f of the bf16 peak)" % (
             x['frac_of_fp32_mfma_peak'], x['issued_bf16_tflops'], x['issued_frac_of_bf16_peak'])
+    if x.get('alg_bytes_per_launch_fixed'):
+        s += " (incl. the table optimiser's %.0f MB per launch; %.0f GB/s without)" % (
+            x['alg_bytes_per_launch_fixed'] / 1e6, x['achieved_without_fixed_bytes'])
     return s + ", %.0f us/launch" % (x['avg_launch_ms'] * 1e3)
 
 
