@@ -333,12 +333,10 @@ class FusedAdam:
                self.betas[0], self.betas[1], self.eps, self.group_steps[group], grad_scale, True,
                weight_decay=self.weight_decay)
 
-    def step(self, grad_scale: float = 1.0, skip=(), done=()) -> None:
-        """One optimiser step over every group except `skip` (see begin_step).  Adjacent groups whose learning rate AND
-        step count coincide share one launch.  done: arena spans whose update a fused kernel already applied for this
-        step (table_adam_args) — they are cut out of the launches."""
-        lrs = self.begin_step(skip)
-        runs = []   # [a, b, lr, group]
+    def plan_runs(self, lrs: Dict[str, float], skip=(), done=()) -> list:
+        """[a, b, lr, group] arena runs of one optimiser step (after begin_step): groups in `skip` left out, adjacent
+        groups merged when learning rate and step count coincide, the `done` spans cut out."""
+        runs = []
         for name, (a, b) in self.arena.group_ranges.items():
             if name in skip:
                 continue
@@ -358,7 +356,14 @@ class FusedAdam:
                     if db < b:
                         cut.append([db, b, lr, name])
             runs = cut
-        runs = [r for r in runs if r[1] > r[0]]
+        return [r for r in runs if r[1] > r[0]]
+
+    def step(self, grad_scale: float = 1.0, skip=(), done=()) -> None:
+        """One optimiser step over every group except `skip` (see begin_step).  Adjacent groups whose learning rate AND
+        step count coincide share one launch.  done: arena spans whose update a fused kernel already applied for this
+        step (table_adam_args) — they are cut out of the launches."""
+        lrs = self.begin_step(skip)
+        runs = self.plan_runs(lrs, skip, done)
         if len(runs) <= 1 or len(runs) > L_MAX_ADAM_SPANS:
             for a, b, lr, name in runs:
                 self.step_span(a, b, lr, grad_scale, group=name)

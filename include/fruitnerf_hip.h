@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 5
+#define FNR_ABI_VERSION 6
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different

@@ -134,6 +134,45 @@ def test_param_arena_views_and_groups():
     assert p.grad is not None and p.grad.data_ptr() >= arena.grads.data_ptr()
 
 
+def test_fused_adam_run_planning():
+    """FusedAdam.plan_runs: which arena spans one optimiser step launches — groups skipped when they got no gradient
+    (torch.optim leaves grad=None parameters alone), adjacent groups merged only while learning rate AND step count
+    coincide, and the span a fused kernel already updated (the main hash table inside the scatter) cut out."""
+    from fruitnerf_amd.training import FusedAdam
+
+    class _Arena:
+        group_ranges = {"proposal_networks": (0, 1000), "fields": (1000, 5000)}
+        params = torch.zeros(5000)
+    opt = FusedAdam.__new__(FusedAdam)
+    opt.arena = _Arena()
+    sched = dict(lr=1e-2, lr_final=1e-4, max_steps=1000)        # fruit_nerf: both groups on the same schedule
+    opt.groups = {"proposal_networks": dict(sched), "fields": dict(sched)}
+    opt.step_count, opt.group_steps = 0, {"proposal_networks": 0, "fields": 0}
+    lrs = opt.begin_step()
+    lr0 = lrs["fields"]
+    assert lrs["proposal_networks"] == lr0 == pytest.approx(1e-2) and opt.step_count == 1
+    # step 1: same lr, same step count -> one run over both groups; the table span [1200, 4200) cut out of it
+    assert opt.plan_runs(lrs) == [[0, 5000, lr0, "proposal_networks"]]
+    assert opt.plan_runs(lrs, done=((1200, 4200),)) == [[0, 1200, lr0, "proposal_networks"],
+                                                         [4200, 5000, lr0, "proposal_networks"]]
+    # a step that did not train the proposal networks: the group is left out and its step count does not advance
+    lrs = opt.begin_step(skip=("proposal_networks",))
+    assert opt.group_steps == {"proposal_networks": 1, "fields": 2}
+    runs = opt.plan_runs(lrs, skip=("proposal_networks",), done=((1200, 4200),))
+    assert [r[:2] for r in runs] == [[1000, 1200], [4200, 5000]] and all(r[3] == "fields" for r in runs)
+    assert runs[0][2] == pytest.approx(1e-2 * (1e-2) ** (1 / 1000))          # update k uses lr(k - 1)
+    # afterwards the groups differ in step count: same lr, but no merge (bias corrections differ)
+    lrs = opt.begin_step()
+    assert lrs["proposal_networks"] == lrs["fields"]
+    assert opt.plan_runs(lrs, done=((1000, 5000),)) == [[0, 1000, lrs["fields"], "proposal_networks"]]
+    assert [r[:2] + r[3:] for r in opt.plan_runs(lrs)] == [[0, 1000, "proposal_networks"], [1000, 5000, "fields"]]
+    # fruit_nerf_big: the proposal group has no schedule -> different learning rates from the second step on
+    opt.groups["proposal_networks"] = dict(lr=1e-2, lr_final=None, max_steps=None)
+    opt.step_count, opt.group_steps = 5, {"proposal_networks": 5, "fields": 5}
+    lrs = opt.begin_step()
+    assert lrs["proposal_networks"] == 1e-2 and lrs["fields"] < 1e-2 and len(opt.plan_runs(lrs)) == 2
+
+
 def test_exponential_decay_schedule():
     from fruitnerf_amd.training import exponential_decay_lr
     assert exponential_decay_lr(0, 1e-2, 1e-4, 200000) == pytest.approx(1e-2)
