@@ -252,21 +252,6 @@ __device__ __forceinline__ void paired_values(const float2 (&va)[4], const float
     v[KB[j]] = odd ? vb[j] : recv;
   }
 }
-// one level, all lanes of the wave active: gather 8 corners (lane pairs) and blend
-__device__ __forceinline__ float2 grid_lookup_paired(const float2* __restrict__ level_table, const float (&x)[3],
-                                                     int scaling, uint32_t mask, bool odd) {
-  GridLevel g = grid_cell(x, scaling);
-  uint32_t h[8];
-  grid_corners(g, mask, h);
-  const PairedRows r = paired_rows(h, odd);
-  float2 va[4], vb[4], v[8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) va[j] = level_table[r.a[j]];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) vb[j] = level_table[r.b[j]];
-  paired_values(va, vb, odd, v);
-  return grid_interp(v, g.o);
-}
 // one level: gather 8 corners and blend
 __device__ __forceinline__ float2 grid_lookup(const float2* __restrict__ level_table, const float (&x)[3], int scaling,
                                               uint32_t mask) {
