@@ -54,6 +54,8 @@ __global__ __launch_bounds__(64) void k_camera_adjust(const float* __restrict__ 
   }
 }
 
+constexpr int CPG_ROUND = 4096;   // rays a pose-gradient workgroup compacts at a time (16 per thread: one round per batch)
+
 struct PinholeDev {
   int H, W;
   float fx, fy, cx, cy;
@@ -73,24 +75,67 @@ __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const 
                                                           const float* __restrict__ d_directions,
                                                           float* __restrict__ pose_grad, TableAdam adam) {
   __shared__ float red[4][12];
+  __shared__ int s_list[CPG_ROUND];        // rays of this camera among the round's CPG_ROUND rays, in ray order
+  __shared__ int s_cnt[CPG_ROUND / 256][4];
   const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* Ma = c2w_adj + 12 * k;  // adjusted camera: R' = rows of Ma[:, :3]
   float acc[12];                       // G (3x3, dL/dR') row-major, then dL/dt'
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
-  // the camera of 8 rays per thread is fetched before any of them is processed: a load-compare-branch chain per ray
-  // made this 90-workgroup kernel take 19 us
-  for (long long base0 = 0; base0 < n_rays; base0 += 8 * 256) {
-    int mine[8];
+  // what the single-thread tail needs (all workgroup-uniform) is fetched NOW: the kernel is a chain of dependent
+  // memory round trips (~1.5 us each), and these were four more of them at its end
+  float Mk[12], wk[3], g_old[6], Pk[6], Mm[6], Vk[6];
+  {
+    const float* Msrc = c2w + train_ids[k] * 12;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int i = 0; i < 12; ++i) Mk[i] = Msrc[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wk[i] = pose[6 * k + 3 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      g_old[i] = pose_grad[6 * k + i];
+      if constexpr (ADAM) {
+        Pk[i] = reinterpret_cast<const float*>(adam.p)[6 * k + i];
+        Mm[i] = reinterpret_cast<const float*>(adam.m)[6 * k + i];
+        Vk[i] = reinterpret_cast<const float*>(adam.v)[6 * k + i];
+      }
+    }
+  }
+  // A camera owns ~n_rays / n_cameras of the batch's rays, scattered over it.  Walking the batch with a
+  // load-compare-branch per ray, or even with the camera indices of 8 rays fetched at once and the matching rays
+  // processed under a divergent branch (one dependent round trip per q in which ANY lane matched: ~12 us), left this
+  // 90-workgroup kernel at 19 us.  So: compact first — ballots + a 32-entry count table give every matching ray its
+  // slot in ray order (deterministic, no atomics) — then one ray per thread, all loads of a round in one round trip.
+  for (long long base0 = 0; base0 < n_rays; base0 += CPG_ROUND) {
+    bool mine[CPG_ROUND / 256];
+    unsigned long long bal[CPG_ROUND / 256];
+#pragma unroll
+    for (int q = 0; q < CPG_ROUND / 256; ++q) {
       const long long r = base0 + q * 256 + threadIdx.x;
-      mine[q] = (r < n_rays) ? cam_idx[r] : -1;
+      mine[q] = (r < n_rays) && cam_idx[r] == k;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (mine[q] != k) continue;
-      const long long r = base0 + q * 256 + threadIdx.x;
+    for (int q = 0; q < CPG_ROUND / 256; ++q) {
+      bal[q] = __ballot(mine[q]);
+      if (lane == 0) s_cnt[q][wave] = __popcll(bal[q]);
+    }
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < CPG_ROUND / 256; ++q) {
+      int before = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += s_cnt[q][w];
+        total += s_cnt[q][w];
+      }
+      // `total` so far counts q' <= q completely; slots of (q, wave) start after all of q' < q and waves < wave of q
+      const int start = total - (s_cnt[q][0] + s_cnt[q][1] + s_cnt[q][2] + s_cnt[q][3]) + before;
+      if (mine[q]) s_list[start + __popcll(bal[q] & ((1ull << lane) - 1ull))] = q * 256 + (int)threadIdx.x;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const long long r = base0 + s_list[i];
       int y = (int)(u[3 * r + 1] * (float)cam.H);
       int x = (int)(u[3 * r + 2] * (float)cam.W);
       y = min(y, cam.H - 1);
@@ -111,6 +156,7 @@ __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const 
         acc[9 + a] += d_origins[3 * r + a];
       }
     }
+    __syncthreads();  // s_list / s_cnt are rewritten by the next round
   }
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
@@ -125,7 +171,7 @@ __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const 
 #pragma unroll
   for (int a = 0; a < 3; ++a) gt[a] = (red[0][9 + a] + red[1][9 + a]) + (red[2][9 + a] + red[3][9 + a]);
   // R' = R1 R, t' = t1 + R1 t  =>  dL/dR = R1^T G,  dL/dt = R1^T gt
-  const float* M = c2w + train_ids[k] * 12;
+  const float* M = Mk;
   float GR[9], gtt[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -133,7 +179,7 @@ __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const 
     for (int b = 0; b < 3; ++b) GR[3 * a + b] = M[a] * G[b] + M[4 + a] * G[3 + b] + M[8 + a] * G[6 + b];
     gtt[a] = M[a] * gt[0] + M[4 + a] * gt[1] + M[8 + a] * gt[2];
   }
-  const float* w = pose + 6 * k + 3;
+  const float* w = wk;
   const SO3 s = so3_exp(w);
   // dR/dw_i = f1 K_i + f2 (K_i K + K K_i) + (df1/dw_i) K + (df2/dw_i) K^2;  d theta/d w_i = w_i / theta above the clamp
   const float th = s.theta, sn = sinf(th), cs = cosf(th);
@@ -162,15 +208,17 @@ __global__ __launch_bounds__(256) void k_camera_pose_grad(PinholeDev cam, const 
     const float dth = above ? wi / th : 0.0f;
     const float g = s.f1 * gK[i] + s.f2 * (Sw[i] - 2.0f * wi * tr) + dth * (df1 * gk + df2 * gk2);
     if constexpr (!ADAM) {
-      out[3 + i] += g;
-      out[i] += gtt[i];
+      out[3 + i] = g_old[3 + i] + g;
+      out[i] = g_old[i] + gtt[i];
     } else {
       float* P = reinterpret_cast<float*>(adam.p) + 6 * k;
-      float* M = reinterpret_cast<float*>(adam.m) + 6 * k;
+      float* M2 = reinterpret_cast<float*>(adam.m) + 6 * k;
       float* V = reinterpret_cast<float*>(adam.v) + 6 * k;
-      const float gr = out[3 + i] + g, gtr = out[i] + gtt[i];
-      table_adam_update(adam, gr, P[3 + i], M[3 + i], V[3 + i]);
-      table_adam_update(adam, gtr, P[i], M[i], V[i]);
+      const float gr = g_old[3 + i] + g, gtr = g_old[i] + gtt[i];
+      table_adam_update(adam, gr, Pk[3 + i], Mm[3 + i], Vk[3 + i]);
+      table_adam_update(adam, gtr, Pk[i], Mm[i], Vk[i]);
+      P[3 + i] = Pk[3 + i], M2[3 + i] = Mm[3 + i], V[3 + i] = Vk[3 + i];
+      P[i] = Pk[i], M2[i] = Mm[i], V[i] = Vk[i];
       out[3 + i] = 0.0f;
       out[i] = 0.0f;
     }
