@@ -357,6 +357,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ld, md = one_step()
+    t_enqueued = time.perf_counter() - t0     # host side done (launches queued); the GPU is still working
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -610,6 +611,9 @@ def main() -> None:
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
+        # host time to enqueue a step (Python + ctypes + HIP launches), without waiting for the GPU: while it stays
+        # below ms_per_step the step is GPU-bound
+        "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
