@@ -248,25 +248,26 @@ def test_ssim_restatement_basic_properties():
 
 def test_product_package_never_imports_the_oracle_or_the_tests():
     """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch
-    it.  No module under fruitnerf_amd/ may import it (or tests/), not even lazily inside a function."""
+    it.  No module under fruitnerf_amd/ (or tools/) may import it (or tests/), not even lazily inside a function."""
     import ast
     import os
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fruitnerf_amd")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     offenders = []
-    for dirpath, _, files in os.walk(root):
-        for f in files:
-            if not f.endswith(".py"):
-                continue
-            path = os.path.join(dirpath, f)
-            for node in ast.walk(ast.parse(open(path).read())):
-                mods = []
-                if isinstance(node, ast.Import):
-                    mods = [a.name for a in node.names]
-                elif isinstance(node, ast.ImportFrom) and node.level == 0:
-                    mods = [node.module or ""]
-                for m in mods:
-                    if m.split(".")[0] in ("oracle", "tests"):
-                        offenders.append(f"{os.path.relpath(path, root)}:{node.lineno} imports {m}")
+    for root in (os.path.join(repo, "fruitnerf_amd"), os.path.join(repo, "tools")):   # tools/: profiling + microbenchmarks
+        for dirpath, _, files in os.walk(root):
+            for f in files:
+                if not f.endswith(".py"):
+                    continue
+                path = os.path.join(dirpath, f)
+                for node in ast.walk(ast.parse(open(path).read())):
+                    mods = []
+                    if isinstance(node, ast.Import):
+                        mods = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom) and node.level == 0:
+                        mods = [node.module or ""]
+                    for m in mods:
+                        if m.split(".")[0] in ("oracle", "tests"):
+                            offenders.append(f"{os.path.relpath(path, repo)}:{node.lineno} imports {m}")
     assert not offenders, offenders
 
 
