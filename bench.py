@@ -498,6 +498,41 @@ def main() -> None:
             torch.cuda.synchronize()
             cam_off = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
             camera = saved
+        # The headline window again on a FRESH model (same seeds, same step numbers -> same proposal update schedule)
+        # with the proposal-network backward on a second HIP stream (FNR_OVERLAP_PROPOSAL_BACKWARD=1): faster, but two
+        # streams share the GPU and the per-kernel timings above would no longer describe one kernel, so it is not
+        # the default of the timed region.
+        import fruitnerf_amd.training as _T
+
+        def headline_window(overlap: bool):
+            torch.manual_seed(0)
+            m2 = FruitModel(model_cfg, apple_metadata(), num_train_data=len(i_train), device=dev)
+            m2.train()
+            o2 = FusedAdam(m2, algorithm=M["algorithm"], group_lr={k: dict(v) for k, v in M["groups"].items()})
+            b2 = sa.PixelBatcher(data, train_ids, seed=1234 + rank)
+            c2 = None
+            if camera is not None:
+                cm = M["camera"]
+                co = CameraOptimizerConfig(mode=args.camera_optimizer, lr=cm["lr"], eps=cm["eps"],
+                                           weight_decay=cm["weight_decay"], lr_final=cm["lr_final"],
+                                           max_steps=cm["max_steps"] or 1).setup(len(i_train), dev)
+                c2 = (co, CameraAdam(co, algorithm=cm["algorithm"]), b2)
+            saved_flag, _T.OVERLAP_PROPOSAL_BACKWARD = _T.OVERLAP_PROPOSAL_BACKWARD, overlap
+            try:
+                t1 = 0.0
+                for s_ in range(args.warmup + 4 + args.steps):     # + 4: the instrumented steps before the timed region
+                    if s_ == args.warmup + 4:
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                    o_, d_, cam_, batch_ = b2.sample(RAYS_PER_BATCH, c2[0] if c2 else None)
+                    train_iteration(m2, o2, RayBundle(o_, d_, None, cam_), batch_, s_, world_size=world, camera=c2)
+                torch.cuda.synchronize()
+                return round(args.steps * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
+            finally:
+                _T.OVERLAP_PROPOSAL_BACKWARD = saved_flag
+        overlap_modes = {"note": "the headline window (same seeds and step numbers) on a fresh model; 'second_stream': the "
+                                 "proposal-network backward runs on a second HIP stream underneath the field backward",
+                         "one_stream": headline_window(False), "second_stream": headline_window(True)}
         # the other arithmetic modes of the field MLPs on the SAME loop (headline mode restored afterwards): bf16x3 is
         # parity grade (tests/test_gpu_bf16.py), bf16 is BASELINE config 2's throughput mode
         mlp_modes = None
@@ -526,7 +561,8 @@ def main() -> None:
                                  remove_outliers_radius=1.8 * spacing, cluster_merge_distance=0.04)
             fruit_count = fc.first_stage_count(PointCloud(pts, None, dev), eps=1.8 * spacing, min_samples=4)
         counting = counting_stage_bench(dev, cpu=not args.no_cpu_baseline)
-        secondary = {"train_rays_per_s_by_mlp_precision": mlp_modes,
+        secondary = {"train_rays_per_s_by_proposal_backward_stream": overlap_modes,
+                     "train_rays_per_s_by_mlp_precision": mlp_modes,
                      "train_rays_per_s_camera_optimizer_off": cam_off,
                      "train_rays_per_s_camera_optimizer_off_note": f"100 steps measured after step {step_idx[0] - 100} "
                      "(proposal nets are updated less often by then than in the headline window)",

@@ -127,16 +127,16 @@ __device__ __forceinline__ void interlevel_block(long long R, int S_f, const flo
                                                  const float* __restrict__ w_f, int S_p,
                                                  const float* __restrict__ spacing_p, const float* __restrict__ w_p,
                                                  float mult, float* __restrict__ loss, float* __restrict__ d_wp,
-                                                 int block, float* lds,  // lds: IL_LDS_FLOATS
+                                                 int block, float* lds, int p_cap,  // lds: 4 * (3 * p_cap + 4) floats
                                                  const float* __restrict__ euclid_p = nullptr,
                                                  const float* __restrict__ density_p = nullptr,
                                                  float* __restrict__ d_density_p = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r = (long long)block * 4 + wave;
   if (r >= R) return;
-  float* cp = lds + wave * (3 * IL_MAX_P + 4);
-  float* cy = cp + IL_MAX_P + 1;
-  float* dd = cy + IL_MAX_P + 1;
+  float* cp = lds + wave * (3 * p_cap + 4);   // p_cap >= S_p: the launch sizes the buffer for its largest level
+  float* cy = cp + p_cap + 1;
+  float* dd = cy + p_cap + 1;
   const float* sp = spacing_p + r * (S_p + 1);
   const float* wp = w_p + r * S_p;
   // cy1 = [0, cumsum(wp)] : lane-chunked scan
@@ -222,31 +222,33 @@ __global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const 
                                                     const float* __restrict__ w_p, float mult,
                                                     float* __restrict__ loss, float* __restrict__ d_wp) {
   __shared__ float lds[IL_LDS_FLOATS];
-  interlevel_block(R, S_f, spacing_f, w_f, S_p, spacing_p, w_p, mult, loss, d_wp, blockIdx.x, lds);
+  interlevel_block(R, S_f, spacing_f, w_f, S_p, spacing_p, w_p, mult, loss, d_wp, blockIdx.x, lds, IL_MAX_P);
 }
 
 // distortion_loss (metric, fruit_nerf.py:400): mean over rays of sum_ij w_i w_j |m_i - m_j| + sum_i w_i^2 ds_i / 3
 __device__ __forceinline__ void distortion_block(long long R, int S, const float* __restrict__ spacing,
                                                  const float* __restrict__ weights, float* __restrict__ out,
-                                                 int block, float* lds) {  // lds: 4096 floats
-  float(*s_m)[512] = reinterpret_cast<float(*)[512]>(lds);
-  float(*s_w)[512] = reinterpret_cast<float(*)[512]>(lds + 2048);
+                                                 int block, float* lds, int s_cap) {  // lds: 8 * s_cap floats, s_cap >= S
+  float* s_m_all = lds;
+  float* s_w_all = lds + 4 * s_cap;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r = (long long)block * 4 + wave;
   if (r >= R) return;
+  float* s_m = s_m_all + wave * s_cap;
+  float* s_w = s_w_all + wave * s_cap;
   const float* t = spacing + r * (S + 1);
   const float* w = weights + r * S;
   for (int k = lane; k < S; k += 64) {
-    s_m[wave][k] = (t[k + 1] + t[k]) / 2.0f;
-    s_w[wave][k] = w[k];
+    s_m[k] = (t[k + 1] + t[k]) / 2.0f;
+    s_w[k] = w[k];
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   float acc = 0.0f;
   for (int i = lane; i < S; i += 64) {
-    const float mi = s_m[wave][i], wi = s_w[wave][i];
+    const float mi = s_m[i], wi = s_w[i];
     float inner = 0.0f;
-    for (int j = 0; j < S; ++j) inner += s_w[wave][j] * fabsf(mi - s_m[wave][j]);
+    for (int j = 0; j < S; ++j) inner += s_w[j] * fabsf(mi - s_m[j]);
     acc += wi * inner + wi * wi * (t[i + 1] - t[i]) / 3.0f;
   }
   acc = wave_sum(acc);
@@ -255,7 +257,7 @@ __device__ __forceinline__ void distortion_block(long long R, int S, const float
 __global__ __launch_bounds__(256) void k_distortion(long long R, int S, const float* __restrict__ spacing,
                                                     const float* __restrict__ weights, float* __restrict__ out) {
   __shared__ float lds[4096];
-  distortion_block(R, S, spacing, weights, out, blockIdx.x, lds);
+  distortion_block(R, S, spacing, weights, out, blockIdx.x, lds, 512);
 }
 
 // Every loss of a training step in ONE launch (fnr_train_losses; five dependent 4-10 us launches before): workgroups
@@ -283,9 +285,8 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
                                                       const float* __restrict__ spacing_f,
                                                       const float* __restrict__ w_f, LevelLossArgs lv, float mult,
                                                       int want_distortion, float* __restrict__ accum,
-                                                      float* __restrict__ losses) {
-  static_assert(IL_LDS_FLOATS >= 4096, "one buffer for both roles");
-  __shared__ float lds[IL_LDS_FLOATS];
+                                                      float* __restrict__ losses, int p_cap) {
+  extern __shared__ float lds[];   // max(4 * (3 * p_cap + 4), 8 * S_f) floats: sized by the launch, not for 512 samples
   __shared__ bool s_last;
   __shared__ float s_red[TL_ROWS][4];
   float* il_slots = accum;
@@ -323,9 +324,9 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
     const int role = b / per, local = b - role * per;
     if (role < lv.n_levels)
       interlevel_block(R, S_f, spacing_f, w_f, lv.S_p[role], lv.spacing_p[role], lv.w_p[role], mult, il_slots,
-                       lv.d_wp[role], local, lds, lv.euclid_p[role], lv.density_p[role], lv.d_density_p[role]);
+                       lv.d_wp[role], local, lds, p_cap, lv.euclid_p[role], lv.density_p[role], lv.d_density_p[role]);
     else
-      distortion_block(R, S_f, spacing_f, w_f, di_slots, local, lds);
+      distortion_block(R, S_f, spacing_f, w_f, di_slots, local, lds, S_f);
   }
   // Completion count WITHOUT __threadfence(): an agent-scope release fence writes the XCD's L2 back (this kernel's
   // outputs are dirty there) and 3000 workgroups doing that cost 100 us.  The slot sums are agent-scope atomics, performed
@@ -776,9 +777,13 @@ extern "C" int fnr_train_losses(int64_t n_rays, const float* rgb, const float* i
   const long long blocks = (n_rays + 255) / 256 + per * (n_levels + (want_distortion ? 1 : 0));
   FNR_CHECK_ARG(blocks < (1ll << 31), "train_losses: too many rays");
   FNR_PROF(OP_LOSSES, n_rays);
-  hipLaunchKernelGGL(k_train_losses, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (long long)n_rays, rgb, image,
-                     semantics, fruit_mask, semantic_loss_weight, d_rgb, d_semantics, S_f, spacing_f, weights_f, lv,
-                     interlevel_mult, want_distortion, accum, losses);
+  int p_cap = 1;
+  for (int l = 0; l < n_levels; ++l) p_cap = S_p[l] > p_cap ? S_p[l] : p_cap;
+  size_t lds_floats = 4 * (size_t)(3 * p_cap + 4);
+  if (want_distortion && (size_t)8 * S_f > lds_floats) lds_floats = (size_t)8 * S_f;
+  hipLaunchKernelGGL(k_train_losses, dim3((unsigned)blocks), dim3(256), lds_floats * sizeof(float), as_stream(stream),
+                     (long long)n_rays, rgb, image, semantics, fruit_mask, semantic_loss_weight, d_rgb, d_semantics, S_f,
+                     spacing_f, weights_f, lv, interlevel_mult, want_distortion, accum, losses, p_cap);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

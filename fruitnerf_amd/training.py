@@ -16,6 +16,8 @@ Gradients are written by the HIP backward kernels straight into the model's flat
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -585,6 +587,9 @@ def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: 
     camera_adam.step(grad_scale=scale)
 
 
+# proposal-network backward on a second HIP stream (see fused_forward_backward); off by default: per-kernel timings stay
+# attributable to one stream
+OVERLAP_PROPOSAL_BACKWARD = os.environ.get("FNR_OVERLAP_PROPOSAL_BACKWARD") == "1"
 FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter
 
@@ -612,7 +617,8 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
         table_adam, span = optimizer.table_adam_args(model.field.mlp_base_grid.hash_table, "fields")
         done = (span,)
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
-                                                     ray_grads, table_adam=table_adam)
+                                                     ray_grads, overlap_proposal_backward=OVERLAP_PROPOSAL_BACKWARD,
+                                                     table_adam=table_adam)
     with torch.no_grad():
         if exchange is None:
             if camera is not None:

@@ -898,3 +898,57 @@ def test_train_losses_is_the_separate_launches(dev, R, n_levels, want_distortion
             assert float(ref.abs().max()) > 0
             assert torch.equal(got, ref)
 
+
+def test_proposal_backward_on_a_second_stream_changes_nothing(dev):
+    """training.OVERLAP_PROPOSAL_BACKWARD (FNR_OVERLAP_PROPOSAL_BACKWARD=1): the proposal-network backward runs on a
+    second HIP stream underneath the field backward.  One full step (camera optimiser included, ray gradients from both
+    chains) from identical states with and without it: every hash table (main + proposal), their moments and the
+    poses are bit-identical, the MLP weights (float atomics) agree to 1e-6."""
+    import fruitnerf_amd.training as T
+    from fruitnerf_amd import _kernels as K
+    from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+    from fruitnerf_amd.data import synthetic_apple as sa
+    from fruitnerf_amd.rays import RayBundle
+    n_cam, HW, focal, R = 8, 64, 90.0, 512
+    cfg = util.small_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, num_images=n_cam, seed=5)
+    scene = sa.make_scene(seed=0)
+    data = {k: (v.to(dev) if torch.is_tensor(v) else v)
+            for k, v in sa.render_dataset(scene, sa.make_cameras(n_cam, seed=0), H=HW, W=HW, fx=focal, fy=focal).items()}
+    g = torch.Generator().manual_seed(4)
+    u = torch.rand(R, 3, generator=g).to(dev)
+    jit = [torch.rand(R, 1, generator=g).to(dev) for _ in range(3)]
+    outs = []
+    saved = T.OVERLAP_PROPOSAL_BACKWARD
+    try:
+        for overlap in (False, True):
+            T.OVERLAP_PROPOSAL_BACKWARD = overlap
+            hm = util.make_hip_like(om, dev)
+            hm.train()
+            opt = T.FusedAdam(hm)
+            cam = CameraOptimizerConfig(mode="SO3xR3").setup(n_cam, dev)
+            cadam = CameraAdam(cam)
+            batcher = sa.PixelBatcher(data, torch.arange(n_cam, device=dev), seed=0)
+            batcher._set = K.ImageSetArg(data["images"], data["masks"], data["c2w"], focal, focal, HW / 2.0, HW / 2.0)
+            c2w_adj = cam.adjusted_cameras(batcher._set, batcher.image_ids)
+            o, d, ci, image, mask = K.sample_pixels(batcher._set, batcher.image_ids, u, c2w_adj)
+            batcher.last_draw = {"u": u, "cam": ci, "c2w_adjusted": c2w_adj}
+            T.fused_train_iteration(hm, opt, RayBundle(o, d, None, ci[:, None]), {"image": image, "fruit_mask": mask[:, None]},
+                                    0, jitter=jit, camera=(cam, cadam, batcher))
+            torch.cuda.synchronize()
+            tables = [hm.field.mlp_base_grid.hash_table] + [p.encoding.hash_table for p in hm.proposal_networks]
+            spans = [[(off, off + k) for _, q, off, k in hm.arena().entries if q is t][0] for t in tables]
+            outs.append((hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                         cam.pose_adjustment.data.clone(), spans))
+    finally:
+        T.OVERLAP_PROPOSAL_BACKWARD = saved
+    a, b = outs
+    for x, y in zip(a[:3], b[:3]):
+        for lo, hi in a[4]:
+            assert torch.equal(x[lo:hi], y[lo:hi])
+        assert float((x - y).abs().max()) <= 1e-6 * max(1.0, float(x.abs().max()))
+    assert torch.equal(a[3], b[3])
+    fresh = util.make_hip_like(om, dev).arena().params
+    for lo, hi in a[4]:
+        assert int((a[0][lo:hi] != fresh[lo:hi]).sum()) > 0      # every table moved (proposal nets train at step 0)
+
