@@ -64,8 +64,9 @@ out = ['# Round 2 - rocprofv3 of `python bench.py --steps 60 --warmup 10 --no-cp
        'Times are per STEP (kernel total / 86; the proposal-network backward runs on 48 of the 86 steps).  FETCH_SIZE is doubled '
        'per MI355X_MICROARCH.md (gfx950 reports half of a wide streaming read) and, like WRITE_SIZE, given in MB per dispatch '
        '(rocprofv3 reports KB).  SQ columns are ratios of per-dispatch counters (wave-cycles count quad-cycles; '
-       'SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs).\n',
-       '| kernel | launches/step | us/step | median us | FETCHx2 MB | WRITE MB | VALU-active / wave-cycles | WAIT_ANY / wave-cycles | MFMA-busy cycles / dispatch |',
+       'SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines: the last column is '
+       'MFMA_BUSY / (32 x SQ_BUSY)).\n',
+       '| kernel | launches/step | us/step | median us | FETCHx2 MB | WRITE MB | VALU-active / wave-cycles | WAIT_ANY / wave-cycles | MFMA-busy / SIMD-cycles |',
        '|---|---|---|---|---|---|---|---|---|']
 tot = 0.0
 for name, n, total, med, mn in rows:
@@ -80,7 +81,7 @@ for name, n, total, med, mn in rows:
     c_w = '' if ws is None else '%.1f' % (ws / 1024)
     c_v = '' if not wc else '%.2f' % (s.get('SQ_ACTIVE_INST_VALU', 0) / wc)
     c_a = '' if not wc else '%.2f' % (s.get('SQ_WAIT_ANY', 0) / wc)
-    c_m = '' if not s else '%.3g' % s.get('SQ_VALU_MFMA_BUSY_CYCLES', 0)
+    c_m = '' if not s or not s.get('SQ_BUSY_CYCLES') else '%.2f' % (s.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (32.0 * s['SQ_BUSY_CYCLES']))
     out.append('| `%s` | %.2f | %.1f | %.1f | %s | %s | %s | %s | %s |' % (short(name), n / steps, total * 1e3 / steps, med, c_f, c_w, c_v, c_a, c_m))
 out.append('\nSum of kernel time: %.0f us per step (the un-profiled step time is in the bench lines below).\n' % (tot * 1e3 / steps))
 out.append('## Bench lines of the same build (un-profiled)\n')
