@@ -310,7 +310,8 @@ int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const f
                         const float* euclid_bins, int S, const float* d_feats, int level_begin, int level_count,
                         void* workspace, size_t workspace_bytes, int workspace_clean, void* stream);
 
-/* fnr_hash_encode_bwd over ALL levels with the optimiser step of the table fused in (single-process training: with
+/* fnr_hash_encode_bwd over ALL levels with the optimiser step of the table ("fields" group, fruit_nerf_config.py:51-56)
+ * fused in (single-process training: with
  * several ranks the gradient has to exist for the all-reduce).  The workgroup that owns a bin of rows holds their summed
  * gradient in LDS and applies torch.optim.Adam (algorithm 0) / RAdam (1) to those rows — parameters, exp_avg and
  * exp_avg_sq are the TABLE's slices [n_levels << log2_hashmap_size, 2] of the caller's arenas, `step` is the
@@ -330,7 +331,8 @@ int fnr_hash_encode_bwd_adam(const fnr_grid* grid_grad, const fnr_warp* warp, co
                              const float* euclid_bins, int S, const float* d_feats, void* workspace,
                              size_t workspace_bytes, int workspace_clean, const fnr_table_adam* adam, void* stream);
 
-/* fnr_camera_pose_grad with the pose table's optimiser step fused in (single-process training): adam->params is
+/* fnr_camera_pose_grad with the pose table's optimiser step (camera_optimizer group, fruit_nerf_config.py:39-43) fused in
+ * (single-process training): adam->params is
  * pose_adjustment [n_train,6] (read for the gradient, then updated), exp_avg / exp_avg_sq its moments; pose_grad is
  * added to the new gradient and left ZERO.  Bit-identical to fnr_camera_pose_grad followed by fnr_adam_step /
  * fnr_radam_step(zero_grad = 1) over the 6 n_train floats. */
@@ -349,7 +351,8 @@ int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, con
                          const float* d_density, float* d_position, void* workspace, size_t workspace_bytes,
                          int workspace_clean, void* stream);
 
-/* All of get_loss_dict / get_metrics_dict for one training batch in ONE launch: fnr_losses_fwd + fnr_interlevel_fwd for
+/* All of get_loss_dict / get_metrics_dict (fruit_nerf.py:359-372, 396-401: rgb_loss, semantics_loss, interlevel_loss; psnr, distortion) for one training batch in ONE launch:
+ * fnr_losses_fwd + fnr_interlevel_fwd for
  * each of the n_levels (<= FNR_MAX_PROPOSAL_LEVELS) proposal levels against the final level + (want_distortion)
  * fnr_distortion, and the sum of the accumulator slots.  losses [5] = rgb_loss, semantics_loss, psnr,
  * interlevel_loss, distortion (0 when not wanted); d_rgb [R,3], d_semantics [R], d_weights_p[l] [R,S_p[l]] as the
@@ -400,7 +403,8 @@ int fnr_radam_step(float* params, float* grads, float* exp_avg, float* exp_avg_s
                    float beta2, float eps, int64_t step, float grad_scale, float weight_decay, int zero_grad,
                    void* stream);
 
-/* Several spans of ONE arena in one launch (the parameter groups of a method differ in learning rate and step count;
+/* The optimisers of a method's parameter groups (fruit_nerf_config.py:47-56, 97-106, 148-160: one torch.optim instance and
+ * scheduler per group) as ONE launch over several spans of one arena (the groups differ in learning rate and step count;
  * each is a few thousand to a few million floats and a launch of its own cost more than its traffic).  Span k updates
  * elements [offset, offset + count) (both multiples of 4) exactly as fnr_adam_step (algorithm 0) / fnr_radam_step (1)
  * with its own lr / step would.  n_spans <= FNR_MAX_ADAM_SPANS; `spans` is host memory. */
