@@ -140,6 +140,28 @@ def roofline_entry(op, units, avg_ms, launches, alg, fixed_bytes=0.0, fixed_note
             "avg_launch_ms": round(avg_ms, 5), "launches": launches, "units_per_launch": int(units), key: per_unit}
 
 
+def usable_cpus() -> int:
+    """Host threads this process may actually keep busy: the hardware count capped by the container's CFS quota
+    (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  On the MI355X boxes the quota is 16 CPUs of 256 hardware threads; a
+    PyTorch / OpenMP pool sized by os.cpu_count() (128 threads) overruns it, and the kernel then freezes the WHOLE
+    process for the rest of each 100 ms period — measured as 70-90 ms stalls of arbitrary host calls (a stream
+    synchronize, a small D2H copy, plain Python) on every third 256^3 export pass, and as a 30x slower CPU baseline."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def split_indices(n: int, frac: float):
     """Nerfstudio-style 'fraction' split (fruitnerf_dataparser.py:171-186): evenly spaced train images."""
     num_train = int(np.ceil(n * frac))
@@ -187,14 +209,14 @@ def counting_stage_bench(dev, cpu: bool):
             from scipy.spatial import cKDTree
             from sklearn.cluster import DBSCAN
             t = time.perf_counter()
-            c_cpu = cKDTree(X).query_ball_point(X, 0.01, return_length=True, workers=-1)
+            c_cpu = cKDTree(X).query_ball_point(X, 0.01, return_length=True, workers=usable_cpus())
             t_c = time.perf_counter() - t
             Xv = vx.cpu().numpy()
             t = time.perf_counter()
-            lab = DBSCAN(eps=0.01, min_samples=100, n_jobs=-1).fit(Xv).labels_
+            lab = DBSCAN(eps=0.01, min_samples=100, n_jobs=usable_cpus()).fit(Xv).labels_
             t_d = time.perf_counter() - t
             out["cpu_ms"] = {"radius_count_scipy_ckdtree": round(t_c * 1e3, 1), "dbscan_sklearn": round(t_d * 1e3, 1),
-                             "cores": os.cpu_count()}
+                             "cores": usable_cpus()}
             out["labels_equal_sklearn"] = bool(np.array_equal(lab, labels.cpu().numpy()))
             out["counts_close_to_ckdtree"] = float(np.mean(c_cpu == counts.cpu().numpy()))  # <= vs < differ on ties
         except Exception as e:  # noqa: BLE001
@@ -233,6 +255,9 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # host thread pools sized by the container's CPU quota (shared by the ranks of a node), not by os.cpu_count():
+    # see usable_cpus() — an oversized OpenMP pool gets the whole process frozen by the CFS bandwidth controller
+    torch.set_num_threads(max(1, usable_cpus() // max(world, 1)))
     # FNR_BENCH_BACKEND=gloo + FNR_BENCH_ONE_DEVICE=1: self-test of the multi-rank control flow on a 1-GPU box
     # (RCCL refuses two ranks on one device); the driver's runs use the defaults (nccl = RCCL, one GPU per rank)
     # FNR_BENCH_FORCE_DIST=1 (single process): a ONE-rank nccl group with the exchange forced on, so that this file's
@@ -582,11 +607,11 @@ def main() -> None:
         from oracle import fruit_oracle as fo
         from oracle import ns_torch as ns
         # BASELINE.md §2 protocol: the method's batch size, oracle/ PyTorch-CPU fp32, median of the timed steps.
-        # Threads: eager PyTorch on this path is a stream of small ops and gets SLOWER beyond a few dozen threads
-        # (measured on the 256-thread GPU box: 124 s per 4096-ray step with 256 threads vs ~4 s with 32), so the
-        # baseline uses min(cpu_count, 32) threads — the best case for the reference — and says so in `cores`.
+        # Threads: what the container's CPU quota allows (usable_cpus(): 16 on the MI355X boxes; more threads than
+        # that get the process throttled — 124 s per 4096-ray step with 256 threads), at most 32 (eager PyTorch on
+        # this path is a stream of small ops and does not scale further) — and says so in `cores`.
         # fruit_nerf_big: a bounded 1024-ray sample of the 8192-ray batch (a full batch takes minutes per step).
-        ncores = min(os.cpu_count() or 1, 32)
+        ncores = min(usable_cpus(), 32)
         CPU_RAYS = args.cpu_rays or (RAYS_PER_BATCH if args.method == "fruit_nerf" else 1024)
         torch.set_num_threads(ncores)
         torch.manual_seed(0)
@@ -635,8 +660,8 @@ def main() -> None:
                          f"{' with the SO3xR3 camera optimizer' if ocam is not None else ''}, fwd+bwd+{M['algorithm']} over "
                          f"all {n_params / 1e6:.1f} M parameters) of {CPU_RAYS} rays each"
                          f"{'' if CPU_RAYS == RAYS_PER_BATCH else f' (bounded sample of the {RAYS_PER_BATCH}-ray batch)'} "
-                         f"after 1 warm-up, oracle/ PyTorch-CPU fp32, {ncores} of {os.cpu_count()} host threads (more "
-                         f"threads are slower for eager PyTorch here), median {med:.2f} s/step, "
+                         f"after 1 warm-up, oracle/ PyTorch-CPU fp32, {ncores} host threads (CPU quota of the container: "
+                         f"{usable_cpus()} of {os.cpu_count()} hardware threads), median {med:.2f} s/step, "
                          f"min {min(times):.2f} s/step"}
 
     result = {

@@ -18,31 +18,40 @@ from .. import _kernels as K
 SET_NAMES = ("semantic_colormap", "semantic", "density")
 
 
+def _ensure_buffers(state, dev):
+    cap = state["cap"]
+    if state.get("buf_cap") != cap:
+        state["points"] = [torch.empty(cap, 3, device=dev) for _ in range(3)]
+        state["colors"] = [torch.empty(cap, 4, device=dev) for _ in range(3)]
+        state["buf_cap"] = cap
+
+
+def _read_counts(counts, state):
+    """The three running totals on the host (pinned destination + one stream synchronize instead of a pageable
+    `counts.cpu()`)."""
+    dev = counts.device
+    if dev.type != "cuda":                      # CPU stand-in kernels of the gloo sharding test
+        return counts.tolist()
+    host = state.get("counts_host")
+    if host is None:
+        host = state["counts_host"] = torch.empty(3, dtype=torch.int64).pin_memory()
+    host.copy_(counts, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    return host.tolist()
+
+
 def _compact_batch(lat, ray_begin, n_rays, positions, density, rgb, logit, state):
+    """One batch compacted into the front of the stream buffers; returns its three counts (one host wait, like the
+    reference's per-batch .cpu(), exporter_utils.py:126-153).  Re-runs the batch with larger buffers when they
+    overflow."""
     dev = density.device
     while True:
-        cap = state["cap"]
-        if state.get("buf_cap") != cap:
-            state["points"] = [torch.empty(cap, 3, device=dev) for _ in range(3)]
-            state["colors"] = [torch.empty(cap, 4, device=dev) for _ in range(3)]
-            state["buf_cap"] = cap
+        _ensure_buffers(state, dev)
         counts = torch.zeros(3, dtype=torch.int64, device=dev)
         K.export_compact(lat, ray_begin, n_rays, positions, density, rgb, logit, state["points"], state["colors"],
                          counts)
-        # the reference also synchronises per batch (.cpu(), exporter_utils.py:126-153).  Pinned destination + stream
-        # sync instead of a pageable `counts.cpu()`: on MI355X / ROCm 7.2 this host wait intermittently takes ~40 ms for
-        # ~4.5 ms of queued kernel time (HIP events around the kernels stay constant; tools/microbench/
-        # export_hostprof.py): every ~3rd 256^3 pass with the pageable copy, every ~8th with the pinned one.
-        if dev.type == "cuda":
-            host = state.get("counts_host")
-            if host is None:
-                host = state["counts_host"] = torch.empty(3, dtype=torch.int64).pin_memory()
-            host.copy_(counts, non_blocking=True)
-            torch.cuda.current_stream(dev).synchronize()
-            c = host.tolist()
-        else:                                   # CPU stand-in kernels of the gloo sharding test
-            c = counts.tolist()
-        if max(c) <= cap:
+        c = _read_counts(counts, state)
+        if max(c) <= state["cap"]:
             return c
         while state["cap"] < max(c):
             state["cap"] *= 2
@@ -77,23 +86,41 @@ def sample_volume(pipeline, num_points: int, output_dir: Optional[Path] = None, 
         from ..sharding import shard_range
         lo, hi = shard_range(n_batches, rank, world_size)
         dm.train_count = lo                     # batch `count` is 1-based: the next one drawn is lo + 1
-    for _ in range(lo, hi):
-        if lat is not None:
-            # fused path: same batches as OrthographicRayGenerator (ray_generators.py:52-58), positions implicit
-            dm.train_count += 1
-            start, end = dm.orthographic_ray_generator.batch_range(dm.train_count)
-            n_rays = end - start
-            density, rgb, logit = model.export_lattice_batch(lat, lattice["direction"], start, n_rays)
-            c = _compact_batch(lat, start, n_rays, None, density, rgb, logit, state)
-        else:
-            with torch.no_grad():
-                ray_bundle, _ = dm.next_sample_volume(0)
-                outputs = model(ray_bundle)
-            n_rays = outputs["point_location"].shape[0]
-            c = _compact_batch(None, 0, 0, outputs["point_location"].reshape(-1, 3),
-                               outputs["density"].reshape(-1).contiguous(),
-                               outputs["rgb"].reshape(-1, 3).contiguous(),
-                               outputs["semantics"].reshape(-1).contiguous(), state)
+    if lat is not None:
+        # fused lattice path: same batches as OrthographicRayGenerator (ray_generators.py:52-58), positions implicit.
+        # The compaction's counts are RUNNING totals on the device (fnr_export_compact), so the batches append to the
+        # stream buffers back to back and the host waits ONCE, at the end of the pass — the point lists are the
+        # per-batch lists concatenated, as before.  The pass is deterministic: if the buffers were too small it is
+        # simply repeated with larger ones.
+        dev = model.device
+        first = dm.train_count
+        while True:
+            _ensure_buffers(state, dev)
+            counts = torch.zeros(3, dtype=torch.int64, device=dev)
+            dm.train_count = first
+            for _ in range(lo, hi):
+                dm.train_count += 1
+                start, end = dm.orthographic_ray_generator.batch_range(dm.train_count)
+                density, rgb, logit = model.export_lattice_batch(lat, lattice["direction"], start, end - start)
+                K.export_compact(lat, start, end - start, None, density, rgb, logit, state["points"], state["colors"],
+                                 counts)
+            c = _read_counts(counts, state)
+            if max(c) <= state["cap"]:
+                break
+            while state["cap"] < max(c):
+                state["cap"] *= 2
+        for s, name in enumerate(SET_NAMES):
+            pts[name].append(state["points"][s][:c[s]].to("cpu", copy=True))
+            cols[name].append(state["colors"][s][:c[s]].to("cpu", copy=True))
+        lo = hi                                  # nothing left for the generic loop
+    for _ in range(lo, hi):                      # generic path (explicit positions, e.g. the jittering sampler)
+        with torch.no_grad():
+            ray_bundle, _ = dm.next_sample_volume(0)
+            outputs = model(ray_bundle)
+        c = _compact_batch(None, 0, 0, outputs["point_location"].reshape(-1, 3),
+                           outputs["density"].reshape(-1).contiguous(),
+                           outputs["rgb"].reshape(-1, 3).contiguous(),
+                           outputs["semantics"].reshape(-1).contiguous(), state)
         for s, name in enumerate(SET_NAMES):
             # copy=True: the stream buffers are reused by the next batch (a no-op distinction on a GPU, where the
             # transfer already copies)
