@@ -31,6 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+from fruitnerf_amd.hostinfo import usable_cpus  # noqa: E402  (the container's CPU quota, see its docstring)
 
 N_CAMERAS = 100
 TRAIN_SPLIT = 0.9              # fruitnerf_dataparser.py:62
@@ -138,28 +139,6 @@ def roofline_entry(op, units, avg_ms, launches, alg, fixed_bytes=0.0, fixed_note
             # profiles/r02_* for the FETCH_SIZE / WRITE_SIZE passes of this command
             "traffic": None,
             "avg_launch_ms": round(avg_ms, 5), "launches": launches, "units_per_launch": int(units), key: per_unit}
-
-
-def usable_cpus() -> int:
-    """Host threads this process may actually keep busy: the hardware count capped by the container's CFS quota
-    (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  On the MI355X boxes the quota is 16 CPUs of 256 hardware threads; a
-    PyTorch / OpenMP pool sized by os.cpu_count() (128 threads) overruns it, and the kernel then freezes the WHOLE
-    process for the rest of each 100 ms period — measured as 70-90 ms stalls of arbitrary host calls (a stream
-    synchronize, a small D2H copy, plain Python) on every third 256^3 export pass, and as a 30x slower CPU baseline."""
-    n = os.cpu_count() or 1
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, -(-int(quota) // int(period))))
-    except (OSError, ValueError):
-        try:
-            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if quota > 0:
-                n = min(n, max(1, -(-quota // period)))
-        except (OSError, ValueError):
-            pass
-    return n
 
 
 def split_indices(n: int, frac: float):

@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` through gpurun)")
+    # the oracle side of the parity tests is PyTorch-CPU: size its thread pool by the container's CPU quota (16 CPUs of
+    # 256 hardware threads on the MI355X boxes), or the CFS controller freezes the process every 100 ms
+    from fruitnerf_amd.hostinfo import usable_cpus
+    torch.set_num_threads(usable_cpus())
 
 
 def pytest_sessionstart(session):

@@ -39,8 +39,8 @@ def main():
     from oracle import camera_opt as oc
     from oracle import fruit_oracle as fo
     from oracle import ns_torch as ns
-    if args.threads:
-        torch.set_num_threads(args.threads)
+    from fruitnerf_amd.hostinfo import usable_cpus
+    torch.set_num_threads(args.threads or usable_cpus())
     hip = args.side == "hip"
     dev = torch.device("cuda:0") if hip else torch.device("cpu")
     focal = 1111.0 * HW / 800.0

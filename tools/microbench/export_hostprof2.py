@@ -9,7 +9,7 @@ from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
 from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
 from fruitnerf_amd.export import exporter_utils as E
-from bench import usable_cpus
+from fruitnerf_amd.hostinfo import usable_cpus
 if os.environ.get('FNR_THREADS_BY_QUOTA', '1') == '1':
     torch.set_num_threads(usable_cpus())
 dev = torch.device('cuda:0')

@@ -7,8 +7,8 @@ from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
 from fruitnerf_amd.data.semantics import apple_metadata
 from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
 from fruitnerf_amd.export.exporter_utils import sample_volume
-from bench import usable_cpus
-torch.set_num_threads(usable_cpus())   # the container's CPU quota (see bench.usable_cpus)
+from fruitnerf_amd.hostinfo import usable_cpus
+torch.set_num_threads(usable_cpus())   # the container's CPU quota (see fruitnerf_amd/hostinfo.py)
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
