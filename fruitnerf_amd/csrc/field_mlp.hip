@@ -43,7 +43,7 @@ int field_ptrs(const fnr_field_net* net, FieldPtrs& p, int* cfg_id) {
 }
 
 // bf16 / bf16x3 modes (field_mlp_bf16.hip)
-int field_mlp_fwd_bf16(int mode, const FieldPtrs& p, const float* packed, void* image_ws, const float* ray_bias,
+int field_mlp_fwd_bf16(int cfg, int mode, const FieldPtrs& p, const float* packed, void* image_ws, const float* ray_bias,
                        const RaysDev& rd, int S, long long N, const float2* feats, const uint8_t* selector, float* density,
                        float* rgb, float* logit, float* geo_out, float* h_buf, hipStream_t st);
 size_t field_bf16_image_bytes();
@@ -216,7 +216,7 @@ int field_mlp_fwd_launch(const FieldPtrs& p, const fnr_field_net* net, const Ray
   // in field_mlp_bwd.hip), base and colour MLPs stay on fp32 MFMA
   if constexpr (Cfg::NSEM == 2) {
     if (net->mlp_mode != FNR_MLP_FP32)
-      return field_mlp_fwd_bf16(net->mlp_mode, p, packed, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),
+      return field_mlp_fwd_bf16(0, net->mlp_mode, p, packed, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),
                                 ray_bias, rd, S, N, f2, selector, density, rgb, logit, geo_out, h_buf, st);
   }
   if constexpr (Cfg::NSEM == 2) {
@@ -227,14 +227,20 @@ int field_mlp_fwd_launch(const FieldPtrs& p, const fnr_field_net* net, const Ray
                        S, N, f2, selector, density, rgb, logit, geo_out, h_buf);
     FNR_LAUNCH_CHECK();
   } else {
+    if (net->mlp_mode != FNR_MLP_FP32) {
+      // bf16-pipe modes: base + colour on the tile-pair kernel, then the semantic branch weight-streamed from the saved h
+      const int rc = field_mlp_fwd_bf16(1, net->mlp_mode, p, packed,
+                                        reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(), ray_bias, rd, S, N, f2,
+                                        selector, density, rgb, logit, geo_out, h_buf, st);
+      if (rc) return rc;
+      return field_mlp_fwd_sem_big_bf16(net->mlp_mode, p, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),
+                                        packed, N, h_buf, logit, st);
+    }
     long long blocks = (n_tiles + 7) / 8;
     if (blocks > 2ll * device_cu_count()) blocks = 2ll * device_cu_count();
     hipLaunchKernelGGL((k_field_mlp_fwd<Cfg, PART_BASE_COLOR, 8>), dim3((unsigned)blocks), dim3(512), 0, st, packed,
                        ray_bias, rd, S, N, f2, selector, density, rgb, logit, geo_out, h_buf);
     FNR_LAUNCH_CHECK();
-    if (net->mlp_mode != FNR_MLP_FP32)  // semantic branch on the bf16 pipe, weight-streamed (field_mlp_bf16.hip)
-      return field_mlp_fwd_sem_big_bf16(net->mlp_mode, p, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),
-                                        packed, N, h_buf, logit, st);
     blocks = (n_tiles + 15) / 16;   // 120 KB of semantic weights: one 16-wave workgroup per CU
     if (blocks > (long long)device_cu_count()) blocks = device_cu_count();
     hipLaunchKernelGGL((k_field_mlp_fwd<Cfg, PART_SEM, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, packed, ray_bias,

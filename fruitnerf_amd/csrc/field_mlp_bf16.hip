@@ -13,6 +13,8 @@
 // exceed the LDS.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "field_bf16.hpp"
 
 namespace fnr {
@@ -22,6 +24,15 @@ template <class Cfg>
 struct SegsFwdAll {  // every layer, forward only
   static constexpr int N = Cfg::NLAYERS;
   static constexpr int layer(int i) { return i; }
+  static constexpr bool isT(int) { return false; }
+};
+
+template <class Cfg>
+struct SegsFwdBaseColor {  // base + colour MLPs, forward only (`fruit_nerf_big`: its semantic branch is weight-streamed)
+  static constexpr int N = 5;
+  static constexpr int layer(int i) {
+    return i == 0 ? Cfg::L_BASE0 : i == 1 ? Cfg::L_BASE1 : i == 2 ? Cfg::L_COL0 : i == 3 ? Cfg::L_COL1 : Cfg::L_COL2;
+  }
   static constexpr bool isT(int) { return false; }
 };
 
@@ -46,14 +57,19 @@ __device__ __forceinline__ void relu2_(f32x4 (&a)[N], f32x4 (&b)[N]) {
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <class Cfg, int NS, int WAVES>
+// WITH_SEM: the `fruit_nerf` shape, every branch in this kernel.  !WITH_SEM: base + colour only (`fruit_nerf_big`, whose
+// 128-wide semantic branch runs in k_field_mlp_fwd_sem_big_bf16 from the h this kernel saves).
+template <class Cfg, int NS, int WAVES, bool WITH_SEM>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_fwd_bf16(
     const float* __restrict__ packed, const __bf16* __restrict__ image, const float* __restrict__ ray_bias, RaysDev rays,
     int S, long long N, const float2* __restrict__ feats, const uint8_t* __restrict__ selector,
     float* __restrict__ density, float* __restrict__ rgb, float* __restrict__ logit, float* __restrict__ geo_out,
     float* __restrict__ h_buf) {
-  static_assert(Cfg::HB == 1 && Cfg::NSEM == 2, "bf16 kernels: `fruit_nerf` shape");
-  using Lds = BfLds<Cfg, SegsFwdAll<Cfg>, NS>;
+  constexpr int HB = Cfg::HB;
+  static_assert(HB == 1 || HB == 2, "built shapes");
+  static_assert(!WITH_SEM || (HB == 1 && Cfg::NSEM == 2), "all-in-one kernel: `fruit_nerf` shape");
+  using Segs = typename std::conditional<WITH_SEM, SegsFwdAll<Cfg>, SegsFwdBaseColor<Cfg>>::type;
+  using Lds = BfLds<Cfg, Segs, NS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
   float* bias = reinterpret_cast<float*>(smem + Lds::BYTES);  // Cfg::B_TOTAL floats, the fp32 image's bias block
@@ -70,16 +86,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_fwd_bf16(
     const long long nna = va ? na : N - 1, nnb = vb ? nb : N - 1;
     const long long raya = nna / S, rayb = nnb / S;
 
-    f32x4 ha[1], hb[1];
+    f32x4 ha[HB], hb[HB];
     {
       f32x4 xa[2], xb[2], a1a[4], a1b[4];
       load_hash_block(feats, N, nna, g, xa);
       load_hash_block(feats, N, nnb, g, xb);
       bf_layer<NS, 4, 2>(Lds::template seg<Cfg::L_BASE0, false>(lds), bias + Cfg::boff(Cfg::L_BASE0), xa, xb, a1a, a1b, lane);
       relu2_(a1a, a1b);
-      bf_layer<NS, 1, 4>(Lds::template seg<Cfg::L_BASE1, false>(lds), bias + Cfg::boff(Cfg::L_BASE1), a1a, a1b, ha, hb, lane);
+      bf_layer<NS, HB, 4>(Lds::template seg<Cfg::L_BASE1, false>(lds), bias + Cfg::boff(Cfg::L_BASE1), a1a, a1b, ha, hb, lane);
     }
-    {  // semantic branch
+    if constexpr (WITH_SEM) {  // semantic branch
       f32x4 s1a[4], s1b[4], s2a[4], s2b[4], hda[1], hdb[1];
       bf_layer<NS, 4, 1>(Lds::template seg<Cfg::L_SEM0, false>(lds), bias + Cfg::boff(Cfg::L_SEM0), ha, hb, s1a, s1b, lane);
       relu2_(s1a, s1b);
@@ -96,23 +112,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_fwd_bf16(
         c1b[ob] = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)rayb * 64 + 16 * ob + 4 * g);
       }
       {
-        bf16x8 xa[1][NS], xb[1][NS];
-        bf_operand<NS, 1>(ha, xa);
-        bf_operand<NS, 1>(hb, xb);
+        bf16x8 xa[1][NS], xb[1][NS];   // h: one K-block of 32 holds both 16-wide blocks of the big shape
+        bf_operand<NS, HB>(ha, xa);
+        bf_operand<NS, HB>(hb, xb);
         bf_layer_acc<NS, 4, 1>(Lds::template seg<Cfg::L_COL0, false>(lds), xa, xb, c1a, c1b, lane);
       }
       relu2_(c1a, c1b);
       bf_layer<NS, 4, 4>(Lds::template seg<Cfg::L_COL1, false>(lds), bias + Cfg::boff(Cfg::L_COL1), c1a, c1b, c2a, c2b, lane);
       relu2_(c2a, c2b);
       bf_layer<NS, 1, 4>(Lds::template seg<Cfg::L_COL2, false>(lds), bias + Cfg::boff(Cfg::L_COL2), c2a, c2b, c3a, c3b, lane);
-      auto finish = [&](long long n, bool valid, const f32x4 (&h)[1], const f32x4 (&c3)[1]) {
+      auto finish = [&](long long n, bool valid, const f32x4 (&h)[HB], const f32x4 (&c3)[1]) {
         if (!valid) return;
-        if (h_buf) *reinterpret_cast<f32x4*>(h_buf + (size_t)n * 16 + 4 * g) = h[0];
-        if (geo_out) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int k = 4 * g + r;
-            if (k >= 1 && k <= Cfg::GEO) geo_out[(size_t)n * Cfg::GEO + (k - 1)] = h[0][r];
+        for (int b = 0; b < HB; ++b) {
+          if (h_buf) *reinterpret_cast<f32x4*>(h_buf + (size_t)n * (16 * HB) + 16 * b + 4 * g) = h[b];
+          if (geo_out) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = 16 * b + 4 * g + r;
+              if (k >= 1 && k <= Cfg::GEO) geo_out[(size_t)n * Cfg::GEO + (k - 1)] = h[b][r];
+            }
           }
         }
         if (g == 0) {
@@ -955,16 +974,17 @@ static int set_dyn_lds(K kernel, int bytes) {
   return FNR_OK;
 }
 
-template <int NS>
+template <class Cfg, int NS>
 static int fwd_launch_bf16(const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd, int S,
                            long long N, const float2* feats, const uint8_t* selector, float* density, float* rgb,
                            float* logit, float* geo_out, float* h_buf, hipStream_t st) {
-  using Cfg = FieldCfgBase;
-  using Lds = BfLds<Cfg, SegsFwdAll<Cfg>, NS>;
+  constexpr bool WITH_SEM = Cfg::NSEM == 2;
+  using Segs = typename std::conditional<WITH_SEM, SegsFwdAll<Cfg>, SegsFwdBaseColor<Cfg>>::type;
+  using Lds = BfLds<Cfg, Segs, NS>;
   constexpr int WAVES = 8;
   constexpr int bytes = Lds::BYTES + Cfg::B_TOTAL * 4;
   static_assert(bytes <= 160 * 1024, "forward fragments exceed the LDS");
-  auto kern = k_field_mlp_fwd_bf16<Cfg, NS, WAVES>;
+  auto kern = k_field_mlp_fwd_bf16<Cfg, NS, WAVES, WITH_SEM>;
   static int once = set_dyn_lds(kern, bytes);
   if (once) return once;
   const long long n_pairs = (N + 31) / 32;
@@ -977,13 +997,17 @@ static int fwd_launch_bf16(const float* packed, const __bf16* image, const float
   return FNR_OK;
 }
 
-int field_mlp_fwd_bf16(int mode, const FieldPtrs& p, const float* packed, void* image_ws, const float* ray_bias,
+// cfg 0: `fruit_nerf` (all branches); cfg 1: `fruit_nerf_big`'s base + colour MLPs (logit untouched: the caller runs
+// field_mlp_fwd_sem_big_bf16 on the saved h afterwards)
+int field_mlp_fwd_bf16(int cfg, int mode, const FieldPtrs& p, const float* packed, void* image_ws, const float* ray_bias,
                        const RaysDev& rd, int S, long long N, const float2* feats, const uint8_t* selector, float* density,
                        float* rgb, float* logit, float* geo_out, float* h_buf, hipStream_t st) {
   __bf16* image = reinterpret_cast<__bf16*>(image_ws);  // packed by the caller (k_prepare_field)
-  if (mode == MLP_BF16)
-    return fwd_launch_bf16<1>(packed, image, ray_bias, rd, S, N, feats, selector, density, rgb, logit, geo_out, h_buf, st);
-  return fwd_launch_bf16<3>(packed, image, ray_bias, rd, S, N, feats, selector, density, rgb, logit, geo_out, h_buf, st);
+#define FNR_FWD16(C, NSV) \
+  fwd_launch_bf16<C, NSV>(packed, image, ray_bias, rd, S, N, feats, selector, density, rgb, logit, geo_out, h_buf, st)
+  if (cfg == 0) return mode == MLP_BF16 ? FNR_FWD16(FieldCfgBase, 1) : FNR_FWD16(FieldCfgBase, 3);
+  return mode == MLP_BF16 ? FNR_FWD16(FieldCfgBig, 1) : FNR_FWD16(FieldCfgBig, 3);
+#undef FNR_FWD16
 }
 
 // branch: 0 colour, 1 semantic, 2 base; cfg: 0 `fruit_nerf`, 1 `fruit_nerf_big` (its semantic branch is
