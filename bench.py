@@ -286,16 +286,11 @@ def main() -> None:
     if args.mlp_precision == "auto":
         args.mlp_precision = "bf16x3"
     # entry points that run on the bf16 pipe (their roofline peak is the dense bf16 MFMA peak) and the bf16 piece
-    # products they issue per algorithmic fp32 product.  fruit_nerf_big: the whole backward and the forward's semantic
-    # branch; its base + colour forward is fp32 MFMA, so field_mlp_fwd keeps the fp32 peak there.
+    # products they issue per algorithmic fp32 product (every method: forward and backward of all three MLPs).
     if args.mlp_precision == "bf16x3":
-        ISSUED_BF16.update({"field_mlp_bwd": 6.0})                          # (6 recompute + 3 dX + 3 dW) per (dX + dW)
-        if args.method == "fruit_nerf":
-            ISSUED_BF16.update({"field_mlp_fwd": 6.0})
+        ISSUED_BF16.update({"field_mlp_bwd": 6.0, "field_mlp_fwd": 6.0})   # bwd: (6 recompute + 3 dX + 3 dW) per (dX + dW)
     elif args.mlp_precision == "bf16":
-        ISSUED_BF16.update({"field_mlp_bwd": 1.5})
-        if args.method == "fruit_nerf":
-            ISSUED_BF16.update({"field_mlp_fwd": 1.0})
+        ISSUED_BF16.update({"field_mlp_bwd": 1.5, "field_mlp_fwd": 1.0})
     model_cfg = FruitNerfModelConfig(mlp_precision=args.mlp_precision, **M["model"])
     model = FruitModel(model_cfg, apple_metadata(), num_train_data=len(i_train), device=dev)
     model.train()
@@ -659,9 +654,7 @@ def main() -> None:
         "vs_baseline": None,
         # arithmetic type of the MLP GEMMs; hash grids, samplers, compositing, losses and the optimiser are fp32 in
         # every mode.  bf16x3 = three bf16 pieces per fp32 operand (fp32-grade results), bf16 = bf16 operands.
-        "dtype": {"fp32": "f32", "bf16x3": "f32 (MLP GEMMs: exact bf16x3 split on the bf16 MFMA pipe"
-                                                    + ("" if args.method == "fruit_nerf" else "; the base + colour "
-                                                       "forward on fp32 MFMA") + ")",
+        "dtype": {"fp32": "f32", "bf16x3": "f32 (MLP GEMMs: exact bf16x3 split on the bf16 MFMA pipe)",
                   "bf16": "bf16"}[args.mlp_precision],
         "data": "synthetic",
         "config": {"workload": f"{args.method} synthetic apple {HW}x{HW}, {N_CAMERAS} cameras ({len(i_train)} train), "

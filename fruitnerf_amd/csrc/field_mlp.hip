@@ -212,8 +212,8 @@ int field_mlp_fwd_launch(const FieldPtrs& p, const fnr_field_net* net, const Ray
   FNR_LAUNCH_CHECK();
   const long long n_tiles = (N + 15) / 16;
   const float2* f2 = reinterpret_cast<const float2*>(feats);
-  // bf16-pipe modes: every layer of the `fruit_nerf` shape; of the `fruit_nerf_big` shape the semantic branch (below and
-  // in field_mlp_bwd.hip), base and colour MLPs stay on fp32 MFMA
+  // bf16-pipe modes: every layer of both shapes (field_mlp_bf16.hip); `fruit_nerf_big` = the tile-pair kernel for base +
+  // colour, then the weight-streamed semantic branch
   if constexpr (Cfg::NSEM == 2) {
     if (net->mlp_mode != FNR_MLP_FP32)
       return field_mlp_fwd_bf16(0, net->mlp_mode, p, packed, reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset(),

@@ -287,8 +287,8 @@ __device__ __forceinline__ void store_bias_block(float* __restrict__ B, int ob, 
 }
 
 // NSF = pieces of the forward recompute, NS = pieces of the dX chain and of dW.  bf16x3 mode: NSF = 3, NS = 2 — the
-// recomputed activations decide the ReLU gates, and a gate that flips against the forward pass (fp32 MFMA for this
-// shape) changes a whole sample's contribution to a dW row: with two pieces (2^-17) that happened ~1000x more often
+// recomputed activations decide the ReLU gates, and a gate that flips against the forward pass
+// changes a whole sample's contribution to a dW row: with two pieces (2^-17) that happened ~1000x more often
 // than with three (2^-27) and single flips showed as ~5e-3 of max |g| under random zero-mean upstream gradients.
 template <class Cfg, int NSF, int NS>
 __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_sem_big_bf16(
