@@ -173,6 +173,29 @@ def test_fused_adam_run_planning():
     assert lrs["proposal_networks"] == 1e-2 and lrs["fields"] < 1e-2 and len(opt.plan_runs(lrs)) == 2
 
 
+def test_usable_cpus_respects_the_cgroup_quota(tmp_path, monkeypatch):
+    """hostinfo.usable_cpus(): the CFS quota of the container caps the hardware thread count (cgroup v2 cpu.max)."""
+    import builtins
+    import os
+    from fruitnerf_amd import hostinfo
+    n = hostinfo.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+    for text, want in (("1600000 100000\n", 16), ("max 100000\n", 256), ("150000 100000\n", 2), ("garbage", 256)):
+        def fake_open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                f = tmp_path / "cpu.max"
+                f.write_text(text)
+                return real_open(f, *a, **k)
+            if str(path).startswith("/sys/fs/cgroup/cpu/"):
+                raise OSError("no cgroup v1 here")
+            return real_open(path, *a, **k)
+        monkeypatch.setattr(builtins, "open", fake_open)
+        monkeypatch.setattr(os, "cpu_count", lambda: 256)
+        assert hostinfo.usable_cpus() == want, text
+        monkeypatch.undo()
+
+
 def test_exponential_decay_schedule():
     from fruitnerf_amd.training import exponential_decay_lr
     assert exponential_decay_lr(0, 1e-2, 1e-4, 200000) == pytest.approx(1e-2)
