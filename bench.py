@@ -12,8 +12,11 @@ backward, gradient all-reduce over RCCL (N > 1), fused Adam over all 19.4 M para
 Every rank draws its own 4096 rays (reference DDP semantics, fruit_pipeline.py:116-118) => weak scaling;
 `value` = N * K * 4096 / max-over-ranks wall time, inputs resident in HBM.
 
-Extra objects in the JSON line:  roofline (dominant kernel, HIP events on the launch stream, live in the
-timed region), cpu_baseline (the oracle's train step on the host cores, rank 0, bounded sample),
+`python bench.py --gpus N` without a launcher starts the N ranks itself (re-executes under torch.distributed.run,
+the reference's counterpart is nerfstudio's mp.spawn around fruit_pipeline.py:116-118) and fails unless N ranks run.
+
+Extra objects in the JSON line:  roofline (dominant entry point among the HBM- / MFMA-bound ones, chosen by its time
+over the timed window itself, HIP events on the launch stream), cpu_baseline (the oracle's train step on the host cores, rank 0, bounded sample),
 breakdown_ms (per entry point, from a short instrumented pass after the timed region), quality (PSNR / IoU on
 held-out views after --quality-steps more steps).
 """
@@ -36,6 +39,7 @@ from fruitnerf_amd.hostinfo import usable_cpus  # noqa: E402  (the container's C
 N_CAMERAS = 100
 TRAIN_SPLIT = 0.9              # fruitnerf_dataparser.py:62
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate over the 8 XCDs
 MFMA_F32_PEAK_TF = 157.3
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA (the roofline of --mlp-precision bf16 / bf16x3)
 # issued bf16 products per algorithmic fp32 product (set in main(): bf16x3 -> fwd 6, bwd (6 + 3 + 3) / 2 per its three
@@ -90,8 +94,10 @@ def alg_table(mlp_flop: float):
         # gradient read-modify-write + d_feats read.  (At N=1 the launch also carries the table's optimiser step: its
         # 28 B per table parameter are added per launch, see roofline_entry(fixed_bytes).)
         "hash_encode_bwd": ("hbm", 2 * 1024.0 + 128.0),
-        "prop_density_fwd": ("hbm", 320.0 + 4.0),            # 5 lvl x 8 corners x 8 B + density
-        "prop_density_bwd": ("hbm", 2 * 320.0 + 40.0 + 4.0),
+        # proposal networks: their 5.2 MB tables live in the XCDs' L2s (PMC: ~0.1 of these bytes reach the fabric), so
+        # the bytes below are L2 traffic, priced against the L2 rate — never an HBM fraction, never the `roofline` entry
+        "prop_density_fwd": ("l2", 320.0 + 4.0),             # 5 lvl x 8 corners x 8 B + density
+        "prop_density_bwd": ("l2", 2 * 320.0 + 40.0 + 4.0),
         "field_mlp_fwd": ("mfma", mlp_flop),                 # useful FLOP / sample
         "field_mlp_bwd": ("mfma", 2 * mlp_flop),             # dX + dW
         "position_grad": ("hbm", 1024.0 + 2 * 256.0 + 128.0),
@@ -108,15 +114,29 @@ FAMILIES = {
 }
 
 
-def roofline_entry(op, units, avg_ms, launches, alg, fixed_bytes=0.0, fixed_note=None):
+def load_pmc_traffic():
+    """HBM bytes per entry-point launch from the COMMITTED rocprofv3 PMC passes of this bench command
+    (profiles/pmc_traffic.json, written by tools/make_profile_summary.py from the FETCH_SIZE / WRITE_SIZE passes of
+    tools/prof_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  PMC counters cannot be read inside this
+    process; the file names the build and command it was collected from."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_entry(op, units, avg_ms, launches, alg, fixed_bytes=0.0, fixed_note=None, method="fruit_nerf", pmc=None):
     """fixed_bytes: algorithmic bytes of the launch that do not scale with `units` (the table optimiser's step when it
     runs inside hash_encode_bwd: torch.optim's 28 B per table parameter, the same figure adam_step is priced with)."""
     bound, per_unit = alg[op]
-    if bound == "hbm":
-        achieved = (per_unit * units + fixed_bytes) / (avg_ms * 1e-3) / 1e9
-        peak, unit, key = HBM_PEAK_GBS, "GB/s", "alg_bytes_per_unit"
+    if bound in ("hbm", "l2"):
+        alg_per_launch = per_unit * units + fixed_bytes
+        achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
+        peak, unit, key = (HBM_PEAK_GBS if bound == "hbm" else L2_PEAK_GBS), "GB/s", "alg_bytes_per_unit"
     else:
-        achieved = per_unit * units / (avg_ms * 1e-3) / 1e12
+        alg_per_launch = per_unit * units
+        achieved = alg_per_launch / (avg_ms * 1e-3) / 1e12
         peak, unit, key = MFMA_F32_PEAK_TF, "TFLOP/s", "alg_flop_per_unit"
     extra = {}
     if bound == "mfma":
@@ -133,12 +153,46 @@ def roofline_entry(op, units, avg_ms, launches, alg, fixed_bytes=0.0, fixed_note
     if bound == "hbm" and fixed_bytes:
         extra = {"alg_bytes_per_launch_fixed": fixed_bytes, "alg_bytes_fixed_note": fixed_note,
                  "achieved_without_fixed_bytes": round(per_unit * units / (avg_ms * 1e-3) / 1e9, 3)}
+    if bound == "l2":
+        extra = {"bound_note": "tables of this entry point are L2-resident: bytes are L2 traffic against the ~34.5 TB/s "
+                               "aggregate L2 rate, not an HBM fraction"}
+    # HBM bytes per launch: PMC counters need rocprofv3, so this is read from the committed passes of THIS command
+    # (profiles/pmc_traffic.json) and only when that file has this method / entry point / launch size
+    traffic = None
+    rec = ((pmc or {}).get("entry_points", {}).get(method, {}) or {}).get(f"{op}[{int(units)}]")
+    if rec and bound != "mfma":
+        traffic = float(rec["bytes_per_launch"])
+        extra["traffic_over_algorithmic"] = round(traffic / alg_per_launch, 3)
+        extra["traffic_source"] = (f"{pmc.get('source', 'profiles/pmc_traffic.json')}; kernels "
+                                   f"{', '.join(rec.get('kernels', []))}; build {pmc.get('build', '?')}")
+    elif rec:
+        traffic = float(rec["bytes_per_launch"])
+        extra["traffic_source"] = f"{pmc.get('source', 'profiles/pmc_traffic.json')}; build {pmc.get('build', '?')}"
     return {"kernel": op, "family": FAMILIES.get(op, op), "bound": bound, "achieved": round(achieved, 3), "peak": peak,
             "unit": unit, "frac": round(achieved / peak, 4), **extra,
-            # HBM bytes of this entry point are NOT measured inside this process (PMC counters need rocprofv3): see
-            # profiles/r02_* for the FETCH_SIZE / WRITE_SIZE passes of this command
-            "traffic": None,
+            "traffic": traffic,
             "avg_launch_ms": round(avg_ms, 5), "launches": launches, "units_per_launch": int(units), key: per_unit}
+
+
+# `roofline` candidates: entry points whose bound is one of the two rooflines of SURVEY 8d.  The proposal networks'
+# kernels work out of the L2 and are reported under breakdown_ms / roofline_l2 only.
+ROOFLINE_OPS = ("hash_encode_bwd", "hash_encode_fwd", "field_mlp_bwd", "field_mlp_fwd", "position_grad", "adam_step")
+
+
+def pick_rooflines(recs, alg, steps):
+    """Dominant (entry point, launch size) of each roofline by its TOTAL time over the timed window (`recs` = HIP-event
+    records of every ROOFLINE_OPS launch in that window) -> ((op, units), (op, units) of the other bound | None).
+    Deterministic for a given build: no separate pre-pass, ties broken by name."""
+    tot = {}
+    for op, units, ms in recs:
+        if op in ROOFLINE_OPS:
+            tot[(op, units)] = tot.get((op, units), 0.0) + ms
+    if not tot:
+        return None, None
+    order = sorted(tot, key=lambda k: (-tot[k], k))
+    first = order[0]
+    other = [k for k in order if alg[k[0]][0] != alg[first[0]][0]]
+    return first, (other[0] if other else None)
 
 
 def split_indices(n: int, frac: float):
@@ -203,37 +257,145 @@ def counting_stage_bench(dev, cpu: bool):
     return out
 
 
+class MethodRun:
+    """Model + optimisers + camera optimiser + pixel batcher of one reference method on the shared synthetic scene."""
+
+    def __init__(self, method, mlp_precision, camera_mode, dev, rank, world, data, train_ids, n_train, batch_seed=1234):
+        from fruitnerf_amd.data import synthetic_apple as sa
+        from fruitnerf_amd.data.semantics import apple_metadata
+        from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+        from fruitnerf_amd.training import FusedAdam
+        self.method, self.M, self.world, self.dev = method, METHODS[method], world, dev
+        M = self.M
+        self.rays = M["rays"]
+        self.batcher = sa.PixelBatcher(data, train_ids, seed=batch_seed + rank)   # each rank draws its own rays
+        torch.manual_seed(0)                                                    # identical initial weights on every rank
+        self.model_cfg = FruitNerfModelConfig(mlp_precision=mlp_precision, **M["model"])
+        self.model = FruitModel(self.model_cfg, apple_metadata(), num_train_data=n_train, device=dev)
+        self.model.train()
+        self.opt = FusedAdam(self.model, algorithm=M["algorithm"], group_lr={k: dict(v) for k, v in M["groups"].items()})
+        self.camera = None
+        if camera_mode != "off":
+            from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+            cm = M["camera"]
+            cam_opt = CameraOptimizerConfig(mode=camera_mode, lr=cm["lr"], eps=cm["eps"],
+                                            weight_decay=cm["weight_decay"], lr_final=cm["lr_final"],
+                                            max_steps=cm["max_steps"] or 1).setup(n_train, dev)
+            self.camera = (cam_opt, CameraAdam(cam_opt, algorithm=cm["algorithm"]), self.batcher)
+        self.step_idx = 0
+
+    def one_step(self, want_metrics=True):
+        from fruitnerf_amd.rays import RayBundle
+        from fruitnerf_amd.training import fused_train_iteration
+        o, d, cam, batch = self.batcher.sample(self.rays, self.camera[0] if self.camera else None)
+        out = fused_train_iteration(self.model, self.opt, RayBundle(o, d, None, cam), batch, self.step_idx,
+                                    world_size=self.world, want_metrics=want_metrics, camera=self.camera)
+        self.step_idx += 1
+        return out
+
+
+def timed_window(run, steps, barrier, dist_on, dev):
+    """EXACTLY `steps` training steps between barrier + synchronize on both sides, HIP events on every launch of the
+    roofline candidates -> (seconds: max over ranks, host enqueue seconds, event records, last (loss_dict, metrics))."""
+    from fruitnerf_amd import _lib as L
+    L.profile_enable(True, ops=list(ROOFLINE_OPS))
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = run.one_step()
+    t_enqueued = time.perf_counter() - t0     # host side done (launches queued); the GPU is still working
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    recs = L.profile_collect()
+    L.profile_enable(False)
+    if dist_on:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, t_enqueued, recs, last
+
+
+def rooflines_of(run, recs, steps, dist_on, pmc):
+    """`roofline` / `roofline_other_bound` objects of a timed window (see pick_rooflines)."""
+    M = run.M
+    alg = alg_table(M["mlp_flop"])
+    table = run.model.field.mlp_base_grid.hash_table
+
+    def entry(key):
+        if key is None:
+            return None
+        op, units = key
+        sel = [ms for o, u, ms in recs if o == op and u == units]
+        fixed, note = 0.0, None
+        if op == "hash_encode_bwd" and not dist_on and units == run.rays * M["samples"][2]:
+            # single process: this entry point also takes the main table's optimiser step (fnr_hash_encode_bwd_adam)
+            fixed = alg["adam_step"][1] * float(table.numel())
+            note = (f"main hash table's {M['algorithm']} step fused into this launch: {alg['adam_step'][1]:.0f} B x "
+                    f"{table.numel()} table parameters (what adam_step is priced with)")
+        e = roofline_entry(op, units, float(np.mean(sel)), len(sel), alg, fixed, note, method=run.method, pmc=pmc)
+        e["ms_per_step_in_window"] = round(float(np.sum(sel)) / steps, 5)
+        e["selection"] = "largest total time over the timed window among the HBM- / MFMA-bound entry points"
+        return e
+
+    first, other = pick_rooflines(recs, alg, steps)
+    return entry(first), entry(other)
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks under torch.distributed.run on this node (one
+    process per GPU, rendezvous on 127.0.0.1) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # RCCL across processes needs dmabuf IPC on these hosts
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--quality-steps", type=int, default=1500, help="extra training steps before the PSNR/IoU eval")
+    ap.add_argument("--quality-steps", type=int, default=-1,
+                    help="training steps before the held-out PSNR / IoU / fruit-count gate; -1 = up to the reference's "
+                         "max_num_iterations (30 000 for fruit_nerf, fruit_nerf_config.py:32; 3 000 for the bigger methods)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
+    ap.add_argument("--no-big", action="store_true", help="skip the short fruit_nerf_big run under secondary")
     ap.add_argument("--image-size", type=int, default=800)
-    ap.add_argument("--roofline-op", default="auto")
     ap.add_argument("--method", default="fruit_nerf", choices=sorted(METHODS),
                     help="reference method configuration (fruit_nerf_config.py); the headline metric is fruit_nerf")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after 1 warm-up)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU-baseline steps (BASELINE.md 2: >= 10)")
+    ap.add_argument("--cpu-warmup", type=int, default=3, help="untimed CPU-baseline steps (BASELINE.md 2: 3)")
     ap.add_argument("--cpu-rays", type=int, default=0, help="rays per CPU-baseline step (0 = the method's batch size "
                     "for fruit_nerf, 1024 for fruit_nerf_big)")
     ap.add_argument("--export-n", type=int, default=256, help="lattice side of the volume-export secondary metric")
     ap.add_argument("--mlp-precision", default="auto", choices=["auto", "fp32", "bf16x3", "bf16"],
-                    help="arithmetic of the field-MLP GEMMs (include/fruitnerf_hip.h FNR_MLP_*): auto = bf16x3 (the fastest "
-                         "parity-grade mode, FruitField's default); fp32 = exact fp32 MFMA "
-                         "chains (default, the parity path); bf16x3 = exact 3-way bf16 split on the bf16 matrix pipe "
-                         "(fp32-grade, parity-tested); bf16 = plain bf16 operands (BASELINE config 2; not parity grade)")
+                    help="arithmetic of the field-MLP GEMMs (include/fruitnerf_hip.h FNR_MLP_*): auto = bf16x3, the exact "
+                         "3-way bf16 split on the bf16 matrix pipe (fp32-grade, parity-tested; FruitField's default); "
+                         "fp32 = fp32 MFMA chains; bf16 = plain bf16 operands (BASELINE config 2; not parity grade)")
     ap.add_argument("--camera-optimizer", default="SO3xR3", choices=["off", "SO3xR3"],
                     help="the method's datamanager default (fruit_nerf_config.py:39-43): pose corrections learned from "
                          "the ray gradients; 'off' skips the input gradient of the hash grids")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))             # N ranks, each re-enters main() with RANK / WORLD_SIZE set
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but {world} rank(s) are running (WORLD_SIZE={os.environ.get('WORLD_SIZE')})")
     # host thread pools sized by the container's CPU quota (shared by the ranks of a node), not by os.cpu_count():
     # see usable_cpus() — an oversized OpenMP pool gets the whole process frozen by the CFS bandwidth controller
     torch.set_num_threads(max(1, usable_cpus() // max(world, 1)))
@@ -246,6 +408,8 @@ def main() -> None:
     backend = os.environ.get("FNR_BENCH_BACKEND", "nccl")
     if os.environ.get("FNR_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
@@ -259,15 +423,15 @@ def main() -> None:
 
     from fruitnerf_amd import _lib as L
     from fruitnerf_amd.data import synthetic_apple as sa
-    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.fruit_nerf import FruitModel
     from fruitnerf_amd.data.semantics import apple_metadata
     from fruitnerf_amd.rays import RayBundle
-    from fruitnerf_amd.training import FusedAdam, fused_train_iteration as train_iteration
 
     if dist_on and world == 1:
         import fruitnerf_amd.training as _training
         _training.EXCHANGE_MIN_WORLD = 1
     info = L.device_check()
+    pmc = load_pmc_traffic()
     HW = args.image_size
     focal = 1111.0 * HW / 800.0
 
@@ -278,8 +442,6 @@ def main() -> None:
     data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
     i_train, i_eval = split_indices(N_CAMERAS, TRAIN_SPLIT)
     train_ids = torch.as_tensor(i_train, device=dev)
-    batcher = sa.PixelBatcher(data, train_ids, seed=1234 + rank)   # each rank draws its own rays (seed + rank)
-    torch.manual_seed(0)                                           # identical initial weights on every rank
     M = METHODS[args.method]
     RAYS_PER_BATCH = M["rays"]
     ALG = alg_table(M["mlp_flop"])
@@ -291,32 +453,12 @@ def main() -> None:
         ISSUED_BF16.update({"field_mlp_bwd": 6.0, "field_mlp_fwd": 6.0})   # bwd: (6 recompute + 3 dX + 3 dW) per (dX + dW)
     elif args.mlp_precision == "bf16":
         ISSUED_BF16.update({"field_mlp_bwd": 1.5, "field_mlp_fwd": 1.0})
-    model_cfg = FruitNerfModelConfig(mlp_precision=args.mlp_precision, **M["model"])
-    model = FruitModel(model_cfg, apple_metadata(), num_train_data=len(i_train), device=dev)
-    model.train()
-    opt = FusedAdam(model, algorithm=M["algorithm"], group_lr={k: dict(v) for k, v in M["groups"].items()})
+    run = MethodRun(args.method, args.mlp_precision, args.camera_optimizer, dev, rank, world, data, train_ids, len(i_train))
+    model, opt, camera, batcher, model_cfg = run.model, run.opt, run.camera, run.batcher, run.model_cfg
     n_params = model.arena().numel
-    camera = None
-    if args.camera_optimizer != "off":
-        from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
-        cm = M["camera"]
-        cam_opt = CameraOptimizerConfig(mode=args.camera_optimizer, lr=cm["lr"], eps=cm["eps"],
-                                        weight_decay=cm["weight_decay"], lr_final=cm["lr_final"],
-                                        max_steps=cm["max_steps"] or 1).setup(len(i_train), dev)
-        camera = (cam_opt, CameraAdam(cam_opt, algorithm=cm["algorithm"]), batcher)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
-
-    step_idx = [0]
-
-    def one_step(want_metrics=True):
-        nonlocal camera
-        o, d, cam, batch = batcher.sample(RAYS_PER_BATCH, camera[0] if camera else None)
-        rb = RayBundle(o, d, None, cam)
-        out = train_iteration(model, opt, rb, batch, step_idx[0], world_size=world, want_metrics=want_metrics,
-                              camera=camera)
-        step_idx[0] += 1
-        return out
+    one_step = run.one_step
 
     def barrier():
         if dist_on:
@@ -327,46 +469,8 @@ def main() -> None:
         one_step()
     torch.cuda.synchronize()
 
-    # pick the dominant entry point from a short instrumented run (not timed)
-    roof_op = args.roofline_op
-    if roof_op == "auto":
-        L.profile_enable(True)
-        for _ in range(4):
-            one_step()
-        torch.cuda.synchronize()
-        recs = L.profile_collect()
-        L.profile_enable(False)
-        tot = {}
-        for op, units, ms in recs:
-            if op in ALG:
-                tot[(op, units)] = tot.get((op, units), 0.0) + ms
-        roof_op, roof_units = max(tot, key=tot.get) if tot else ("hash_encode_fwd", RAYS_PER_BATCH * M["samples"][2])
-        # the runner-up of the OTHER roofline (the path is mixed, report the MFMA and the HBM fraction)
-        other = {k: v for k, v in tot.items() if ALG[k[0]][0] != ALG[roof_op][0]}
-        roof2_op, roof2_units = max(other, key=other.get) if other else (None, None)
-    else:
-        roof_units = None
-        roof2_op = roof2_units = None
-
     # ---- timed region: exactly K steps -------------------------------------------------------------------
-    # two events per launch of the dominant entry point of each roofline, recorded on the launch stream
-    L.profile_enable(True, ops=[o for o in (roof_op, roof2_op) if o])
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ld, md = one_step()
-    t_enqueued = time.perf_counter() - t0     # host side done (launches queued); the GPU is still working
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    recs = L.profile_collect()
-    L.profile_enable(False)
-    if dist_on:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, t_enqueued, recs, (ld, md) = timed_window(run, args.steps, barrier, dist_on, dev)
     rays_per_s = world * args.steps * RAYS_PER_BATCH / dt
 
     if rank != 0:
@@ -377,20 +481,7 @@ def main() -> None:
         return
 
     # ---- roofline of the dominant entry point (and of the dominant one bound by the other roofline) --------------------
-    def _roof(op, want_units):
-        sel = [(u, ms) for o, u, ms in recs if o == op and (want_units is None or u == want_units)]
-        if not sel:
-            return None
-        fixed, note = 0.0, None
-        if op == "hash_encode_bwd" and not dist_on and sel[0][0] == RAYS_PER_BATCH * M["samples"][2]:
-            # single process: this entry point also takes the main table's optimiser step (fnr_hash_encode_bwd_adam)
-            fixed = ALG["adam_step"][1] * float(model.field.mlp_base_grid.hash_table.numel())
-            note = (f"main hash table's {M['algorithm']} step fused into this launch: {ALG['adam_step'][1]:.0f} B x "
-                    f"{model.field.mlp_base_grid.hash_table.numel()} table parameters (what adam_step is priced with)")
-        return roofline_entry(op, sel[0][0], float(np.mean([ms for _, ms in sel])), len(sel), ALG, fixed, note)
-
-    roofline = _roof(roof_op, roof_units)
-    roofline_other = _roof(roof2_op, roof2_units) if roof2_op else None
+    roofline, roofline_other = rooflines_of(run, recs, args.steps, dist_on, pmc)
     # whole-step fractions against both rooflines (SURVEY §8d per-ray figures): never "the path is MFMA-bound"
     whole_step = {"mfma_f32_frac": round(M["flop_per_ray_train"] * rays_per_s / world / (MFMA_F32_PEAK_TF * 1e12), 4),
                   "hbm_frac": round(M["bytes_per_ray_train"] * rays_per_s / world / (HBM_PEAK_GBS * 1e9), 4),
@@ -413,11 +504,8 @@ def main() -> None:
         breakdown[key] = breakdown.get(key, 0.0) + ms / nb
     breakdown = {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])}
 
-    # ---- quality: keep training, then PSNR / IoU on held-out views ---------------------------------------------
-    quality = None
-    if not args.no_quality and world == 1:
-        for _ in range(args.quality_steps):
-            one_step(want_metrics=False)
+    # ---- quality gate: keep training to the reference's iteration count, then PSNR / IoU on held-out views -------------
+    def heldout_quality():
         model.eval()
         psnrs, inter, union = [], 0.0, 0.0
         g = torch.Generator(device=dev)
@@ -439,8 +527,31 @@ def main() -> None:
                     inter += float((pred * msk[s:s + 32768]).sum())
                     union += float(((pred + msk[s:s + 32768]) > 0).float().sum())
         model.train()
-        quality = {"train_steps": step_idx[0], "psnr_heldout": round(float(np.mean(psnrs)), 3),
-                   "semantic_iou_heldout": round(inter / max(union, 1.0), 4),
+        return round(float(np.mean(psnrs)), 3), round(inter / max(union, 1.0), 4)
+
+    quality = None
+    if not args.no_quality and world == 1:
+        # the reference trains fruit_nerf for 30 000 iterations (fruit_nerf_config.py:32); the bigger methods (100 000
+        # iterations there) get a bounded 3 000-step look
+        target = run.step_idx + args.quality_steps if args.quality_steps >= 0 else \
+            (30000 if args.method == "fruit_nerf" else 3000)
+        marks = sorted({m for m in (2000, 10000) if run.step_idx < m < target} | {target})
+        trajectory = []
+        torch.cuda.synchronize()
+        t_q, s_q = time.perf_counter(), run.step_idx
+        for mark in marks:
+            while run.step_idx < mark:
+                ld, md = one_step(want_metrics=False)
+            psnr, iou = heldout_quality()
+            trajectory.append({"train_steps": run.step_idx, "psnr_heldout": psnr, "semantic_iou_heldout": iou})
+        torch.cuda.synchronize()
+        t_q = time.perf_counter() - t_q
+        quality = {"train_steps": run.step_idx, "psnr_heldout": trajectory[-1]["psnr_heldout"],
+                   "semantic_iou_heldout": trajectory[-1]["semantic_iou_heldout"],
+                   "reference_max_num_iterations": 30000 if args.method == "fruit_nerf" else 100000,
+                   "trajectory": trajectory,
+                   "train_rays_per_s_over_these_steps": round((run.step_idx - s_q) * RAYS_PER_BATCH / max(t_q, 1e-9), 1),
+                   "heldout": "5 held-out views x 65 536 random pixels, eval mode; IoU of sigmoid(semantics) > 0.5 vs mask",
                    "final_train_losses": {k: round(float(v), 6) for k, v in ld.items()}}
 
     # ---- secondary metrics: full-image eval rays/s and volume-export samples/s, trained weights ----
@@ -486,8 +597,8 @@ def main() -> None:
                 exp_times.append(time.perf_counter() - t1)
         exp_s = float(np.median(exp_times))
         cam_off = None
-        if camera is not None:  # the same loop without the camera optimiser (no input gradient of the hash grids)
-            saved, camera = camera, None
+        if run.camera is not None:  # the same loop without the camera optimiser (no input gradient of the hash grids)
+            saved, run.camera = run.camera, None
             for _ in range(10):
                 one_step()
             torch.cuda.synchronize()
@@ -496,7 +607,7 @@ def main() -> None:
                 one_step()
             torch.cuda.synchronize()
             cam_off = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
-            camera = saved
+            run.camera = saved
         # The headline window again on a FRESH model (same seeds, same step numbers -> same proposal update schedule)
         # with the proposal-network backward on a second HIP stream (FNR_OVERLAP_PROPOSAL_BACKWARD=1): faster, but two
         # streams share the GPU and the per-kernel timings above would no longer describe one kernel, so it is not
@@ -504,27 +615,16 @@ def main() -> None:
         import fruitnerf_amd.training as _T
 
         def headline_window(overlap: bool):
-            torch.manual_seed(0)
-            m2 = FruitModel(model_cfg, apple_metadata(), num_train_data=len(i_train), device=dev)
-            m2.train()
-            o2 = FusedAdam(m2, algorithm=M["algorithm"], group_lr={k: dict(v) for k, v in M["groups"].items()})
-            b2 = sa.PixelBatcher(data, train_ids, seed=1234 + rank)
-            c2 = None
-            if camera is not None:
-                cm = M["camera"]
-                co = CameraOptimizerConfig(mode=args.camera_optimizer, lr=cm["lr"], eps=cm["eps"],
-                                           weight_decay=cm["weight_decay"], lr_final=cm["lr_final"],
-                                           max_steps=cm["max_steps"] or 1).setup(len(i_train), dev)
-                c2 = (co, CameraAdam(co, algorithm=cm["algorithm"]), b2)
+            r2 = MethodRun(args.method, args.mlp_precision, args.camera_optimizer, dev, rank, world, data, train_ids,
+                           len(i_train))
             saved_flag, _T.OVERLAP_PROPOSAL_BACKWARD = _T.OVERLAP_PROPOSAL_BACKWARD, overlap
             try:
-                t1 = 0.0
-                for s_ in range(args.warmup + 4 + args.steps):     # + 4: the instrumented steps before the timed region
-                    if s_ == args.warmup + 4:
-                        torch.cuda.synchronize()
-                        t1 = time.perf_counter()
-                    o_, d_, cam_, batch_ = b2.sample(RAYS_PER_BATCH, c2[0] if c2 else None)
-                    train_iteration(m2, o2, RayBundle(o_, d_, None, cam_), batch_, s_, world_size=world, camera=c2)
+                for _ in range(args.warmup):
+                    r2.one_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    r2.one_step()
                 torch.cuda.synchronize()
                 return round(args.steps * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
             finally:
@@ -537,7 +637,7 @@ def main() -> None:
         mlp_modes = None
         if True:
             mlp_modes = {"note": "train rays/s, 100 steps each after 10 untimed, same model / loop as the headline, "
-                                 f"measured after step {step_idx[0]}"}
+                                 f"measured after step {run.step_idx}"}
             for mode in (("fp32", "bf16x3", "bf16") if args.method == "fruit_nerf" else ("fp32", "bf16x3")):
                 model.field.mlp_precision = mode
                 for _ in range(10):
@@ -563,7 +663,7 @@ def main() -> None:
         secondary = {"train_rays_per_s_by_proposal_backward_stream": overlap_modes,
                      "train_rays_per_s_by_mlp_precision": mlp_modes,
                      "train_rays_per_s_camera_optimizer_off": cam_off,
-                     "train_rays_per_s_camera_optimizer_off_note": f"100 steps measured after step {step_idx[0] - 100} "
+                     "train_rays_per_s_camera_optimizer_off_note": f"100 steps measured after step {run.step_idx - 100} "
                      "(proposal nets are updated less often by then than in the headline window)",
                      "eval_rays_per_s": round(HW * HW / eval_s, 1), "eval_image": f"{HW}x{HW}, chunks of 32768 rays",
                      "export_samples_per_s": round(n_rays * N_EXP / exp_s, 1), "export_lattice": f"{N_EXP}^3",
@@ -573,7 +673,40 @@ def main() -> None:
                      "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()},
                      "fruit_count_first_stage_on_semantic_export": fruit_count, "fruit_count_scene": scene.n_fruits,
                      "counting_front_end": counting}
+        if quality is not None:   # the north star's count gate: first-stage count of the exported semantic set vs the scene
+            quality["fruit_count_first_stage"] = fruit_count
+            quality["fruit_count_scene"] = scene.n_fruits
         model.train()
+
+    # ---- fruit_nerf_big (BASELINE configs 3, 5) on the same scene: a short window of the bigger method, so that its
+    # throughput and both roofline fractions are in the default line (8192 rays, 512/256/128 samples, T = 2^21, RAdam)
+    big = None
+    if args.method == "fruit_nerf" and not args.no_big and not args.no_quality and world == 1:
+        del emodel, pipe, sets
+        torch.cuda.empty_cache()
+        rb_ = MethodRun("fruit_nerf_big", args.mlp_precision, args.camera_optimizer, dev, rank, world, data, train_ids,
+                        len(i_train))
+        for _ in range(5):
+            rb_.one_step()
+        torch.cuda.synchronize()
+        nb_steps = 20
+        dt_b, enq_b, recs_b, _ = timed_window(rb_, nb_steps, barrier, dist_on, dev)
+        r_b, r_b2 = rooflines_of(rb_, recs_b, nb_steps, dist_on, pmc)
+        Mb = METHODS["fruit_nerf_big"]
+        v_b = nb_steps * Mb["rays"] / dt_b
+        big = {"metric": f"train rays/sec, fruit_nerf_big on synthetic apple {HW}x{HW}", "value": round(v_b, 1),
+               "unit": "rays/s", "steps": nb_steps, "warmup": 5, "ms_per_step": round(dt_b / nb_steps * 1e3, 4),
+               "host_enqueue_ms_per_step": round(enq_b / nb_steps * 1e3, 4),
+               "config": f"{Mb['rays']} rays/step, samples {'/'.join(map(str, Mb['samples']))}, hash 16x2^21x2, geo 30, "
+                         f"semantic MLP 3x128, fwd+bwd+radam over {rb_.model.arena().numel / 1e6:.1f} M parameters, "
+                         f"mlp_precision {args.mlp_precision}, camera optimizer {args.camera_optimizer}",
+               "roofline": r_b, "roofline_other_bound": r_b2,
+               "whole_step": {"mfma_f32_frac": round(Mb["flop_per_ray_train"] * v_b / (MFMA_F32_PEAK_TF * 1e12), 4),
+                              "hbm_frac": round(Mb["bytes_per_ray_train"] * v_b / (HBM_PEAK_GBS * 1e9), 4)}}
+        del rb_
+        torch.cuda.empty_cache()
+        if secondary is not None:
+            secondary["fruit_nerf_big"] = big
 
     # ---- CPU baseline: the oracle's training step on the host cores -------------------------------------------------
     cpu = None
@@ -606,8 +739,8 @@ def main() -> None:
             oopts.append(OptCls(ocam.parameters(), lr=6e-4, eps=1e-8, weight_decay=M["camera"]["weight_decay"]))
         gen_u = torch.Generator().manual_seed(99)
         times = []
-        n_cpu = max(1, args.cpu_steps)
-        for i in range(n_cpu + 1):
+        n_cpu, n_cpu_warm = max(1, args.cpu_steps), max(0, args.cpu_warmup)
+        for i in range(n_cpu_warm + n_cpu):
             u = torch.rand(CPU_RAYS, 3, generator=gen_u)
             t1 = time.perf_counter()
             o, d, cam, batch = cb.sample_torch(u)
@@ -626,7 +759,7 @@ def main() -> None:
             for op_ in oopts:
                 op_.step()
             om.proposal_sampler.step_cb(i)
-            if i > 0:  # first iteration = warm-up
+            if i >= n_cpu_warm:  # 3 warm-up + >= 10 timed iterations, median and min
                 times.append(time.perf_counter() - t1)
         med = float(np.median(times))
         cpu = {"value": round(CPU_RAYS / med, 1), "unit": "rays/s", "cores": ncores, "kind": "port",
@@ -634,7 +767,7 @@ def main() -> None:
                          f"{' with the SO3xR3 camera optimizer' if ocam is not None else ''}, fwd+bwd+{M['algorithm']} over "
                          f"all {n_params / 1e6:.1f} M parameters) of {CPU_RAYS} rays each"
                          f"{'' if CPU_RAYS == RAYS_PER_BATCH else f' (bounded sample of the {RAYS_PER_BATCH}-ray batch)'} "
-                         f"after 1 warm-up, oracle/ PyTorch-CPU fp32, {ncores} host threads (CPU quota of the container: "
+                         f"after {n_cpu_warm} warm-up, oracle/ PyTorch-CPU fp32, {ncores} host threads (CPU quota of the container: "
                          f"{usable_cpus()} of {os.cpu_count()} hardware threads), median {med:.2f} s/step, "
                          f"min {min(times):.2f} s/step"}
 

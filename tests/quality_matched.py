@@ -32,9 +32,24 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--steps", type=int, default=EVAL_AT[-1])
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--method", default="fruit_nerf", help="bench.py METHODS key (fruit_nerf | fruit_nerf_big | ...)")
+    ap.add_argument("--rays", type=int, default=R, help="rays per step (a bounded batch keeps the oracle side affordable)")
+    ap.add_argument("--eval-at", default=",".join(map(str, EVAL_AT)))
+    ap.add_argument("--data-cache", default="", help="torch.save / load the rendered dataset here (the analytic renderer "
+                    "takes ~8 min for 100 x 800 x 800 on 8 host cores, seconds on the GPU)")
+    ap.add_argument("--eval-pixels", type=int, default=EVAL_PIXELS, help="held-out pixels per view (5 views)")
+    ap.add_argument("--save-state", default="", help="write the final state dict (torch.save) here")
+    ap.add_argument("--load-state", default="", help="skip training: load this state dict (e.g. the oracle's trained "
+                    "weights on the hip side, for an export / count comparison on IDENTICAL weights)")
+    ap.add_argument("--count", action="store_true",
+                    help="after the last step: 128^3 volume export + first-stage fruit count of the semantic set "
+                         "(clustering_base.py:183-207) on both sides")
     args = ap.parse_args()
     from bench import METHODS, split_indices
-    M = METHODS["fruit_nerf"]
+    M = METHODS[args.method]
+    globals()["R"] = args.rays
+    globals()["EVAL_AT"] = tuple(int(x) for x in args.eval_at.split(","))
+    globals()["EVAL_PIXELS"] = args.eval_pixels
     from fruitnerf_amd.data import synthetic_apple as sa
     from oracle import camera_opt as oc
     from oracle import fruit_oracle as fo
@@ -46,17 +61,25 @@ def main():
     focal = 1111.0 * HW / 800.0
     scene = sa.make_scene(seed=0, device=dev)
     c2w = sa.make_cameras(N_CAMERAS, seed=0, device=dev)
-    data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
+    if args.data_cache and os.path.exists(args.data_cache):
+        data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in torch.load(args.data_cache).items()}
+    else:
+        data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
+        if args.data_cache:
+            torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()}, args.data_cache)
     i_train, i_eval = split_indices(N_CAMERAS, TRAIN_SPLIT)
     train_ids = torch.as_tensor(i_train, device=dev)
     n_train = len(i_train)
     torch.manual_seed(0)
-    om = fo.FruitModel(fo.FruitNerfModelConfig(), num_train_data=n_train)       # identical initial weights
+    ocfg = fo.FruitNerfModelConfig()
+    for k, v in M["model"].items():
+        setattr(ocfg, k, v)
+    om = fo.FruitModel(ocfg, num_train_data=n_train)                            # identical initial weights
     g = torch.Generator().manual_seed(2024)                                     # rays + jitter stream (CPU generator)
     ge = torch.Generator().manual_seed(7)                                       # held-out pixels
     eval_px = [(int(img), torch.randint(0, HW, (EVAL_PIXELS,), generator=ge), torch.randint(0, HW, (EVAL_PIXELS,), generator=ge))
                for img in i_eval[:5]]
-    results = {"side": args.side, "rays_per_step": R, "evals": []}
+    results = {"side": args.side, "method": args.method, "rays_per_step": R, "evals": []}
 
     if hip:
         from tests import util
@@ -66,10 +89,10 @@ def main():
         from fruitnerf_amd.training import FusedAdam, fused_train_iteration
         model = util.make_hip_like(om, dev)
         model.train()
-        opt = FusedAdam(model, group_lr={k: dict(v) for k, v in M["groups"].items()})
+        opt = FusedAdam(model, algorithm=M["algorithm"], group_lr={k: dict(v) for k, v in M["groups"].items()})
         cm = M["camera"]
         cam_opt = CameraOptimizerConfig(mode="SO3xR3", lr=cm["lr"], eps=cm["eps"], weight_decay=cm["weight_decay"],
-                                        lr_final=cm["lr_final"], max_steps=cm["max_steps"]).setup(n_train, dev)
+                                        lr_final=cm["lr_final"], max_steps=cm["max_steps"] or 1).setup(n_train, dev)
         cadam = CameraAdam(cam_opt, algorithm=cm["algorithm"])
         batcher = sa.PixelBatcher(data, train_ids, seed=0)
         batcher._set = K.ImageSetArg(data["images"], data["masks"], data["c2w"], data["fx"], data["fy"], data["cx"], data["cy"])
@@ -79,9 +102,11 @@ def main():
         ocam = oc.CameraOptimizer(n_train)
         cm = M["camera"]
         hyper = [M["groups"]["proposal_networks"], M["groups"]["fields"], cm]
-        opts = [torch.optim.Adam(groups["proposal_networks"], lr=hyper[0]["lr"], eps=1e-15),
-                torch.optim.Adam(groups["fields"], lr=hyper[1]["lr"], eps=1e-15),
-                torch.optim.Adam(ocam.parameters(), lr=cm["lr"], eps=cm["eps"], weight_decay=cm["weight_decay"])]
+        Opt = torch.optim.Adam if M["algorithm"] == "adam" else torch.optim.RAdam
+        OptC = torch.optim.Adam if cm["algorithm"] == "adam" else torch.optim.RAdam
+        opts = [Opt(groups["proposal_networks"], lr=hyper[0]["lr"], eps=1e-15),
+                Opt(groups["fields"], lr=hyper[1]["lr"], eps=1e-15),
+                OptC(ocam.parameters(), lr=cm["lr"], eps=cm["eps"], weight_decay=cm["weight_decay"])]
 
         def decay(h):   # nerfstudio ExponentialDecay without warm-up (fruit_nerf_config.py:47-56)
             return lambda s: float(np.exp(np.log(h["lr_final"] / h["lr"]) * min(s / h["max_steps"], 1.0)))
@@ -115,6 +140,75 @@ def main():
         print(json.dumps(rec), flush=True)
         with open(args.out, "w") as f:
             json.dump(results, f, indent=1)
+
+    def count_fruits():
+        """128^3 volume export of the current weights (bin-centre lattice) -> sizes of the three point sets and the
+        first-stage fruit count of the semantic set (radius-outlier removal -> voxel down-sampling -> DBSCAN ->
+        centre-distance merge, clustering_base.py:183-258; parameters as in bench.py, scaled to the lattice pitch)."""
+        N_EXP = 128
+        spacing = 2.0 / N_EXP * 2.0
+        kw = dict(nb_points=2, radius=1.8 * spacing, voxel_size=spacing / 4, eps=1.8 * spacing, min_samples=4)
+        aabb = ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
+        from fruitnerf_amd.clustering import FruitClustering
+        fc = FruitClustering(voxel_size_down_sample=kw["voxel_size"], remove_outliers_nb_points=kw["nb_points"],
+                             remove_outliers_radius=kw["radius"], cluster_merge_distance=0.04)
+        if hip:
+            import copy
+            from fruitnerf_amd.clustering import PointCloud
+            from fruitnerf_amd.data.fruit_datamanager import ExportDataManager
+            from fruitnerf_amd.data.semantics import apple_metadata
+            from fruitnerf_amd.export.exporter_utils import sample_volume
+            from fruitnerf_amd.fruit_nerf import FruitModel
+            em = FruitModel(copy.deepcopy(model.config), apple_metadata(), num_train_data=n_train, device=dev, test_mode="export")
+            em.load_state_dict(model.state_dict(), strict=True)
+            em.eval()
+
+            class _Pipe:
+                pass
+            pipe = _Pipe()
+            pipe.model, pipe.datamanager = em, ExportDataManager(dev, eval_num_rays_per_batch=32768)
+            em.setup_inference(True, N_EXP)
+            n_rays = pipe.datamanager.setup_inference(aabb=aabb, num_points=N_EXP)
+            sets = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})
+            pts = sets["semantic"]["points"]
+            count = fc.first_stage_count(PointCloud(pts, None, dev), eps=kw["eps"], min_samples=kw["min_samples"]) \
+                if pts.shape[0] >= 5 else 0
+        else:
+            from oracle import cloud as ocl
+            emo = fo.FruitModel(ocfg, num_train_data=n_train, test_mode="export")
+            emo.load_state_dict(om.state_dict(), strict=True)
+            emo.eval()
+            emo.setup_inference(True, N_EXP)
+            sets = fo.sample_volume(emo, torch.tensor(aabb), N_EXP, 32768)
+            pts = sets["semantic"]["points"].numpy()
+            count = 0
+            if pts.shape[0] >= 5:
+                X, _, labels = ocl.cluster_front_end(pts, None, kw["nb_points"], kw["radius"], kw["voxel_size"], kw["eps"],
+                                                     kw["min_samples"])
+                fc.merge_small_clusters(X, None, labels)
+                count = fc.counter - fc.fuse_counter
+        import hashlib
+        rec = {"export_lattice": f"{N_EXP}^3", "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()},
+               "export_points_sha1": {k: hashlib.sha1(np.ascontiguousarray(
+                   (v["points"].cpu().numpy() if torch.is_tensor(v["points"]) else v["points"]).astype(np.float64)).tobytes()).hexdigest()
+                   for k, v in sets.items()},
+               "fruit_count_first_stage": int(count), "fruit_count_scene": int(scene.n_fruits)}
+        results["count"] = rec
+        print(json.dumps(rec), flush=True)
+
+    if args.load_state:
+        sd = torch.load(args.load_state, map_location="cpu")
+        if hip:
+            model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+        else:
+            om.load_state_dict(sd, strict=True)
+        results["loaded_state"] = args.load_state
+        evaluate(-1)
+        if args.count:
+            count_fruits()
+        with open(args.out, "w") as f:
+            json.dump(results, f, indent=1)
+        return
 
     t0 = time.time()
     for step in range(args.steps):
@@ -150,6 +244,11 @@ def main():
         if step + 1 in EVAL_AT:
             evaluate(step + 1)
     results["train_seconds"] = round(time.time() - t0, 1)
+    if args.save_state:
+        sd = (model if hip else om).state_dict()
+        torch.save({k: v.detach().cpu() for k, v in sd.items()}, args.save_state)
+    if args.count:
+        count_fruits()
     with open(args.out, "w") as f:
         json.dump(results, f, indent=1)
 

@@ -35,6 +35,24 @@ def test_bench_runs_over_a_one_rank_rccl_group(dev):
     assert d["config"]["table_optimizer"].startswith("separate")
 
 
+def test_bench_gpus_2_starts_two_ranks(dev):
+    """`python bench.py --gpus 2` with no launcher around it must start the two ranks itself (torch.distributed.run on
+    127.0.0.1) and report them.  On the one-GPU test box the ranks share device 0 over gloo (RCCL refuses two ranks on
+    one device): FNR_BENCH_BACKEND=gloo FNR_BENCH_ONE_DEVICE=1 — the control flow, exchange path and timing protocol
+    are the N > 1 code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(FNR_BENCH_BACKEND="gloo", FNR_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-quality"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["steps"] == 4 and d["value"] > 0
+    assert d["config"]["table_optimizer"].startswith("separate")
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["kernel"] in ("hash_encode_bwd", "field_mlp_bwd")
+
+
 def test_exchange_path_step_is_the_single_process_step(dev):
     """Training steps (camera optimiser included) from identical states: the exchange path — scatter in level
     groups with an all-reduce per group, separate optimiser launches per bucket, pose gradient all-reduced — against

@@ -337,3 +337,47 @@ def test_model_is_constructed_and_driven_the_way_fruit_pipeline_and_the_trainer_
     cfg2 = FruitNerfModelConfig(log2_hashmap_size=6, use_proposal_weight_anneal=False)
     cfg2.proposal_net_args_list = cfg.proposal_net_args_list
     assert FruitModel(cfg2, metadata, num_train_data=1, device="cpu").get_training_callbacks(None) == []
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """`--gpus N` is a promise about the number of ranks: inside a launcher's environment (WORLD_SIZE set) a mismatch is
+    an error, never a silent N = 1 run that prints n_gpus: 1 (without WORLD_SIZE bench.py starts the N ranks itself:
+    tests/test_gpu_distributed.py::test_bench_gpus_2_starts_two_ranks)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-quality"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 2 but 1 rank(s)" in (out.stderr + out.stdout)
+
+
+def test_bench_roofline_bookkeeping():
+    """The `roofline` entry is the dominant HBM- / MFMA-bound entry point by total time over the timed window (ties by
+    name), the proposal networks' L2-resident kernels are never candidates, and `frac` follows from the line's own
+    numbers; `traffic` comes from the committed PMC file when it has that entry point."""
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    alg = bench.alg_table(33024.0)
+    assert alg["prop_density_bwd"][0] == "l2" and alg["prop_density_fwd"][0] == "l2"
+    recs = [("prop_density_bwd", 1048576, 0.30), ("hash_encode_bwd", 196608, 0.20), ("field_mlp_bwd", 196608, 0.16),
+            ("hash_encode_fwd", 196608, 0.09)] * 5
+    first, other = bench.pick_rooflines(recs, alg, 5)
+    assert first == ("hash_encode_bwd", 196608) and other == ("field_mlp_bwd", 196608)
+    # tie -> by name, deterministically
+    first, _ = bench.pick_rooflines([("hash_encode_fwd", 8, 1.0), ("adam_step", 8, 1.0)], alg, 1)
+    assert first == ("adam_step", 8)
+    e = bench.roofline_entry("hash_encode_bwd", 196608, 0.2, 5, alg, fixed_bytes=28.0 * 16777216, fixed_note="x")
+    want = (2176.0 * 196608 + 28.0 * 16777216) / 0.2e-3 / 1e9
+    assert abs(e["achieved"] - want) < 1e-2 and abs(e["frac"] - want / 8000.0) < 1e-4 and e["traffic"] is None
+    pmc = {"source": "s", "build": "b", "entry_points": {"fruit_nerf": {"hash_encode_bwd[196608]": {
+        "bytes_per_launch": 8.0e8, "kernels": ["k_scatter_emit", "k_scatter_accumulate"]}}}}
+    e = bench.roofline_entry("hash_encode_bwd", 196608, 0.2, 5, alg, 28.0 * 16777216, "x", pmc=pmc)
+    assert e["traffic"] == 8.0e8 and abs(e["traffic_over_algorithmic"] - 8.0e8 / (want * 0.2e-3 * 1e9)) < 1e-3
+    l2 = bench.roofline_entry("prop_density_fwd", 1048576, 0.0343, 1, alg)
+    assert l2["bound"] == "l2" and l2["peak"] == bench.L2_PEAK_GBS and l2["frac"] < 1.0

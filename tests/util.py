@@ -48,6 +48,31 @@ def fruit_nerf_big_config():
     return cfg
 
 
+def fruit_nerf_huge_config():
+    """The model part of the `fruit_nerf_huge` method at its real sizes (fruit_nerf_config.py:113-164): the big field at
+    max_res 8192, 512/512/64 samples, proposal networks 5 levels -> 512 and 7 levels -> 2048 (T = 2^17)."""
+    cfg = fruit_nerf_big_config()
+    cfg.max_res = 8192
+    cfg.num_nerf_samples_per_ray, cfg.num_proposal_samples_per_ray = 64, (512, 512)
+    cfg.proposal_net_args_list = [
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 512, "use_linear": False},
+        {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 7, "max_res": 2048, "use_linear": False},
+    ]
+    return cfg
+
+
+def smooth_tables_(model: fo.FruitModel):
+    """Give the hash tables the spectrum of a trained field: level l's entries scaled by base_res / res_l, so that every
+    level contributes the same SLOPE (a white table at max_res 4096 turns 1e-6 of sample position into 4e-3 of a
+    feature — the encoding of noise, not of a scene; trained fine levels are small corrections)."""
+    with torch.no_grad():
+        for enc in [model.field.mlp_base_grid] + [n.encoding for n in model.proposal_networks]:
+            T = enc.hash_table.shape[0] // enc.num_levels
+            for l in range(enc.num_levels):
+                enc.hash_table[l * T:(l + 1) * T].mul_(float(enc.scalings[0]) / float(enc.scalings[l]))
+    return model
+
+
 def randomize_(model: fo.FruitModel, seed: int, density_boost: float = 2.0):
     """'Trained-like' parameters: O(1) hash features, non-trivial densities and logits."""
     g = torch.Generator().manual_seed(seed)
