@@ -294,16 +294,25 @@ class MethodRun:
         return out
 
 
+PROFILE_EVERY = 4   # HIP events on the roofline candidates' launches of every 4th step of the timed window
+
+
 def timed_window(run, steps, barrier, dist_on, dev):
-    """EXACTLY `steps` training steps between barrier + synchronize on both sides, HIP events on every launch of the
-    roofline candidates -> (seconds: max over ranks, host enqueue seconds, event records, last (loss_dict, metrics))."""
+    """EXACTLY `steps` training steps between barrier + synchronize on both sides.  On every PROFILE_EVERY-th step the
+    launches of the roofline candidates are bracketed by HIP events on the launch stream (an event pair costs the GPU
+    a ~3 us bubble: all candidates on every step cost 5 % of the step, measured) -> (seconds: max over ranks, host
+    enqueue seconds, event records, profiled steps, last (loss_dict, metrics))."""
     from fruitnerf_amd import _lib as L
     L.profile_enable(True, ops=list(ROOFLINE_OPS))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
-    for _ in range(steps):
+    n_prof = 0
+    for i in range(steps):
+        on = i % PROFILE_EVERY == 0
+        L.profile_pause(not on)
+        n_prof += on
         last = run.one_step()
     t_enqueued = time.perf_counter() - t0     # host side done (launches queued); the GPU is still working
     torch.cuda.synchronize()
@@ -316,10 +325,11 @@ def timed_window(run, steps, barrier, dist_on, dev):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, t_enqueued, recs, last
+    return dt, t_enqueued, recs, n_prof, last
 
 
 def rooflines_of(run, recs, steps, dist_on, pmc):
+    # steps = the number of PROFILED steps the records come from
     """`roofline` / `roofline_other_bound` objects of a timed window (see pick_rooflines)."""
     M = run.M
     alg = alg_table(M["mlp_flop"])
@@ -338,7 +348,8 @@ def rooflines_of(run, recs, steps, dist_on, pmc):
                     f"{table.numel()} table parameters (what adam_step is priced with)")
         e = roofline_entry(op, units, float(np.mean(sel)), len(sel), alg, fixed, note, method=run.method, pmc=pmc)
         e["ms_per_step_in_window"] = round(float(np.sum(sel)) / steps, 5)
-        e["selection"] = "largest total time over the timed window among the HBM- / MFMA-bound entry points"
+        e["selection"] = (f"largest total time among the HBM- / MFMA-bound entry points over the {steps} event-timed "
+                          f"steps (every {PROFILE_EVERY}th) of the timed window")
         return e
 
     first, other = pick_rooflines(recs, alg, steps)
@@ -470,7 +481,7 @@ def main() -> None:
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps -------------------------------------------------------------------
-    dt, t_enqueued, recs, (ld, md) = timed_window(run, args.steps, barrier, dist_on, dev)
+    dt, t_enqueued, recs, n_prof, (ld, md) = timed_window(run, args.steps, barrier, dist_on, dev)
     rays_per_s = world * args.steps * RAYS_PER_BATCH / dt
 
     if rank != 0:
@@ -481,7 +492,7 @@ def main() -> None:
         return
 
     # ---- roofline of the dominant entry point (and of the dominant one bound by the other roofline) --------------------
-    roofline, roofline_other = rooflines_of(run, recs, args.steps, dist_on, pmc)
+    roofline, roofline_other = rooflines_of(run, recs, n_prof, dist_on, pmc)
     # whole-step fractions against both rooflines (SURVEY §8d per-ray figures): never "the path is MFMA-bound"
     whole_step = {"mfma_f32_frac": round(M["flop_per_ray_train"] * rays_per_s / world / (MFMA_F32_PEAK_TF * 1e12), 4),
                   "hbm_frac": round(M["bytes_per_ray_train"] * rays_per_s / world / (HBM_PEAK_GBS * 1e9), 4),
@@ -690,8 +701,8 @@ def main() -> None:
             rb_.one_step()
         torch.cuda.synchronize()
         nb_steps = 20
-        dt_b, enq_b, recs_b, _ = timed_window(rb_, nb_steps, barrier, dist_on, dev)
-        r_b, r_b2 = rooflines_of(rb_, recs_b, nb_steps, dist_on, pmc)
+        dt_b, enq_b, recs_b, n_prof_b, _ = timed_window(rb_, nb_steps, barrier, dist_on, dev)
+        r_b, r_b2 = rooflines_of(rb_, recs_b, n_prof_b, dist_on, pmc)
         Mb = METHODS["fruit_nerf_big"]
         v_b = nb_steps * Mb["rays"] / dt_b
         big = {"metric": f"train rays/sec, fruit_nerf_big on synthetic apple {HW}x{HW}", "value": round(v_b, 1),

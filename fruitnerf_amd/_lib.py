@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FNR_LIB_PATH") or os.path.join(_HERE, "lib", "libfrui
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 6      # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 7      # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -92,6 +92,7 @@ SIGNATURES = {
     "fnr_last_error": (C.c_char_p, []),
     "fnr_device_check": (_i, [P(C.c_int), C.c_char_p, _i]),
     "fnr_profile_enable": (_i, [_i, C.c_uint64]),
+    "fnr_profile_pause": (_i, [_i]),
     "fnr_profile_collect": (_i64, [P(C.c_int32), P(C.c_int64), P(C.c_float), _i64]),
     "fnr_sample_pixels": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_sample_spaced": (_i, [P(fnr_rays), _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -220,6 +221,10 @@ PROFILE_OPS = ["sample_spaced", "weights_pdf", "prop_density_fwd", "hash_encode_
 def profile_enable(on: bool, ops=None) -> None:
     mask = (1 << 64) - 1 if ops is None else sum(1 << PROFILE_OPS.index(o) for o in ops)
     check(load().fnr_profile_enable(1 if on else 0, mask), "profile_enable")
+
+
+def profile_pause(paused: bool) -> None:
+    check(load().fnr_profile_pause(1 if paused else 0), "profile_pause")
 
 
 def profile_collect(capacity: int = 1 << 20):

@@ -604,24 +604,34 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_sem_big(
   }
 }
 
-// sum the per-workgroup partial images and add them into the nn.Linear-layout gradients
+// sum the per-workgroup partial images and add them into the nn.Linear-layout gradients.  FIXED summation order and a
+// single writer per gradient entry (no float atomics: training is bit-reproducible run to run): a workgroup is
+// RD_IDX entries x RD_Y slices; slice y sums the images y, y + RD_Y, ... (8 independent loads in flight), the slices
+// meet in LDS and are added up in slice order by the thread of slice 0.
+constexpr int RD_IDX = 128, RD_Y = 8;
 template <class Cfg>
-__global__ __launch_bounds__(256) void k_reduce_dw(const float* __restrict__ partials, int nblocks, FieldPtrs grads) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __restrict__ partials, int nblocks, FieldPtrs grads) {
+  __shared__ float s_part[RD_Y][RD_IDX];
+  const int t = threadIdx.x % RD_IDX, y = threadIdx.x / RD_IDX;
+  const int idx = blockIdx.x * RD_IDX + t;
   constexpr int TOT = Cfg::W_TOTAL + Cfg::B_TOTAL;
-  if (idx >= TOT) return;
-  // blockIdx.y takes every gridDim.y-th group of 8 partial images; the <= gridDim.y results meet with atomics
   float s = 0.0f;
-  int b = 8 * blockIdx.y;
-  for (; b + 8 <= nblocks; b += 8 * gridDim.y) {  // 8 independent loads in flight (the plain loop is one HBM latency per row)
-    float v[8];
+  if (idx < TOT) {
+    int b = y;
+    for (; b + 7 * RD_Y < nblocks; b += 8 * RD_Y) {  // 8 independent loads in flight (a plain loop is one latency per row)
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u) * TOT + idx];
+      for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * RD_Y) * TOT + idx];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nblocks; b += RD_Y) s += partials[(size_t)b * TOT + idx];
   }
-  if (blockIdx.y == gridDim.y - 1)
-    for (b = nblocks & ~7; b < nblocks; ++b) s += partials[(size_t)b * TOT + idx];
+  s_part[y][t] = s;
+  __syncthreads();
+  if (y != 0 || idx >= TOT) return;
+#pragma unroll
+  for (int q = 1; q < RD_Y; ++q) s += s_part[q][t];
   if (s == 0.0f) return;
   if (idx < Cfg::W_TOTAL) {
     int l = 0;
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(256) void k_reduce_dw(const float* __restrict__ par
     const int col = kmap<Cfg>(Cfg::km(l), ib, g, r, Cfg::in_dim(l));
     if (out < Cfg::out_dim(l) && col >= 0) {
       float* dst = const_cast<float*>(grads.w[l]) + out * Cfg::in_dim(l) + col;
-      atomicAdd(dst, s);
+      *dst += s;  // sole writer of this entry
     }
   } else {
     const int bi = idx - Cfg::W_TOTAL;
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(256) void k_reduce_dw(const float* __restrict__ par
     const int o = bi - Cfg::boff(l);
     if (o < Cfg::out_dim(l)) {
       float* dst = const_cast<float*>(grads.b[l]) + o;
-      atomicAdd(dst, s);
+      *dst += s;
     }
   }
 }
@@ -914,8 +924,8 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     FNR_LAUNCH_CHECK();
   }
   constexpr int TOT = Cfg::W_TOTAL + Cfg::B_TOTAL;
-  hipLaunchKernelGGL((k_reduce_dw<Cfg>), dim3((TOT + 255) / 256, (unsigned)(blocks >= 64 ? 8 : 1)), dim3(256), 0, st,
-                     partials, (int)blocks, gp);
+  hipLaunchKernelGGL((k_reduce_dw<Cfg>), dim3((TOT + RD_IDX - 1) / RD_IDX), dim3(RD_IDX * RD_Y), 0, st, partials,
+                     (int)blocks, gp);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -718,33 +718,42 @@ __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restri
   }
 }
 
-// gradient += sum over workgroups of their partial vectors.  grid (PROP_PART / 64, PROP_RED_Y): thread = one entry,
-// blockIdx.y strides over the rows; <= PROP_RED_Y atomics per gradient address.
-__global__ __launch_bounds__(64) void k_prop_reduce(const float* __restrict__ partials, int nblocks, int K,
-                                                    float* __restrict__ g_w0, float* __restrict__ g_b0,
-                                                    float* __restrict__ g_w1, float* __restrict__ g_b1) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e > 288) return;
+// gradient += sum over workgroups of their partial vectors, in a FIXED order with one writer per entry (no float
+// atomics: bit-reproducible training).  Workgroup = 64 entries x PROP_RED_Y slices: slice y sums rows y, y + Y, ...,
+// the slices meet in LDS and slice 0 adds them up in order.
+__global__ __launch_bounds__(64 * PROP_RED_Y) void k_prop_reduce(const float* __restrict__ partials, int nblocks, int K,
+                                                                  float* __restrict__ g_w0, float* __restrict__ g_b0,
+                                                                  float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  __shared__ float s_part[PROP_RED_Y][64];
+  const int t = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + t;
   float s = 0.0f;
-  int b = blockIdx.y;
-  for (; b + 7 * (int)gridDim.y < nblocks; b += 8 * gridDim.y) {
-    float v[8];
+  if (e <= 288) {
+    int b = y;
+    for (; b + 7 * PROP_RED_Y < nblocks; b += 8 * PROP_RED_Y) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * gridDim.y) * PROP_PART + e];
+      for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * PROP_RED_Y) * PROP_PART + e];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nblocks; b += PROP_RED_Y) s += partials[(size_t)b * PROP_PART + e];
   }
-  for (; b < nblocks; b += gridDim.y) s += partials[(size_t)b * PROP_PART + e];
+  s_part[y][t] = s;
+  __syncthreads();
+  if (y != 0 || e > 288) return;
+#pragma unroll
+  for (int q = 1; q < PROP_RED_Y; ++q) s += s_part[q][t];
   if (s == 0.0f) return;
   if (e < 256) {
     const int o = e >> 4, k = e & 15;
-    if (k < K) atomicAdd(&g_w0[o * K + k], s);
+    if (k < K) g_w0[o * K + k] += s;
   } else if (e < 272) {
-    atomicAdd(&g_w1[e - 256], s);
+    g_w1[e - 256] += s;
   } else if (e < 288) {
-    atomicAdd(&g_b0[e - 272], s);
+    g_b0[e - 272] += s;
   } else {
-    atomicAdd(&g_b1[0], s);
+    g_b1[0] += s;
   }
 }
 
@@ -860,7 +869,7 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
   }
 #undef FNR_PROPB_CASE
   FNR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_prop_reduce, dim3(PROP_PART / 64, PROP_RED_Y), dim3(64), 0, as_stream(stream), partials,
+  hipLaunchKernelGGL(k_prop_reduce, dim3(PROP_PART / 64), dim3(64 * PROP_RED_Y), 0, as_stream(stream), partials,
                      (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1);
   FNR_LAUNCH_CHECK();
   return binned_scatter(&grads->grid, w, src, N, d_feats, 0, L, reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,

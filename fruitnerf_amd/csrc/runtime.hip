@@ -33,23 +33,35 @@ int device_cu_count() {
 }
 
 // ---- event timing ---------------------------------------------------------------------------------
+// Events are pooled: hipEventCreate costs ~10 us of host time, a profiled step records a dozen scopes.
 struct ProfRec {
   hipEvent_t a, b;
   int op;
   long long units;
 };
 static bool g_prof_on = false;
+static bool g_prof_paused = false;
 static unsigned long long g_prof_mask = ~0ull;
 static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static bool prof_event(hipEvent_t* e) {
+  if (!g_prof_pool.empty()) {
+    *e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return true;
+  }
+  return hipEventCreate(e) == hipSuccess;
+}
 
 ProfScope::ProfScope(int op, long long units, void* stream) : slot(-1), st(as_stream(stream)) {
-  if (!g_prof_on || !((g_prof_mask >> op) & 1ull) || g_prof.size() >= (1u << 20)) return;
+  if (!g_prof_on || g_prof_paused || !((g_prof_mask >> op) & 1ull) || g_prof.size() >= (1u << 20)) return;
   ProfRec r;
   r.op = op;
   r.units = units;
-  if (hipEventCreate(&r.a) != hipSuccess) return;
-  if (hipEventCreate(&r.b) != hipSuccess) {
-    (void)hipEventDestroy(r.a);
+  if (!prof_event(&r.a)) return;
+  if (!prof_event(&r.b)) {
+    g_prof_pool.push_back(r.a);
     return;
   }
   (void)hipEventRecord(r.a, st);
@@ -63,13 +75,19 @@ ProfScope::~ProfScope() {
 }  // namespace fnr
 
 extern "C" int fnr_profile_enable(int on, uint64_t op_mask) {
-  for (auto& r : fnr::g_prof) {
-    (void)hipEventDestroy(r.a);
-    (void)hipEventDestroy(r.b);
+  for (auto& r : fnr::g_prof) {  // back to the pool (a pending event is re-recorded by its next user)
+    fnr::g_prof_pool.push_back(r.a);
+    fnr::g_prof_pool.push_back(r.b);
   }
   fnr::g_prof.clear();
   fnr::g_prof_on = on != 0;
+  fnr::g_prof_paused = false;
   fnr::g_prof_mask = op_mask;
+  return FNR_OK;
+}
+
+extern "C" int fnr_profile_pause(int paused) {
+  fnr::g_prof_paused = paused != 0;
   return FNR_OK;
 }
 

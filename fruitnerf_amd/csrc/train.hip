@@ -123,6 +123,26 @@ __device__ __forceinline__ int searchsorted_right(const float* a, int n, float v
   return lo;
 }
 
+// A wave's contribution to a loss accumulator row (FNR_LOSS_SLOTS floats spread over 32 cache lines: same-line atomics
+// serialise).  FIXED (fnr_train_losses): the row is read as 512 64-bit words and the value is added as two's-complement
+// fixed point (2^-44 resolution, |sum| < 5e5) — integer adds commute, so the logged losses and metrics are bit-identical
+// run to run like the gradients; a non-finite value raises `flag` instead (the result is then NaN).
+constexpr double TL_FIX_SCALE = 17592186044416.0;  // 2^44
+template <bool FIXED>
+__device__ __forceinline__ void slot_add(float* __restrict__ row, int block, int wave, float v, unsigned* flag = nullptr) {
+  if constexpr (FIXED) {
+    if (!(fabsf(v) < 4.0e5f)) {  // inf / nan / absurd
+      if (flag) atomicOr(flag, 1u);
+      return;
+    }
+    const long long q = __double2ll_rn((double)v * TL_FIX_SCALE);
+    atomicAdd(reinterpret_cast<unsigned long long*>(row) + (block & 31) * 16 + wave, (unsigned long long)q);
+  } else {
+    atomicAdd(&row[(block & 31) * 32 + wave], v);
+  }
+}
+
+template <bool FIXED = false>
 __device__ __forceinline__ void interlevel_block(long long R, int S_f, const float* __restrict__ spacing_f,
                                                  const float* __restrict__ w_f, int S_p,
                                                  const float* __restrict__ spacing_p, const float* __restrict__ w_p,
@@ -130,7 +150,7 @@ __device__ __forceinline__ void interlevel_block(long long R, int S_f, const flo
                                                  int block, float* lds, int p_cap,  // lds: 4 * (3 * p_cap + 4) floats
                                                  const float* __restrict__ euclid_p = nullptr,
                                                  const float* __restrict__ density_p = nullptr,
-                                                 float* __restrict__ d_density_p = nullptr) {
+                                                 float* __restrict__ d_density_p = nullptr, unsigned* flag = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r = (long long)block * 4 + wave;
   if (r >= R) return;
@@ -182,7 +202,7 @@ __device__ __forceinline__ void interlevel_block(long long R, int S_f, const flo
   }
   lsum = wave_sum(lsum);
   // atomics to one L2 line serialise at ~12 ns each (4096 rays = ~35-50 us): 32 lines, 4 words (waves) per line
-  if (lane == 0) atomicAdd(&loss[(block & 31) * 32 + wave], lsum * scale);
+  if (lane == 0) slot_add<FIXED>(loss, block, wave, lsum * scale, flag);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   // d_wp = inclusive scan of the difference array
@@ -226,9 +246,10 @@ __global__ __launch_bounds__(256) void k_interlevel(long long R, int S_f, const 
 }
 
 // distortion_loss (metric, fruit_nerf.py:400): mean over rays of sum_ij w_i w_j |m_i - m_j| + sum_i w_i^2 ds_i / 3
+template <bool FIXED = false>
 __device__ __forceinline__ void distortion_block(long long R, int S, const float* __restrict__ spacing,
                                                  const float* __restrict__ weights, float* __restrict__ out,
-                                                 int block, float* lds, int s_cap) {  // lds: 8 * s_cap floats, s_cap >= S
+                                                 int block, float* lds, int s_cap, unsigned* flag = nullptr) {  // lds: 8 * s_cap floats, s_cap >= S
   float* s_m_all = lds;
   float* s_w_all = lds + 4 * s_cap;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -252,7 +273,7 @@ __device__ __forceinline__ void distortion_block(long long R, int S, const float
     acc += wi * inner + wi * wi * (t[i + 1] - t[i]) / 3.0f;
   }
   acc = wave_sum(acc);
-  if (lane == 0) atomicAdd(&out[(block & 31) * 32 + wave], acc / (float)R);
+  if (lane == 0) slot_add<FIXED>(out, block, wave, acc / (float)R, flag);
 }
 __global__ __launch_bounds__(256) void k_distortion(long long R, int S, const float* __restrict__ spacing,
                                                     const float* __restrict__ weights, float* __restrict__ out) {
@@ -288,12 +309,13 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
                                                       float* __restrict__ losses, int p_cap) {
   extern __shared__ float lds[];   // max(4 * (3 * p_cap + 4), 8 * S_f) floats: sized by the launch, not for 512 samples
   __shared__ bool s_last;
-  __shared__ float s_red[TL_ROWS][4];
+  __shared__ long long s_red[TL_ROWS][4];
   float* il_slots = accum;
   float* di_slots = accum + FNR_LOSS_SLOTS;
   float* rgb_slots = accum + 2 * FNR_LOSS_SLOTS;
   float* sem_slots = accum + 3 * FNR_LOSS_SLOTS;
   unsigned* cnt = reinterpret_cast<unsigned*>(accum + TL_ROWS * FNR_LOSS_SLOTS);
+  unsigned* flag = cnt + 32 * 32 + 1;  // a non-finite contribution was seen (second word of the top counter's line)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nbl = (int)((R + 255) / 256);
   const int per = (int)((R + 3) / 4);
@@ -316,17 +338,18 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
     l_rgb = wave_sum(l_rgb);
     l_sem = wave_sum(l_sem);
     if (lane == 0) {
-      atomicAdd(&rgb_slots[(blockIdx.x & 31) * 32 + wave], l_rgb);
-      atomicAdd(&sem_slots[(blockIdx.x & 31) * 32 + wave], l_sem);
+      slot_add<true>(rgb_slots, blockIdx.x, wave, l_rgb, flag);
+      slot_add<true>(sem_slots, blockIdx.x, wave, l_sem, flag);
     }
   } else {
     const int b = (int)blockIdx.x - nbl;
     const int role = b / per, local = b - role * per;
     if (role < lv.n_levels)
-      interlevel_block(R, S_f, spacing_f, w_f, lv.S_p[role], lv.spacing_p[role], lv.w_p[role], mult, il_slots,
-                       lv.d_wp[role], local, lds, p_cap, lv.euclid_p[role], lv.density_p[role], lv.d_density_p[role]);
+      interlevel_block<true>(R, S_f, spacing_f, w_f, lv.S_p[role], lv.spacing_p[role], lv.w_p[role], mult, il_slots,
+                             lv.d_wp[role], local, lds, p_cap, lv.euclid_p[role], lv.density_p[role],
+                             lv.d_density_p[role], flag);
     else
-      distortion_block(R, S_f, spacing_f, w_f, di_slots, local, lds, S_f);
+      distortion_block<true>(R, S_f, spacing_f, w_f, di_slots, local, lds, S_f, flag);
   }
   // Completion count WITHOUT __threadfence(): an agent-scope release fence writes the XCD's L2 back (this kernel's
   // outputs are dirty there) and 3000 workgroups doing that cost 100 us.  The slot sums are agent-scope atomics, performed
@@ -343,21 +366,28 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
   }
   __syncthreads();
   if (!s_last) return;
-  float acc[TL_ROWS] = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (int i = threadIdx.x; i < FNR_LOSS_SLOTS; i += 256)
+  // the rows hold 64-bit fixed point (slot_add<true>): integer sums, any order
+  long long acc[TL_ROWS] = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < FNR_LOSS_SLOTS / 2; i += 256)
 #pragma unroll
     for (int q = 0; q < TL_ROWS; ++q)
-      acc[q] += __hip_atomic_load(accum + q * FNR_LOSS_SLOTS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc[q] += (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(accum + q * FNR_LOSS_SLOTS) + i,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int q = 0; q < TL_ROWS; ++q) {
-    acc[q] = wave_sum(acc[q]);
+#pragma unroll
+    for (int dsh = 32; dsh >= 1; dsh >>= 1) acc[q] += __shfl_xor(acc[q], dsh, 64);
     if (lane == 0) s_red[q][wave] = acc[q];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    const bool bad = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     float t[TL_ROWS];
 #pragma unroll
-    for (int q = 0; q < TL_ROWS; ++q) t[q] = (s_red[q][0] + s_red[q][1]) + (s_red[q][2] + s_red[q][3]);
+    for (int q = 0; q < TL_ROWS; ++q) {
+      const long long tot = (s_red[q][0] + s_red[q][1]) + (s_red[q][2] + s_red[q][3]);
+      t[q] = bad ? __builtin_nanf("") : (float)((double)tot / TL_FIX_SCALE);
+    }
     const float mse = t[2] * inv3r;
     losses[0] = mse;
     losses[1] = sem_weight * t[3] * invr;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 6
+#define FNR_ABI_VERSION 7
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -136,6 +136,9 @@ int fnr_device_check(int* cu_count_out, char* name_out, int name_len);
  * 5 field_mlp_fwd, 6 composite_fwd, 7 losses_fwd, 8 interlevel_fwd, 9 distortion, 10 composite_bwd,
  * 11 weights_bwd, 12 field_mlp_bwd, 13 hash_encode_bwd, 14 prop_density_bwd, 15 adam_step, 16 export_compact. */
 int fnr_profile_enable(int on, uint64_t op_mask);
+/* paused != 0: entry points stop recording events but the records collected so far are kept (bench.py times every
+ * fourth step of its timed window: each event pair costs the GPU a ~3 us bubble). */
+int fnr_profile_pause(int paused);
 int64_t fnr_profile_collect(int32_t* ops_host, int64_t* units_host, float* ms_host, int64_t capacity);
 
 /* ---- caller side: pixel sampling + ray generation --------------------------------------------- */

@@ -1,0 +1,68 @@
+"""Training on the HIP path is bit-reproducible: the reference's CPU path is deterministic, and so is this one — every
+sum that crosses workgroups has a fixed order (per-workgroup partial images reduced by a single writer:
+k_reduce_dw / k_prop_reduce; the hash-grid scatter adds 64-bit fixed-point values, which commute; pose and embedding
+gradients gather their rays by ballot)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, steps, mlp_precision, overlap=False):
+    import fruitnerf_amd.training as T
+    from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+    from fruitnerf_amd.data import synthetic_apple as sa
+    from fruitnerf_amd.data.semantics import apple_metadata
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    from fruitnerf_amd.rays import RayBundle
+    HW, focal, n_train = 96, 1111.0 * 96 / 800, 40
+    scene = sa.make_scene(seed=0, device=dev)
+    c2w = sa.make_cameras(n_train, seed=0, device=dev)
+    data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
+    batcher = sa.PixelBatcher(data, torch.arange(n_train, device=dev), seed=1)
+    torch.manual_seed(0)
+    hm = FruitModel(FruitNerfModelConfig(mlp_precision=mlp_precision), apple_metadata(), num_train_data=n_train, device=dev)
+    hm.train()
+    opt = T.FusedAdam(hm)
+    cam_opt = CameraOptimizerConfig(mode="SO3xR3").setup(n_train, dev)
+    camera = (cam_opt, CameraAdam(cam_opt), batcher)
+    saved, T.OVERLAP_PROPOSAL_BACKWARD = T.OVERLAP_PROPOSAL_BACKWARD, overlap
+    losses = []
+    try:
+        for step in range(steps):
+            o, d, cam, batch = batcher.sample(4096, cam_opt)
+            ld, md = T.fused_train_iteration(hm, opt, RayBundle(o, d, None, cam), batch, step, camera=camera)
+            if step % 20 == 19 or step == steps - 1:
+                losses.append(torch.stack([ld["rgb_loss"], ld["semantics_loss"], ld["interlevel_loss"], md["psnr"],
+                                           md["distortion"]]).clone())
+    finally:
+        T.OVERLAP_PROPOSAL_BACKWARD = saved
+    torch.cuda.synchronize()
+    return (hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), cam_opt.pose_adjustment.data.clone(),
+            torch.stack(losses))
+
+
+@pytest.mark.parametrize("mlp_precision", ["bf16x3", "fp32"])
+def test_two_training_runs_from_one_seed_end_bit_identical(dev, mlp_precision):
+    """200 full training steps (4096 rays, SO3xR3 camera optimiser, proposal-network updates, fused table optimiser)
+    twice from the same seeds: every parameter, both Adam moments, the camera poses and the logged losses / metrics
+    are bit-identical."""
+    a = _run(dev, 200, mlp_precision)
+    b = _run(dev, 200, mlp_precision)
+    names = ("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics")
+    for name, x, y in zip(names, a, b):
+        n_diff = int((x != y).sum())
+        print(f"[determinism {mlp_precision}] {name}: {n_diff} of {x.numel()} entries differ "
+              f"(max abs diff {float((x - y).abs().max()):.3e})")
+    for name, x, y in zip(names, a, b):
+        assert torch.equal(x, y), f"{name} differ between two runs from one seed"
+    assert float(a[4][-1][0]) < 5e-3, "the runs did train"
+
+
+def test_second_stream_run_is_bit_identical_too(dev):
+    """The proposal-network backward on a second HIP stream (FNR_OVERLAP_PROPOSAL_BACKWARD) changes the interleaving of
+    kernels, not the arithmetic."""
+    a = _run(dev, 60, "bf16x3", overlap=False)
+    b = _run(dev, 60, "bf16x3", overlap=True)
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)

@@ -100,11 +100,13 @@ def test_eval_outputs_at_a_trained_state_meet_the_output_bar(dev, shape):
     R = 4096
     o, d, cam, batch = batcher.sample(R)
     hm.eval()
-    with torch.no_grad():
+    hm.set_anneal(steps)         # the sampler keeps the exponent its last BEFORE_TRAIN_ITERATION callback set
+    with torch.no_grad():        # (fruit_nerf_big anneals over 5000 iterations: 0.76 here, not the constructor's 1.0)
         hout = hm(RayBundle(o, d, None, cam))
     torch.cuda.synchronize()
     om = _oracle_of(hm, ocfg, n_train)
     om.eval()
+    om.set_anneal(steps)
     with torch.no_grad():
         oout = om(ns.RayBundle(o.cpu(), d.cpu(), torch.ones(R, 1), camera_indices=cam.cpu().long()))
     ctx = hout["_ctx"]
@@ -166,8 +168,8 @@ def test_eval_outputs_at_a_trained_state_meet_the_output_bar(dev, shape):
               f"level-1/2 spacing-bin error {worst_bin[1][r].item():.2e} / {worst_bin[2][r].item():.2e}")
     # Residual: a ray is off only where a last-bit difference of a proposal density moved a PDF sample
     # across a density jump of orders of magnitude — the reference on another CPU / BLAS shows the same noise.
-    assert frac_ok >= 0.99, f"only {frac_ok:.4%} of the rays within {BAR:g} end to end"
-    assert worst.median().item() <= 2e-6
+    assert frac_ok >= 0.995, f"only {frac_ok:.4%} of the rays within {BAR:g} end to end"
+    assert worst.median().item() <= 5e-6 and worst.max().item() <= 5e-3
     hm.train()
 
 

@@ -153,12 +153,11 @@ def test_losses_and_all_gradients_at_the_real_configuration(dev, shape, step, ta
     for k in ("rgb", "semantics", "accumulation"):
         err = (hout[k].detach().cpu() - out[k].detach()).abs().max().item()
         print(f"[real {shape} step={step} {tables}] output {k}: max abs err {err:.3e}")
-        assert err <= (1e-4 if tables == "smooth" else 1e-3), k
+        assert err <= 1e-5, k            # measured 1e-6 (round 3): an order inside the 1e-4 bar
     worst, worst_agg = _grad_report(om, hm, f" real {shape} step={step} {tables}", with_aggregate=True)
-    if tables == "smooth":
-        assert worst <= 2e-2 and worst_agg <= 2e-3, f"gradient error: max-norm {worst}, L1 {worst_agg}"
-    else:
-        assert worst <= 1e-1 and worst_agg <= 1e-2, f"gradient error: max-norm {worst}, L1 {worst_agg}"
+    # measured (round 3, bf16x3 default): max-norm <= 1e-4, L1 <= 5e-5 on all four legs — the round-1 bar of 5e-4 holds
+    # at the real sizes for white and smooth tables alike
+    assert worst <= 5e-4 and worst_agg <= 2e-4, f"gradient error: max-norm {worst}, L1 {worst_agg}"
 
 
 def test_adam_matches_torch(dev):
