@@ -378,9 +378,11 @@ def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weig
 
 
 def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, h_saved,
-                  selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor) -> Tensor:
+                  selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor, jacobian: Optional[Tensor] = None):
     """h_saved: what field_mlp_fwd(want_h=True) returned — (h [N,16], ray_bias [R,64], packed weights); a bare h tensor
-    is accepted too (the per-ray bias and the fragment image are then recomputed)."""
+    is accepted too (the per-ray bias and the fragment image are then recomputed).
+    jacobian (hash_encode_fwd(want_jacobian=True)): -> (d_feats, d_position [N,4]): the hash grid's input gradient per
+    sample rides along (fnr_field_mlp_bwd_rays); position_grad_reduce(..., d_position.view(1, N, 4), ...) finishes it."""
     lib = L.load()
     fwd_mode = h_saved[3] if isinstance(h_saved, tuple) and len(h_saved) > 3 else None
     h_saved, ray_bias, packed = (tuple(h_saved) + (None, None))[:3] if isinstance(h_saved, tuple) else (h_saved, None, None)
@@ -391,6 +393,13 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
     d_feats = torch.empty_like(feats)
     nbytes = lib.fnr_field_mlp_bwd_workspace_bytes(rays.n, S)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if jacobian is not None:
+        d_pos = torch.empty(N, 4, device=dev)
+        L.check(lib.fnr_field_mlp_bwd_rays(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
+                                           L.ptr(ray_bias), L.ptr(packed), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb),
+                                           L.ptr(d_logit), L.ptr(d_feats), L.ptr(jacobian), L.ptr(d_pos), L.ptr(ws), nbytes,
+                                           L.stream_ptr(dev)), "field_mlp_bwd_rays")
+        return d_feats, d_pos
     L.check(lib.fnr_field_mlp_bwd(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
                                   L.ptr(ray_bias), L.ptr(packed), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(ws), nbytes,
                                   L.stream_ptr(dev)), "field_mlp_bwd")

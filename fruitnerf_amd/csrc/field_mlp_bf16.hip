@@ -831,11 +831,17 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_sem_coop(
 }
 
 // ---- base branch -----------------------------------------------------------------------------------------------------
-template <class Cfg, int NSF, int NS>
+// POSGRAD: the input gradient of the hash grid rides along (camera-pose optimisation, fruit_nerf_config.py:39-43).  The
+// forward encode saved J = d feats / d(unit-cube position) [L][3][N] float2; this kernel holds dL/dfeats of its samples
+// in registers (lane (g, j): levels g, 4 + g, 8 + g, 12 + g of sample j), so it contracts them with J right here —
+// d_pos [N] float4 = sum over levels and features of dL/dfeat * J — instead of a separate launch that re-reads d_feats
+// and waits 91 % of its cycles on 64 dependent loads per lane (k_position_from_jacobian: 32 us per 196 608 samples).
+template <class Cfg, int NSF, int NS, bool POSGRAD>
 __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
     const float* __restrict__ packed, const __bf16* __restrict__ image, long long N, const float2* __restrict__ feats,
     const uint8_t* __restrict__ selector, const float* __restrict__ d_density, const float* __restrict__ d_h,
-    float2* __restrict__ d_feats, float* __restrict__ partials) {
+    float2* __restrict__ d_feats, float* __restrict__ partials, const float2* __restrict__ jac,
+    float4* __restrict__ d_pos) {
   constexpr int HB = Cfg::HB;
   static_assert(HB == 1 || HB == 2, "built shapes");
   constexpr int THREADS = 512;  // 8 waves
@@ -901,6 +907,13 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
     cs_write<NS, 4, CB_ROWS>(sG, 0, Ga, lane, wave);
     cs_write<NS, 2, CB_ROWS>(sX, 0, x0, lane, wave);
     __syncthreads();
+    float2 jv[POSGRAD ? 12 : 1];
+    if constexpr (POSGRAD) {  // issued before the dW round and the last dX layer: consumed after them
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) jv[3 * m + a] = jac[((size_t)(4 * m + g) * 3 + a) * N + nn];
+    }
     cs_dw<NS, 1, CB_ROWS>(sG, sX, wave >> 1, 0, wave & 1, accA, lane);
     if (wave >= 4) cs_bias<NS, CB_ROWS>(sG, wave - 4, bA, lane);
     f32x4 Gx[2];
@@ -909,6 +922,21 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
 #pragma unroll
       for (int m = 0; m < 4; ++m)
         d_feats[(size_t)(4 * m + g) * N + n] = make_float2(Gx[m >> 1][2 * (m & 1)], Gx[m >> 1][2 * (m & 1) + 1]);
+    }
+    if constexpr (POSGRAD) {
+      float gp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float gx = Gx[m >> 1][2 * (m & 1)], gy = Gx[m >> 1][2 * (m & 1) + 1];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gp[a] += gx * jv[3 * m + a].x + gy * jv[3 * m + a].y;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {  // the four level groups of a sample sit 16 lanes apart
+        gp[a] += __shfl_xor(gp[a], 16, 64);
+        gp[a] += __shfl_xor(gp[a], 32, 64);
+      }
+      if (valid && g == 0) d_pos[n] = make_float4(gp[0], gp[1], gp[2], 0.0f);
     }
   }
   const int lane = lane0;
@@ -925,7 +953,7 @@ static int bwd_launch_coop(const float* packed, const __bf16* image, const float
                            long long N, const float2* feats, const float* h_saved, const uint8_t* selector,
                            const float* d_density, const float* d_rgb, const float* d_logit, float2* d_feats, float* d_h,
                            float* gsum_tile, float* gsum_extra, float* partials, long long blocks, int branch,
-                           hipStream_t st) {
+                           hipStream_t st, const float2* jac = nullptr, float4* d_pos = nullptr) {
   // exactly `blocks` workgroups: every one of the caller's partial images must receive this branch's blocks (a
   // workgroup without a batch stores zeros)
   auto attr = [](auto kern, int bytes) -> int {
@@ -957,11 +985,19 @@ static int bwd_launch_coop(const float* packed, const __bf16* image, const float
     using CL = CoopLds<Cfg, SegsBaseF<Cfg>, SegsBaseT<Cfg>, NSF, NS>;
     constexpr int bytes = CL::FB_OFF + (64 + 16 * Cfg::HB) * 4;
     static_assert(bytes <= 160 * 1024, "base branch exceeds the LDS");
-    auto kern = k_field_mlp_bwd_base_coop<Cfg, NSF, NS>;
-    static int once = attr(kern, bytes);
-    if (once) return once;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, feats, selector, d_density, d_h,
-                       d_feats, partials);
+    if (jac && d_pos) {
+      auto kern = k_field_mlp_bwd_base_coop<Cfg, NSF, NS, true>;
+      static int once = attr(kern, bytes);
+      if (once) return once;
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, feats, selector, d_density,
+                         d_h, d_feats, partials, jac, d_pos);
+    } else {
+      auto kern = k_field_mlp_bwd_base_coop<Cfg, NSF, NS, false>;
+      static int once = attr(kern, bytes);
+      if (once) return once;
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, feats, selector, d_density,
+                         d_h, d_feats, partials, jac, d_pos);
+    }
   }
   FNR_LAUNCH_CHECK();
   return FNR_OK;
@@ -1016,7 +1052,7 @@ int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool p
                        const float* ray_bias, const RaysDev& rd, int S, long long N, const float2* feats,
                        const float* h_saved, const uint8_t* selector, const float* d_density, const float* d_rgb,
                        const float* d_logit, float2* d_feats, float* d_h, float* gsum_tile, float* gsum_extra,
-                       float* partials, long long blocks, hipStream_t st) {
+                       float* partials, long long blocks, hipStream_t st, const float2* jac, float4* d_pos) {
   __bf16* image = reinterpret_cast<__bf16*>(image_ws);
   if (pack) {
     if (cfg == 0)
@@ -1028,15 +1064,15 @@ int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool p
   if (cfg == 1) {
     if (mode == MLP_BF16)
       return bwd_launch_coop<FieldCfgBig, 1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
-                                                d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+                                                d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st, jac, d_pos);
     return bwd_launch_coop<FieldCfgBig, 3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
-                                              d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+                                              d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st, jac, d_pos);
   }
   if (mode == MLP_BF16)
     return bwd_launch_coop<FieldCfgBase, 1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
-                                               d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+                                               d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st, jac, d_pos);
   return bwd_launch_coop<FieldCfgBase, 3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
-                                             d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st);
+                                             d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st, jac, d_pos);
 }
 
 size_t field_bf16_image_bytes() {

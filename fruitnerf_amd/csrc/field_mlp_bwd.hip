@@ -790,7 +790,9 @@ int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool p
                        const float* ray_bias, const RaysDev& rd, int S, long long N, const float2* feats,
                        const float* h_saved, const uint8_t* selector, const float* d_density, const float* d_rgb,
                        const float* d_logit, float2* d_feats, float* d_h, float* gsum_tile, float* gsum_extra,
-                       float* partials, long long blocks, hipStream_t st);
+                       float* partials, long long blocks, hipStream_t st, const float2* jac = nullptr,
+                       float4* d_pos = nullptr);
+int position_contract(long long N, int n_levels, const float2* jac, const float2* d_feats, float4* d_pos, hipStream_t st);
 int field_mlp_bwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, const float* packed, long long N,
                                const float* h_saved, const float* d_logit, float* partials, long long blocks,
                                hipStream_t st);
@@ -834,7 +836,10 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                          const RaysDev& rd, int S, long long N, const float* feats, const float* h_saved,
                          const float* ray_bias_saved, const float* packed_saved, const uint8_t* selector,
                          const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
-                         const BwdWorkspace& ws, hipStream_t st) {
+                         const BwdWorkspace& ws, hipStream_t st, const float* jacobian = nullptr,
+                         float* d_position = nullptr) {
+  const float2* jac = reinterpret_cast<const float2*>(jacobian);
+  float4* d_pos = reinterpret_cast<float4*>(d_position);
   const long long n_tiles = (N + 15) / 16;
   const long long max_blocks = device_cu_count();
   float* partials = ws.partials;
@@ -899,12 +904,13 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     int rc = field_mlp_bwd_sem_big_bf16(mode, p, bf16_image, packed, N, h_saved, d_logit, partials, blocks, st);
     if (rc) return rc;
     rc = field_mlp_bwd_bf16(cfg_id, mode, 2, p, false, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector, d_density,
-                            d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
+                            d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st, jac, d_pos);
     if (rc) return rc;
   } else if (bf_all) {
     for (int branch = 1; branch <= 2; ++branch) {
       const int rc = field_mlp_bwd_bf16(cfg_id, mode, branch, p, false, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
-                                        d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
+                                        d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st,
+                                        branch == 2 ? jac : nullptr, branch == 2 ? d_pos : nullptr);
       if (rc) return rc;
     }
   } else if constexpr (Cfg::NSEM == 2) {
@@ -927,6 +933,8 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
   hipLaunchKernelGGL((k_reduce_dw<Cfg>), dim3((TOT + RD_IDX - 1) / RD_IDX), dim3(RD_IDX * RD_Y), 0, st, partials,
                      (int)blocks, gp);
   FNR_LAUNCH_CHECK();
+  // fp32 chains: their base-branch kernel does not carry the contraction with the encode's Jacobian
+  if (jac && d_pos && !bf_all) return position_contract(N, net->grid.n_levels, jac, df2, d_pos, st);
   return FNR_OK;
 }
 }  // namespace
@@ -936,10 +944,11 @@ extern "C" size_t fnr_field_mlp_bwd_workspace_bytes(int64_t n_rays, int S) {
   return bwd_workspace(nullptr, n_rays, S).bytes;
 }
 
-extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
+static int field_mlp_bwd_entry(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
                                  const float* feats, const float* h_saved, const float* ray_bias_saved,
                                  const float* packed_saved, const uint8_t* selector, const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 void* workspace, size_t workspace_bytes, void* stream, const float* jacobian,
+                               float* d_position) {
   FNR_CHECK_ARG(net && grads && rays && feats && h_saved && d_density && d_rgb && d_logit && d_feats && workspace && S > 0,
                 "field_mlp_bwd: null argument");
   FNR_CHECK_ARG(rays->directions && rays->camera_indices && net->embedding && grads->embedding,
@@ -962,7 +971,26 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
   FNR_PROF(OP_MLP_BWD, N);
   if (cfg == 0)
     return field_mlp_bwd_launch<FieldCfgBase>(p, gp, net, grads, rd, S, N, feats, h_saved, ray_bias_saved, packed_saved,
-                                              selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream));
+                                              selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream), jacobian, d_position);
   return field_mlp_bwd_launch<FieldCfgBig>(p, gp, net, grads, rd, S, N, feats, h_saved, ray_bias_saved, packed_saved,
-                                           selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream));
+                                           selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream), jacobian, d_position);
+}
+
+extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
+                                 const float* feats, const float* h_saved, const float* ray_bias_saved,
+                                 const float* packed_saved, const uint8_t* selector, const float* d_density,
+                                 const float* d_rgb, const float* d_logit, float* d_feats, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
+                             d_logit, d_feats, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int fnr_field_mlp_bwd_rays(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
+                                      const float* feats, const float* h_saved, const float* ray_bias_saved,
+                                      const float* packed_saved, const uint8_t* selector, const float* d_density,
+                                      const float* d_rgb, const float* d_logit, float* d_feats, const float* jacobian,
+                                      float* d_position, void* workspace, size_t workspace_bytes, void* stream) {
+  FNR_CHECK_ARG(jacobian && d_position, "field_mlp_bwd_rays: jacobian / d_position missing");
+  return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
+                             d_logit, d_feats, workspace, workspace_bytes, stream, jacobian, d_position);
 }

@@ -142,6 +142,52 @@ __global__ __launch_bounds__(256) void k_position_reduce(Warp warp, RaysDev rays
   }
 }
 
+// g[a] = sum over levels l (in level order) of gf_l . J_l[a].  The loads of 8 levels are issued before the first use: the
+// plain loop waited for one level's four loads at a time (SQ_WAIT_ANY 0.91 of the kernel's wave-cycles).
+__device__ __forceinline__ void contract_jacobian(const float2* __restrict__ jac, const float2* __restrict__ d_feats,
+                                                  long long N, long long n, int n_levels, float (&g)[3]) {
+  g[0] = g[1] = g[2] = 0.0f;
+  int l = 0;
+  for (; l + 8 <= n_levels; l += 8) {
+    float2 gf[8], j[8][3];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      gf[u] = d_feats[(size_t)(l + u) * N + n];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) j[u][a] = jac[((size_t)(l + u) * 3 + a) * N + n];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[a] += gf[u].x * j[u][a].x + gf[u].y * j[u][a].y;
+  }
+  for (; l < n_levels; ++l) {
+    const float2 gf = d_feats[(size_t)l * N + n];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float2 j = jac[((size_t)l * 3 + a) * N + n];
+      g[a] += gf.x * j.x + gf.y * j.y;
+    }
+  }
+}
+
+// thread = sample: d_pos [N] float4 = the contraction alone (fnr_field_mlp_bwd_rays in fp32 mode; the bf16-pipe base
+// kernel forms it from the dL/dfeats it holds in registers)
+__global__ __launch_bounds__(256) void k_position_contract(long long N, int n_levels, const float2* __restrict__ jac,
+                                                           const float2* __restrict__ d_feats, float4* __restrict__ d_pos) {
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float g[3];
+  contract_jacobian(jac, d_feats, N, n, n_levels, g);
+  d_pos[n] = make_float4(g[0], g[1], g[2], 0.0f);
+}
+
+int position_contract(long long N, int n_levels, const float2* jac, const float2* d_feats, float4* d_pos, hipStream_t st) {
+  hipLaunchKernelGGL(k_position_contract, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, n_levels, jac, d_feats, d_pos);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
 // wave = ray, lane = sample: d(loss)/d(unit-cube position) = sum over levels and features of gf * J, with the input
 // Jacobian J [L][3][N] float2 (axis-major, feature pair) saved by the forward encode — no table gathers in the
 // backward pass; then the same warp / frustum chain as k_position_reduce.
@@ -159,15 +205,8 @@ __global__ __launch_bounds__(256) void k_position_from_jacobian(Warp warp, RaysD
   float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
   for (int k = lane; k < S; k += 64) {
     const long long n = r * S + k;
-    float g[3] = {0.f, 0.f, 0.f};
-    for (int l = 0; l < n_levels; ++l) {
-      const float2 gf = d_feats[(size_t)l * N + n];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float2 j = jac[((size_t)l * 3 + a) * N + n];
-        g[a] += gf.x * j.x + gf.y * j.y;
-      }
-    }
+    float g[3];
+    contract_jacobian(jac, d_feats, N, n, n_levels, g);
     const float* b = euclid + r * (S + 1) + k;
     const float tm = (b[0] + b[1]) * 0.5f;
     float p[3];

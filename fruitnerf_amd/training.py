@@ -35,11 +35,18 @@ def _anchor(model) -> Tensor:
     return a
 
 
-def _field_ray_grads(model, rctx, d_feats: Tensor, d_origins: Tensor, d_directions: Tensor) -> None:
+def _field_ray_grads(model, rctx, d_feats: Tensor, d_origins: Tensor, d_directions: Tensor,
+                     d_position: Optional[Tensor] = None) -> None:
     """d(loss)/d(ray origins, directions) through the main field's hash grid (position_grad.hip): the only path from
-    the losses to the rays — PDFSampler detaches its bins, SHEncoding runs under no_grad."""
+    the losses to the rays — PDFSampler detaches its bins, SHEncoding runs under no_grad.
+    d_position [N,4]: the per-sample input gradient field_mlp_bwd(jacobian=...) already formed — only the warp /
+    frustum chain and the sum over each ray are left."""
     fld = model.field
     lv = rctx.levels[-1]
+    if d_position is not None:
+        K.position_grad_reduce(fld.warp_struct(), rctx.rays, lv["euclid"], lv["S"], d_position.view(1, -1, 4), d_origins,
+                               d_directions)
+        return
     if rctx.field_jacobian is not None:   # saved by the forward encode: no table gathers here
         K.position_grad_from_jacobian(fld.warp_struct(), rctx.rays, lv["euclid"], lv["S"], rctx.field_jacobian, d_feats,
                                       d_origins, d_directions)
@@ -84,14 +91,23 @@ class _RenderFn(torch.autograd.Function):
                                                     rctx.weights, g_rgb.contiguous(), g_sem.contiguous())
         fld = model.field
         net, gnet = fld.net_struct(), fld.net_struct(grads=True)
-        d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density, d_rgb,
-                                  d_logit)
-        K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, lv["euclid"], S, d_feats)
+        want_rays = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        d_pos = None
+        if want_rays and rctx.field_jacobian is not None:
+            d_feats, d_pos = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector,
+                                             d_density, d_rgb, d_logit, jacobian=rctx.field_jacobian)
+        else:
+            d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
+                                      d_rgb, d_logit)
         d_o = d_d = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if want_rays:
             d_o = torch.zeros(rays.n, 3, device=dev)
             d_d = torch.zeros(rays.n, 3, device=dev)
-            _field_ray_grads(model, rctx, d_feats, d_o, d_d)
+            if d_pos is None:   # no saved Jacobian: the gather path reads the table, so it runs BEFORE any table update
+                _field_ray_grads(model, rctx, d_feats, d_o, d_d)
+        K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, lv["euclid"], S, d_feats)
+        if d_pos is not None:
+            _field_ray_grads(model, rctx, d_feats, d_o, d_d, d_pos)
         return None, d_o, d_d, None, None, None
 
 
@@ -535,8 +551,24 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                                                       rctx.weights, d_rgb, d_sem)
         fld = model.field
         net, gnet = fld.net_struct(), fld.net_struct(grads=True)
-        d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
-                                  d_rgb_s, d_logit)
+        d_pos = None
+        if ray_grads is not None and rctx.field_jacobian is not None:
+            d_feats, d_pos = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector,
+                                             d_density, d_rgb_s, d_logit, jacobian=rctx.field_jacobian)
+        else:
+            d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
+                                      d_rgb_s, d_logit)
+        field_rays_done = False
+        if ray_grads is not None and d_pos is None and table_adam is not None:
+            # no saved Jacobian (the model is not in training mode): the gather path reads the TABLE, which the fused
+            # scatter below updates in place — take the field's ray gradients first (after the side stream's share:
+            # both add into d_o / d_d)
+            if side is not None:
+                main.wait_stream(side)
+                side = None
+                prop_bwd = False
+            _field_ray_grads(model, rctx, d_feats, d_o, d_d)
+            field_rays_done = True
         if exchange is None and table_adam is not None:
             K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, table_adam)
         elif exchange is None:
@@ -553,8 +585,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             main.wait_stream(side)                 # proposal gradients (and their share of the ray gradients) are final
         elif prop_bwd:
             _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
-        if ray_grads is not None:
-            _field_ray_grads(model, rctx, d_feats, d_o, d_d)   # after the join: both chains add into d_o / d_d
+        if ray_grads is not None and not field_rays_done:
+            _field_ray_grads(model, rctx, d_feats, d_o, d_d, d_pos)   # after the join: both chains add into d_o / d_d
     return loss_dict, metrics_dict
 
 

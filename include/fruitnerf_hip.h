@@ -300,6 +300,18 @@ int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, cons
                       const float* d_rgb, const float* d_logit, float* d_feats, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* fnr_field_mlp_bwd + the input gradient of the hash grid for rays that carry gradients (camera-pose optimisation,
+ * fruit_nerf_config.py:39-43; the reference's positions are forced requires_grad, fruit_field.py:180-182):
+ * jacobian [L][3][N][2] = what fnr_hash_encode_fwd saved (d feats / d unit-cube position), d_position [N][4] receives
+ * dL/d(unit-cube position) of every sample (xyz, w = 0) — the contraction of d_feats with the Jacobian, formed by the
+ * base-branch kernel from the dL/dfeats it holds in registers (bf16-pipe modes; one extra launch in fp32 mode).
+ * fnr_position_grad_reduce(n_levels = 1, partial = d_position) finishes dL/d(origins, directions). */
+int fnr_field_mlp_bwd_rays(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
+                           const float* feats, const float* h_saved, const float* ray_bias_saved /* optional */,
+                           const float* packed_saved /* optional */, const uint8_t* selector, const float* d_density,
+                           const float* d_rgb, const float* d_logit, float* d_feats, const float* jacobian,
+                           float* d_position, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of fnr_hash_encode_fwd: adds (+=) the trilinear scatter of d_feats [L][N][2] into
  * grid_grad->table for the levels [level_begin, level_begin + level_count) (all levels: 0, n_levels; data-parallel
  * training calls it per group of levels so that a group's rows can be all-reduced while the next group is being

@@ -572,6 +572,51 @@ def test_ray_gradient_paths_agree(dev):
         assert float((x - y).abs().max()) <= 1e-4 * float(y.abs().max())
 
 
+@pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
+def test_input_gradient_inside_the_mlp_backward_is_the_separate_launch(dev, shape, mode):
+    """fnr_field_mlp_bwd_rays: the base-branch kernel contracts the dL/dfeats it holds in registers with the encode's
+    saved Jacobian; finished by fnr_position_grad_reduce this must give the ray gradients of
+    fnr_position_grad_from_jacobian on the d_feats the same call wrote (only the summation order over levels differs),
+    and every other output of the backward must be bit-identical to the call without a Jacobian."""
+    from fruitnerf_amd import _kernels as K
+    cfg = (util.small_config if shape == "fruit_nerf" else util.big_config)(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, seed=3)
+    hm = util.make_hip_like(om, dev)
+    hm.field.mlp_precision = mode
+    hm.train()
+    hm.arena()
+    fld = hm.field
+    R, S = 200, 40                      # 8000 samples: a ragged last batch of the 128-sample workgroups
+    o, d, pa, cam = util.random_rays(R, 7, seed=4)
+    rays = K.RaysArg(o.to(dev), d.to(dev), torch.full((R, 1), 0.05, device=dev), torch.full((R, 1), 6.0, device=dev),
+                     cam.to(dev))
+    _, eu = K.sample_spaced(rays, 1, S, None)
+    net, gnet = fld.net_struct(), fld.net_struct(grads=True)
+    feats, sel, jac = K.hash_encode_fwd(net.grid, fld.warp_struct(), rays, eu, S, want_jacobian=True)
+    density, rgb, logit, _, saved = K.field_mlp_fwd(net, rays, S, feats, sel, None, want_h=True)
+    g = torch.Generator().manual_seed(1)
+    N = R * S
+    dd, dr, dl = (torch.randn(N, generator=g).to(dev), torch.randn(N, 3, generator=g).to(dev), torch.randn(N, generator=g).to(dev))
+    hm.arena().grads.zero_()
+    d_feats0 = K.field_mlp_bwd(net, gnet, rays, S, feats, saved, sel, dd, dr, dl)
+    g0 = hm.arena().grads.clone()
+    hm.arena().grads.zero_()
+    d_feats1, d_pos = K.field_mlp_bwd(net, gnet, rays, S, feats, saved, sel, dd, dr, dl, jacobian=jac)
+    torch.cuda.synchronize()
+    assert torch.equal(d_feats0, d_feats1) and torch.equal(g0, hm.arena().grads)
+    a = [torch.zeros(R, 3, device=dev) for _ in range(2)]
+    b = [torch.zeros(R, 3, device=dev) for _ in range(2)]
+    K.position_grad_reduce(fld.warp_struct(), rays, eu, S, d_pos.view(1, N, 4), a[0], a[1])
+    K.position_grad_from_jacobian(fld.warp_struct(), rays, eu, S, jac, d_feats1, b[0], b[1])
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert float(y.abs().max()) > 0
+        err = float((x - y).abs().max()) / float(y.abs().max())
+        print(f"[input grad in mlp bwd {shape} {mode}] rel err {err:.3e}")
+        assert err <= 2e-6
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_ray_gradients_match_autograd(dev, fused):
     """d(loss)/d(origins), d(loss)/d(directions): the gradient a camera-pose optimiser consumes
