@@ -314,6 +314,7 @@ def timed_window(run, steps, barrier, dist_on, dev):
         L.profile_pause(not on)
         n_prof += on
         last = run.one_step()
+    run.model.field.flush_deferred_update()   # N > 1: the last step's field collective + optimiser step (training.DEFER_FIELD_UPDATE)
     t_enqueued = time.perf_counter() - t0     # host side done (launches queued); the GPU is still working
     torch.cuda.synchronize()
     barrier()
@@ -438,9 +439,13 @@ def main() -> None:
     from fruitnerf_amd.data.semantics import apple_metadata
     from fruitnerf_amd.rays import RayBundle
 
+    import fruitnerf_amd.training as _training
     if dist_on and world == 1:
-        import fruitnerf_amd.training as _training
         _training.EXCHANGE_MIN_WORLD = 1
+    if dist_on and os.environ.get("FNR_DEFER_FIELD_UPDATE") != "0":
+        # the field's collective keeps running underneath the next step's sampling and proposal passes; its wait and the
+        # table's optimiser step sit just before that step's field encode (same results, tests/test_gpu_distributed.py)
+        _training.DEFER_FIELD_UPDATE = True
     info = L.device_check()
     pmc = load_pmc_traffic()
     HW = args.image_size
@@ -812,7 +817,9 @@ def main() -> None:
                    "method": args.method, "mlp_precision": args.mlp_precision, "rays_per_rank": RAYS_PER_BATCH, "parallelism": f"dp{world}",
                    # N=1: the main table's optimiser step runs inside the scatter's accumulate kernel (its launches are
                    # the hash_encode_bwd entry; no gradient table is written or re-read); N>1: separate step after RCCL
-                   "table_optimizer": "fused into hash_encode_bwd" if not dist_on else "separate (after the exchange)",
+                   "table_optimizer": "fused into hash_encode_bwd" if not dist_on else
+                   ("separate (after the exchange" + (", deferred to the next step's field encode)" if _training.DEFER_FIELD_UPDATE else ")")),
+                   "exchange": None if not dist_on else f"{_training.EXCHANGE_LEVEL_GROUPS} field collective(s) per step + proposal networks on update steps + poses",
                    "device": info["arch"], "setup_s": round(setup_s, 1)},
         "roofline": roofline,
         "roofline_other_bound": roofline_other,

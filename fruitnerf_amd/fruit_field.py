@@ -148,8 +148,25 @@ class FruitField(nn.Module):
             self._arena_owner = True
             self._net_c = None
 
+    # ---- deferred optimiser step (data-parallel training, training.DEFER_FIELD_UPDATE) ------------------------------
+    def defer_update(self, finish) -> None:
+        """`finish()` waits for the field's gradient collective and applies its optimiser step; it runs before the next
+        use of the field's parameters (net_struct) or their export (state_dict)."""
+        self.flush_deferred_update()
+        self.__dict__["_deferred_update"] = finish
+
+    def flush_deferred_update(self) -> None:
+        finish = self.__dict__.pop("_deferred_update", None)
+        if finish is not None:
+            finish()
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_deferred_update()
+        return super()._save_to_state_dict(destination, prefix, keep_vars)
+
     def net_struct(self, grads: bool = False) -> L.fnr_field_net:
         """fnr_field_net over the parameters (or, grads=True, over the arena's gradient views)."""
+        self.flush_deferred_update()
         self._ensure_arena()
         def P(p: nn.Parameter):
             return (p.grad if grads else p.data).data_ptr()

@@ -340,15 +340,17 @@ class FusedAdam:
                                 L.ptr(self.exp_avg_sq[a:a + n]))
         return args, (a, a + n)
 
-    def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0, group: Optional[str] = None) -> None:
+    def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0, group: Optional[str] = None,
+                  step: Optional[int] = None) -> None:
         """Adam update (+ zero_grad) of arena elements [a, b); begin_step() must have been called for this step.
-        group: whose step counter feeds the bias corrections (default: the group that contains a)."""
+        group: whose step counter feeds the bias corrections (default: the group that contains a); step: that counter's
+        value when the update was planned (a deferred update runs after later bookkeeping)."""
         if b > a:
             if group is None:
                 group = next(n for n, (ga, gb) in self.arena.group_ranges.items() if ga <= a < gb)
             fn = K.adam_step if self.algorithm == "adam" else K.radam_step
             fn(self.arena.params[a:b], self.arena.grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr,
-               self.betas[0], self.betas[1], self.eps, self.group_steps[group], grad_scale, True,
+               self.betas[0], self.betas[1], self.eps, self.group_steps[group] if step is None else step, grad_scale, True,
                weight_decay=self.weight_decay)
 
     def plan_runs(self, lrs: Dict[str, float], skip=(), done=()) -> list:
@@ -400,6 +402,15 @@ def skipped_groups(model) -> tuple:
 # 2 in production; the single-GPU RCCL self-test (tools/microbench/rccl_single_rank.py) lowers it to 1 so that a
 # one-rank process group runs the full exchange code path (all-reduce over one rank is the identity)
 EXCHANGE_MIN_WORLD = 2
+# The field's gradient table is scattered and handed to the communicator in this many groups of levels.  1 (default since
+# round 3): one scatter over all levels and ONE 67 MB collective — on the one-rank RCCL self-test four groups cost
+# +14 us of kernels (four emit / accumulate pairs) and eight cross-stream handshakes (~12 us each on the GPU) per step;
+# more groups start the first collective earlier (FNR_EXCHANGE_LEVEL_GROUPS for measurements on real peers).
+EXCHANGE_LEVEL_GROUPS = max(1, int(os.environ.get("FNR_EXCHANGE_LEVEL_GROUPS", "1")))
+# True: the wait for the field's collective and the table's optimiser step move from the end of step k to just before
+# the field encode of step k + 1 (FruitField flushes them before any use of its parameters), so the collective also runs
+# underneath the next step's pixel sampling and proposal passes.  Same arithmetic, same results.
+DEFER_FIELD_UPDATE = os.environ.get("FNR_DEFER_FIELD_UPDATE") == "1"
 GRAD_BUCKET_ELEMS = 4 << 20   # 16 MiB fp32 buckets: large enough for xGMI ring bandwidth, small enough to pipeline
 
 
@@ -452,10 +463,10 @@ class _FieldGradientExchange:
     weights, embedding: final before the scatter starts) ride in the first / last level group's collective when they
     are adjacent to the table in the arena — one collective and two stream handshakes fewer per step."""
 
-    def __init__(self, model, world_size: int, level_groups: int = 4):
+    def __init__(self, model, world_size: int, level_groups: Optional[int] = None):
         self.arena = model.arena()
         self.world = world_size
-        self.level_groups = level_groups
+        self.level_groups = EXCHANGE_LEVEL_GROUPS if level_groups is None else level_groups
         self.pending = []
         table = model.field.mlp_base_grid.hash_table
         hit = [(off, n) for _, p, off, n in self.arena.entries if p is table]
@@ -670,10 +681,23 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             # ... and, as in the reference (grad = None -> torch.optim skips them), neither is their optimiser step
             lrs = optimizer.begin_step(skip=() if prop_updated else ("proposal_networks",))
             scale = 1.0 / world_size
+            deferred = []
             for a, b, work in pending:
-                work.wait()                                    # the compute stream waits for this bucket only
                 name = "fields" if a >= spans["fields"][0] else "proposal_networks"
+                if DEFER_FIELD_UPDATE and name == "fields":
+                    deferred.append((a, b, work))
+                    continue
+                work.wait()                                    # the compute stream waits for this bucket only
                 optimizer.step_span(a, b, lrs[name], scale, group=name)
+            if deferred:
+                lr_f, step_f = lrs["fields"], optimizer.group_steps["fields"]
+
+                def finish(deferred=deferred, lr_f=lr_f, step_f=step_f, scale=scale):
+                    with torch.no_grad():
+                        for a, b, work in deferred:
+                            work.wait()
+                            optimizer.step_span(a, b, lr_f, scale, group="fields", step=step_f)
+                model.field.defer_update(finish)
             if camera is not None:
                 if cam_work is not None:
                     cam_work.wait()

@@ -91,6 +91,8 @@ def test_exchange_path_step_is_the_single_process_step(dev):
             batcher.last_draw = {"u": us[step], "cam": ci, "c2w_adjusted": c2w_adj}
             T.fused_train_iteration(hm, opt, RayBundle(o, d, None, ci[:, None]), {"image": image, "fruit_mask": mask[:, None]},
                                     step, world_size=world_arg, jitter=jits[step], camera=(cam, cadam, batcher))
+            if step == 1:
+                hm.field.flush_deferred_update()     # a pending deferred field update (step 0's is applied by step 1's forward)
             torch.cuda.synchronize()
             snaps.append((hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
                           cam.pose_adjustment.data.clone()))
@@ -106,10 +108,24 @@ def test_exchange_path_step_is_the_single_process_step(dev):
     T.EXCHANGE_MIN_WORLD = 1
     try:
         exch = run(1)
+        # the same steps with the field's wait + optimiser step deferred to the next step's encode (and flushed by the
+        # parameter read at the end), and with the scatter / collectives in four level groups: bit-identical states
+        T.DEFER_FIELD_UPDATE = True
+        deferred = run(1)
+        T.DEFER_FIELD_UPDATE = False
+        old_groups, T.EXCHANGE_LEVEL_GROUPS = T.EXCHANGE_LEVEL_GROUPS, 4
+        grouped = run(1)
+        T.EXCHANGE_LEVEL_GROUPS = old_groups
     finally:
+        T.DEFER_FIELD_UPDATE = False
         T.EXCHANGE_MIN_WORLD = old
         if created:
             dist.destroy_process_group()
+    for x, y in zip(exch[0][1], deferred[0][1]):            # after the second step (the first one's field update was
+        assert torch.equal(x, y)                            # applied inside the second step's forward pass)
+    for snap_a, snap_b in zip(exch[0], grouped[0]):
+        for x, y in zip(snap_a, snap_b):
+            assert torch.equal(x, y)
     (s1, s2), (a, b) = single
     (e1, e2), _ = exch
     for x, y in zip(s1[:3], e1[:3]):                     # after the first step
