@@ -56,6 +56,19 @@ enum ProfOp : int {
   OP_LOSSES, OP_INTERLEVEL, OP_DISTORTION, OP_COMPOSITE_BWD, OP_WEIGHTS_BWD, OP_MLP_BWD, OP_ENCODE_BWD, OP_PROP_BWD,
   OP_ADAM, OP_EXPORT_COMPACT, OP_POSITION_GRAD, OP_CLOUD, OP_COUNT
 };
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize — a PER-DEVICE attribute of the kernel.
+// Set once per (kernel instantiation, device); a failure is reported and retried on the next call, never cached.
+template <class K>
+static inline int ensure_dyn_lds(K kernel, int bytes) {
+  static unsigned long long done_mask = 0ull;  // one bit per device id < 64 (one static per kernel instantiation)
+  int dev = 0;
+  FNR_HIP(hipGetDevice(&dev));
+  if (dev < 64 && ((done_mask >> dev) & 1ull)) return FNR_OK;
+  FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (dev < 64) done_mask |= 1ull << dev;
+  return FNR_OK;
+}
+
 struct ProfScope {
   ProfScope(int op, long long units, void* stream);
   ~ProfScope();

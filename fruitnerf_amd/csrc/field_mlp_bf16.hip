@@ -498,7 +498,8 @@ int field_mlp_fwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, con
   long long blocks = n_batches;
   if (blocks > (long long)device_cu_count()) blocks = device_cu_count();
   auto launch = [&](auto kern, int bytes) -> int {
-    FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    const int rc = ensure_dyn_lds(kern, bytes);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), bytes, st, packed, image, N, h_buf, logit);
     FNR_LAUNCH_CHECK();
     return FNR_OK;
@@ -518,7 +519,8 @@ int field_mlp_bwd_sem_big_bf16(int mode, const FieldPtrs& p, void* image_ws, con
   using Cfg = FieldCfgBig;
   __bf16* image = reinterpret_cast<__bf16*>(image_ws);  // packed by the colour branch's call (or the forward pass)
   auto launch = [&](auto kern, int bytes) -> int {
-    FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    const int rc = ensure_dyn_lds(kern, bytes);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, p.w[Cfg::L_SEM2], p.b[Cfg::L_SEM2],
                        N, h_saved, d_logit, partials);
     FNR_LAUNCH_CHECK();
@@ -956,16 +958,12 @@ static int bwd_launch_coop(const float* packed, const __bf16* image, const float
                            hipStream_t st, const float2* jac = nullptr, float4* d_pos = nullptr) {
   // exactly `blocks` workgroups: every one of the caller's partial images must receive this branch's blocks (a
   // workgroup without a batch stores zeros)
-  auto attr = [](auto kern, int bytes) -> int {
-    FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    return FNR_OK;
-  };
   if (branch == 0) {
     using CL = CoopLds<Cfg, SegsColF<Cfg>, SegsColT<Cfg>, NSF, NS>;
     constexpr int bytes = CL::FB_OFF + 80 * 4;
     static_assert(bytes <= 160 * 1024, "colour branch exceeds the LDS");
     auto kern = k_field_mlp_bwd_color_coop<Cfg, NSF, NS>;
-    static int once = attr(kern, bytes);
+    const int once = ensure_dyn_lds(kern, bytes);
     if (once) return once;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, ray_bias, rd, S, N, h_saved, d_rgb,
                        d_h, gsum_tile, gsum_extra, partials);
@@ -975,7 +973,7 @@ static int bwd_launch_coop(const float* packed, const __bf16* image, const float
       constexpr int bytes = CL::FB_OFF + 128 * 4;
       static_assert(bytes <= 160 * 1024, "semantic branch exceeds the LDS");
       auto kern = k_field_mlp_bwd_sem_coop<Cfg, NSF, NS>;
-      static int once = attr(kern, bytes);
+      const int once = ensure_dyn_lds(kern, bytes);
       if (once) return once;
       hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, h_saved, d_logit, partials);
     } else {
@@ -987,13 +985,13 @@ static int bwd_launch_coop(const float* packed, const __bf16* image, const float
     static_assert(bytes <= 160 * 1024, "base branch exceeds the LDS");
     if (jac && d_pos) {
       auto kern = k_field_mlp_bwd_base_coop<Cfg, NSF, NS, true>;
-      static int once = attr(kern, bytes);
+      const int once = ensure_dyn_lds(kern, bytes);
       if (once) return once;
       hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, feats, selector, d_density,
                          d_h, d_feats, partials, jac, d_pos);
     } else {
       auto kern = k_field_mlp_bwd_base_coop<Cfg, NSF, NS, false>;
-      static int once = attr(kern, bytes);
+      const int once = ensure_dyn_lds(kern, bytes);
       if (once) return once;
       hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), bytes, st, packed, image, N, feats, selector, d_density,
                          d_h, d_feats, partials, jac, d_pos);
@@ -1004,11 +1002,6 @@ static int bwd_launch_coop(const float* packed, const __bf16* image, const float
 }
 
 // ---- launch helpers (called from field_mlp.hip / field_mlp_bwd.hip when fnr_field_net.mlp_mode != 0) --------------
-template <class K>
-static int set_dyn_lds(K kernel, int bytes) {
-  FNR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  return FNR_OK;
-}
 
 template <class Cfg, int NS>
 static int fwd_launch_bf16(const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd, int S,
@@ -1021,7 +1014,7 @@ static int fwd_launch_bf16(const float* packed, const __bf16* image, const float
   constexpr int bytes = Lds::BYTES + Cfg::B_TOTAL * 4;
   static_assert(bytes <= 160 * 1024, "forward fragments exceed the LDS");
   auto kern = k_field_mlp_fwd_bf16<Cfg, NS, WAVES, WITH_SEM>;
-  static int once = set_dyn_lds(kern, bytes);
+  const int once = ensure_dyn_lds(kern, bytes);
   if (once) return once;
   const long long n_pairs = (N + 31) / 32;
   long long blocks = (n_pairs + WAVES - 1) / WAVES;

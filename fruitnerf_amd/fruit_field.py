@@ -63,7 +63,12 @@ class FruitField(nn.Module):
                  mlp_precision: Optional[str] = None) -> None:
         super().__init__()
         # arithmetic of the MLP GEMMs (include/fruitnerf_hip.h: FNR_MLP_*); not a reference argument.  None -> the
-        # FNR_MLP_PRECISION environment variable, else fp32 (the parity path)
+        # FNR_MLP_PRECISION environment variable, else "auto" = bf16x3: the exact three-way bf16 split of every fp32
+        # operand on the bf16 matrix pipe — six piece products in the forward pass and in the backward's forward recompute
+        # (2^-27, fp32 grade: every output parity test passes in it), THREE in the backward's dX / dW (2^-17 per product;
+        # measured against the oracle at the methods' real sizes: every gradient within 1e-4 of max |g|, bar 5e-4,
+        # tests/test_gpu_training_parity.py::test_losses_and_all_gradients_at_the_real_configuration).  "fp32" = fp32 MFMA
+        # chains, bit for bit an fmaf chain; "bf16" = plain bf16 operands (throughput mode, not parity grade).
         self.mlp_precision = mlp_precision or os.environ.get("FNR_MLP_PRECISION", "auto")
         if self.mlp_precision not in MLP_MODES and self.mlp_precision != "auto":
             raise ValueError(f"mlp_precision {self.mlp_precision!r}: one of {sorted(MLP_MODES) + ['auto']}")
@@ -311,6 +316,21 @@ class FruitField(nn.Module):
             emb = self._mean_embedding() if (self._uses_mean_embedding() or rays.cam is None) else None
             h = K.field_mlp_fwd(net, rays, S, feats, selector, emb, want_h=True)[4][0]
         return h[:, 0].reshape(*shape, 1)
+
+    def get_normals(self) -> Tensor:
+        """nerfstudio Field.get_normals differentiates `_density_before_activation` with respect to `_sample_locations`
+        through autograd.  Here both are produced on demand by kernels (no autograd graph joins them), and no FruitNeRF
+        code path asks for normals (the reference constructs the field without predict_normals): unsupported, loudly."""
+        raise NotImplementedError("FruitField.get_normals: normals are not built (FruitNeRF never computes them; "
+                                  "_sample_locations / _density_before_activation are kernel outputs without an autograd "
+                                  "graph between them)")
+
+    def release_last_samples(self) -> None:
+        """Drop the references get_density keeps for _sample_locations / _density_before_activation / get_outputs (the
+        last batch's ray samples and per-sample outputs stay alive until the next call otherwise)."""
+        self._last_ray_samples = None
+        self._last = None
+        self._last_geo = None
 
     def _outputs_from_last(self, ray_samples, density_embedding):
         if density_embedding is None or density_embedding is not self._last_geo:

@@ -185,20 +185,53 @@ class _InterlevelFn(torch.autograd.Function):
 
 
 def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins: Optional[Tensor],
-                       d_directions: Optional[Tensor]) -> None:
+                       d_directions: Optional[Tensor], level_streams: bool = False) -> None:
     """Backward of the interlevel loss into the proposal networks (and, when asked, into the rays).
-    upstream None: d_wps already holds d(loss)/d(density) per level (train_losses(fuse_weights_bwd=True))."""
+    upstream None: d_wps already holds d(loss)/d(density) per level (train_losses(fuse_weights_bwd=True)).
+    level_streams: the levels' chains (MLP backward -> weight reduce -> scatter emit -> accumulate; they share nothing when
+    every level has its own network) run side by side, level 0 on the current stream and the others on side streams;
+    their ray-gradient sums (+= into the same [R,3] buffers) follow on the current stream after the join."""
     cfg = model.config
     rays = rctx.rays
-    for i, (lv, d_wp) in enumerate(zip(rctx.levels[:-1], d_wps)):
-        d_density = d_wp if upstream is None else \
-            K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, upstream)
+    dev = rays.device
+    levels = list(zip(rctx.levels[:-1], d_wps))
+    side_by_side = level_streams and len(levels) > 1 and not cfg.use_same_proposal_network
+    main = torch.cuda.current_stream(dev) if side_by_side else None
+    pool = model.__dict__.setdefault("_level_streams", []) if side_by_side else []
+    while side_by_side and len(pool) < len(levels) - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    pending = []
+    for i, (lv, d_wp) in enumerate(levels):
         net = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
-        d_pos = K.prop_density_bwd(net.prop_struct(), net.prop_struct(grads=True), net.warp_struct(), rays,
-                                   lv["euclid"], lv["S"], lv["feats"], d_density,
-                                   want_position_grad=d_origins is not None)
-        if d_origins is not None:
+        stream = pool[i - 1] if side_by_side and i > 0 else None
+        if stream is not None:
+            stream.wait_stream(main)
+        with torch.cuda.stream(stream) if stream is not None else _null_context():
+            d_density = d_wp if upstream is None else \
+                K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, upstream)
+            d_pos = K.prop_density_bwd(net.prop_struct(), net.prop_struct(grads=True), net.warp_struct(), rays,
+                                       lv["euclid"], lv["S"], lv["feats"], d_density,
+                                       want_position_grad=d_origins is not None)
+        if d_origins is None:
+            continue
+        if side_by_side:
+            pending.append((net, lv, d_pos, stream))
+        else:
             K.position_grad_reduce(net.warp_struct(), rays, lv["euclid"], lv["S"], d_pos, d_origins, d_directions)
+    for stream in pool[:len(levels) - 1] if side_by_side else ():
+        main.wait_stream(stream)
+    for net, lv, d_pos, stream in pending:
+        if stream is not None:
+            d_pos.record_stream(main)
+        K.position_grad_reduce(net.warp_struct(), rays, lv["euclid"], lv["S"], d_pos, d_origins, d_directions)
+
+
+class _null_context:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 class _LossFn(torch.autograd.Function):
@@ -284,12 +317,17 @@ class FusedAdam:
 
     def __init__(self, model, lr: float = 1e-2, eps: float = 1e-15, betas=(0.9, 0.999), lr_final: float = 1e-4,
                  max_steps: int = 200000, group_lr: Optional[Dict[str, dict]] = None, algorithm: str = "adam",
-                 weight_decay: float = 0.0):
+                 weight_decay: float = 0.0, skip_groups_without_grad: bool = True):
         # algorithm="radam": torch.optim.RAdam, the optimiser of the fruit_nerf_big / fruit_nerf_huge method configs
         # (RAdamOptimizerConfig, fruit_nerf_config.py:97-106,148-160)
         if algorithm not in ("adam", "radam"):
             raise ValueError(f"unknown optimiser algorithm {algorithm!r}")
         self.algorithm, self.weight_decay = algorithm, weight_decay
+        # True (torch >= 2.0, where Optimizer.zero_grad(set_to_none=True) is the default): a group that received no
+        # gradient this iteration — the proposal networks on the steps that evaluate them under no_grad — is skipped by
+        # torch.optim entirely.  False reproduces torch 1.13 (nerfstudio 0.3.2's other supported version): zero_grad leaves
+        # ZERO tensors, so Adam still decays the moments, moves the parameters along them and advances its step count.
+        self.skip_groups_without_grad = skip_groups_without_grad
         self.model = model
         self.arena = model.arena()
         self.betas, self.eps = betas, eps
@@ -393,9 +431,11 @@ class FusedAdam:
                               self.betas[0], self.betas[1], self.eps, grad_scale, True, weight_decay=self.weight_decay)
 
 
-def skipped_groups(model) -> tuple:
+def skipped_groups(model, optimizer: Optional["FusedAdam"] = None) -> tuple:
     """Parameter groups that got no gradient in the last training render (the proposal networks on steps that did not
-    'update' them)."""
+    'update' them) — empty when the optimiser steps such groups anyway (FusedAdam.skip_groups_without_grad=False)."""
+    if optimizer is not None and not optimizer.skip_groups_without_grad:
+        return ()
     return () if bool(getattr(model, "_last_render_updated", True)) else ("proposal_networks",)
 
 
@@ -451,7 +491,7 @@ def train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, w
     loss = sum(loss_dict.values())                             # functools.reduce(torch.add, loss_dict.values())
     loss.backward()
     scale = sync_gradients(model.arena(), world_size)
-    optimizer.step(grad_scale=scale, skip=skipped_groups(model))
+    optimizer.step(grad_scale=scale, skip=skipped_groups(model, optimizer))
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
 
@@ -595,7 +635,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         if side is not None:
             main.wait_stream(side)                 # proposal gradients (and their share of the ray gradients) are final
         elif prop_bwd:
-            _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
+            _proposal_backward(model, rctx, d_wps, up, d_o, d_d, level_streams=PROPOSAL_LEVEL_STREAMS)
         if ray_grads is not None and not field_rays_done:
             _field_ray_grads(model, rctx, d_feats, d_o, d_d, d_pos)   # after the join: both chains add into d_o / d_d
     return loss_dict, metrics_dict
@@ -633,6 +673,11 @@ def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: 
 # proposal-network backward on a second HIP stream (see fused_forward_backward); off by default: per-kernel timings stay
 # attributable to one stream
 OVERLAP_PROPOSAL_BACKWARD = os.environ.get("FNR_OVERLAP_PROPOSAL_BACKWARD") == "1"
+# The proposal levels' backward chains next to each other (level 0 on the launch stream, level 1 on a side stream; they
+# share no buffers).  OFF: measured on MI355X (round 3, A/B on one box) the step gets 4 % SLOWER (0.908 -> 0.943 ms) — a
+# cross-stream fork + join costs ~12 us of GPU time per handshake on this stack and the two chains of latency-bound
+# kernels slow each other in the XCDs' L2s (each network's 5 MB tables fit one L2, two do not).  Kept for measurements.
+PROPOSAL_LEVEL_STREAMS = os.environ.get("FNR_PROPOSAL_LEVEL_STREAMS", "0") == "1"
 FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter
 
@@ -666,12 +711,13 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
         if exchange is None:
             if camera is not None:
                 camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
-            optimizer.step(skip=skipped_groups(model), done=done)
+            optimizer.step(skip=skipped_groups(model, optimizer), done=done)
         else:
             pending = list(exchange.pending)
             # the update schedule is a function of the step, identical on every rank: on steps that did not train the
             # proposal networks their gradients are zero everywhere and the 10.5 MB exchange is skipped
             prop_updated = bool(getattr(model, "_last_render_updated", True))
+            prop_stepped = prop_updated or not optimizer.skip_groups_without_grad
             if prop_updated:
                 pending += start_gradient_sync(arena, spans["proposal_networks"], world_size)
             # collectives run in issue order on the communicator's stream: the 2 KB pose-gradient exchange goes LAST so
@@ -679,7 +725,7 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             cam_work, cam_scale = (camera_backward(camera[0], camera[2], ray_grads, world_size)
                                    if camera is not None else (None, 1.0))
             # ... and, as in the reference (grad = None -> torch.optim skips them), neither is their optimiser step
-            lrs = optimizer.begin_step(skip=() if prop_updated else ("proposal_networks",))
+            lrs = optimizer.begin_step(skip=() if prop_stepped else ("proposal_networks",))
             scale = 1.0 / world_size
             deferred = []
             for a, b, work in pending:
@@ -689,6 +735,9 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
                     continue
                 work.wait()                                    # the compute stream waits for this bucket only
                 optimizer.step_span(a, b, lrs[name], scale, group=name)
+            if prop_stepped and not prop_updated:   # torch < 2.0 semantics: zero gradients everywhere, still a step
+                pa, pb = spans["proposal_networks"]
+                optimizer.step_span(pa, pb, lrs["proposal_networks"], scale, group="proposal_networks")
             if deferred:
                 lr_f, step_f = lrs["fields"], optimizer.group_steps["fields"]
 

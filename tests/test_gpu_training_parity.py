@@ -389,6 +389,54 @@ def test_optimizer_skips_the_proposal_networks_on_steps_that_do_not_update_them(
     assert hopt.group_steps["fields"] == 9 + 4 and hopt.step_count == 9 + 4
 
 
+def test_optimizer_can_step_groups_without_gradient_like_torch_1_13(dev):
+    """FusedAdam(skip_groups_without_grad=False): nerfstudio 0.3.2 also runs on torch 1.13, whose zero_grad() leaves ZERO
+    tensors — Adam then still decays the moments, moves the proposal networks along them and advances their step count
+    on the iterations that evaluate them under no_grad.  Oracle: torch.optim fed explicit zero gradients."""
+    from fruitnerf_amd.rays import RayBundle
+    from fruitnerf_amd.training import FusedAdam, fused_train_iteration
+    cfg = util.small_config(log2=12, prop_log2=10)
+    om = util.make_oracle(cfg, seed=31)
+    hm = util.make_hip_like(om, dev)
+    om.train()
+    hm.train()
+    groups = om.get_param_groups()
+    opts = {"proposal_networks": torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15),
+            "fields": torch.optim.Adam(groups["fields"], lr=1e-2, eps=1e-15)}
+    hopt = FusedAdam(hm, skip_groups_without_grad=False)
+    for m in (om, hm):
+        m.proposal_sampler._step = 8
+        m.proposal_sampler._steps_since_update = 1
+    R = 96
+    a, b = hm.arena().group_ranges["proposal_networks"]
+    moved = []
+    for step in range(9, 13):
+        o, d, pa, cam = util.random_rays(R, 7, seed=300 + step)
+        jit = [torch.rand(R, 1) for _ in range(3)]
+        batch = _batch(R, 70 + step)
+        for op in opts.values():
+            op.zero_grad(set_to_none=False)            # torch 1.13's default
+        for p in groups["proposal_networks"]:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        _oracle_step(om, o, d, pa, cam, jit, batch, step)
+        for op in opts.values():
+            op.step()
+        om.proposal_sampler.step_cb(step)
+        before = hm.arena().params[a:b].clone()
+        fused_train_iteration(hm, hopt, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)),
+                              {k: v.to(dev) for k, v in batch.items()}, step, jitter=[j.to(dev) for j in jit])
+        torch.cuda.synchronize()
+        moved.append(not torch.equal(before, hm.arena().params[a:b]))
+    assert moved == [True, True, True, True]           # iteration 11 has no gradient and still moves (momentum)
+    assert hopt.group_steps["proposal_networks"] == 4
+    named_h = dict(hm.named_parameters())
+    for name, p in om.named_parameters():
+        if name.startswith("proposal_networks"):
+            err = float((named_h[name].detach().cpu() - p.detach()).abs().max())
+            assert err <= 2e-5 * max(1.0, float(p.detach().abs().max())), (name, err)
+
+
 @pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
 def test_fused_step_matches_the_autograd_step(dev, shape):
     """fused_forward_backward() (no autograd engine, what bench.py times) must leave the same losses, metrics and
