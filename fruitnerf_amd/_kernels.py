@@ -378,11 +378,14 @@ def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weig
 
 
 def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, h_saved,
-                  selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor, jacobian: Optional[Tensor] = None):
+                  selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor, jacobian: Optional[Tensor] = None,
+                  weight_adam=None):
     """h_saved: what field_mlp_fwd(want_h=True) returned — (h [N,16], ray_bias [R,64], packed weights); a bare h tensor
     is accepted too (the per-ray bias and the fragment image are then recomputed).
     jacobian (hash_encode_fwd(want_jacobian=True)): -> (d_feats, d_position [N,4]): the hash grid's input gradient per
-    sample rides along (fnr_field_mlp_bwd_rays); position_grad_reduce(..., d_position.view(1, N, 4), ...) finishes it."""
+    sample rides along (fnr_field_mlp_bwd_rays); position_grad_reduce(..., d_position.view(1, N, 4), ...) finishes it.
+    weight_adam = (fnr_table_adam, gradient arena): the optimiser step of the MLP weights + embedding is taken by the
+    kernels that finish their gradients (fnr_field_mlp_bwd_adam, FusedAdam.weight_adam_args)."""
     lib = L.load()
     fwd_mode = h_saved[3] if isinstance(h_saved, tuple) and len(h_saved) > 3 else None
     h_saved, ray_bias, packed = (tuple(h_saved) + (None, None))[:3] if isinstance(h_saved, tuple) else (h_saved, None, None)
@@ -393,6 +396,14 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
     d_feats = torch.empty_like(feats)
     nbytes = lib.fnr_field_mlp_bwd_workspace_bytes(rays.n, S)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if weight_adam is not None:
+        adam, grad_arena = weight_adam
+        d_pos = torch.empty(N, 4, device=dev) if jacobian is not None else None
+        L.check(lib.fnr_field_mlp_bwd_adam(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
+                                           L.ptr(ray_bias), L.ptr(packed), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb),
+                                           L.ptr(d_logit), L.ptr(d_feats), L.ptr(jacobian), L.ptr(d_pos), C.byref(adam),
+                                           L.ptr(grad_arena), L.ptr(ws), nbytes, L.stream_ptr(dev)), "field_mlp_bwd_adam")
+        return (d_feats, d_pos) if jacobian is not None else d_feats
     if jacobian is not None:
         d_pos = torch.empty(N, 4, device=dev)
         L.check(lib.fnr_field_mlp_bwd_rays(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),

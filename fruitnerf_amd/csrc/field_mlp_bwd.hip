@@ -608,9 +608,27 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_sem_big(
 // single writer per gradient entry (no float atomics: training is bit-reproducible run to run): a workgroup is
 // RD_IDX entries x RD_Y slices; slice y sums the images y, y + RD_Y, ... (8 independent loads in flight), the slices
 // meet in LDS and are added up in slice order by the thread of slice 0.
+// ADAM (single-process training, fnr_field_mlp_bwd_adam): the thread that owns a gradient entry also takes that
+// parameter's optimiser step (torch.optim.Adam / RAdam exactly as fnr_adam_step / fnr_radam_step: same operations in the
+// same order) and leaves the gradient entry zero — the ~20 k weights of the field's MLPs no longer need a launch of
+// their own, and a step that does not train the proposal networks ends without any optimiser launch.
+struct WeightAdam {
+  TableAdam t;               // hyper-parameters and step-dependent scalars (its p / m / v pointers are unused here)
+  long long p_off, m_off, v_off;   // element offsets from a GRADIENT address to the parameter / exp_avg / exp_avg_sq entry
+};
+__device__ __forceinline__ void weight_adam_entry(const WeightAdam& wa, float* __restrict__ g_entry, float s) {
+  const float g = *g_entry + s;
+  float P = g_entry[wa.p_off], M = g_entry[wa.m_off], V = g_entry[wa.v_off];
+  table_adam_update(wa.t, g, P, M, V);
+  g_entry[wa.p_off] = P;
+  g_entry[wa.m_off] = M;
+  g_entry[wa.v_off] = V;
+  *g_entry = 0.0f;
+}
 constexpr int RD_IDX = 128, RD_Y = 8;
-template <class Cfg>
-__global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __restrict__ partials, int nblocks, FieldPtrs grads) {
+template <class Cfg, bool ADAM>
+__global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __restrict__ partials, int nblocks, FieldPtrs grads,
+                                                             WeightAdam wa) {
   __shared__ float s_part[RD_Y][RD_IDX];
   const int t = threadIdx.x % RD_IDX, y = threadIdx.x / RD_IDX;
   const int idx = blockIdx.x * RD_IDX + t;
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __rest
   if (y != 0 || idx >= TOT) return;
 #pragma unroll
   for (int q = 1; q < RD_Y; ++q) s += s_part[q][t];
-  if (s == 0.0f) return;
+  if (!ADAM && s == 0.0f) return;
   if (idx < Cfg::W_TOTAL) {
     int l = 0;
 #pragma unroll
@@ -647,7 +665,8 @@ __global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __rest
     const int col = kmap<Cfg>(Cfg::km(l), ib, g, r, Cfg::in_dim(l));
     if (out < Cfg::out_dim(l) && col >= 0) {
       float* dst = const_cast<float*>(grads.w[l]) + out * Cfg::in_dim(l) + col;
-      *dst += s;  // sole writer of this entry
+      if constexpr (ADAM) weight_adam_entry(wa, dst, s);
+      else *dst += s;  // sole writer of this entry
     }
   } else {
     const int bi = idx - Cfg::W_TOTAL;
@@ -658,7 +677,8 @@ __global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __rest
     const int o = bi - Cfg::boff(l);
     if (o < Cfg::out_dim(l)) {
       float* dst = const_cast<float*>(grads.b[l]) + o;
-      *dst += s;
+      if constexpr (ADAM) weight_adam_entry(wa, dst, s);
+      else *dst += s;
     }
   }
 }
@@ -749,10 +769,10 @@ static_assert(RAYG_RB * COLOR_CONST_K % 256 == 0, "staging loop covers the batch
 // of its rays (each wave tests 64 rays per ballot), then g_embedding[c][k] += sum_o W[o][emb col k] * gcam[o].
 // No atomics: direct adds into the [n_images, 32] table serialise at ~12 ns per same-address add (393k adds on
 // 90 rows made the colour branch 4x slower than its MFMA time).
-template <class Cfg>
+template <class Cfg, bool ADAM>
 __global__ __launch_bounds__(1024) void k_embedding_grad(RaysDev rays, const float* __restrict__ g_ray,
                                                          const float* __restrict__ packed,
-                                                         float* __restrict__ g_embedding) {
+                                                         float* __restrict__ g_embedding, WeightAdam wa) {
   __shared__ float red[16][64];
   const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.0f;
@@ -780,7 +800,11 @@ __global__ __launch_bounds__(1024) void k_embedding_grad(RaysDev rays, const flo
   float s = fmaf(Wt[oo], red[0][oo], Wt[oo + 32] * red[0][oo + 32]);
 #pragma unroll
   for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-  if (oo == 0 && s != 0.0f) g_embedding[(size_t)c * 32 + k] += s;
+  if constexpr (ADAM) {
+    if (oo == 0) weight_adam_entry(wa, g_embedding + (size_t)c * 32 + k, s);  // every row takes its step (moment decay)
+  } else {
+    if (oo == 0 && s != 0.0f) g_embedding[(size_t)c * 32 + k] += s;
+  }
 }
 
 int field_ptrs(const fnr_field_net* net, FieldPtrs& p, int* cfg_id);  // field_mlp.hip
@@ -837,7 +861,7 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                          const float* ray_bias_saved, const float* packed_saved, const uint8_t* selector,
                          const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
                          const BwdWorkspace& ws, hipStream_t st, const float* jacobian = nullptr,
-                         float* d_position = nullptr) {
+                         float* d_position = nullptr, const WeightAdam* wadam = nullptr) {
   const float2* jac = reinterpret_cast<const float2*>(jacobian);
   float4* d_pos = reinterpret_cast<float4*>(d_position);
   const long long n_tiles = (N + 15) / 16;
@@ -896,8 +920,12 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     hipLaunchKernelGGL((k_color_ray_grads<Cfg>), dim3((unsigned)rb), dim3(256), 0, st, rd, S, N, net->embedding,
                        ws.gsum_tile, gsum_extra, ws.g_ray, partials);
     FNR_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_embedding_grad<Cfg>), dim3((unsigned)net->n_images), dim3(1024), 0, st, rd, ws.g_ray, packed,
-                       grads->embedding);
+    if (wadam)
+      hipLaunchKernelGGL((k_embedding_grad<Cfg, true>), dim3((unsigned)net->n_images), dim3(1024), 0, st, rd, ws.g_ray,
+                         packed, grads->embedding, *wadam);
+    else
+      hipLaunchKernelGGL((k_embedding_grad<Cfg, false>), dim3((unsigned)net->n_images), dim3(1024), 0, st, rd, ws.g_ray,
+                         packed, grads->embedding, WeightAdam{});
     FNR_LAUNCH_CHECK();
   }
   if (bf_sem_big) {
@@ -930,8 +958,12 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     FNR_LAUNCH_CHECK();
   }
   constexpr int TOT = Cfg::W_TOTAL + Cfg::B_TOTAL;
-  hipLaunchKernelGGL((k_reduce_dw<Cfg>), dim3((TOT + RD_IDX - 1) / RD_IDX), dim3(RD_IDX * RD_Y), 0, st, partials,
-                     (int)blocks, gp);
+  if (wadam)
+    hipLaunchKernelGGL((k_reduce_dw<Cfg, true>), dim3((TOT + RD_IDX - 1) / RD_IDX), dim3(RD_IDX * RD_Y), 0, st, partials,
+                       (int)blocks, gp, *wadam);
+  else
+    hipLaunchKernelGGL((k_reduce_dw<Cfg, false>), dim3((TOT + RD_IDX - 1) / RD_IDX), dim3(RD_IDX * RD_Y), 0, st, partials,
+                       (int)blocks, gp, WeightAdam{});
   FNR_LAUNCH_CHECK();
   // fp32 chains: their base-branch kernel does not carry the contraction with the encode's Jacobian
   if (jac && d_pos && !bf_all) return position_contract(N, net->grid.n_levels, jac, df2, d_pos, st);
@@ -948,7 +980,17 @@ static int field_mlp_bwd_entry(const fnr_field_net* net, const fnr_field_net* gr
                                  const float* feats, const float* h_saved, const float* ray_bias_saved,
                                  const float* packed_saved, const uint8_t* selector, const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
                                  void* workspace, size_t workspace_bytes, void* stream, const float* jacobian,
-                               float* d_position) {
+                               float* d_position, const fnr_table_adam* weight_adam = nullptr,
+                               const float* grad_arena = nullptr) {
+  WeightAdam wa{};
+  if (weight_adam) {
+    FNR_CHECK_ARG(grad_arena, "field_mlp_bwd_adam: grad_arena missing");
+    const int rca = make_table_adam(weight_adam, wa.t);
+    if (rca) return rca;
+    wa.p_off = weight_adam->params - grad_arena;
+    wa.m_off = weight_adam->exp_avg - grad_arena;
+    wa.v_off = weight_adam->exp_avg_sq - grad_arena;
+  }
   FNR_CHECK_ARG(net && grads && rays && feats && h_saved && d_density && d_rgb && d_logit && d_feats && workspace && S > 0,
                 "field_mlp_bwd: null argument");
   FNR_CHECK_ARG(rays->directions && rays->camera_indices && net->embedding && grads->embedding,
@@ -971,9 +1013,11 @@ static int field_mlp_bwd_entry(const fnr_field_net* net, const fnr_field_net* gr
   FNR_PROF(OP_MLP_BWD, N);
   if (cfg == 0)
     return field_mlp_bwd_launch<FieldCfgBase>(p, gp, net, grads, rd, S, N, feats, h_saved, ray_bias_saved, packed_saved,
-                                              selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream), jacobian, d_position);
+                                              selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream), jacobian, d_position,
+                                              weight_adam ? &wa : nullptr);
   return field_mlp_bwd_launch<FieldCfgBig>(p, gp, net, grads, rd, S, N, feats, h_saved, ray_bias_saved, packed_saved,
-                                           selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream), jacobian, d_position);
+                                           selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream), jacobian, d_position,
+                                              weight_adam ? &wa : nullptr);
 }
 
 extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
@@ -983,6 +1027,19 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
                                  size_t workspace_bytes, void* stream) {
   return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
                              d_logit, d_feats, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int fnr_field_mlp_bwd_adam(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
+                                      const float* feats, const float* h_saved, const float* ray_bias_saved,
+                                      const float* packed_saved, const uint8_t* selector, const float* d_density,
+                                      const float* d_rgb, const float* d_logit, float* d_feats, const float* jacobian,
+                                      float* d_position, const fnr_table_adam* weight_adam, const float* grad_arena,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  FNR_CHECK_ARG(weight_adam && grad_arena, "field_mlp_bwd_adam: weight_adam / grad_arena missing");
+  FNR_CHECK_ARG((jacobian == nullptr) == (d_position == nullptr), "field_mlp_bwd_adam: jacobian and d_position go together");
+  return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
+                             d_logit, d_feats, workspace, workspace_bytes, stream, jacobian, d_position, weight_adam,
+                             grad_arena);
 }
 
 extern "C" int fnr_field_mlp_bwd_rays(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,

@@ -378,6 +378,19 @@ class FusedAdam:
                                 L.ptr(self.exp_avg_sq[a:a + n]))
         return args, (a, a + n)
 
+    def weight_adam_args(self, group: str = "fields", grad_scale: float = 1.0):
+        """fnr_table_adam for the NEXT update of `group`, addressed through the whole arenas (fnr_field_mlp_bwd_adam: the
+        kernels that finish the gradients of the field's MLP weights and embedding take those parameters' step).
+        -> ((struct, gradient arena), the group's arena span)."""
+        from . import _lib as L
+        g = self.groups[group]
+        lr = (exponential_decay_lr(self.step_count, g["lr"], g["lr_final"], g["max_steps"])
+              if g.get("lr_final") is not None else g["lr"])
+        args = L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], self.eps,
+                                self.group_steps[group] + 1, grad_scale, self.weight_decay,
+                                L.ptr(self.arena.params), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq))
+        return (args, self.arena.grads), tuple(self.arena.group_ranges[group])
+
     def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0, group: Optional[str] = None,
                   step: Optional[int] = None) -> None:
         """Adam update (+ zero_grad) of arena elements [a, b); begin_step() must have been called for this step.
@@ -539,7 +552,7 @@ class _FieldGradientExchange:
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
                            ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False,
-                           table_adam=None):
+                           table_adam=None, weight_adam=None):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -605,10 +618,11 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         d_pos = None
         if ray_grads is not None and rctx.field_jacobian is not None:
             d_feats, d_pos = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector,
-                                             d_density, d_rgb_s, d_logit, jacobian=rctx.field_jacobian)
+                                             d_density, d_rgb_s, d_logit, jacobian=rctx.field_jacobian,
+                                             weight_adam=weight_adam)
         else:
             d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
-                                      d_rgb_s, d_logit)
+                                      d_rgb_s, d_logit, weight_adam=weight_adam)
         field_rays_done = False
         if ray_grads is not None and d_pos is None and table_adam is not None:
             # no saved Jacobian (the model is not in training mode): the gather path reads the TABLE, which the fused
@@ -679,6 +693,7 @@ OVERLAP_PROPOSAL_BACKWARD = os.environ.get("FNR_OVERLAP_PROPOSAL_BACKWARD") == "
 # kernels slow each other in the XCDs' L2s (each network's 5 MB tables fit one L2, two do not).  Kept for measurements.
 PROPOSAL_LEVEL_STREAMS = os.environ.get("FNR_PROPOSAL_LEVEL_STREAMS", "0") == "1"
 FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
+FUSE_WEIGHT_OPTIMIZER = True  # ... and the field's MLP weights + embedding step inside k_reduce_dw / k_embedding_grad
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter
 
 
@@ -700,13 +715,19 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
     # 16.8 M parameters are 86 % of the arena: 40 -> 24 bytes of HBM traffic per parameter and step, bit-identical
     # results); the table's gradient stays zero.
     fuse = FUSE_TABLE_OPTIMIZER if fuse_table_optimizer is None else fuse_table_optimizer
-    table_adam, done = None, ()
+    table_adam, weight_adam, done = None, None, ()
     if exchange is None and fuse:
         table_adam, span = optimizer.table_adam_args(model.field.mlp_base_grid.hash_table, "fields")
         done = (span,)
+        if FUSE_WEIGHT_OPTIMIZER:
+            # ... and the rest of the "fields" group (MLP weights, embedding) in the kernels that finish ITS gradients:
+            # the whole group is done when the backward returns, and a step that does not train the proposal networks
+            # ends without an optimiser launch
+            weight_adam, span = optimizer.weight_adam_args("fields")
+            done = (span,)
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads, overlap_proposal_backward=OVERLAP_PROPOSAL_BACKWARD,
-                                                     table_adam=table_adam)
+                                                     table_adam=table_adam, weight_adam=weight_adam)
     with torch.no_grad():
         if exchange is None:
             if camera is not None:

@@ -312,6 +312,22 @@ int fnr_field_mlp_bwd_rays(const fnr_field_net* net, const fnr_field_net* grads,
                            const float* d_rgb, const float* d_logit, float* d_feats, const float* jacobian,
                            float* d_position, void* workspace, size_t workspace_bytes, void* stream);
 
+/* fnr_field_mlp_bwd (+ optionally the input gradient, as fnr_field_mlp_bwd_rays: jacobian and d_position both NULL or
+ * both set) with the optimiser step of every parameter this backward produces the gradient of — the Linear weights and
+ * biases of mlp_base_mlp / mlp_semantics / field_head_semantics / mlp_head and the appearance embedding, i.e. the
+ * "fields" group without the hash table (fruit_nerf_config.py:51-56) — fused in (single-process training).  The thread
+ * that owns a gradient entry (k_reduce_dw, k_embedding_grad: fixed-order sums, single writer) applies torch.optim.Adam /
+ * RAdam to that parameter and leaves the gradient entry ZERO.  grad_arena: base of the gradient buffer `grads` points
+ * into; weight_adam->params / exp_avg / exp_avg_sq: bases of the buffers that parallel it element for element (the
+ * caller's flat arenas).  Bit-identical to fnr_field_mlp_bwd followed by fnr_adam_step / fnr_radam_step(zero_grad = 1)
+ * on those spans (tests/test_gpu_training_parity.py). */
+int fnr_field_mlp_bwd_adam(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
+                           const float* feats, const float* h_saved, const float* ray_bias_saved /* optional */,
+                           const float* packed_saved /* optional */, const uint8_t* selector, const float* d_density,
+                           const float* d_rgb, const float* d_logit, float* d_feats, const float* jacobian /* optional */,
+                           float* d_position /* optional */, const struct fnr_table_adam* weight_adam,
+                           const float* grad_arena, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of fnr_hash_encode_fwd: adds (+=) the trilinear scatter of d_feats [L][N][2] into
  * grid_grad->table for the levels [level_begin, level_begin + level_count) (all levels: 0, n_levels; data-parallel
  * training calls it per group of levels so that a group's rows can be all-reduced while the next group is being
