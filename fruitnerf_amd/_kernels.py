@@ -492,6 +492,22 @@ def position_grad_from_jacobian(warp: L.fnr_warp, rays: RaysArg, euclid: Tensor,
                                                 L.stream_ptr(rays.device)), "position_grad_from_jacobian")
 
 
+def position_grad_reduce_multi(sources, rays: RaysArg, d_origins: Tensor, d_directions: Tensor,
+                              accumulate: bool = False) -> None:
+    """One launch for several ray-gradient sources [(warp, euclid [R,S+1], S, partial [n_levels,N,4] | [N,4]), ...]:
+    d_origins / d_directions [R,3] = (or +=) the sum of their ray gradients, in source order."""
+    lib = L.load()
+    n = len(sources)
+    warps = (C.POINTER(L.fnr_warp) * n)(*[C.pointer(w) for w, _, _, _ in sources])
+    euclid = (C.c_void_p * n)(*[L.ptr(e) for _, e, _, _ in sources])
+    S = (C.c_int * n)(*[int(s_) for _, _, s_, _ in sources])
+    levels = (C.c_int * n)(*[(p.shape[0] if p.dim() == 3 else 1) for _, _, _, p in sources])
+    partials = (C.c_void_p * n)(*[L.ptr(p) for _, _, _, p in sources])
+    L.check(lib.fnr_position_grad_reduce_multi(n, warps, rays.ref, euclid, S, levels, partials, 1 if accumulate else 0,
+                                               L.ptr(d_origins), L.ptr(d_directions), L.stream_ptr(rays.device)),
+            "position_grad_reduce_multi")
+
+
 def position_grad_reduce(warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int, partial: Tensor, d_origins: Tensor,
                          d_directions: Tensor) -> None:
     """d_origins / d_directions [R,3] += the ray gradient carried by `partial` ([n_levels][N][4] or [N][4])."""

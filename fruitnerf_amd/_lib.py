@@ -128,6 +128,8 @@ SIGNATURES = {
                                   _vp, C.c_size_t, _i, _vp]),
     "fnr_hash_encode_input_grad": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
     "fnr_position_grad_reduce": (_i, [P(fnr_warp), P(fnr_rays), _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "fnr_position_grad_reduce_multi": (_i, [_i, P(P(fnr_warp)), P(fnr_rays), P(C.c_void_p), P(C.c_int), P(C.c_int),
+                                            P(C.c_void_p), _i, _vp, _vp, _vp]),
     "fnr_train_losses": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _i, P(C.c_int), P(C.c_void_p),
                               P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), _f, _i, _vp,
                               _vp, _vp]),

@@ -142,6 +142,70 @@ __global__ __launch_bounds__(256) void k_position_reduce(Warp warp, RaysDev rays
   }
 }
 
+// k_position_reduce over several sources in ONE launch (a training step with a camera optimiser has three: the two
+// proposal levels' d_position and the main field's): wave = ray, the sources' per-ray sums are formed one after the
+// other in source order and WRITTEN (accumulate = 0: the [R,3] buffers need no zero fill) or added.
+struct PosSource {
+  Warp warp;
+  const float* euclid;
+  const float4* partial;
+  int S, n_levels;
+};
+struct PosSources {
+  int n;
+  PosSource s[FNR_MAX_POSITION_SOURCES];
+};
+__global__ __launch_bounds__(256) void k_position_reduce_multi(PosSources src, RaysDev rays, int accumulate,
+                                                               float* __restrict__ d_origins,
+                                                               float* __restrict__ d_directions) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= rays.n_rays) return;
+  const float* o = rays.origins + 3 * r;
+  const float* d = rays.directions + 3 * r;
+  float tot_o[3] = {0.f, 0.f, 0.f}, tot_d[3] = {0.f, 0.f, 0.f};
+  for (int q = 0; q < src.n; ++q) {
+    const PosSource& ps = src.s[q];
+    const int S = ps.S;
+    const long long N = rays.n_rays * (long long)S;
+    float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+    for (int k = lane; k < S; k += 64) {
+      const long long n = r * S + k;
+      float g[3] = {0.f, 0.f, 0.f};
+      for (int l = 0; l < ps.n_levels; ++l) {
+        const float4 v = ps.partial[(size_t)l * N + n];
+        g[0] += v.x, g[1] += v.y, g[2] += v.z;
+      }
+      const float* b = ps.euclid + r * (S + 1) + k;
+      const float tm = (b[0] + b[1]) * 0.5f;
+      float p[3];
+      ray_position(o, d, b[0], b[1], p[0], p[1], p[2]);
+      warp_backward(ps.warp, p, g);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        go[a] += g[a];
+        gd[a] += tm * g[a];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // the same per-source sums k_position_reduce forms, added in source order
+      tot_o[a] += wave_sum(go[a]);
+      tot_d[a] += wave_sum(gd[a]);
+    }
+  }
+  if (lane < 3) {
+    const float vo = (lane == 0) ? tot_o[0] : (lane == 1) ? tot_o[1] : tot_o[2];
+    const float vd = (lane == 0) ? tot_d[0] : (lane == 1) ? tot_d[1] : tot_d[2];
+    if (accumulate) {
+      d_origins[3 * r + lane] += vo;
+      d_directions[3 * r + lane] += vd;
+    } else {
+      d_origins[3 * r + lane] = vo;
+      d_directions[3 * r + lane] = vd;
+    }
+  }
+}
+
 // g[a] = sum over levels l (in level order) of gf_l . J_l[a].  The loads of 8 levels are issued before the first use: the
 // plain loop waited for one level's four loads at a time (SQ_WAIT_ANY 0.91 of the kernel's wave-cycles).
 __device__ __forceinline__ void contract_jacobian(const float2* __restrict__ jac, const float2* __restrict__ d_feats,
@@ -264,6 +328,34 @@ extern "C" int fnr_hash_encode_input_grad(const fnr_grid* grid, const fnr_warp* 
   FNR_PROF(OP_POSITION_GRAD, N);
   hipLaunchKernelGGL((k_hash_input_grad<RaySource>), dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), make_grid(grid),
                      make_warp(warp), src, N, reinterpret_cast<const float2*>(d_feats), reinterpret_cast<float4*>(partial));
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_position_grad_reduce_multi(int n_sources, const fnr_warp* const* warps, const fnr_rays* rays,
+                                              const float* const* euclid_bins, const int* S, const int* n_levels,
+                                              const float* const* partials, int accumulate, float* d_origins,
+                                              float* d_directions, void* stream) {
+  FNR_CHECK_ARG(n_sources >= 1 && n_sources <= FNR_MAX_POSITION_SOURCES && warps && rays && euclid_bins && S && n_levels &&
+                    partials && d_origins && d_directions,
+                "position_grad_reduce_multi: bad argument (1..%d sources)", FNR_MAX_POSITION_SOURCES);
+  if (rays->n_rays == 0) return FNR_OK;
+  PosSources src;
+  src.n = n_sources;
+  long long units = 0;
+  for (int q = 0; q < n_sources; ++q) {
+    FNR_CHECK_ARG(warps[q] && euclid_bins[q] && partials[q] && S[q] > 0 && n_levels[q] >= 1,
+                  "position_grad_reduce_multi: source %d", q);
+    src.s[q].warp = make_warp(warps[q]);
+    src.s[q].euclid = euclid_bins[q];
+    src.s[q].partial = reinterpret_cast<const float4*>(partials[q]);
+    src.s[q].S = S[q];
+    src.s[q].n_levels = n_levels[q];
+    units += rays->n_rays * (long long)S[q];
+  }
+  FNR_PROF(OP_POSITION_GRAD, units);
+  hipLaunchKernelGGL(k_position_reduce_multi, dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream), src,
+                     make_rays(rays), accumulate, d_origins, d_directions);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -395,6 +395,10 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
     losses[3] = t[0];
     losses[4] = want_distortion ? t[1] : 0.0f;
   }
+  // self-cleaning: this (last) workgroup has read every slot and every other workgroup is done, so the accumulator goes
+  // back to zero here — a caller that keeps the buffer needs no fill launch before the next step
+  __syncthreads();
+  for (int i = threadIdx.x; i < TL_ACCUM_FLOATS; i += 256) accum[i] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------

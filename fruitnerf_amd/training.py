@@ -185,12 +185,15 @@ class _InterlevelFn(torch.autograd.Function):
 
 
 def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins: Optional[Tensor],
-                       d_directions: Optional[Tensor], level_streams: bool = False) -> None:
+                       d_directions: Optional[Tensor], level_streams: bool = False,
+                       collect: Optional[list] = None) -> None:
     """Backward of the interlevel loss into the proposal networks (and, when asked, into the rays).
     upstream None: d_wps already holds d(loss)/d(density) per level (train_losses(fuse_weights_bwd=True)).
     level_streams: the levels' chains (MLP backward -> weight reduce -> scatter emit -> accumulate; they share nothing when
     every level has its own network) run side by side, level 0 on the current stream and the others on side streams;
-    their ray-gradient sums (+= into the same [R,3] buffers) follow on the current stream after the join."""
+    their ray-gradient sums (+= into the same [R,3] buffers) follow on the current stream after the join.
+    collect: a list that receives the levels' ray-gradient sources (warp, euclid, S, d_position) INSTEAD of their
+    reduction into d_origins / d_directions — the caller reduces all sources of the step in one launch."""
     cfg = model.config
     rays = rctx.rays
     dev = rays.device
@@ -214,7 +217,9 @@ def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins
                                        want_position_grad=d_origins is not None)
         if d_origins is None:
             continue
-        if side_by_side:
+        if collect is not None:
+            collect.append((net.warp_struct(), lv["euclid"], lv["S"], d_pos))
+        elif side_by_side:
             pending.append((net, lv, d_pos, stream))
         else:
             K.position_grad_reduce(net.warp_struct(), rays, lv["euclid"], lv["S"], d_pos, d_origins, d_directions)
@@ -575,8 +580,12 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         image, mask = batch["image"].to(dev), batch["fruit_mask"].to(dev)
         # one fill for everything this step accumulates into: the loss slots (+ completion counter) and, with a camera
         # optimiser, the ray gradients d(loss)/d(origins | directions); one launch for every loss and metric
+        # the loss / metric accumulator is persistent: fnr_train_losses leaves it zeroed (its last workgroup cleans up),
+        # so a step launches no fill; the ray gradients are WRITTEN by the one reduction over all their sources
         n_slots = L.FNR_TRAIN_LOSSES_ACCUM_FLOATS
-        zeros = torch.zeros(n_slots + (6 * rays.n if ray_grads is not None else 0), device=dev)
+        accum = model.__dict__.get("_loss_accum")
+        if accum is None or accum.device != dev:
+            accum = model.__dict__["_loss_accum"] = torch.zeros(n_slots, device=dev)
         # on steps that train the proposal networks their weights backward (unit upstream) rides along: the list
         # then holds d(loss)/d(density) per level instead of d(loss)/d(weights)
         prop_bwd = bool(rctx.training and rctx.updated)
@@ -585,7 +594,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         losses, d_rgb, d_sem, d_wps = K.train_losses(outputs["rgb"], image, outputs["semantics"], mask,
                                                      cfg.semantic_loss_weight, S, fin["spacing"], fin["weights"],
                                                      prop_levels, cfg.interlevel_loss_mult, want_metrics,
-                                                     zeros[:n_slots], fuse_weights_bwd=prop_bwd)
+                                                     accum, fuse_weights_bwd=prop_bwd)
         loss_dict = {"rgb_loss": losses[0], "semantics_loss": losses[1], "interlevel_loss": losses[3]}
         metrics_dict = {"psnr": losses[2], "distortion": losses[4]} if want_metrics else {}
 
@@ -593,9 +602,10 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         arena = model.arena()
         arena.reattach_grads()
         d_o = d_d = None
+        ray_sources = [] if ray_grads is not None else None     # (warp, euclid, S, partial) of every chain, in order
         if ray_grads is not None:
-            d_o = ray_grads["origins"] = zeros[n_slots:n_slots + 3 * rays.n].view(rays.n, 3)
-            d_d = ray_grads["directions"] = zeros[n_slots + 3 * rays.n:].view(rays.n, 3)
+            both = torch.empty(2, rays.n, 3, device=dev)
+            d_o, d_d = ray_grads["origins"], ray_grads["directions"] = both[0], both[1]
         # The proposal-network backward (interlevel loss) and the field backward (rgb + semantic losses) share no
         # buffers.  overlap_proposal_backward=True runs the former on a second HIP stream so that its ~14 small/medium
         # launches fill the gaps and tails of the field kernels (measured: -2 % step time); off by default because
@@ -610,7 +620,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                     side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    _proposal_backward(model, rctx, d_wps, up, d_o, d_d)
+                    _proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources)
         d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
                                                       rctx.weights, d_rgb, d_sem)
         fld = model.field
@@ -623,17 +633,15 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         else:
             d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
                                       d_rgb_s, d_logit, weight_adam=weight_adam)
-        field_rays_done = False
-        if ray_grads is not None and d_pos is None and table_adam is not None:
-            # no saved Jacobian (the model is not in training mode): the gather path reads the TABLE, which the fused
-            # scatter below updates in place — take the field's ray gradients first (after the side stream's share:
-            # both add into d_o / d_d)
-            if side is not None:
-                main.wait_stream(side)
-                side = None
-                prop_bwd = False
-            _field_ray_grads(model, rctx, d_feats, d_o, d_d)
-            field_rays_done = True
+        field_source = None
+        if ray_grads is not None:
+            if d_pos is not None:
+                field_source = (fld.warp_struct(), fin["euclid"], S, d_pos)
+            else:
+                # no saved Jacobian (the model is not in training mode): the gather path reads the TABLE, which the
+                # fused scatter below may update in place — gather now
+                partial = K.hash_encode_input_grad(net.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
+                field_source = (fld.warp_struct(), fin["euclid"], S, partial)
         if exchange is None and table_adam is not None:
             K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, table_adam)
         elif exchange is None:
@@ -647,11 +655,15 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 exchange.levels_done(lb, cnt)      # this slice of the gradient table is final: all-reduce it now
             exchange.field_done()
         if side is not None:
-            main.wait_stream(side)                 # proposal gradients (and their share of the ray gradients) are final
+            main.wait_stream(side)                 # proposal gradients (and their ray-gradient sources) are final
+            for src in ray_sources or ():
+                src[3].record_stream(main)
         elif prop_bwd:
-            _proposal_backward(model, rctx, d_wps, up, d_o, d_d, level_streams=PROPOSAL_LEVEL_STREAMS)
-        if ray_grads is not None and not field_rays_done:
-            _field_ray_grads(model, rctx, d_feats, d_o, d_d, d_pos)   # after the join: both chains add into d_o / d_d
+            _proposal_backward(model, rctx, d_wps, up, d_o, d_d, level_streams=PROPOSAL_LEVEL_STREAMS,
+                               collect=ray_sources)
+        if ray_grads is not None:
+            # one launch: proposal levels first, the field last (the order the separate launches added them in)
+            K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
     return loss_dict, metrics_dict
 
 

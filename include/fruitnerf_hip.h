@@ -413,6 +413,16 @@ int fnr_hash_encode_input_grad(const fnr_grid* grid, const fnr_warp* warp, const
 int fnr_position_grad_reduce(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,
                              int n_levels, const float* partial, float* d_origins, float* d_directions,
                              void* stream);
+/* fnr_position_grad_reduce over up to FNR_MAX_POSITION_SOURCES sources in one launch: source q contributes the ray
+ * gradient carried by partials[q] ([n_levels[q]][N_q][4], N_q = n_rays * S[q]) through warps[q] and the frustum chain of
+ * euclid_bins[q] ([n_rays, S[q] + 1]).  accumulate = 0: d_origins / d_directions are WRITTEN (no zero fill needed);
+ * 1: added to.  The per-source sums are those of fnr_position_grad_reduce, added in source order. */
+#define FNR_MAX_POSITION_SOURCES 4
+int fnr_position_grad_reduce_multi(int n_sources, const fnr_warp* const* warps, const fnr_rays* rays,
+                                   const float* const* euclid_bins, const int* S, const int* n_levels,
+                                   const float* const* partials, int accumulate, float* d_origins, float* d_directions,
+                                   void* stream);
+
 /* Same result from the Jacobian fnr_hash_encode_fwd saved: d_origins / d_directions [R,3] += the ray gradient of
  * d_feats [L][N][2] (no table gathers in the backward pass). */
 int fnr_position_grad_from_jacobian(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,

@@ -448,332 +448,6 @@ def test_optimizer_can_step_groups_without_gradient_like_torch_1_13(dev):
     assert {int(opts["proposal_networks"].state[p]["step"]) for p in groups["proposal_networks"]} == {4}
 
 
-@pytest.mark.parametrize("shape,step,tables", [("fruit_nerf_big", 0, "white"), ("fruit_nerf_big", 2500, "smooth"),
-                                               ("fruit_nerf_huge", 2500, "smooth"), ("fruit_nerf_huge", 0, "white")])
-def test_losses_and_all_gradients_at_the_real_configuration(dev, shape, step, tables):
-    """The gradient legs of `fruit_nerf_big` / `fruit_nerf_huge` WITHOUT the shrinking of the test above: the methods'
-    own sizes (fruit_nerf_config.py:82-95 / 113-164 — T = 2^21, max_res 4096 / 8192, 512/256/128 and 512/512/64 samples,
-    the 5- and 7-level proposal grids at T = 2^17, anneal over 5000 iterations).  step 0: anneal exponent 0 (flat
-    proposal PDFs); step 2500: exponent 0.909.  Both are 'updated' steps (proposal networks get gradients).
-    tables = "white": uniform random entries at every level — at max_res 4096 / 8192 the finest levels then encode
-    noise with a slope of thousands per unit length, so the 1e-6 sampler noise is visible in single entries;
-    "smooth": the same entries scaled by base_res / res_l per level (every level the same slope, as in a trained
-    field), where the well-conditioned bar must hold."""
-    from fruitnerf_amd.rays import RayBundle
-    cfg = {"fruit_nerf_big": util.fruit_nerf_big_config, "fruit_nerf_huge": util.fruit_nerf_huge_config}[shape]()
-    om = util.make_oracle(cfg, seed=5)
-    if tables == "smooth":
-        util.smooth_tables_(om)
-    hm = util.make_hip_like(om, dev)
-    om.train()
-    hm.train()
-    for m in (om, hm):
-        m.proposal_sampler._step = step
-        m.proposal_sampler._steps_since_update = 100
-    R = 96
-    o, d, pa, cam = util.random_rays(R, 7, seed=21)
-    jit = [torch.rand(R, 1) for _ in range(3)]
-    batch = _batch(R, 3)
-    out, ld_ref, md_ref = _oracle_step(om, o, d, pa, cam, jit, batch, step)
-    hm.set_anneal(step)
-    hout = hm(RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), jitter=[j.to(dev) for j in jit])
-    hb = {k: v.to(dev) for k, v in batch.items()}
-    md = hm.get_metrics_dict(hout, hb)
-    ld = hm.get_loss_dict(hout, hb)
-    sum(ld.values()).backward()
-    torch.cuda.synchronize()
-    for k in ld_ref:
-        a, b = float(ld[k]), float(ld_ref[k])
-        print(f"[real {shape} step={step} {tables}] {k}: hip {a:.8e} oracle {b:.8e} rel {abs(a - b) / max(abs(b), 1e-12):.2e}")
-        tol = 1e-3 * abs(b) + 1e-8 if k == "interlevel_loss" else 1e-4 * max(abs(b), 1e-3)
-        assert abs(a - b) <= tol, k
-    for k in ("rgb", "semantics", "accumulation"):
-        err = (hout[k].detach().cpu() - out[k].detach()).abs().max().item()
-        print(f"[real {shape} step={step} {tables}] output {k}: max abs err {err:.3e}")
-        assert err <= 1e-5, k            # measured 1e-6 (round 3): an order inside the 1e-4 bar
-    worst, worst_agg = _grad_report(om, hm, f" real {shape} step={step} {tables}", with_aggregate=True)
-    # measured (round 3, bf16x3 default): max-norm <= 1e-4, L1 <= 5e-5 on all four legs — the round-1 bar of 5e-4 holds
-    # at the real sizes for white and smooth tables alike
-    assert worst <= 5e-4 and worst_agg <= 2e-4, f"gradient error: max-norm {worst}, L1 {worst_agg}"
-
-
-def test_adam_matches_torch(dev):
-    from fruitnerf_amd import _kernels as K
-    torch.manual_seed(0)
-    n = 4096 * 4
-    p0 = torch.randn(n)
-    ref = p0.clone().requires_grad_(True)
-    opt = torch.optim.Adam([ref], lr=1e-2, eps=1e-15)
-    p = p0.clone().to(dev)
-    m = torch.zeros(n, device=dev)
-    v = torch.zeros(n, device=dev)
-    for step in range(1, 6):
-        g = torch.randn(n) * (torch.rand(n) > 0.5)  # half the entries see zero gradients
-        ref.grad = g.clone()
-        opt.step()
-        gd = (g * 2.0).to(dev)  # all-reduced SUM of 2 ranks -> scale 0.5
-        K.adam_step(p, gd, m, v, 1e-2, 0.9, 0.999, 1e-15, step, grad_scale=0.5, zero_grad=True)
-        assert float(gd.abs().max()) == 0.0
-    a, _ = util.report("adam.params", p, ref.detach())
-    assert a <= 2e-6
-
-
-def test_three_training_steps_track_the_oracle(dev):
-    """forward + backward + Adam for 3 steps from identical weights and identical jitter."""
-    from fruitnerf_amd.rays import RayBundle
-    from fruitnerf_amd.training import FusedAdam, train_iteration
-    cfg = util.small_config(log2=14, prop_log2=12)
-    om = util.make_oracle(cfg, seed=8)
-    hm = util.make_hip_like(om, dev)
-    om.train()
-    hm.train()
-    groups = om.get_param_groups()
-    opts = [torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15),
-            torch.optim.Adam(groups["fields"], lr=1e-2, eps=1e-15)]
-    hopt = FusedAdam(hm)
-    p0 = {n: p.detach().clone() for n, p in om.named_parameters()}
-    R = 128
-    for step in range(3):
-        o, d, pa, cam = util.random_rays(R, 7, seed=100 + step)
-        jit = [torch.rand(R, 1) for _ in range(3)]
-        batch = _batch(R, 50 + step)
-        for op in opts:
-            op.zero_grad()
-        _, ld_ref, _ = _oracle_step(om, o, d, pa, cam, jit, batch, step)
-        for op in opts:
-            op.step()
-        om.proposal_sampler.step_cb(step)
-        ld, _ = train_iteration(hm, hopt, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)),
-                                {k: v.to(dev) for k, v in batch.items()}, step, jitter=[j.to(dev) for j in jit])
-        for k in ld_ref:
-            a, b = float(ld[k]), float(ld_ref[k])
-            print(f"[train step {step}] {k}: hip {a:.8e} oracle {b:.8e}")
-            # Adam (eps=1e-15) turns every non-zero gradient into a +-lr step on the first iterations, so
-            # entries whose gradient is rounding noise take different signs on the two sides: trajectories
-            # agree to ~1e-3 (the tiny interlevel term to a few %), not to fp32 rounding.
-            tol = 5e-2 if k == "interlevel_loss" else 2e-3
-            assert abs(a - b) <= tol * max(abs(b), 1e-3), (step, k)
-    torch.cuda.synchronize()
-    named_h = dict(hm.named_parameters())
-    for name, p in om.named_parameters():
-        diff = (named_h[name].detach().cpu() - p.detach()).abs().max().item()
-        print(f"[params after 3 steps] {name}: max_abs_diff {diff:.3e}")
-        # Adam's first steps move every touched entry by ~lr regardless of gradient magnitude, so entries
-        # whose gradient is rounding-level noise may differ by O(lr); bound the bulk instead of the max
-        d_abs = (named_h[name].detach().cpu() - p.detach()).abs()
-        moved = (p.detach() - p0[name]).abs()
-        print(f"    median diff {d_abs.median().item():.3e}  mean diff {d_abs.mean().item():.3e}  "
-              f"mean |update| {moved.mean().item():.3e}")
-        # the bulk of the entries must agree far better than the size of the update itself
-        assert d_abs.median().item() <= 0.05 * max(moved.mean().item(), 1e-9) + 1e-7, name
-        assert d_abs.max().item() <= 3 * 3 * 1e-2 + 1e-6, name  # nothing moves further than steps * lr apart
-
-
-@pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
-def test_field_api_is_differentiable(dev, shape):
-    """FruitField.forward / get_density -> get_outputs in training mode carry autograd history w.r.t. the field's
-    parameters (fruit_field.py:168-301 is an ordinary differentiable nn.Module in the reference): a loss on the
-    per-sample density, rgb and semantics back-propagates into every field parameter like the oracle's autograd."""
-    from fruitnerf_amd.fruit_field import FieldHeadNames
-    from fruitnerf_amd.rays import RayBundle
-    cfg = (util.small_config if shape == "fruit_nerf" else util.big_config)(log2=14)
-    om = util.make_oracle(cfg, seed=41)
-    hm = util.make_hip_like(om, dev)
-    om.train()
-    hm.train()
-    R, S = 64, 24
-    o, d, pa, cam = util.random_rays(R, 7, seed=5)
-    euclid = torch.sort(torch.rand(R, S + 1) * 1.6 + 0.2, dim=-1).values
-    g = torch.Generator().manual_seed(3)
-    wd, wr, ws = torch.rand(R, S, 1, generator=g) * 1e-3, torch.randn(R, S, 3, generator=g), torch.randn(R, S, 1, generator=g)
-    rs = ns.RayBundle(o, d, pa, camera_indices=cam).get_ray_samples(euclid[:, :-1, None], euclid[:, 1:, None])
-    ref = om.field(rs)
-    ((ref["density"] * wd).sum() + (ref["rgb"] * wr).sum() + (ref["semantics"] * ws).sum()).backward()
-    hb = RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev))
-    hs = hb.get_ray_samples(euclid[:, :-1, None].to(dev), euclid[:, 1:, None].to(dev))
-    for two_calls in (False, True):
-        hm.arena().grads.zero_()
-        if two_calls:                                           # the Field base class's own forward()
-            dens, emb = hm.field.get_density(hs)
-            out = hm.field.get_outputs(hs, density_embedding=emb)
-            rgb, sem = out[FieldHeadNames.RGB], out[FieldHeadNames.SEMANTICS]
-            assert not emb.requires_grad
-        else:
-            out = hm.field(hs)
-            dens, rgb, sem = out[FieldHeadNames.DENSITY], out[FieldHeadNames.RGB], out[FieldHeadNames.SEMANTICS]
-        assert dens.requires_grad and rgb.requires_grad and sem.requires_grad
-        ((dens * wd.to(dev)).sum() + (rgb * wr.to(dev)).sum() + (sem * ws.to(dev)).sum()).backward()
-        torch.cuda.synchronize()
-        named_h = dict(hm.field.named_parameters())
-        for name, p in om.field.named_parameters():
-            g_ref = p.grad if p.grad is not None else torch.zeros_like(p)
-            diff = (named_h[name].grad.cpu() - g_ref).abs()
-            scale = g_ref.abs().max().item()
-            l1 = diff.double().sum().item() / max(g_ref.abs().double().sum().item(), 1e-30)
-            print(f"[field api two_calls={two_calls}] {name}: max|ref| {scale:.3e} max_err {diff.max().item():.3e} L1-rel {l1:.3e}")
-            assert diff.max().item() <= 2e-2 * scale + 1e-12 and l1 <= 2e-3, name    # ReLU kinks: see the big-shape note above
-    # the side-effect attributes of get_density (fruit_field.py:180-186)
-    loc, dba = hm.field._sample_locations, hm.field._density_before_activation
-    assert loc.shape == (R, S, 3) and loc.requires_grad and dba.shape == (R, S, 1)
-    with torch.no_grad():
-        om.field.get_density(rs)
-    assert (loc.detach().cpu() - om.field._sample_locations.detach()).abs().max().item() <= 1e-6
-    assert (dba.cpu() - om.field._density_before_activation.detach()).abs().max().item() <= 1e-4
-    # eval mode: the same API without autograd history
-    hm.eval()
-    assert not hm.field(hs)[FieldHeadNames.RGB].requires_grad
-
-
-def test_trainer_shaped_loop_over_the_plugin_api(dev):
-    """Nerfstudio's Trainer.train_iteration, spelled out over the plugin surface only (callbacks by location, forward,
-    get_metrics_dict, get_loss_dict, reduce(add), backward, optimiser) — must leave the model exactly where
-    fused_train_iteration() (what bench.py times) leaves its twin."""
-    import functools
-    from fruitnerf_amd.engine.callbacks import TrainingCallbackAttributes, TrainingCallbackLocation as Loc
-    from fruitnerf_amd.rays import RayBundle
-    from fruitnerf_amd.training import FusedAdam, fused_train_iteration, skipped_groups
-    cfg = util.small_config(log2=13, prop_log2=11)
-    om = util.make_oracle(cfg, seed=23)
-    a, b = util.make_hip_like(om, dev), util.make_hip_like(om, dev)
-    a.train()
-    b.train()
-    opt_a, opt_b = FusedAdam(a), FusedAdam(b)
-    callbacks = a.get_training_callbacks(TrainingCallbackAttributes(optimizers=None, grad_scaler=None, pipeline=None))
-    R = 128
-    for step in range(12):                                       # crosses the end of the every-step update phase
-        o, d, pa, cam = util.random_rays(R, 7, seed=500 + step)
-        batch = {k: v.to(dev) for k, v in _batch(R, 90 + step).items()}
-        for cb in callbacks:
-            cb.run_callback_at_location(step, location=Loc.BEFORE_TRAIN_ITERATION)
-        torch.manual_seed(1000 + step)                           # the model draws its jitter from the device generator
-        outputs = a(RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)))
-        metrics_dict = a.get_metrics_dict(outputs, batch)
-        loss_dict = a.get_loss_dict(outputs, batch, metrics_dict)
-        functools.reduce(torch.add, loss_dict.values()).backward()
-        opt_a.step(skip=skipped_groups(a))
-        for cb in callbacks:
-            cb.run_callback_at_location(step, location=Loc.AFTER_TRAIN_ITERATION)
-        torch.manual_seed(1000 + step)
-        ld_b, md_b = fused_train_iteration(b, opt_b, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), batch, step)
-        for k in loss_dict:
-            # same kernels on both sides; only the order of a few float atomics differs, and Adam (eps 1e-15) turns
-            # rounding-level gradient noise into +-lr steps, so the twins agree to ~1e-3, not to fp32 rounding
-            tol = 5e-2 if k == "interlevel_loss" else 2e-3
-            assert abs(float(loss_dict[k]) - float(ld_b[k])) <= tol * max(abs(float(ld_b[k])), 1e-6), (step, k)
-    torch.cuda.synchronize()
-    pa_, pb_ = a.arena().params, b.arena().params
-    moved = (pb_ - util.make_hip_like(om, dev).arena().params).abs()
-    assert (pa_ - pb_).abs().median().item() <= 0.05 * moved.mean().item() + 1e-7
-    assert (pa_ - pb_).abs().max().item() <= 3 * 12 * 1e-2
-    assert a.proposal_sampler._step == b.proposal_sampler._step == 11
-    assert opt_a.group_steps == opt_b.group_steps
-
-
-@pytest.mark.parametrize("fused", [False, True])
-def test_optimizer_skips_the_proposal_networks_on_steps_that_do_not_update_them(dev, fused):
-    """Steps 9..12 cross the end of the every-step phase (ProposalNetworkSampler: step < 10).  On iteration 11 the
-    proposal densities are computed under no_grad, the reference's zero_grad() leaves those .grad = None and
-    torch.optim skips the parameters: no movement, no moment decay, no step-count advance (bias correction).  The
-    oracle side is driven with torch.optim exactly as nerfstudio's Optimizers does; the HIP side must show the same
-    pattern and the same per-group step counts."""
-    from fruitnerf_amd.rays import RayBundle
-    from fruitnerf_amd.training import FusedAdam, fused_train_iteration, train_iteration
-    cfg = util.small_config(log2=12, prop_log2=10)
-    om = util.make_oracle(cfg, seed=31)
-    hm = util.make_hip_like(om, dev)
-    om.train()
-    hm.train()
-    groups = om.get_param_groups()
-    opts = {"proposal_networks": torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15),
-            "fields": torch.optim.Adam(groups["fields"], lr=1e-2, eps=1e-15)}
-    hopt = FusedAdam(hm)
-    for m in (om, hm):                       # as after 9 warm-up iterations
-        m.proposal_sampler._step = 8
-        m.proposal_sampler._steps_since_update = 1
-    hopt.step_count = 9
-    hopt.group_steps = {k: 9 for k in hopt.group_steps}
-    R = 96
-    a, b = hm.arena().group_ranges["proposal_networks"]
-    moved_ref, moved_hip = [], []
-    for step in range(9, 13):
-        o, d, pa, cam = util.random_rays(R, 7, seed=300 + step)
-        jit = [torch.rand(R, 1) for _ in range(3)]
-        batch = _batch(R, 70 + step)
-        before_ref = [p.detach().clone() for p in groups["proposal_networks"]]
-        for op in opts.values():
-            op.zero_grad()                  # torch >= 2.0: set_to_none=True
-        _oracle_step(om, o, d, pa, cam, jit, batch, step)
-        for op in opts.values():
-            op.step()
-        om.proposal_sampler.step_cb(step)
-        moved_ref.append(any(not torch.equal(x, p.detach()) for x, p in zip(before_ref, groups["proposal_networks"])))
-        before = hm.arena().params[a:b].clone()
-        m_before, v_before = hopt.exp_avg[a:b].clone(), hopt.exp_avg_sq[a:b].clone()
-        fn = fused_train_iteration if fused else train_iteration
-        fn(hm, hopt, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), {k: v.to(dev) for k, v in batch.items()},
-           step, jitter=[j.to(dev) for j in jit])
-        torch.cuda.synchronize()
-        moved_hip.append(not torch.equal(before, hm.arena().params[a:b]))
-        if not moved_hip[-1]:
-            assert torch.equal(m_before, hopt.exp_avg[a:b]) and torch.equal(v_before, hopt.exp_avg_sq[a:b])
-        assert float(hm.arena().grads.abs().max()) == 0.0       # zero_grad fused into the step, skipped span included
-    print("[optimizer skip] proposal networks moved on steps 9..12: oracle", moved_ref, "hip", moved_hip)
-    # nerfstudio's rule: updated iff steps_since_update > update_sched(step) or step < 10, evaluated with the step
-    # number the AFTER_TRAIN_ITERATION callback stored -> iterations 9 and 10 still update, 11 does not, 12 does
-    assert moved_ref == [True, True, False, True] and moved_hip == moved_ref
-    ref_steps = {int(opts["proposal_networks"].state[p]["step"]) for p in groups["proposal_networks"]}
-    assert ref_steps == {3} and hopt.group_steps["proposal_networks"] == 9 + 3
-    assert hopt.group_steps["fields"] == 9 + 4 and hopt.step_count == 9 + 4
-
-
-def test_optimizer_can_step_groups_without_gradient_like_torch_1_13(dev):
-    """FusedAdam(skip_groups_without_grad=False): nerfstudio 0.3.2 also runs on torch 1.13, whose zero_grad() leaves ZERO
-    tensors — Adam then still decays the moments, moves the proposal networks along them and advances their step count
-    on the iterations that evaluate them under no_grad.  Oracle: torch.optim fed explicit zero gradients."""
-    from fruitnerf_amd.rays import RayBundle
-    from fruitnerf_amd.training import FusedAdam, fused_train_iteration
-    cfg = util.small_config(log2=12, prop_log2=10)
-    om = util.make_oracle(cfg, seed=31)
-    hm = util.make_hip_like(om, dev)
-    om.train()
-    hm.train()
-    groups = om.get_param_groups()
-    opts = {"proposal_networks": torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15),
-            "fields": torch.optim.Adam(groups["fields"], lr=1e-2, eps=1e-15)}
-    hopt = FusedAdam(hm, skip_groups_without_grad=False)
-    for m in (om, hm):
-        m.proposal_sampler._step = 8
-        m.proposal_sampler._steps_since_update = 1
-    R = 96
-    a, b = hm.arena().group_ranges["proposal_networks"]
-    moved = []
-    for step in range(9, 13):
-        o, d, pa, cam = util.random_rays(R, 7, seed=300 + step)
-        jit = [torch.rand(R, 1) for _ in range(3)]
-        batch = _batch(R, 70 + step)
-        for op in opts.values():
-            op.zero_grad(set_to_none=False)            # torch 1.13's default
-        for p in groups["proposal_networks"]:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        _oracle_step(om, o, d, pa, cam, jit, batch, step)
-        for op in opts.values():
-            op.step()
-        om.proposal_sampler.step_cb(step)
-        before = hm.arena().params[a:b].clone()
-        fused_train_iteration(hm, hopt, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)),
-                              {k: v.to(dev) for k, v in batch.items()}, step, jitter=[j.to(dev) for j in jit])
-        torch.cuda.synchronize()
-        moved.append(not torch.equal(before, hm.arena().params[a:b]))
-    assert moved == [True, True, True, True]           # iteration 11 has no gradient and still moves (momentum)
-    assert hopt.group_steps["proposal_networks"] == 4
-    named_h = dict(hm.named_parameters())
-    for name, p in om.named_parameters():
-        if name.startswith("proposal_networks"):
-            err = float((named_h[name].detach().cpu() - p.detach()).abs().max())
-            assert err <= 2e-5 * max(1.0, float(p.detach().abs().max())), (name, err)
-
-
 @pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
 def test_fused_step_matches_the_autograd_step(dev, shape):
     """fused_forward_backward() (no autograd engine, what bench.py times) must leave the same losses, metrics and
