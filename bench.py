@@ -287,8 +287,11 @@ class MethodRun:
     def one_step(self, want_metrics=True):
         from fruitnerf_amd.rays import RayBundle
         from fruitnerf_amd.training import fused_train_iteration
-        o, d, cam, batch = self.batcher.sample(self.rays, self.camera[0] if self.camera else None)
-        out = fused_train_iteration(self.model, self.opt, RayBundle(o, d, None, cam), batch, self.step_idx,
+        # the start of the step in one launch: pixels, corrected cameras, rays, level-0 bins, jitters (fnr_train_prologue)
+        o, d, cam, batch = self.batcher.sample(self.rays, self.camera[0] if self.camera else None,
+                                               level0=self.model.level0_spec())
+        out = fused_train_iteration(self.model, self.opt, RayBundle(o, d, None, cam, presampled=self.batcher.last_presample),
+                                    batch, self.step_idx,
                                     world_size=self.world, want_metrics=want_metrics, camera=self.camera)
         self.step_idx += 1
         return out

@@ -666,6 +666,35 @@ def camera_pose_grad_adam(image_set: ImageSetArg, train_ids: Tensor, u: Tensor, 
             "camera_pose_grad_adam")
 
 
+def train_prologue(image_set: ImageSetArg, train_ids: Tensor, n_rays: int, seed: int, offset: int,
+                   pose_adjustment: Optional[Tensor], near: float, far: float, S0: int, n_jitter: int = 3,
+                   spacing_kind: int = 1) -> dict:
+    """fnr_train_prologue: random numbers + camera adjust + pixel sampling + level-0 spaced sampling in one launch."""
+    lib = L.load()
+    dev = image_set.images.device
+    R = int(n_rays)
+    ids = train_ids.to(torch.int64).contiguous()
+    n_train = ids.numel()
+    out = {
+        "u": torch.empty(R, 3, device=dev), "jitter": torch.empty(n_jitter, R, device=dev),
+        "origins": torch.empty(R, 3, device=dev), "directions": torch.empty(R, 3, device=dev),
+        "cam": torch.empty(R, dtype=torch.int32, device=dev), "image": torch.empty(R, 3, device=dev),
+        "mask": torch.empty(R, device=dev), "spacing": torch.empty(R, S0 + 1, device=dev),
+        "euclid": torch.empty(R, S0 + 1, device=dev),
+        "c2w_adjusted": torch.empty(n_train, 3, 4, device=dev) if pose_adjustment is not None else None,
+        "S0": S0, "near": float(near), "far": float(far), "spacing_kind": spacing_kind,
+    }
+    base = host_linspace(0.0, 1.0, S0 + 1, dev)
+    L.check(lib.fnr_train_prologue(C.byref(image_set.c), L.ptr(ids), n_train, R, int(seed) & (2 ** 64 - 1),
+                                   int(offset) & (2 ** 64 - 1),
+                                   L.ptr(_f32c(pose_adjustment)) if pose_adjustment is not None else None,
+                                   L.ptr(out["c2w_adjusted"]), L.ptr(out["u"]), L.ptr(out["jitter"]), n_jitter,
+                                   L.ptr(out["origins"]), L.ptr(out["directions"]), L.ptr(out["cam"]), L.ptr(out["image"]),
+                                   L.ptr(out["mask"]), float(near), float(far), spacing_kind, S0, L.ptr(base),
+                                   L.ptr(out["spacing"]), L.ptr(out["euclid"]), L.stream_ptr(dev)), "train_prologue")
+    return out
+
+
 def sample_pixels(image_set: ImageSetArg, train_ids: Tensor, u: Tensor, c2w_adjusted: Optional[Tensor] = None):
     lib = L.load()
     dev = u.device

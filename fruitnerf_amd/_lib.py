@@ -95,6 +95,8 @@ SIGNATURES = {
     "fnr_profile_pause": (_i, [_i]),
     "fnr_profile_collect": (_i64, [P(C.c_int32), P(C.c_int64), P(C.c_float), _i64]),
     "fnr_sample_pixels": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_train_prologue": (_i, [P(fnr_image_set), _vp, _i, _i64, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, _i, _vp, _vp,
+                                _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "fnr_sample_spaced": (_i, [P(fnr_rays), _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "fnr_weights_pdf": (_i, [P(fnr_rays), _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_prop_density_fwd": (_i, [P(fnr_prop_net), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),

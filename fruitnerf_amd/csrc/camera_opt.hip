@@ -9,31 +9,9 @@
 // k_camera_adjust builds c2w' (thread = camera); k_camera_pose_grad maps d(loss)/d(origins, directions) back to the
 // [n_train, 6] tangent vectors: one workgroup per camera gathers its rays (ballot), so there are no atomics on the
 // shared rows.
-#include "common.hpp"
+#include "camera_math.hpp"
 
 namespace fnr {
-
-struct SO3 {
-  float R[9];
-  float theta2_raw, theta, f1, f2;
-};
-
-__device__ __forceinline__ SO3 so3_exp(const float* w) {
-  SO3 s;
-  s.theta2_raw = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const float t2 = fmaxf(s.theta2_raw, 1e-4f);
-  s.theta = sqrtf(t2);
-  const float inv = 1.0f / s.theta;
-  s.f1 = inv * sinf(s.theta);
-  s.f2 = inv * inv * (1.0f - cosf(s.theta));
-  // K = [[0,-wz,wy],[wz,0,-wx],[-wy,wx,0]];  K^2 = w w^T - |w|^2 I
-  const float x = w[0], y = w[1], z = w[2];
-  const float K[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
-  const float K2[9] = {-(y * y + z * z), x * y, x * z, x * y, -(x * x + z * z), y * z, x * z, y * z, -(x * x + y * y)};
-#pragma unroll
-  for (int i = 0; i < 9; ++i) s.R[i] = s.f1 * K[i] + s.f2 * K2[i] + ((i % 4 == 0) ? 1.0f : 0.0f);
-  return s;
-}
 
 // c2w' = multiply(c2w[train_ids[k]], exp_map_SO3xR3(pose[k]))
 __global__ __launch_bounds__(64) void k_camera_adjust(const float* __restrict__ c2w, const long long* __restrict__ train_ids,
@@ -41,17 +19,10 @@ __global__ __launch_bounds__(64) void k_camera_adjust(const float* __restrict__ 
                                                       float* __restrict__ c2w_adj) {
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k >= n_train) return;
-  const float* M = c2w + train_ids[k] * 12;
-  const float* tv = pose + 6 * k;
-  const SO3 s = so3_exp(tv + 3);
-  float* out = c2w_adj + 12 * k;
+  float out[12];
+  adjusted_camera(c2w + train_ids[k] * 12, pose + 6 * k, out);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-      out[4 * a + b] = M[4 * a] * s.R[b] + M[4 * a + 1] * s.R[3 + b] + M[4 * a + 2] * s.R[6 + b];
-    out[4 * a + 3] = M[4 * a + 3] + (M[4 * a] * tv[0] + M[4 * a + 1] * tv[1] + M[4 * a + 2] * tv[2]);
-  }
+  for (int i = 0; i < 12; ++i) c2w_adj[12 * k + i] = out[i];
 }
 
 constexpr int CPG_ROUND = 4096;   // rays a pose-gradient workgroup compacts at a time (16 per thread: one round per batch)

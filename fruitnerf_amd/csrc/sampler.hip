@@ -4,22 +4,9 @@
 // per-lane binary search.  These kernels are latency-trivial next to the field queries (HBM-bound reads
 // of S floats per ray); they exist so the whole sampling chain stays on the device without launches of
 // dozens of small elementwise ops.
-#include "common.hpp"
+#include "sampler_math.hpp"
 
 namespace fnr {
-
-// spacing <-> euclidean (SpacedSampler.generate_ray_samples; UniformLinDispPiecewiseSampler)
-__device__ __forceinline__ float spacing_fn(int kind, float x) {
-  if (kind == 0) return x;
-  return (x < 1.0f) ? fdiv(x, 2.0f) : fsub(1.0f, fdiv(1.0f, fmul(2.0f, x)));
-}
-__device__ __forceinline__ float spacing_fn_inv(int kind, float x) {
-  if (kind == 0) return x;
-  return (x < 0.5f) ? fmul(2.0f, x) : fdiv(1.0f, fsub(2.0f, fmul(2.0f, x)));
-}
-__device__ __forceinline__ float spacing_to_euclid(int kind, float x, float s_near, float s_far) {
-  return spacing_fn_inv(kind, fadd(fmul(x, s_far), fmul(fsub(1.0f, x), s_near)));
-}
 
 __global__ __launch_bounds__(256) void k_sample_spaced(RaysDev rays, int kind, int S,
                                                        const float* __restrict__ base_bins,
@@ -30,14 +17,8 @@ __global__ __launch_bounds__(256) void k_sample_spaced(RaysDev rays, int kind, i
   if (idx >= total) return;
   const long long r = idx / (S + 1);
   const int j = (int)(idx - r * (S + 1));
-  float b = base_bins[j];
-  if (t_rand) {
-    // bin_centers / bin_upper / bin_lower of components/ray_samplers.py:84-87
-    const float upper = (j < S) ? fdiv(fadd(base_bins[j + 1], base_bins[j]), 2.0f) : base_bins[S];
-    const float lower = (j > 0) ? fdiv(fadd(base_bins[j], base_bins[j - 1]), 2.0f) : base_bins[0];
-    // single_jitter: one number per ray; otherwise one per bin edge, t_rand [R, S+1] (ray_samplers.py:79-83)
-    b = fadd(lower, fmul(fsub(upper, lower), t_rand[t_rand_per_bin ? idx : r]));
-  }
+  // single_jitter: one number per ray; otherwise one per bin edge, t_rand [R, S+1] (ray_samplers.py:79-83)
+  const float b = spaced_bin_edge(base_bins, S, j, t_rand != nullptr, t_rand ? t_rand[t_rand_per_bin ? idx : r] : 0.0f);
   const float s_near = spacing_fn(kind, rays.nears[r]), s_far = spacing_fn(kind, rays.fars[r]);
   spacing[idx] = b;
   euclid[idx] = spacing_to_euclid(kind, b, s_near, s_far);

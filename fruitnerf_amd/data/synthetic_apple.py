@@ -12,7 +12,7 @@ Everything is seeded; pure torch so it runs on the HIP device (bench) or the CPU
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -139,13 +139,29 @@ class PixelBatcher:
         self.gen.manual_seed(seed)
         self._set = None
 
-    def sample(self, n_rays: int, camera_optimizer=None):
+    def sample(self, n_rays: int, camera_optimizer=None, level0: Optional[dict] = None):
         """On a HIP device: one fused kernel (fnr_sample_pixels).  On the CPU (oracle baseline, host tests):
         the equivalent torch ops below — this is data preparation for the oracle, not a fallback of the hot path.
         camera_optimizer (cameras.camera_optimizers.CameraOptimizer, mode SO3xR3): rays come from the pose-corrected
-        cameras; `last_draw` keeps what training.camera_backward_and_step needs to back-propagate into the poses."""
+        cameras; `last_draw` keeps what training.camera_backward_and_step needs to back-propagate into the poses.
+        level0 (FruitModel.level0_spec(): S, near, far, n_jitter): the whole start of the step in ONE launch
+        (fnr_train_prologue: counter-based random numbers, camera adjust, pixel sampling and the proposal sampler's
+        level-0 bins); `last_presample` then holds what to hand to the model as RayBundle.presampled."""
         d = self.data
         dev = d["images"].device
+        if level0 is not None and dev.type == "cuda":
+            from .. import _kernels as K
+            if self._set is None:
+                self._set = K.ImageSetArg(d["images"], d["masks"], d["c2w"], d["fx"], d["fy"], d["cx"], d["cy"])
+            pose = camera_optimizer.pose_adjustment.data if (camera_optimizer is not None and camera_optimizer.enabled) else None
+            self._offset = getattr(self, "_offset", 0) + 1
+            out = K.train_prologue(self._set, self.image_ids, n_rays, self.gen.initial_seed(), self._offset, pose,
+                                   level0["near"], level0["far"], level0["S"], n_jitter=level0.get("n_jitter", 3))
+            self.last_draw = {"u": out["u"], "cam": out["cam"], "c2w_adjusted": out["c2w_adjusted"]}
+            self.last_presample = {"S0": out["S0"], "near": out["near"], "far": out["far"], "spacing": out["spacing"],
+                                   "euclid": out["euclid"], "jitter": [out["jitter"][i] for i in range(out["jitter"].shape[0])]}
+            return out["origins"], out["directions"], out["cam"][:, None], \
+                {"image": out["image"], "fruit_mask": out["mask"][:, None]}
         u = torch.rand(n_rays, 3, device=dev, generator=self.gen)
         if dev.type == "cuda":
             from .. import _kernels as K
@@ -154,6 +170,7 @@ class PixelBatcher:
             c2w_adj = camera_optimizer.adjusted_cameras(self._set, self.image_ids) if camera_optimizer is not None else None
             o, dirs, cam, image, mask = K.sample_pixels(self._set, self.image_ids, u, c2w_adj)
             self.last_draw = {"u": u, "cam": cam, "c2w_adjusted": c2w_adj}
+            self.last_presample = None
             return o, dirs, cam[:, None], {"image": image, "fruit_mask": mask[:, None]}
         return self.sample_torch(u)
 

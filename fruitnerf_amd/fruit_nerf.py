@@ -325,8 +325,19 @@ class FruitModel(nn.Module):
                                               update_every_num_iters=1, func=self.proposal_sampler.step_cb))
         return callbacks
 
+    def level0_spec(self) -> Optional[dict]:
+        """What a datamanager needs to pre-sample the proposal sampler's level 0 in the launch that draws the rays
+        (PixelBatcher.sample(level0=...) -> RayBundle.presampled): training mode, piecewise spacing, single jitter."""
+        sampler = self.proposal_sampler
+        if not self.training or not isinstance(sampler, ProposalNetworkSampler):
+            return None
+        return {"S": sampler.num_proposal_samples_per_ray[0], "near": float(self.config.near_plane),
+                "far": float(self.config.far_plane), "n_jitter": sampler.num_proposal_network_iterations + 1}
+
     def _collide(self, ray_bundle: RayBundle) -> RayBundle:  # NearFarCollider, fruit_nerf.py:161,382-383
         if ray_bundle.nears is not None and ray_bundle.fars is not None:
+            if getattr(ray_bundle, "presampled", None) is not None:
+                ray_bundle.presampled = None    # pre-sampled for the collider's planes, not for the caller's own
             return ray_bundle
         near_plane = self.config.near_plane if self.training else 0
         # constant per (shape, mode): built once instead of 4 launches per call; the hot path only reads them
@@ -356,15 +367,24 @@ class FruitModel(nn.Module):
         n_prop = sampler.num_proposal_network_iterations
         updated = sampler.updated_now()
         jit = list(jitter) if jitter is not None else [None] * (n_prop + 1)
-        if training:
+        S0 = sampler.num_proposal_samples_per_ray[0]
+        # level 0 + the jitters may come with the rays (fnr_train_prologue drew them in the launch that sampled the
+        # pixels): used when they match this sampler, the collider's planes and no explicit jitter was passed
+        pre = getattr(ray_bundle, "presampled", None) if (training and jitter is None) else None
+        if pre is not None and not (pre.get("S0") == S0 and len(pre.get("jitter", ())) >= n_prop + 1
+                                    and pre["spacing"].shape[0] == rays.n and pre.get("near") == float(cfg.near_plane)
+                                    and pre.get("far") == float(cfg.far_plane)):
+            pre = None
+        if pre is not None:
+            jit = list(pre["jitter"][:n_prop + 1])
+        elif training:
             if any(j is None for j in jit):
                 fresh = torch.rand(n_prop + 1, rays.n, device=dev)  # one launch for all sampling levels
                 jit = [j if j is not None else fresh[i] for i, j in enumerate(jit)]
         else:
             jit = [None] * (n_prop + 1)
         levels: List[dict] = []
-        S0 = sampler.num_proposal_samples_per_ray[0]
-        spacing, euclid = K.sample_spaced(rays, 1, S0, jit[0])
+        spacing, euclid = (pre["spacing"], pre["euclid"]) if pre is not None else K.sample_spaced(rays, 1, S0, jit[0])
         S = S0
         for i in range(n_prop):
             net = self.proposal_networks[0 if cfg.use_same_proposal_network else i]

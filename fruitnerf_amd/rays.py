@@ -58,6 +58,10 @@ class RayBundle:
     camera_indices: Optional[Tensor] = None  # [R, 1]
     nears: Optional[Tensor] = None  # [R, 1]
     fars: Optional[Tensor] = None  # [R, 1]
+    # Not a nerfstudio field: what fnr_train_prologue already produced for these rays in the launch that drew them
+    # (level-0 bins of the proposal sampler and the samplers' jitters; data/synthetic_apple.py::PixelBatcher.sample with
+    # level0=).  FruitModel uses it when it matches its sampler configuration and ignores it otherwise.
+    presampled: Optional[dict] = None
 
     def __len__(self) -> int:
         return self.origins.shape[:-1].numel()

@@ -161,6 +161,19 @@ int fnr_sample_pixels(const fnr_image_set* set, const int64_t* train_ids, int n_
                       const float* c2w_adjusted, float* origins, float* directions, int32_t* camera_indices,
                       float* image, float* fruit_mask, void* stream);
 
+/* The start of a training step in ONE launch (single jitter per ray, the Nerfacto default): draws the step's random
+ * numbers itself — Philox4x32-10, counter = (ray, word group, offset), key = seed; the caller advances `offset` by one per
+ * step — and performs fnr_camera_adjust (pose_adjustment / c2w_adjusted both set, or both NULL), fnr_sample_pixels and
+ * fnr_sample_spaced(level 0, near / far as the collider sets them, one jitter per ray) on them.
+ * Outputs besides those of the three entry points: u [R,3] (what fnr_camera_pose_grad needs again) and
+ * jitter [n_jitter, R]: row 0 is the jitter level 0 was sampled with, rows 1.. are for the PDF samplers of the following
+ * levels.  Given u and jitter, every output is bit-identical to the separate entry points (tests/test_gpu_properties.py). */
+int fnr_train_prologue(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays, uint64_t seed,
+                       uint64_t offset, const float* pose_adjustment, float* c2w_adjusted, float* u, float* jitter,
+                       int n_jitter, float* origins, float* directions, int32_t* camera_indices, float* image,
+                       float* fruit_mask, float near_plane, float far_plane, int spacing_kind, int S0,
+                       const float* base_bins, float* spacing0, float* euclid0, void* stream);
+
 /* nerfstudio CameraOptimizer(mode="SO3xR3") (fruit_nerf_config.py:39-43): c2w_adjusted[k] =
  * pose_utils.multiply(c2w[train_ids[k]], exp_map_SO3xR3(pose_adjustment[k])), pose_adjustment [n_train,6] =
  * (translation, so3 log-rotation) per training camera. */

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, steps, mlp_precision, overlap=False):
+def _run(dev, steps, mlp_precision, overlap=False, prologue=True):
     import fruitnerf_amd.training as T
     from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
     from fruitnerf_amd.data import synthetic_apple as sa
@@ -30,8 +30,11 @@ def _run(dev, steps, mlp_precision, overlap=False):
     losses = []
     try:
         for step in range(steps):
-            o, d, cam, batch = batcher.sample(4096, cam_opt)
-            ld, md = T.fused_train_iteration(hm, opt, RayBundle(o, d, None, cam), batch, step, camera=camera)
+            # prologue: the step's random numbers, corrected cameras, rays and level-0 bins in one launch
+            # (fnr_train_prologue, what bench.py runs); otherwise torch.rand + the separate entry points
+            o, d, cam, batch = batcher.sample(4096, cam_opt, level0=hm.level0_spec() if prologue else None)
+            rb = RayBundle(o, d, None, cam, presampled=batcher.last_presample)
+            ld, md = T.fused_train_iteration(hm, opt, rb, batch, step, camera=camera)
             if step % 20 == 19 or step == steps - 1:
                 losses.append(torch.stack([ld["rgb_loss"], ld["semantics_loss"], ld["interlevel_loss"], md["psnr"],
                                            md["distortion"]]).clone())
@@ -57,6 +60,13 @@ def test_two_training_runs_from_one_seed_end_bit_identical(dev, mlp_precision):
     for name, x, y in zip(names, a, b):
         assert torch.equal(x, y), f"{name} differ between two runs from one seed"
     assert float(a[4][-1][0]) < 5e-3, "the runs did train"
+
+
+def test_runs_without_the_prologue_launch_are_reproducible_too(dev):
+    a = _run(dev, 40, "bf16x3", prologue=False)
+    b = _run(dev, 40, "bf16x3", prologue=False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
 
 
 def test_second_stream_run_is_bit_identical_too(dev):

@@ -208,3 +208,45 @@ def test_export_is_invariant_to_the_ray_batch_size(dev, fused):
         assert a[name]["points"].shape == b[name]["points"].shape, name
         assert np.array_equal(a[name]["points"], b[name]["points"]), name
         assert np.array_equal(a[name]["colors"], b[name]["colors"]), name
+
+
+def test_train_prologue_is_the_separate_launches(dev):
+    """fnr_train_prologue (random numbers + camera adjust + pixel sampling + level-0 spaced sampling in one launch): given
+    the numbers it drew, every output is bit-identical to fnr_camera_adjust / fnr_sample_pixels / fnr_sample_spaced; the
+    numbers are uniform in [0, 1), differ between rays, words and steps, and repeat for the same (seed, offset)."""
+    import torch
+    from fruitnerf_amd import _kernels as K
+    from fruitnerf_amd.cameras.camera_optimizers import CameraOptimizerConfig
+    from fruitnerf_amd.data import synthetic_apple as sa
+    n_cam, HW, focal, R, S0 = 12, 64, 90.0, 5000, 256
+    scene = sa.make_scene(seed=0, device=dev)
+    c2w = sa.make_cameras(n_cam, seed=0, device=dev)
+    data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
+    iset = K.ImageSetArg(data["images"], data["masks"], data["c2w"], focal, focal, HW / 2.0, HW / 2.0)
+    ids = torch.arange(n_cam, device=dev)
+    cam_opt = CameraOptimizerConfig(mode="SO3xR3").setup(n_cam, dev)
+    with torch.no_grad():
+        cam_opt.pose_adjustment.copy_(0.02 * torch.randn(n_cam, 6, device=dev))
+    for pose in (cam_opt.pose_adjustment.data, None):
+        out = K.train_prologue(iset, ids, R, seed=1234, offset=7, pose_adjustment=pose, near=0.05, far=1000.0, S0=S0)
+        again = K.train_prologue(iset, ids, R, seed=1234, offset=7, pose_adjustment=pose, near=0.05, far=1000.0, S0=S0)
+        other = K.train_prologue(iset, ids, R, seed=1234, offset=8, pose_adjustment=pose, near=0.05, far=1000.0, S0=S0)
+        torch.cuda.synchronize()
+        rnd = torch.cat([out["u"].t(), out["jitter"]])                       # [6, R]
+        assert torch.equal(out["u"], again["u"]) and torch.equal(out["jitter"], again["jitter"])
+        assert float(rnd.min()) >= 0.0 and float(rnd.max()) < 1.0
+        assert abs(float(rnd.mean()) - 0.5) < 0.01 and abs(float(rnd.var()) - 1.0 / 12.0) < 0.005
+        assert int(torch.unique(rnd).numel()) > 0.99 * rnd.numel()          # 24-bit numbers, 30 000 of them
+        assert float((rnd != torch.cat([other["u"].t(), other["jitter"]])).float().mean()) > 0.99
+        c = torch.corrcoef(rnd)
+        assert float((c - torch.eye(6, device=dev)).abs().max()) < 0.06     # words of a ray are uncorrelated
+        c2w_adj = K.camera_adjust(iset, ids, pose) if pose is not None else None
+        if pose is not None:
+            assert torch.equal(out["c2w_adjusted"], c2w_adj)
+        o, d, cam, image, mask = K.sample_pixels(iset, ids, out["u"], c2w_adj)
+        for name, got, ref in (("origins", out["origins"], o), ("directions", out["directions"], d), ("cam", out["cam"], cam),
+                               ("image", out["image"], image), ("mask", out["mask"], mask)):
+            assert torch.equal(got, ref), name
+        rays = K.RaysArg(o, d, torch.full((R, 1), 0.05, device=dev), torch.full((R, 1), 1000.0, device=dev), cam)
+        spacing, euclid = K.sample_spaced(rays, 1, S0, out["jitter"][0])
+        assert torch.equal(out["spacing"], spacing) and torch.equal(out["euclid"], euclid)

@@ -504,7 +504,7 @@ def test_level_group_scatter_matches_single_scatter(dev, monkeypatch):
         hm = util.make_hip_like(om, dev)
         hm.train()
         hm.set_anneal(0)
-        ex = T._FieldGradientExchange(hm, 2) if grouped else None
+        ex = T._FieldGradientExchange(hm, 2, level_groups=4) if grouped else None
         T.fused_forward_backward(hm, RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)), hb, jitter=jit,
                                  exchange=ex)
         torch.cuda.synchronize()
