@@ -1051,6 +1051,14 @@ def test_train_losses_is_the_separate_launches(dev, R, n_levels, want_distortion
             ref = K.weights_bwd(S, eu, dens, w, dwp, one)
             assert float(ref.abs().max()) > 0
             assert torch.equal(got, ref)
+    # the accumulator comes back zeroed (the loss slots are self-cleaning: a training loop launches no fill per step),
+    # and a second call on the buffer the first one left behind gives the same numbers
+    accum = torch.zeros(L.FNR_TRAIN_LOSSES_ACCUM_FLOATS, device=dev)
+    for _ in range(2):
+        losses3, d_rgb3, _, _ = K.train_losses(rgb, img, sem, msk, 2.0, S_f, sp_f, w_f, props, 1.0, want_distortion, accum)
+        torch.cuda.synchronize()
+        assert torch.equal(d_rgb3, ref_drgb) and torch.equal(losses3, losses)
+        assert float(accum.abs().max()) == 0.0
 
 
 def test_proposal_backward_on_a_second_stream_changes_nothing(dev):
