@@ -573,7 +573,6 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
 // Weight gradients leave the workgroup once, at the end (one atomicAdd per weight per workgroup).
 // ------------------------------------------------------------------------------------------------
 constexpr int PROP_PART = 320;   // floats per workgroup partial: dW0 tile 256 + dW1 16 + db0 16 + db1 (+ pad)
-constexpr int PROP_RED_Y = 16;
 
 template <int L, int H, bool POSGRAD>
 __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restrict__ d_xw, Warp warp, RaySource src,
@@ -719,31 +718,33 @@ __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restri
 }
 
 // gradient += sum over workgroups of their partial vectors, in a FIXED order with one writer per entry (no float
-// atomics: bit-reproducible training).  Workgroup = 64 entries x PROP_RED_Y slices: slice y sums rows y, y + Y, ...,
-// the slices meet in LDS and slice 0 adds them up in order.
-__global__ __launch_bounds__(64 * PROP_RED_Y) void k_prop_reduce(const float* __restrict__ partials, int nblocks, int K,
-                                                                  float* __restrict__ g_w0, float* __restrict__ g_b0,
-                                                                  float* __restrict__ g_w1, float* __restrict__ g_b1) {
-  __shared__ float s_part[PROP_RED_Y][64];
-  const int t = threadIdx.x & 63, y = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + t;
+// atomics: bit-reproducible training).  Workgroup = PRD_E entries x PRD_Y slices: slice y sums rows y, y + PRD_Y, ... (a
+// few hundred rows: two or three batches of 8 independent loads per thread), the slices meet in LDS and the thread of
+// slice 0 adds them up in slice order.
+constexpr int PRD_E = 16, PRD_Y = 64;
+__global__ __launch_bounds__(PRD_E * PRD_Y) void k_prop_reduce(const float* __restrict__ partials, int nblocks, int K,
+                                                               float* __restrict__ g_w0, float* __restrict__ g_b0,
+                                                               float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  __shared__ float s_part[PRD_Y][PRD_E];
+  const int t = threadIdx.x % PRD_E, y = threadIdx.x / PRD_E;
+  const int e = blockIdx.x * PRD_E + t;
   float s = 0.0f;
   if (e <= 288) {
     int b = y;
-    for (; b + 7 * PROP_RED_Y < nblocks; b += 8 * PROP_RED_Y) {
+    for (; b + 7 * PRD_Y < nblocks; b += 8 * PRD_Y) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * PROP_RED_Y) * PROP_PART + e];
+      for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * PRD_Y) * PROP_PART + e];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; b < nblocks; b += PROP_RED_Y) s += partials[(size_t)b * PROP_PART + e];
+    for (; b < nblocks; b += PRD_Y) s += partials[(size_t)b * PROP_PART + e];
   }
   s_part[y][t] = s;
   __syncthreads();
   if (y != 0 || e > 288) return;
-#pragma unroll
-  for (int q = 1; q < PROP_RED_Y; ++q) s += s_part[q][t];
+#pragma unroll 8
+  for (int q = 1; q < PRD_Y; ++q) s += s_part[q][t];
   if (s == 0.0f) return;
   if (e < 256) {
     const int o = e >> 4, k = e & 15;
@@ -869,7 +870,7 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
   }
 #undef FNR_PROPB_CASE
   FNR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_prop_reduce, dim3(PROP_PART / 64), dim3(64 * PROP_RED_Y), 0, as_stream(stream), partials,
+  hipLaunchKernelGGL(k_prop_reduce, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), partials,
                      (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1);
   FNR_LAUNCH_CHECK();
   return binned_scatter(&grads->grid, w, src, N, d_feats, 0, L, reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,

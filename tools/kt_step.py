@@ -9,7 +9,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if "k_sample_pixels" in r[2]]
+marks = [i for i, r in enumerate(rows) if "k_train_prologue" in r[2] or "k_sample_pixels" in r[2]]
 a, b = marks[-4], marks[-3]
 t0 = rows[a][0]
 for s, e, k in rows[a:b]:

@@ -1,18 +1,23 @@
-"""profiles/r02_kernel_trace_pmc.md from the aggregates tools/prof_round.sh left under profiles/r02_raw/."""
+"""profiles/<tag>_kernel_trace_pmc.md and profiles/pmc_traffic.json from the aggregates tools/prof_round.sh left under
+profiles/<tag>_raw/.   usage: python tools/make_profile_summary.py [tag, default r03] [git revision the run was made from]"""
 import json
 import re
+import subprocess
 import sys
 
-base = sys.argv[1] if len(sys.argv) > 1 else '/root/repo/profiles/r02_raw/'
-dst = sys.argv[2] if len(sys.argv) > 2 else '/root/repo/profiles/r02_kernel_trace_pmc.md'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+rev = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True,
+                                                           text=True, cwd='/root/repo').stdout.strip()
+base = f'/root/repo/profiles/{tag}_raw/'
+dst = f'/root/repo/profiles/{tag}_kernel_trace_pmc.md'
 
 
 def kt(path):
     rows = []
     for l in open(path):
-        m = re.match(r'(\S.*?)\s+grid\s+n\s+(\d+)\s+total\s+([\d.]+) ms median\s+([\d.]+) us min\s+([\d.]+)', l)
+        m = re.match(r'(\S.*?)\s+grid\s+(\d*)\s+n\s+(\d+)\s+total\s+([\d.]+) ms median\s+([\d.]+) us min\s+([\d.]+)', l)
         if m:
-            rows.append((m.group(1).strip(), int(m.group(2)), float(m.group(3)), float(m.group(4)), float(m.group(5))))
+            rows.append((m.group(1).strip(), m.group(2), int(m.group(3)), float(m.group(4)), float(m.group(5)), float(m.group(6))))
     return rows
 
 
@@ -21,7 +26,7 @@ def pmc(path):
     for l in open(path):
         if 'dispatches' in l:
             cur = l.split(' dispatches')[0].strip()
-            d[cur] = {}
+            d[cur] = {'_n': int(l.split('dispatches')[1])}
         else:
             p = l.split()
             if len(p) == 2 and cur:
@@ -33,8 +38,8 @@ def short(n):
     n = n.replace('fnr::', '')
     m = re.match(r'_ZN3fnr\d+(k_[a-z_0-9]+?)INS', n)
     if m:
-        n = m.group(1) + '<...> (mangled in the trace)'
-    return n[:64]
+        n = m.group(1) + '<...> (mangled)'
+    return n[:72]
 
 
 def line(fn):
@@ -54,27 +59,55 @@ def rf(x):
     return s + ", %.0f us/launch" % (x['avg_launch_ms'] * 1e3)
 
 
+def find(d, name_part, also=None):
+    for k in d:
+        if name_part in k and (also is None or also in k):
+            return d[k]
+    return {}
+
+
 rows = kt(base + 'prof_kernel_trace.txt')
 f, w, sq = pmc(base + 'prof_fetch.txt'), pmc(base + 'prof_write.txt'), pmc(base + 'prof_sq.txt')
-steps = 86
-out = ['# Round 2 - rocprofv3 of `python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality` (default arithmetic: bf16x3)\n',
-       'Collected by `tools/prof_round.sh` on 1xMI355X (gfx950, ROCm 7.2): one `--kernel-trace --stats` pass and three separate '
-       '`--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ counters), 86 training steps each (10 warm-up + 4 instrumented + 60 timed + '
-       '12 of the per-entry-point breakdown).  Raw aggregates: `profiles/r02_raw/`; this table: `tools/make_profile_summary.py`.  '
-       'Times are per STEP (kernel total / 86; the proposal-network backward runs on 48 of the 86 steps).  FETCH_SIZE is doubled '
-       'per MI355X_MICROARCH.md (gfx950 reports half of a wide streaming read) and, like WRITE_SIZE, given in MB per dispatch '
-       '(rocprofv3 reports KB).  SQ columns are ratios of per-dispatch counters (wave-cycles count quad-cycles; '
-       'SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines: the last column is '
-       'MFMA_BUSY / (32 x SQ_BUSY)).\n',
-       '| kernel | launches/step | us/step | median us | FETCHx2 MB | WRITE MB | VALU-active / wave-cycles | WAIT_ANY / wave-cycles | MFMA-busy / SIMD-cycles |',
-       '|---|---|---|---|---|---|---|---|---|']
+steps = max(n for name, g, n, *_ in rows if 'k_train_prologue' in name or 'k_sample_pixels' in name)
+out = [f'# Round 3 - rocprofv3 of `python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality` (default arithmetic: bf16x3), build {rev}\n',
+       f'Collected by `tools/prof_round.sh` on 1xMI355X (gfx950, ROCm 7.2): one `--kernel-trace --stats` pass and three separate '
+       f'`--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ counters, each with `--kernel-trace` only), {steps} training steps each (10 '
+       'warm-up + 60 timed + 12 of the per-entry-point breakdown).  Raw aggregates: `profiles/' + tag + '_raw/`; this table: '
+       '`tools/make_profile_summary.py`.  Times are per STEP (kernel total / steps; the proposal-network backward runs on about '
+       'half of the steps of this window).  FETCH_SIZE is doubled per MI355X_MICROARCH.md "HBM" (gfx950 reports half of a wide '
+       'streaming read) and, like WRITE_SIZE, given in MB per dispatch (rocprofv3 reports KB).  SQ columns are ratios of '
+       'per-dispatch counters (SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader '
+       'engines: the last column is MFMA_BUSY / (32 x SQ_BUSY)).  A kernel that serves several entry points appears once per '
+       'grid size (x dimension).\n',
+       '| kernel | grid x | launches/step | us/step | median us | FETCHx2 MB | WRITE MB | VALU-active / wave-cycles | WAIT_ANY / wave-cycles | MFMA-busy / SIMD-cycles |',
+       '|---|---|---|---|---|---|---|---|---|---|']
 tot = 0.0
-for name, n, total, med, mn in rows:
-    key = [k for k in f if k[:50] == name[:50]]
-    k = key[0] if key else None
-    fs = f.get(k, {}).get('FETCH_SIZE')
-    ws = w.get(k, {}).get('WRITE_SIZE')
-    s = sq.get(k, {})
+
+
+def pmc_for(name, grid_x, d):
+    """counter record of a kernel-trace row: same kernel; the emit's main-field call is the one after k_reduce_dw"""
+    cands = [k for k in d if k.split(' grid ')[0].split(' after ')[0][:50] == name[:50]]
+    if 'k_scatter_emit' in name:
+        main = [k for k in cands if 'after k_reduce_dw' in k]
+        prop = [k for k in cands if 'after k_prop_reduce' in k]
+        if grid_x == '196608' and main:
+            return d[main[0]]
+        if prop:   # both proposal levels' calls: dispatch-weighted mean is what the aggregate holds per key
+            want = {'1048576': '1048576', '393216': '786432'}.get(grid_x)
+            hit = [k for k in prop if want and k.endswith('grid ' + want)]
+            return d[hit[0]] if hit else {}
+        return {}
+    if len(cands) == 1:
+        return d[cands[0]]
+    # several grid sizes (proposal levels): counter files carry the TOTAL grid, the trace the x dimension — same for 1-D grids
+    hit = [k for k in cands if k.endswith('grid ' + grid_x)]
+    return d[hit[0]] if hit else (d[cands[0]] if cands else {})
+
+
+for name, grid_x, n, total, med, mn in rows:
+    fs = pmc_for(name, grid_x, f).get('FETCH_SIZE')
+    ws = pmc_for(name, grid_x, w).get('WRITE_SIZE')
+    s = pmc_for(name, grid_x, sq)
     wc = s.get('SQ_WAVE_CYCLES')
     tot += total
     c_f = '' if fs is None else '%.1f' % (2 * fs / 1024)
@@ -82,26 +115,71 @@ for name, n, total, med, mn in rows:
     c_v = '' if not wc else '%.2f' % (s.get('SQ_ACTIVE_INST_VALU', 0) / wc)
     c_a = '' if not wc else '%.2f' % (s.get('SQ_WAIT_ANY', 0) / wc)
     c_m = '' if not s or not s.get('SQ_BUSY_CYCLES') else '%.2f' % (s.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (32.0 * s['SQ_BUSY_CYCLES']))
-    out.append('| `%s` | %.2f | %.1f | %.1f | %s | %s | %s | %s | %s |' % (short(name), n / steps, total * 1e3 / steps, med, c_f, c_w, c_v, c_a, c_m))
+    out.append('| `%s` | %s | %.2f | %.1f | %.1f | %s | %s | %s | %s | %s |' % (short(name), grid_x, n / steps, total * 1e3 / steps, med, c_f, c_w, c_v, c_a, c_m))
 out.append('\nSum of kernel time: %.0f us per step (the un-profiled step time is in the bench lines below).\n' % (tot * 1e3 / steps))
-out.append('## Bench lines of the same build (un-profiled)\n')
-out.append('| command | rays/s | ms/step | dominant entry point (`roofline`) | `roofline_other_bound` |')
+
+# ---- HBM traffic per entry-point launch (what bench.py prints as roofline.traffic) --------------------------------------
+ENTRY = {
+    'hash_encode_bwd[196608]': [('k_scatter_emit', '196608'), ('k_scatter_accumulate<true>', None)],
+    'hash_encode_fwd[196608]': [('k_hash_encode', None)],
+    'field_mlp_bwd[196608]': [('k_field_mlp_bwd_color_coop', None), ('k_color_ray_grads', None), ('k_embedding_grad', None),
+                              ('k_field_mlp_bwd_sem_coop', None), ('k_field_mlp_bwd_base_coop', None), ('k_reduce_dw', None)],
+    'field_mlp_fwd[196608]': [('k_prepare_field', None), ('k_field_mlp_fwd_bf16', None)],
+}
+traffic = {}
+out.append('## HBM traffic per entry-point launch (counters: FETCH_SIZE x 2 + WRITE_SIZE, summed over the entry point\'s kernels)\n')
+out.append('| entry point | kernels | counter MB / launch | algorithmic MB / launch (bench.py) | counter / algorithmic |')
+out.append('|---|---|---|---|---|')
+bench = line('bench_fruit_nerf.log')
+ALG = {'hash_encode_bwd[196608]': (2 * 1024.0 + 128.0) * 196608 + 28.0 * 16777216, 'hash_encode_fwd[196608]': (1024.0 + 128.0) * 196608}
+for ep, parts in ENTRY.items():
+    total_b, names = 0.0, []
+    ok = True
+    for part, gx in parts:
+        row = [r for r in rows if part in r[0] and (gx is None or r[1] == gx)]
+        if not row:
+            ok = False
+            break
+        fs = pmc_for(row[0][0], row[0][1], f).get('FETCH_SIZE')
+        ws = pmc_for(row[0][0], row[0][1], w).get('WRITE_SIZE')
+        if fs is None or ws is None:
+            ok = False
+            break
+        total_b += (2 * fs + ws) * 1024.0
+        names.append(short(row[0][0]).split('<')[0])
+    if not ok:
+        continue
+    traffic[ep] = {'bytes_per_launch': round(total_b), 'kernels': names}
+    alg = ALG.get(ep)
+    out.append('| `%s` | %s | %.1f | %s | %s |' % (ep, ', '.join(names), total_b / 1e6, '%.1f' % (alg / 1e6) if alg else '(MFMA-bound: FLOP)',
+                                                   '%.2f' % (total_b / alg) if alg else ''))
+json.dump({'source': f'profiles/{tag}_kernel_trace_pmc.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only) of '
+                     '`python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality`, FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM" '
+                     '(tools/prof_round.sh, tools/make_profile_summary.py)',
+           'build': rev, 'entry_points': {'fruit_nerf': traffic}}, open('/root/repo/profiles/pmc_traffic.json', 'w'), indent=1)
+
+out.append('\n## Bench lines of the same build (un-profiled)\n')
+out.append('| command | rays/s | ms/step | `roofline` | `roofline_other_bound` |')
 out.append('|---|---|---|---|---|')
 for fn, cmd in (('bench_fruit_nerf.log', 'python bench.py'), ('bench_fruit_nerf_fp32.log', 'python bench.py --mlp-precision fp32'),
-                ('bench_fruit_nerf_big.log', 'python bench.py --method fruit_nerf_big'),
-                ('bench_fruit_nerf_big_fp32.log', 'python bench.py --method fruit_nerf_big --mlp-precision fp32')):
+                ('bench_fruit_nerf_big.log', 'python bench.py --method fruit_nerf_big')):
     d = line(fn)
     out.append('| `%s` | %.0f | %s | %s | %s |' % (cmd, d['value'], d['ms_per_step'], rf(d['roofline']), rf(d['roofline_other_bound'])))
-d = line('bench_fruit_nerf.log')
+d = bench
 sec = d['secondary']
-out.append('\nDefault line, other fields: cpu_baseline ' + json.dumps(d['cpu_baseline'])[:420] + '; quality ' + json.dumps(d['quality'])
-           + '; rays/s by MLP arithmetic after 1846 steps ' + json.dumps(sec['train_rays_per_s_by_mlp_precision'])
-           + '; eval %.3g rays/s; export 256^3 %.3g samples/s (passes %s ms).\n' % (sec['eval_rays_per_s'], sec['export_samples_per_s'], sec['export_pass_ms']))
+out.append('\nDefault line, other fields: cpu_baseline ' + json.dumps(d['cpu_baseline'])[:460] + '; quality ' + json.dumps(d['quality'])
+           + '; rays/s by MLP arithmetic ' + json.dumps(sec['train_rays_per_s_by_mlp_precision'])
+           + '; eval %.3g rays/s; export 256^3 %.3g samples/s (passes %s ms); export points %s; fruit_nerf_big window %s rays/s (%s ms/step).\n'
+           % (sec['eval_rays_per_s'], sec['export_samples_per_s'], sec['export_pass_ms'], json.dumps(sec['export_points']),
+              sec.get('fruit_nerf_big', {}).get('value'), sec.get('fruit_nerf_big', {}).get('ms_per_step')))
+dbig = line('bench_fruit_nerf_big.log')
+out.append('`fruit_nerf_big` line: quality ' + json.dumps(dbig['quality']) + '.\n')
 big = kt(base + 'prof_kernel_trace_big.txt')
-out.append('## `fruit_nerf_big` (8192 rays, samples 512/256/128, T = 2^21): kernel trace of `bench.py --method fruit_nerf_big --steps 40 --warmup 10`, 66 steps\n')
-out.append('| kernel | launches/step | us/step | median us |')
-out.append('|---|---|---|---|')
-for name, n, total, med, mn in big[:24]:
-    out.append('| `%s` | %.2f | %.0f | %.0f |' % (short(name), n / 66, total * 1e3 / 66, med))
+sb = max(n for name, g, n, *_ in big if 'k_train_prologue' in name or 'k_sample_pixels' in name)
+out.append(f'## `fruit_nerf_big` (8192 rays, samples 512/256/128, T = 2^21): kernel trace of `bench.py --method fruit_nerf_big --steps 40 --warmup 10`, {sb} steps\n')
+out.append('| kernel | grid x | launches/step | us/step | median us |')
+out.append('|---|---|---|---|---|')
+for name, grid_x, n, total, med, mn in big[:26]:
+    out.append('| `%s` | %s | %.2f | %.0f | %.0f |' % (short(name), grid_x, n / sb, total * 1e3 / sb, med))
 open(dst, 'w').write('\n'.join(out) + '\n')
 print(dst)

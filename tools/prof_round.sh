@@ -1,13 +1,14 @@
 #!/bin/bash
-# on the GPU box: everything profiles/r02_* is made from.  bench lines (both methods, default arithmetic + fp32),
-# rocprofv3 kernel trace + the three PMC passes of the default bench command, kernel trace of fruit_nerf_big.
-mkdir -p /root/repo/gpurun_out/r02
-OUT=/root/repo/gpurun_out/r02
+# on the GPU box: everything profiles/r03_* is made from.  usage: bash tools/prof_round.sh [round tag, default r03]
+# bench lines (default arithmetic, fp32, fruit_nerf_big), rocprofv3 kernel trace + the three PMC passes (separate runs:
+# FETCH_SIZE | WRITE_SIZE | SQ counters, each with --kernel-trace only) of ONE bench command, kernel trace of fruit_nerf_big.
+TAG=${1:-r03}
+mkdir -p /root/repo/gpurun_out/$TAG
+OUT=/root/repo/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
-python /root/repo/bench.py > $OUT/bench_fruit_nerf.log 2>&1
-python /root/repo/bench.py --mlp-precision fp32 --no-cpu-baseline > $OUT/bench_fruit_nerf_fp32.log 2>&1
-python /root/repo/bench.py --method fruit_nerf_big > $OUT/bench_fruit_nerf_big.log 2>&1
-python /root/repo/bench.py --method fruit_nerf_big --mlp-precision fp32 --no-cpu-baseline --no-quality > $OUT/bench_fruit_nerf_big_fp32.log 2>&1
+python /root/repo/bench.py > $OUT/bench_fruit_nerf.log 2>$OUT/bench_fruit_nerf.err
+python /root/repo/bench.py --mlp-precision fp32 --no-cpu-baseline --no-quality > $OUT/bench_fruit_nerf_fp32.log 2>&1
+python /root/repo/bench.py --method fruit_nerf_big --no-cpu-baseline > $OUT/bench_fruit_nerf_big.log 2>&1
 CMD="python /root/repo/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_kt -o p -- $CMD > $OUT/prof_bench.json 2>/tmp/pf_kt.err
 python /root/repo/tools/kt_agg.py /tmp/pf_kt/p_kernel_trace.csv > $OUT/prof_kernel_trace_top40.txt
