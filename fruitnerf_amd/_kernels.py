@@ -460,12 +460,22 @@ def hash_encode_bwd_adam(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg,
 
 
 def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor,
-                     S: int, feats: Tensor, d_density: Tensor, want_position_grad: bool = False) -> Optional[Tensor]:
-    """want_position_grad: also return d(loss)/d(unit-cube position) [N,4] for position_grad_reduce(n_levels=1)."""
+                     S: int, feats: Tensor, d_density: Tensor, want_position_grad: bool = False,
+                     adam=None) -> Optional[Tensor]:
+    """want_position_grad: also return d(loss)/d(unit-cube position) [N,4] for position_grad_reduce(n_levels=1).
+    adam = (table fnr_table_adam, weight fnr_table_adam, gradient arena): the network's optimiser step is taken by the
+    kernels that finish its gradients (fnr_prop_density_bwd_adam)."""
     lib = L.load()
     nbytes = lib.fnr_prop_density_bwd_workspace_bytes(rays.n * S, net.grid.n_levels, net.grid.log2_hashmap_size)
     ws, clean = _scatter_workspace(rays.device, nbytes, "prop")
     d_pos = torch.empty(rays.n * S, 4, device=rays.device) if want_position_grad else None
+    if adam is not None:
+        t_adam, w_adam, grad_arena = adam
+        L.check(lib.fnr_prop_density_bwd_adam(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
+                                              L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), C.byref(t_adam),
+                                              C.byref(w_adam), L.ptr(grad_arena), L.ptr(ws), nbytes, clean,
+                                              L.stream_ptr(rays.device)), "prop_density_bwd_adam")
+        return d_pos
     L.check(lib.fnr_prop_density_bwd(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
                                      L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), L.ptr(ws), nbytes, clean,
                                      L.stream_ptr(rays.device)),

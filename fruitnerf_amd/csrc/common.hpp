@@ -336,6 +336,21 @@ __device__ __forceinline__ void table_adam_update(const TableAdam& a, float g, f
     }
   }
 }
+// The optimiser step of a parameter taken by the thread that finishes its gradient entry (k_reduce_dw,
+// k_embedding_grad, k_prop_reduce: single writers): the parameter / moment arrays parallel the gradient arena.
+struct WeightAdam {
+  TableAdam t;               // hyper-parameters and step-dependent scalars (its p / m / v pointers are unused here)
+  long long p_off, m_off, v_off;   // element offsets from a GRADIENT address to the parameter / exp_avg / exp_avg_sq entry
+};
+__device__ __forceinline__ void weight_adam_entry(const WeightAdam& wa, float* __restrict__ g_entry, float s) {
+  const float g = *g_entry + s;
+  float P = g_entry[wa.p_off], M = g_entry[wa.m_off], V = g_entry[wa.v_off];
+  table_adam_update(wa.t, g, P, M, V);
+  g_entry[wa.p_off] = P;
+  g_entry[wa.m_off] = M;
+  g_entry[wa.v_off] = V;
+  *g_entry = 0.0f;
+}
 // host side of TableAdam: the step-dependent scalars exactly as fnr_adam_step / fnr_radam_step compute them (double)
 static inline int make_table_adam(const fnr_table_adam* a, TableAdam& t) {
   FNR_CHECK_ARG(a && a->params && a->exp_avg && a->exp_avg_sq, "table adam: null argument");

@@ -612,19 +612,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_sem_big(
 // parameter's optimiser step (torch.optim.Adam / RAdam exactly as fnr_adam_step / fnr_radam_step: same operations in the
 // same order) and leaves the gradient entry zero — the ~20 k weights of the field's MLPs no longer need a launch of
 // their own, and a step that does not train the proposal networks ends without any optimiser launch.
-struct WeightAdam {
-  TableAdam t;               // hyper-parameters and step-dependent scalars (its p / m / v pointers are unused here)
-  long long p_off, m_off, v_off;   // element offsets from a GRADIENT address to the parameter / exp_avg / exp_avg_sq entry
-};
-__device__ __forceinline__ void weight_adam_entry(const WeightAdam& wa, float* __restrict__ g_entry, float s) {
-  const float g = *g_entry + s;
-  float P = g_entry[wa.p_off], M = g_entry[wa.m_off], V = g_entry[wa.v_off];
-  table_adam_update(wa.t, g, P, M, V);
-  g_entry[wa.p_off] = P;
-  g_entry[wa.m_off] = M;
-  g_entry[wa.v_off] = V;
-  *g_entry = 0.0f;
-}
 constexpr int RD_IDX = 128, RD_Y = 8;
 template <class Cfg, bool ADAM>
 __global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __restrict__ partials, int nblocks, FieldPtrs grads,

@@ -721,10 +721,13 @@ __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restri
 // atomics: bit-reproducible training).  Workgroup = PRD_E entries x PRD_Y slices: slice y sums rows y, y + PRD_Y, ... (a
 // few hundred rows: two or three batches of 8 independent loads per thread), the slices meet in LDS and the thread of
 // slice 0 adds them up in slice order.
+// ADAM (fnr_prop_density_bwd_adam): the owning thread also takes the parameter's optimiser step (weight_adam_entry).
 constexpr int PRD_E = 16, PRD_Y = 64;
+template <bool ADAM>
 __global__ __launch_bounds__(PRD_E * PRD_Y) void k_prop_reduce(const float* __restrict__ partials, int nblocks, int K,
                                                                float* __restrict__ g_w0, float* __restrict__ g_b0,
-                                                               float* __restrict__ g_w1, float* __restrict__ g_b1) {
+                                                               float* __restrict__ g_w1, float* __restrict__ g_b1,
+                                                               WeightAdam wa) {
   __shared__ float s_part[PRD_Y][PRD_E];
   const int t = threadIdx.x % PRD_E, y = threadIdx.x / PRD_E;
   const int e = blockIdx.x * PRD_E + t;
@@ -745,17 +748,21 @@ __global__ __launch_bounds__(PRD_E * PRD_Y) void k_prop_reduce(const float* __re
   if (y != 0 || e > 288) return;
 #pragma unroll 8
   for (int q = 1; q < PRD_Y; ++q) s += s_part[q][t];
-  if (s == 0.0f) return;
+  if (!ADAM && s == 0.0f) return;
+  float* dst = nullptr;
   if (e < 256) {
     const int o = e >> 4, k = e & 15;
-    if (k < K) g_w0[o * K + k] += s;
+    if (k < K) dst = &g_w0[o * K + k];
   } else if (e < 272) {
-    g_w1[e - 256] += s;
+    dst = &g_w1[e - 256];
   } else if (e < 288) {
-    g_b0[e - 272] += s;
+    dst = &g_b0[e - 272];
   } else {
-    g_b1[0] += s;
+    dst = &g_b1[0];
   }
+  if (!dst) return;
+  if constexpr (ADAM) weight_adam_entry(wa, dst, s);
+  else *dst += s;
 }
 
 }  // namespace fnr
@@ -820,12 +827,26 @@ extern "C" size_t fnr_prop_density_bwd_workspace_bytes(int64_t n_samples, int n_
   return dfeat + partials + fnr_hash_scatter_workspace_bytes(n_samples, n_levels, log2_hashmap_size);
 }
 
-extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
+static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
                                     const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
                                     const float* d_density, float* d_position, void* workspace,
-                                    size_t workspace_bytes, int workspace_clean, void* stream) {
+                                    size_t workspace_bytes, int workspace_clean, void* stream,
+                                    const fnr_table_adam* table_adam, const fnr_table_adam* weight_adam,
+                                    const float* grad_arena) {
   FNR_CHECK_ARG(net && grads && warp && rays && euclid_bins && feat_save && d_density && workspace && S > 0,
                 "prop_density_bwd: null argument");
+  WeightAdam wa{};
+  TableAdam ta;
+  if (table_adam) {
+    FNR_CHECK_ARG(weight_adam && grad_arena, "prop_density_bwd_adam: weight_adam / grad_arena missing");
+    int rca = make_table_adam(weight_adam, wa.t);
+    if (rca) return rca;
+    wa.p_off = weight_adam->params - grad_arena;
+    wa.m_off = weight_adam->exp_avg - grad_arena;
+    wa.v_off = weight_adam->exp_avg_sq - grad_arena;
+    rca = make_table_adam(table_adam, ta);
+    if (rca) return rca;
+  }
   FNR_UNSUPPORTED(net->hidden_dim == 16, "prop_density_bwd: hidden_dim %d not built (16 only)", net->hidden_dim);
   FNR_CHECK_ARG(grads->grid.table && grads->w0 && grads->b0 && grads->w1 && grads->b1,
                 "prop_density_bwd: null gradient pointer");
@@ -870,9 +891,32 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
   }
 #undef FNR_PROPB_CASE
   FNR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_prop_reduce, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), partials,
-                     (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1);
+  if (table_adam)
+    hipLaunchKernelGGL(k_prop_reduce<true>, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), partials,
+                       (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1, wa);
+  else
+    hipLaunchKernelGGL(k_prop_reduce<false>, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), partials,
+                       (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1, WeightAdam{});
   FNR_LAUNCH_CHECK();
   return binned_scatter(&grads->grid, w, src, N, d_feats, 0, L, reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,
-                        workspace_bytes - dfeat_bytes - partial_bytes, workspace_clean, as_stream(stream));
+                        workspace_bytes - dfeat_bytes - partial_bytes, workspace_clean, as_stream(stream),
+                        table_adam ? &ta : nullptr);
+}
+
+extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
+                                    const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
+                                    const float* d_density, float* d_position, void* workspace,
+                                    size_t workspace_bytes, int workspace_clean, void* stream) {
+  return prop_density_bwd_entry(net, grads, warp, rays, euclid_bins, S, feat_save, d_density, d_position, workspace,
+                                workspace_bytes, workspace_clean, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int fnr_prop_density_bwd_adam(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
+                                         const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
+                                         const float* d_density, float* d_position, const fnr_table_adam* table_adam,
+                                         const fnr_table_adam* weight_adam, const float* grad_arena, void* workspace,
+                                         size_t workspace_bytes, int workspace_clean, void* stream) {
+  FNR_CHECK_ARG(table_adam && weight_adam && grad_arena, "prop_density_bwd_adam: optimiser descriptors missing");
+  return prop_density_bwd_entry(net, grads, warp, rays, euclid_bins, S, feat_save, d_density, d_position, workspace,
+                                workspace_bytes, workspace_clean, stream, table_adam, weight_adam, grad_arena);
 }

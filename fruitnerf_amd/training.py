@@ -186,14 +186,16 @@ class _InterlevelFn(torch.autograd.Function):
 
 def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins: Optional[Tensor],
                        d_directions: Optional[Tensor], level_streams: bool = False,
-                       collect: Optional[list] = None) -> None:
+                       collect: Optional[list] = None, optimizer: Optional["FusedAdam"] = None) -> None:
     """Backward of the interlevel loss into the proposal networks (and, when asked, into the rays).
     upstream None: d_wps already holds d(loss)/d(density) per level (train_losses(fuse_weights_bwd=True)).
     level_streams: the levels' chains (MLP backward -> weight reduce -> scatter emit -> accumulate; they share nothing when
     every level has its own network) run side by side, level 0 on the current stream and the others on side streams;
     their ray-gradient sums (+= into the same [R,3] buffers) follow on the current stream after the join.
     collect: a list that receives the levels' ray-gradient sources (warp, euclid, S, d_position) INSTEAD of their
-    reduction into d_origins / d_directions — the caller reduces all sources of the step in one launch."""
+    reduction into d_origins / d_directions — the caller reduces all sources of the step in one launch.
+    optimizer: the networks' optimiser steps are taken by the kernels that finish their gradients
+    (fnr_prop_density_bwd_adam; single process, one network per level)."""
     cfg = model.config
     rays = rctx.rays
     dev = rays.device
@@ -212,9 +214,14 @@ def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins
         with torch.cuda.stream(stream) if stream is not None else _null_context():
             d_density = d_wp if upstream is None else \
                 K.weights_bwd(lv["S"], lv["euclid"], lv["density"], lv["weights"], d_wp, upstream)
+            adam = None
+            if optimizer is not None:
+                t_adam, _ = optimizer.table_adam_args(net.encoding.hash_table, "proposal_networks")
+                (w_adam, grad_arena), _ = optimizer.weight_adam_args("proposal_networks")
+                adam = (t_adam, w_adam, grad_arena)
             d_pos = K.prop_density_bwd(net.prop_struct(), net.prop_struct(grads=True), net.warp_struct(), rays,
                                        lv["euclid"], lv["S"], lv["feats"], d_density,
-                                       want_position_grad=d_origins is not None)
+                                       want_position_grad=d_origins is not None, adam=adam)
         if d_origins is None:
             continue
         if collect is not None:
@@ -557,7 +564,7 @@ class _FieldGradientExchange:
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
                            ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False,
-                           table_adam=None, weight_adam=None):
+                           table_adam=None, weight_adam=None, proposal_optimizer: Optional["FusedAdam"] = None):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -620,7 +627,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                     side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    _proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources)
+                    _proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources,
+                                       optimizer=proposal_optimizer)
         d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
                                                       rctx.weights, d_rgb, d_sem)
         fld = model.field
@@ -660,7 +668,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 src[3].record_stream(main)
         elif prop_bwd:
             _proposal_backward(model, rctx, d_wps, up, d_o, d_d, level_streams=PROPOSAL_LEVEL_STREAMS,
-                               collect=ray_sources)
+                               collect=ray_sources, optimizer=proposal_optimizer)
         if ray_grads is not None:
             # one launch: proposal levels first, the field last (the order the separate launches added them in)
             K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
@@ -737,9 +745,17 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             # ends without an optimiser launch
             weight_adam, span = optimizer.weight_adam_args("fields")
             done = (span,)
+    # ... and the proposal networks' on the steps that train them (one network per level: a shared network needs both
+    # levels' gradients summed before its step)
+    prop_opt = None
+    if exchange is None and fuse and FUSE_WEIGHT_OPTIMIZER and not model.config.use_same_proposal_network \
+            and model.training and model.proposal_sampler.updated_now():
+        prop_opt = optimizer
+        done = done + (tuple(spans["proposal_networks"]),)
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads, overlap_proposal_backward=OVERLAP_PROPOSAL_BACKWARD,
-                                                     table_adam=table_adam, weight_adam=weight_adam)
+                                                     table_adam=table_adam, weight_adam=weight_adam,
+                                                     proposal_optimizer=prop_opt)
     with torch.no_grad():
         if exchange is None:
             if camera is not None:

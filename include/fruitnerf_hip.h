@@ -395,6 +395,18 @@ int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, con
                          const float* d_density, float* d_position, void* workspace, size_t workspace_bytes,
                          int workspace_clean, void* stream);
 
+/* fnr_prop_density_bwd with the optimiser step of THIS network's parameters fused in (single-process training; a network
+ * that serves one proposal level — with use_same_proposal_network the levels' gradients have to be summed first):
+ * table_adam = the hash table's slices of the caller's arenas (as in fnr_hash_encode_bwd_adam: the scatter's accumulate
+ * kernel steps the rows it owns, the gradient table stays zero), weight_adam / grad_arena = the arenas' bases (as in
+ * fnr_field_mlp_bwd_adam: k_prop_reduce steps w0 / b0 / w1 / b1 and leaves their gradient entries zero).  Bit-identical to
+ * fnr_prop_density_bwd followed by fnr_adam_step / fnr_radam_step(zero_grad = 1) on the network's spans. */
+int fnr_prop_density_bwd_adam(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
+                              const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
+                              const float* d_density, float* d_position, const fnr_table_adam* table_adam,
+                              const fnr_table_adam* weight_adam, const float* grad_arena, void* workspace,
+                              size_t workspace_bytes, int workspace_clean, void* stream);
+
 /* All of get_loss_dict / get_metrics_dict (fruit_nerf.py:359-372, 396-401: rgb_loss, semantics_loss, interlevel_loss; psnr, distortion) for one training batch in ONE launch:
  * fnr_losses_fwd + fnr_interlevel_fwd for
  * each of the n_levels (<= FNR_MAX_PROPOSAL_LEVELS) proposal levels against the final level + (want_distortion)
