@@ -483,6 +483,33 @@ def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_war
     return d_pos
 
 
+def prop_density_bwd_pair(nets, grads, warps, rays: RaysArg, euclids, S, feats, d_density, want_position_grad: bool = False,
+                          adam=None):
+    """fnr_prop_density_bwd_pair: both proposal levels of a step (lists of two), their accumulate launches as one.
+    adam = ([table fnr_table_adam x 2], weight fnr_table_adam, gradient arena) or None.  -> [d_position | None] x 2."""
+    lib = L.load()
+    dev = rays.device
+    ws, nbytes, clean, d_pos = [], [], [], []
+    for q in range(2):
+        nb = lib.fnr_prop_density_bwd_workspace_bytes(rays.n * S[q], nets[q].grid.n_levels, nets[q].grid.log2_hashmap_size)
+        w, c = _scatter_workspace(dev, nb, f"prop{q}")
+        ws.append(w), nbytes.append(nb), clean.append(c)
+        d_pos.append(torch.empty(rays.n * S[q], 4, device=dev) if want_position_grad else None)
+    PN, PW, PT = C.POINTER(L.fnr_prop_net), C.POINTER(L.fnr_warp), C.POINTER(L.fnr_table_adam)
+    vp = lambda ts: (C.c_void_p * 2)(*[L.ptr(t) for t in ts])   # noqa: E731
+    t_adams = w_adam = grad_arena = None
+    if adam is not None:
+        t_list, w_adam_s, grad_arena = adam
+        t_adams = (PT * 2)(*[C.pointer(t) for t in t_list])
+        w_adam = C.byref(w_adam_s)
+    L.check(lib.fnr_prop_density_bwd_pair((PN * 2)(*[C.pointer(n) for n in nets]), (PN * 2)(*[C.pointer(g) for g in grads]),
+                                          (PW * 2)(*[C.pointer(w) for w in warps]), rays.ref, vp(euclids),
+                                          (C.c_int * 2)(*[int(x) for x in S]), vp(feats), vp(d_density), vp(d_pos), t_adams,
+                                          w_adam, L.ptr(grad_arena), vp(ws), (C.c_size_t * 2)(*nbytes),
+                                          (C.c_int * 2)(*clean), L.stream_ptr(dev)), "prop_density_bwd_pair")
+    return d_pos
+
+
 def hash_encode_input_grad(grid: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
                            d_feats: Tensor) -> Tensor:
     """Per-level gradient w.r.t. the unit-cube sample positions: [L][N][4]."""

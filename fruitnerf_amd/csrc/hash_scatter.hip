@@ -394,18 +394,34 @@ __device__ __forceinline__ void acc_record(unsigned long long* __restrict__ s_ac
 }
 
 // (TableAdam / table_adam_update: common.hpp — the optimiser step fused into the accumulate kernel)
+// everything one accumulate launch needs about one scatter call (a launch can serve two calls: k_scatter_accumulate2)
+struct AccArgs {
+  GridDev grid;
+  const float2* queue_v;
+  const unsigned short* queue_r;
+  unsigned *qcount, *qmax, *qdone;
+  long long cap;
+  int log2_rows, level0, nbins;   // nbins = level_count * bins per level = workgroups of this call
+  TableAdam adam;
+};
+
+// s_acc: [rows][2] two's-complement fixed point in DYNAMIC LDS, 16 bytes per row of the bin (128 KiB for the main
+// table's 8192-row bins, 64 KiB for the proposal tables' 4096: two workgroups per CU there)
 template <bool ADAM>
-__global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const float2* __restrict__ queue_v,
-                                                             const unsigned short* __restrict__ queue_r,
-                                                             unsigned* __restrict__ qcount,
-                                                             unsigned* __restrict__ qmax,
-                                                             unsigned* __restrict__ qdone, long long cap,
-                                                             int log2_rows, int level0, TableAdam adam) {
-  __shared__ unsigned long long s_acc[2 * SC_MAX_ROWS];  // [rows][2] two's-complement fixed point, 128 KiB
+__device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, unsigned long long* __restrict__ s_acc) {
+  const GridDev& grid = A.grid;
+  const float2* __restrict__ queue_v = A.queue_v;
+  const unsigned short* __restrict__ queue_r = A.queue_r;
+  unsigned* __restrict__ qcount = A.qcount;
+  unsigned* __restrict__ qmax = A.qmax;
+  unsigned* __restrict__ qdone = A.qdone;
+  const long long cap = A.cap;
+  const int log2_rows = A.log2_rows, level0 = A.level0;
+  const TableAdam& adam = A.adam;
   const int rows = 1 << log2_rows;
   const int bins = 1 << (grid.log2_T - log2_rows);
   // fine levels (long queues) are dispatched first, the short coarse-level bins fill the tail
-  const int gbin = (int)gridDim.x - 1 - (int)blockIdx.x;  // (level - level0) * bins + bin
+  const int gbin = A.nbins - 1 - vblock;  // (level - level0) * bins + bin
   const int lrel = gbin / bins, bin = gbin - lrel * bins;
   const int level = level0 + lrel;
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
@@ -505,10 +521,25 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(GridDev grid, const
   }
 }
 
+extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
+template <bool ADAM>
+__global__ __launch_bounds__(1024) void k_scatter_accumulate(AccArgs a) {
+  accumulate_bin<ADAM>(a, (int)blockIdx.x, reinterpret_cast<unsigned long long*>(acc_smem));
+}
+// two scatter calls in one launch (the two proposal levels' tables: 160 workgroups each on 256 CUs — side by side they
+// cost the longer of the two instead of their sum); the longer queues (call a) are dispatched first
+template <bool ADAM>
+__global__ __launch_bounds__(1024) void k_scatter_accumulate2(AccArgs a, AccArgs b) {
+  unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(acc_smem);
+  if ((int)blockIdx.x < a.nbins) accumulate_bin<ADAM>(a, (int)blockIdx.x, s_acc);
+  else accumulate_bin<ADAM>(b, (int)blockIdx.x - a.nbins, s_acc);
+}
+
+// emit of one scatter call -> the arguments its accumulate launch needs
 template <class Source>
-static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Source& src, long long N,
-                          const float2* d_feats, int level0, int level_count, void* workspace, size_t workspace_bytes,
-                          int workspace_clean, hipStream_t st, const TableAdam* adam = nullptr) {
+static int scatter_emit(const fnr_grid* grid_grad, const Warp& warp, const Source& src, long long N,
+                        const float2* d_feats, int level0, int level_count, void* workspace, size_t workspace_bytes,
+                        int workspace_clean, hipStream_t st, const TableAdam* adam, AccArgs& acc) {
   FNR_CHECK_ARG(level0 >= 0 && level_count >= 1 && level0 + level_count <= grid_grad->n_levels,
                 "hash scatter: level range [%d,+%d) outside the %d levels", level0, level_count, grid_grad->n_levels);
   const ScatterPlan p = scatter_plan(N, level_count, grid_grad->log2_hashmap_size);
@@ -549,17 +580,58 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
                        0, st, gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap,
                        p.log2_rows, level0, level_count, lpb);
   FNR_LAUNCH_CHECK();
-  const unsigned nbins = (unsigned)(level_count * p.bins_per_level);
-  if (adam)
-    hipLaunchKernelGGL(k_scatter_accumulate<true>, dim3(nbins), dim3(1024), 0, st, gd, queue_v, queue_r, qcount,
-                       qcount + nbins_all * SC_CNT_STRIDE, qcount + (nbins_all + level_count) * SC_CNT_STRIDE, p.cap,
-                       p.log2_rows, level0, *adam);
-  else
-    hipLaunchKernelGGL(k_scatter_accumulate<false>, dim3(nbins), dim3(1024), 0, st, gd, queue_v, queue_r, qcount,
-                       qcount + nbins_all * SC_CNT_STRIDE, qcount + (nbins_all + level_count) * SC_CNT_STRIDE, p.cap,
-                       p.log2_rows, level0, TableAdam{});
+  acc.grid = gd;
+  acc.queue_v = queue_v, acc.queue_r = queue_r, acc.qcount = qcount;
+  acc.qmax = qcount + nbins_all * SC_CNT_STRIDE;
+  acc.qdone = qcount + (nbins_all + level_count) * SC_CNT_STRIDE;
+  acc.cap = p.cap, acc.log2_rows = p.log2_rows, acc.level0 = level0;
+  acc.nbins = level_count * p.bins_per_level;
+  acc.adam = adam ? *adam : TableAdam{};
+  return FNR_OK;
+}
+
+static int acc_lds_bytes(const AccArgs& a) { return (2 << a.log2_rows) * (int)sizeof(unsigned long long); }
+
+static int scatter_accumulate(const AccArgs& a, bool adam, hipStream_t st) {
+  const int bytes = acc_lds_bytes(a);
+  if (adam) {
+    const int rc = ensure_dyn_lds(k_scatter_accumulate<true>, 2 * SC_MAX_ROWS * (int)sizeof(unsigned long long));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_accumulate<true>, dim3((unsigned)a.nbins), dim3(1024), bytes, st, a);
+  } else {
+    const int rc = ensure_dyn_lds(k_scatter_accumulate<false>, 2 * SC_MAX_ROWS * (int)sizeof(unsigned long long));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_accumulate<false>, dim3((unsigned)a.nbins), dim3(1024), bytes, st, a);
+  }
   FNR_LAUNCH_CHECK();
   return FNR_OK;
+}
+
+// the accumulate launches of two scatter calls as one (a's queues are the longer ones)
+static int scatter_accumulate2(const AccArgs& a, const AccArgs& b, bool adam, hipStream_t st) {
+  const int bytes = acc_lds_bytes(a) > acc_lds_bytes(b) ? acc_lds_bytes(a) : acc_lds_bytes(b);
+  if (adam) {
+    const int rc = ensure_dyn_lds(k_scatter_accumulate2<true>, 2 * SC_MAX_ROWS * (int)sizeof(unsigned long long));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_accumulate2<true>, dim3((unsigned)(a.nbins + b.nbins)), dim3(1024), bytes, st, a, b);
+  } else {
+    const int rc = ensure_dyn_lds(k_scatter_accumulate2<false>, 2 * SC_MAX_ROWS * (int)sizeof(unsigned long long));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_accumulate2<false>, dim3((unsigned)(a.nbins + b.nbins)), dim3(1024), bytes, st, a, b);
+  }
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+template <class Source>
+static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Source& src, long long N,
+                          const float2* d_feats, int level0, int level_count, void* workspace, size_t workspace_bytes,
+                          int workspace_clean, hipStream_t st, const TableAdam* adam = nullptr) {
+  AccArgs acc;
+  const int rc = scatter_emit(grid_grad, warp, src, N, d_feats, level0, level_count, workspace, workspace_bytes,
+                              workspace_clean, st, adam, acc);
+  if (rc) return rc;
+  return scatter_accumulate(acc, adam != nullptr, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -832,7 +904,7 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
                                     const float* d_density, float* d_position, void* workspace,
                                     size_t workspace_bytes, int workspace_clean, void* stream,
                                     const fnr_table_adam* table_adam, const fnr_table_adam* weight_adam,
-                                    const float* grad_arena) {
+                                    const float* grad_arena, AccArgs* defer_acc = nullptr) {
   FNR_CHECK_ARG(net && grads && warp && rays && euclid_bins && feat_save && d_density && workspace && S > 0,
                 "prop_density_bwd: null argument");
   WeightAdam wa{};
@@ -898,9 +970,17 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
     hipLaunchKernelGGL(k_prop_reduce<false>, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), partials,
                        (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1, WeightAdam{});
   FNR_LAUNCH_CHECK();
-  return binned_scatter(&grads->grid, w, src, N, d_feats, 0, L, reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,
-                        workspace_bytes - dfeat_bytes - partial_bytes, workspace_clean, as_stream(stream),
-                        table_adam ? &ta : nullptr);
+  AccArgs acc;
+  const int rce = scatter_emit(&grads->grid, w, src, N, d_feats, 0, L,
+                               reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,
+                               workspace_bytes - dfeat_bytes - partial_bytes, workspace_clean, as_stream(stream),
+                               table_adam ? &ta : nullptr, acc);
+  if (rce) return rce;
+  if (defer_acc) {   // the caller launches the accumulate kernel (together with another call's)
+    *defer_acc = acc;
+    return FNR_OK;
+  }
+  return scatter_accumulate(acc, table_adam != nullptr, as_stream(stream));
 }
 
 extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net* grads, const fnr_warp* warp,
@@ -919,4 +999,35 @@ extern "C" int fnr_prop_density_bwd_adam(const fnr_prop_net* net, const fnr_prop
   FNR_CHECK_ARG(table_adam && weight_adam && grad_arena, "prop_density_bwd_adam: optimiser descriptors missing");
   return prop_density_bwd_entry(net, grads, warp, rays, euclid_bins, S, feat_save, d_density, d_position, workspace,
                                 workspace_bytes, workspace_clean, stream, table_adam, weight_adam, grad_arena);
+}
+
+// Both proposal levels of a training step (two networks, two sets of samples) as one entry point: their MLP backward,
+// weight reduction and emit launches run one after the other, their accumulate launches as ONE (k_scatter_accumulate2:
+// 160 workgroups of 64 KiB each per level on 256 CUs — side by side instead of one after the other).  table_adam /
+// weight_adam all NULL (gradients are left in `grads`) or all set (fnr_prop_density_bwd_adam semantics per network).
+extern "C" int fnr_prop_density_bwd_pair(const fnr_prop_net* const* nets, const fnr_prop_net* const* grads,
+                                         const fnr_warp* const* warps, const fnr_rays* rays,
+                                         const float* const* euclid_bins, const int* S, const float* const* feat_save,
+                                         const float* const* d_density, float* const* d_position,
+                                         const fnr_table_adam* const* table_adam, const fnr_table_adam* weight_adam,
+                                         const float* grad_arena, void* const* workspace, const size_t* workspace_bytes,
+                                         const int* workspace_clean, void* stream) {
+  FNR_CHECK_ARG(nets && grads && warps && rays && euclid_bins && S && feat_save && d_density && d_position && workspace &&
+                    workspace_bytes && workspace_clean,
+                "prop_density_bwd_pair: null argument");
+  FNR_CHECK_ARG(nets[0] != nets[1] && grads[0] != grads[1] && workspace[0] != workspace[1],
+                "prop_density_bwd_pair: the two levels must have their own network, gradients and workspace");
+  const bool adam = table_adam && table_adam[0] && table_adam[1];
+  FNR_CHECK_ARG(adam || !(table_adam && (table_adam[0] || table_adam[1])), "prop_density_bwd_pair: one table_adam missing");
+  if (rays->n_rays == 0) return FNR_OK;
+  AccArgs acc[2];
+  for (int q = 0; q < 2; ++q) {
+    const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
+                                          d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
+                                          adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
+                                          adam ? grad_arena : nullptr, &acc[q]);
+    if (rc) return rc;
+  }
+  const bool first_longer = (long long)S[0] >= (long long)S[1];
+  return scatter_accumulate2(first_longer ? acc[0] : acc[1], first_longer ? acc[1] : acc[0], adam, as_stream(stream));
 }

@@ -206,6 +206,27 @@ def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins
     while side_by_side and len(pool) < len(levels) - 1:
         pool.append(torch.cuda.Stream(device=dev))
     pending = []
+    if PAIR_PROPOSAL_LEVELS and len(levels) == 2 and not cfg.use_same_proposal_network and not side_by_side \
+            and upstream is None:
+        # both levels through one entry point: their accumulate launches run as one (fnr_prop_density_bwd_pair)
+        nets = [model.proposal_networks[0], model.proposal_networks[1]]
+        adam = None
+        if optimizer is not None:
+            t_adams = [optimizer.table_adam_args(n.encoding.hash_table, "proposal_networks")[0] for n in nets]
+            (w_adam, grad_arena), _ = optimizer.weight_adam_args("proposal_networks")
+            adam = (t_adams, w_adam, grad_arena)
+        d_pos = K.prop_density_bwd_pair([n.prop_struct() for n in nets], [n.prop_struct(grads=True) for n in nets],
+                                        [n.warp_struct() for n in nets], rays, [lv["euclid"] for lv, _ in levels],
+                                        [lv["S"] for lv, _ in levels], [lv["feats"] for lv, _ in levels],
+                                        [d_wp for _, d_wp in levels], want_position_grad=d_origins is not None, adam=adam)
+        for net, (lv, _), dp in zip(nets, levels, d_pos):
+            if d_origins is None:
+                continue
+            if collect is not None:
+                collect.append((net.warp_struct(), lv["euclid"], lv["S"], dp))
+            else:
+                K.position_grad_reduce(net.warp_struct(), rays, lv["euclid"], lv["S"], dp, d_origins, d_directions)
+        return
     for i, (lv, d_wp) in enumerate(levels):
         net = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
         stream = pool[i - 1] if side_by_side and i > 0 else None
@@ -712,6 +733,7 @@ OVERLAP_PROPOSAL_BACKWARD = os.environ.get("FNR_OVERLAP_PROPOSAL_BACKWARD") == "
 # cross-stream fork + join costs ~12 us of GPU time per handshake on this stack and the two chains of latency-bound
 # kernels slow each other in the XCDs' L2s (each network's 5 MB tables fit one L2, two do not).  Kept for measurements.
 PROPOSAL_LEVEL_STREAMS = os.environ.get("FNR_PROPOSAL_LEVEL_STREAMS", "0") == "1"
+PAIR_PROPOSAL_LEVELS = os.environ.get("FNR_PAIR_PROPOSAL_LEVELS", "1") != "0"   # see _proposal_backward
 FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
 FUSE_WEIGHT_OPTIMIZER = True  # ... and the field's MLP weights + embedding step inside k_reduce_dw / k_embedding_grad
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter

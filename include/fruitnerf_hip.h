@@ -407,6 +407,19 @@ int fnr_prop_density_bwd_adam(const fnr_prop_net* net, const fnr_prop_net* grads
                               const fnr_table_adam* weight_adam, const float* grad_arena, void* workspace,
                               size_t workspace_bytes, int workspace_clean, void* stream);
 
+/* Both proposal levels of a training step through ONE entry point (arrays of two: network, gradients, warp, bins, S,
+ * saved features, d_density, d_position, workspace, ...; the same rays): each level's MLP backward, weight reduction and
+ * scatter emit as in fnr_prop_density_bwd, then ONE accumulate launch over both levels' bins (each level has 160
+ * workgroups of 64 KiB LDS on 256 CUs: side by side they cost the longer of the two).  The two levels need their own
+ * network, gradients and workspace.  table_adam [2] + weight_adam + grad_arena: all NULL, or all set for the fused
+ * optimiser steps of fnr_prop_density_bwd_adam.  Results are those of the two separate calls, bit for bit. */
+int fnr_prop_density_bwd_pair(const fnr_prop_net* const* nets, const fnr_prop_net* const* grads,
+                              const fnr_warp* const* warps, const fnr_rays* rays, const float* const* euclid_bins,
+                              const int* S, const float* const* feat_save, const float* const* d_density,
+                              float* const* d_position, const fnr_table_adam* const* table_adam,
+                              const fnr_table_adam* weight_adam, const float* grad_arena, void* const* workspace,
+                              const size_t* workspace_bytes, const int* workspace_clean, void* stream);
+
 /* All of get_loss_dict / get_metrics_dict (fruit_nerf.py:359-372, 396-401: rgb_loss, semantics_loss, interlevel_loss; psnr, distortion) for one training batch in ONE launch:
  * fnr_losses_fwd + fnr_interlevel_fwd for
  * each of the n_levels (<= FNR_MAX_PROPOSAL_LEVELS) proposal levels against the final level + (want_distortion)

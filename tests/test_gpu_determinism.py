@@ -69,6 +69,20 @@ def test_runs_without_the_prologue_launch_are_reproducible_too(dev):
         assert torch.equal(x, y)
 
 
+def test_paired_proposal_levels_are_the_separate_calls(dev):
+    """fnr_prop_density_bwd_pair (both proposal levels through one entry point, their accumulate launches as one) against
+    one fnr_prop_density_bwd(_adam) call per level: identical states after 30 steps."""
+    import fruitnerf_amd.training as T
+    a = _run(dev, 30, "bf16x3")
+    saved, T.PAIR_PROPOSAL_LEVELS = T.PAIR_PROPOSAL_LEVELS, False
+    try:
+        b = _run(dev, 30, "bf16x3")
+    finally:
+        T.PAIR_PROPOSAL_LEVELS = saved
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_second_stream_run_is_bit_identical_too(dev):
     """The proposal-network backward on a second HIP stream (FNR_OVERLAP_PROPOSAL_BACKWARD) changes the interleaving of
     kernels, not the arithmetic."""
