@@ -943,6 +943,25 @@ def test_export_at_a_trained_state_matches_the_oracle(dev):
         a, b = got[name]["points"], ref[name]["points"].numpy()
         print(f"[trained export] {name}: hip {a.shape[0]} oracle {b.shape[0]}")
         assert a.shape == b.shape and np.array_equal(a, b), name
+    # ... and therefore the same fruit count (north star: "identical fruit count"): the first-stage count of the semantic
+    # set — radius-outlier removal -> voxel down-sampling -> DBSCAN -> centre-distance merge (clustering_base.py:183-258)
+    # — through the GPU front-end on the HIP export and through the CPU libraries' restatement on the oracle's export
+    from fruitnerf_amd.clustering import FruitClustering, PointCloud
+    from oracle import cloud as ocl
+    spacing = 1.0 / N * 2.0                       # lattice pitch of the [-0.5, 0.5]^3 box after sample_volume's x2 scaling
+    kw = dict(nb_points=2, radius=1.8 * spacing, voxel_size=spacing / 4, eps=1.8 * spacing, min_samples=4)
+    fc = FruitClustering(voxel_size_down_sample=kw["voxel_size"], remove_outliers_nb_points=kw["nb_points"],
+                         remove_outliers_radius=kw["radius"], cluster_merge_distance=0.04)
+    count_hip = fc.first_stage_count(PointCloud(got["semantic"]["points"], None, dev), eps=kw["eps"], min_samples=kw["min_samples"])
+    X, _, labels = ocl.cluster_front_end(ref["semantic"]["points"].numpy(), None, kw["nb_points"], kw["radius"], kw["voxel_size"],
+                                         kw["eps"], kw["min_samples"])
+    fc2 = FruitClustering(cluster_merge_distance=0.04)
+    count_ref = 0
+    if not isinstance(X, int):
+        fc2.merge_small_clusters(X, None, labels)
+        count_ref = fc2.counter - fc2.fuse_counter
+    print(f"[trained export] first-stage fruit count: hip {count_hip} oracle {count_ref}")
+    assert count_hip == count_ref and count_hip >= 1
 
 
 def test_radam_matches_torch(dev):
