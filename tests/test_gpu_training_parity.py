@@ -274,7 +274,11 @@ def test_field_api_is_differentiable(dev, shape):
             scale = g_ref.abs().max().item()
             l1 = diff.double().sum().item() / max(g_ref.abs().double().sum().item(), 1e-30)
             print(f"[field api two_calls={two_calls}] {name}: max|ref| {scale:.3e} max_err {diff.max().item():.3e} L1-rel {l1:.3e}")
-            assert diff.max().item() <= 2e-2 * scale + 1e-12 and l1 <= 2e-3, name    # ReLU kinks: see the big-shape note above
+            # `fruit_nerf`: the round-1 bar (2e-3 of max |g|) in every arithmetic; the big shape's 448 hidden units x
+            # 20 k samples on a white 2^14-row table produce the occasional ReLU gate on the other side of 0 (see the
+            # big-shape note above): max-norm 2e-2 AND L1 2e-3 there
+            tol = 2e-3 if shape == "fruit_nerf" else 2e-2
+            assert diff.max().item() <= tol * scale + 1e-12 and l1 <= 2e-3, name
     # the side-effect attributes of get_density (fruit_field.py:180-186)
     loc, dba = hm.field._sample_locations, hm.field._density_before_activation
     assert loc.shape == (R, S, 3) and loc.requires_grad and dba.shape == (R, S, 1)
