@@ -282,19 +282,24 @@ class MethodRun:
                                             weight_decay=cm["weight_decay"], lr_final=cm["lr_final"],
                                             max_steps=cm["max_steps"] or 1).setup(n_train, dev)
             self.camera = (cam_opt, CameraAdam(cam_opt, algorithm=cm["algorithm"]), self.batcher)
-        self.step_idx = 0
+        from fruitnerf_amd.training import TrainingSteps
+        # the loop body: batcher.sample -> fused_train_iteration, the next step's rays + proposal sampling enqueued at the
+        # end of the current one (training.SAMPLE_AHEAD)
+        self.steps = TrainingSteps(self.model, self.opt, self.batcher, self.rays,
+                                   camera=self.camera[:2] if self.camera else None, world_size=world)
+
+    @property
+    def step_idx(self):
+        return self.steps.step_idx
+
+    def set_camera(self, camera):
+        """camera optimiser on (the (optimizer, adam, batcher) triple) / off (None) for the following steps."""
+        self.camera = camera
+        self.steps.camera = camera
+        self.steps.drop_lookahead()
 
     def one_step(self, want_metrics=True):
-        from fruitnerf_amd.rays import RayBundle
-        from fruitnerf_amd.training import fused_train_iteration
-        # the start of the step in one launch: pixels, corrected cameras, rays, level-0 bins, jitters (fnr_train_prologue)
-        o, d, cam, batch = self.batcher.sample(self.rays, self.camera[0] if self.camera else None,
-                                               level0=self.model.level0_spec())
-        out = fused_train_iteration(self.model, self.opt, RayBundle(o, d, None, cam, presampled=self.batcher.last_presample),
-                                    batch, self.step_idx,
-                                    world_size=self.world, want_metrics=want_metrics, camera=self.camera)
-        self.step_idx += 1
-        return out
+        return self.steps.step(want_metrics)
 
 
 PROFILE_EVERY = 4   # HIP events on the roofline candidates' launches of every 4th step of the timed window
@@ -303,20 +308,29 @@ PROFILE_EVERY = 4   # HIP events on the roofline candidates' launches of every 4
 def timed_window(run, steps, barrier, dist_on, dev):
     """EXACTLY `steps` training steps between barrier + synchronize on both sides.  On every PROFILE_EVERY-th step the
     launches of the roofline candidates are bracketed by HIP events on the launch stream (an event pair costs the GPU
-    a ~3 us bubble: all candidates on every step cost 5 % of the step, measured) -> (seconds: max over ranks, host
-    enqueue seconds, event records, profiled steps, last (loss_dict, metrics))."""
+    a ~3 us bubble: all candidates on every step cost 5 % of the step, measured) and the second HIP stream's launches
+    are serialised with the launch stream's -> (seconds: max over ranks, host enqueue seconds, event records, profiled
+    steps, last (loss_dict, metrics))."""
     from fruitnerf_amd import _lib as L
+    import fruitnerf_amd.training as T
     L.profile_enable(True, ops=list(ROOFLINE_OPS))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
     n_prof = 0
-    for i in range(steps):
-        on = i % PROFILE_EVERY == 0
-        L.profile_pause(not on)
-        n_prof += on
-        last = run.one_step()
+    try:
+        for i in range(steps):
+            on = i % PROFILE_EVERY == 0
+            L.profile_pause(not on)
+            # a bracketed launch must have the GPU to itself: on the profiled steps the second stream's launches (proposal
+            # backward, ray-gradient reduction, camera step, next step's sampling) run before / after the launch stream's,
+            # not next to them (training.SERIALIZE_STREAMS; same results either way)
+            T.SERIALIZE_STREAMS = bool(on)
+            n_prof += on
+            last = run.one_step()
+    finally:
+        T.SERIALIZE_STREAMS = False
     run.model.field.flush_deferred_update()   # N > 1: the last step's field collective + optimiser step (training.DEFER_FIELD_UPDATE)
     t_enqueued = time.perf_counter() - t0     # host side done (launches queued); the GPU is still working
     torch.cuda.synchronize()
@@ -512,9 +526,11 @@ def main() -> None:
     # other ranks have left, so no collective may run here) ------------------------------------------------
     nb = 12 if world == 1 else 0
     L.profile_enable(True)
+    _training.SERIALIZE_STREAMS = True      # nothing next to a bracketed launch
     for _ in range(nb):
         one_step()
     torch.cuda.synchronize()
+    _training.SERIALIZE_STREAMS = False
     recs = L.profile_collect() if nb else []
     L.profile_enable(False)
     breakdown = {}
@@ -617,7 +633,8 @@ def main() -> None:
         exp_s = float(np.median(exp_times))
         cam_off = None
         if run.camera is not None:  # the same loop without the camera optimiser (no input gradient of the hash grids)
-            saved, run.camera = run.camera, None
+            saved = run.camera
+            run.set_camera(None)
             for _ in range(10):
                 one_step()
             torch.cuda.synchronize()
@@ -626,11 +643,10 @@ def main() -> None:
                 one_step()
             torch.cuda.synchronize()
             cam_off = round(100 * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
-            run.camera = saved
+            run.set_camera(saved)
         # The headline window again on a FRESH model (same seeds, same step numbers -> same proposal update schedule)
-        # with the proposal-network backward on a second HIP stream (FNR_OVERLAP_PROPOSAL_BACKWARD=1): faster, but two
-        # streams share the GPU and the per-kernel timings above would no longer describe one kernel, so it is not
-        # the default of the timed region.
+        # with everything on one stream (FNR_OVERLAP_PROPOSAL_BACKWARD=0) and with the second HIP stream on every step
+        # (the timed region itself keeps the steps whose launches it brackets with events on one stream).
         import fruitnerf_amd.training as _T
 
         def headline_window(overlap: bool):
@@ -822,6 +838,10 @@ def main() -> None:
                    # the hash_encode_bwd entry; no gradient table is written or re-read); N>1: separate step after RCCL
                    "table_optimizer": "fused into hash_encode_bwd" if not dist_on else
                    ("separate (after the exchange" + (", deferred to the next step's field encode)" if _training.DEFER_FIELD_UPDATE else ")")),
+                   "streams": (f"2: proposal-network backward underneath the field backward; ray-gradient reduction, camera "
+                               f"step and the next step's rays + proposal sampling underneath the table scatter (serialised "
+                               f"on every {PROFILE_EVERY}th step, whose launches are timed)"
+                               if _training.OVERLAP_PROPOSAL_BACKWARD else "1"),
                    "exchange": None if not dist_on else f"{_training.EXCHANGE_LEVEL_GROUPS} field collective(s) per step + proposal networks on update steps + poses",
                    "device": info["arch"], "setup_s": round(setup_s, 1)},
         "roofline": roofline,

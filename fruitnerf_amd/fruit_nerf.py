@@ -153,6 +153,10 @@ class ProposalNetworkSampler(nn.Module):
     def updated_now(self) -> bool:
         return bool(self._steps_since_update > self.update_sched(self._step) or self._step < 10)
 
+    def updated_after(self, step: int) -> bool:
+        """What updated_now() will answer once step_cb(step) has run (the next iteration's forward pass)."""
+        return bool(self._steps_since_update + 1 > self.update_sched(step) or step < 10)
+
 
 @dataclass
 class RenderContext:
@@ -303,14 +307,17 @@ class FruitModel(nn.Module):
         return {"proposal_networks": list(self.proposal_networks.parameters()),
                 "fields": list(self.field.parameters())}
 
-    def set_anneal(self, step: int) -> None:  # the BEFORE_TRAIN_ITERATION callback, fruit_nerf.py:199-207
+    def anneal_at(self, step: int) -> float:  # fruit_nerf.py:199-207
         N = self.config.proposal_weights_anneal_max_num_iters
         train_frac = np.clip(step / N, 0, 1)
 
         def bias(x, b):
             return b * x / ((b - 1) * x + 1)
 
-        self.proposal_sampler.set_anneal(bias(train_frac, self.config.proposal_weights_anneal_slope))
+        return bias(train_frac, self.config.proposal_weights_anneal_slope)
+
+    def set_anneal(self, step: int) -> None:  # the BEFORE_TRAIN_ITERATION callback, fruit_nerf.py:199-207
+        self.proposal_sampler.set_anneal(self.anneal_at(step))
 
     def get_training_callbacks(self, training_callback_attributes=None) -> List["TrainingCallback"]:
         """fruit_nerf.py:191-223: the anneal callback before and the sampler's step callback after every training
@@ -336,6 +343,8 @@ class FruitModel(nn.Module):
 
     def _collide(self, ray_bundle: RayBundle) -> RayBundle:  # NearFarCollider, fruit_nerf.py:161,382-383
         if ray_bundle.nears is not None and ray_bundle.fars is not None:
+            if ray_bundle.__dict__.get("_collided_by") is self:
+                return ray_bundle               # this collider's planes already (sample_ahead)
             if getattr(ray_bundle, "presampled", None) is not None:
                 ray_bundle.presampled = None    # pre-sampled for the collider's planes, not for the caller's own
             return ray_bundle
@@ -349,6 +358,7 @@ class FruitModel(nn.Module):
             ones = torch.ones_like(ray_bundle.origins[..., 0:1])
             cache[key] = (ones * near_plane, ones * self.config.far_plane)
         ray_bundle.nears, ray_bundle.fars = cache[key]
+        ray_bundle.__dict__["_collided_by"] = self
         return ray_bundle
 
     # ---- the hot path ----------------------------------------------------------------------------------------
@@ -383,20 +393,14 @@ class FruitModel(nn.Module):
                 jit = [j if j is not None else fresh[i] for i, j in enumerate(jit)]
         else:
             jit = [None] * (n_prop + 1)
-        levels: List[dict] = []
-        spacing, euclid = (pre["spacing"], pre["euclid"]) if pre is not None else K.sample_spaced(rays, 1, S0, jit[0])
-        S = S0
-        for i in range(n_prop):
-            net = self.proposal_networks[0 if cfg.use_same_proposal_network else i]
-            save = training and updated
-            density, feats = K.prop_density_fwd(net.prop_struct(), net.warp_struct(), rays, euclid, S,
-                                                save_feats=save)
-            S_next = sampler.num_proposal_samples_per_ray[i + 1] if i + 1 < n_prop else sampler.num_nerf_samples_per_ray
-            weights, depth, spacing_n, euclid_n = K.weights_pdf(rays, 1, S, S_next, density, spacing, euclid,
-                                                                sampler._anneal, jit[i + 1])
-            levels.append(dict(S=S, spacing=spacing, euclid=euclid, density=density, weights=weights, depth=depth,
-                               feats=feats))
-            spacing, euclid, S = spacing_n, euclid_n, S_next
+        ahead = pre.get("ahead") if pre is not None else None
+        if ahead is not None and ahead["updated"] == updated and ahead["anneal"] == sampler._anneal:
+            # the proposal levels of these rays were sampled ahead (sample_ahead: enqueued at the end of the previous
+            # iteration) under the schedule this pass sees
+            levels, spacing, euclid, S = list(ahead["levels"]), ahead["spacing"], ahead["euclid"], ahead["S"]
+            self.__dict__["_ahead_used"] = self.__dict__.get("_ahead_used", 0) + 1   # (tests: the look-ahead is what ran)
+        else:
+            levels, spacing, euclid, S = self._proposal_levels(rays, pre, jit, training and updated, sampler._anneal)
         if updated:
             sampler._steps_since_update = 0
         self._last_render_updated = bool(training and updated)   # did this pass keep the proposal nets' graph?
@@ -426,6 +430,57 @@ class FruitModel(nn.Module):
         for i in range(n_prop):
             outputs[f"prop_depth_{i}"] = levels[i]["depth"][:, None]
         return outputs, ctx
+
+    def _proposal_levels(self, rays, pre, jit, save_feats: bool, anneal: float):
+        """ProposalNetworkSampler.generate_ray_samples: level-0 bins (taken from the prologue's `pre` when given), then
+        per proposal network density -> weights -> inverse-CDF bins of the next level -> (levels, spacing, euclid, S)."""
+        cfg, sampler = self.config, self.proposal_sampler
+        n_prop = sampler.num_proposal_network_iterations
+        S = sampler.num_proposal_samples_per_ray[0]
+        levels: List[dict] = []
+        spacing, euclid = (pre["spacing"], pre["euclid"]) if pre is not None else K.sample_spaced(rays, 1, S, jit[0])
+        for i in range(n_prop):
+            net = self.proposal_networks[0 if cfg.use_same_proposal_network else i]
+            density, feats = K.prop_density_fwd(net.prop_struct(), net.warp_struct(), rays, euclid, S,
+                                                save_feats=save_feats)
+            S_next = sampler.num_proposal_samples_per_ray[i + 1] if i + 1 < n_prop else sampler.num_nerf_samples_per_ray
+            weights, depth, spacing_n, euclid_n = K.weights_pdf(rays, 1, S, S_next, density, spacing, euclid,
+                                                                anneal, jit[i + 1])
+            levels.append(dict(S=S, spacing=spacing, euclid=euclid, density=density, weights=weights, depth=depth,
+                               feats=feats))
+            spacing, euclid, S = spacing_n, euclid_n, S_next
+        return levels, spacing, euclid, S
+
+    @torch.no_grad()
+    def sample_ahead(self, ray_bundle: RayBundle, step: int) -> bool:
+        """The proposal sampling of the NEXT training iteration (`step` = the iteration that is finishing), enqueued
+        ahead of it: neither the rays (drawn by fnr_train_prologue) nor the proposal networks depend on what the
+        current iteration still has in flight once the proposal networks' and the cameras' optimiser steps are enqueued
+        — the main table's scatter + optimiser step, the longest launch pair of the step (training.TrainingSteps).
+        The result rides in ray_bundle.presampled["ahead"] together with the schedule it assumed (proposal update flag
+        after step_cb(step), anneal of step + 1); _render recomputes when that is not the schedule it finds.
+        Valid only while the proposal networks' parameters stay what they were when this ran."""
+        sampler = self.proposal_sampler
+        pre = getattr(ray_bundle, "presampled", None)
+        if not self.training or pre is None or not isinstance(sampler, ProposalNetworkSampler) \
+                or ray_bundle.origins.shape[0] == 0:
+            return False
+        self.arena()
+        ray_bundle = self._collide(ray_bundle)
+        pre = ray_bundle.presampled
+        cfg = self.config
+        n_prop = sampler.num_proposal_network_iterations
+        if pre is None or not (pre.get("S0") == sampler.num_proposal_samples_per_ray[0]
+                               and len(pre.get("jitter", ())) >= n_prop + 1
+                               and pre["spacing"].shape[0] == ray_bundle.origins.shape[0]
+                               and pre.get("near") == float(cfg.near_plane) and pre.get("far") == float(cfg.far_plane)):
+            return False
+        rays = K.RaysArg(ray_bundle.origins, ray_bundle.directions, ray_bundle.nears, ray_bundle.fars,
+                         ray_bundle.camera_indices)
+        updated, anneal = sampler.updated_after(step), self.anneal_at(step + 1)
+        levels, spacing, euclid, S = self._proposal_levels(rays, pre, list(pre["jitter"][:n_prop + 1]), updated, anneal)
+        pre["ahead"] = dict(levels=levels, spacing=spacing, euclid=euclid, S=S, updated=updated, anneal=anneal)
+        return True
 
     def _empty_render(self, ray_bundle: RayBundle) -> Tuple[Dict, RenderContext]:
         dev = ray_bundle.origins.device

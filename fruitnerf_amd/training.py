@@ -585,7 +585,8 @@ class _FieldGradientExchange:
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
                            ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False,
-                           table_adam=None, weight_adam=None, proposal_optimizer: Optional["FusedAdam"] = None):
+                           table_adam=None, weight_adam=None, proposal_optimizer: Optional["FusedAdam"] = None,
+                           after_ray_grads=None, serialize_streams: bool = False):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -596,7 +597,13 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
     ray_grads: pass a dict to also receive d(loss)/d(origins) and d(loss)/d(directions) [R,3] under the keys
     "origins" / "directions" (what a camera-pose optimiser back-propagates further).
     table_adam: fnr_table_adam of the main hash table (FusedAdam.table_adam_args): its gradient is not materialised,
-    the scatter's accumulate kernel applies the optimiser step to the table (single process only)."""
+    the scatter's accumulate kernel applies the optimiser step to the table (single process only).
+    after_ray_grads: called once the ray gradients are final (the camera optimiser's backward + step); with
+    overlap_proposal_backward it runs, like the reduction of the ray gradients itself, on the second stream underneath
+    the table scatter, which neither of them depends on.
+    serialize_streams (with overlap_proposal_backward): the same launches on the same two streams (same allocator pools),
+    but each stream waits for everything the other has enqueued — nothing runs concurrently (bench.py: the steps whose
+    launches it brackets with HIP events)."""
     from . import _lib as L
     cfg = model.config
     dev = model.device
@@ -636,8 +643,9 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             d_o, d_d = ray_grads["origins"], ray_grads["directions"] = both[0], both[1]
         # The proposal-network backward (interlevel loss) and the field backward (rgb + semantic losses) share no
         # buffers.  overlap_proposal_backward=True runs the former on a second HIP stream so that its ~14 small/medium
-        # launches fill the gaps and tails of the field kernels (measured: -2 % step time); off by default because
-        # the per-kernel HIP-event timings bench.py reports would then include the other stream's kernels.
+        # launches fill the gaps and tails of the field kernels (measured: -3 % on the steps that have one); bench.py
+        # turns it off on the steps whose launches it brackets with HIP events (a duration measured while another
+        # stream's kernels share the CUs describes neither kernel).
         main = torch.cuda.current_stream(dev)
         side = None
         up = None   # d_wps is d(loss)/d(density) already (fuse_weights_bwd above)
@@ -650,6 +658,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 with torch.cuda.stream(side):
                     _proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources,
                                        optimizer=proposal_optimizer)
+                if serialize_streams:
+                    main.wait_stream(side)
         d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
                                                       rctx.weights, d_rgb, d_sem)
         fld = model.field
@@ -671,6 +681,15 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 # fused scatter below may update in place — gather now
                 partial = K.hash_encode_input_grad(net.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
                 field_source = (fld.warp_struct(), fin["euclid"], S, partial)
+        # The ray gradients' sources are complete once the MLP backward is (its d_pos) and the proposal chain has run;
+        # their reduction and the camera optimiser's ~30 us of small launches do not need the scatter (~200 us) that
+        # follows: single process + second stream -> they go underneath it
+        tail_on_side = bool(overlap_proposal_backward and ray_grads is not None and exchange is None)
+        if tail_on_side:
+            mlp_done = model.__dict__.get("_mlp_done_event")
+            if mlp_done is None:
+                mlp_done = model.__dict__["_mlp_done_event"] = torch.cuda.Event()
+            mlp_done.record(main)
         if exchange is None and table_adam is not None:
             K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, table_adam)
         elif exchange is None:
@@ -683,6 +702,21 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, lb, cnt)
                 exchange.levels_done(lb, cnt)      # this slice of the gradient table is final: all-reduce it now
             exchange.field_done()
+        if tail_on_side:
+            if side is None:                       # a step without a proposal backward: the event is the whole fork
+                side = model.__dict__.get("_side_stream")
+                if side is None or side.device != dev:
+                    side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                if serialize_streams:
+                    side.wait_stream(main)         # behind the scatter instead of underneath it
+                else:
+                    side.wait_event(mlp_done)
+                K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
+                if after_ray_grads is not None:
+                    after_ray_grads()
+            main.wait_stream(side)                 # every local of this call outlives the second stream's launches
+            return loss_dict, metrics_dict
         if side is not None:
             main.wait_stream(side)                 # proposal gradients (and their ray-gradient sources) are final
             for src in ray_sources or ():
@@ -693,6 +727,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         if ray_grads is not None:
             # one launch: proposal levels first, the field last (the order the separate launches added them in)
             K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
+        if after_ray_grads is not None:
+            after_ray_grads()
     return loss_dict, metrics_dict
 
 
@@ -725,9 +761,16 @@ def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: 
     camera_adam.step(grad_scale=scale)
 
 
-# proposal-network backward on a second HIP stream (see fused_forward_backward); off by default: per-kernel timings stay
-# attributable to one stream
-OVERLAP_PROPOSAL_BACKWARD = os.environ.get("FNR_OVERLAP_PROPOSAL_BACKWARD") == "1"
+# proposal-network backward on a second HIP stream (see fused_forward_backward): same bits (tests/test_gpu_determinism.py,
+# test_proposal_backward_on_a_second_stream_changes_nothing), -3 % step time on the steps that train the proposal networks.
+# FNR_OVERLAP_PROPOSAL_BACKWARD=0 keeps every launch on one stream (per-kernel timings attributable to one kernel:
+# what the profiles under profiles/ and the profiled steps of bench.py use)
+OVERLAP_PROPOSAL_BACKWARD = os.environ.get("FNR_OVERLAP_PROPOSAL_BACKWARD", "1") != "0"
+# with the second stream: same launches on the same streams, but nothing concurrent (fused_forward_backward's
+# serialize_streams): a step like this gives per-kernel durations that describe one kernel, without switching allocator
+# pools between steps (one-stream and two-stream steps alternating made the caching allocator grow both pools: hipMalloc
+# calls inside bench.py's timed window)
+SERIALIZE_STREAMS = False
 # The proposal levels' backward chains next to each other (level 0 on the launch stream, level 1 on a side stream; they
 # share no buffers).  OFF: measured on MI355X (round 3, A/B on one box) the step gets 4 % SLOWER (0.908 -> 0.943 ms) — a
 # cross-stream fork + join costs ~12 us of GPU time per handshake on this stack and the two chains of latency-bound
@@ -741,8 +784,11 @@ FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAd
 
 def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, world_size: int = 1,
                           jitter: Optional[List[Tensor]] = None, want_metrics: bool = True, camera=None,
-                          fuse_table_optimizer: Optional[bool] = None):
+                          fuse_table_optimizer: Optional[bool] = None, ahead=None):
     """train_iteration() on fused_forward_backward(); returns the same (loss_dict, metrics_dict) tensors.
+
+    ahead: called with no arguments once the proposal networks' and the cameras' optimiser steps of this iteration are
+    enqueued — the point from which the next iteration's rays and proposal sampling can be enqueued (TrainingSteps).
 
     world_size > 1 (DDP semantics, fruit_pipeline.py:116-118): the field's gradient (67 MB of the 78 MB arena) is
     all-reduced in 16 MiB buckets on the communication stream, each bucket = the table rows of 4 levels, issued as
@@ -774,14 +820,21 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             and model.training and model.proposal_sampler.updated_now():
         prop_opt = optimizer
         done = done + (tuple(spans["proposal_networks"]),)
+    camera_step = None
+    if exchange is None and (camera is not None or ahead is not None):
+        def camera_step():   # the datamanager's backward + optimiser step, as soon as it can run; then the look-ahead
+            with torch.no_grad():
+                if camera is not None:
+                    camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
+                if ahead is not None:
+                    ahead()
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads, overlap_proposal_backward=OVERLAP_PROPOSAL_BACKWARD,
                                                      table_adam=table_adam, weight_adam=weight_adam,
-                                                     proposal_optimizer=prop_opt)
+                                                     proposal_optimizer=prop_opt, after_ray_grads=camera_step,
+                                                     serialize_streams=SERIALIZE_STREAMS)
     with torch.no_grad():
         if exchange is None:
-            if camera is not None:
-                camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
             optimizer.step(skip=skipped_groups(model, optimizer), done=done)
         else:
             pending = list(exchange.pending)
@@ -822,5 +875,69 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
                 if cam_work is not None:
                     cam_work.wait()
                 camera[1].step(grad_scale=cam_scale)
+            if ahead is not None:
+                ahead()
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
+
+
+# The next iteration's rays and proposal sampling, enqueued at the end of the current one (TrainingSteps): -6 % step time
+# with the second stream (they run underneath the main table's scatter), bit-identical training either way
+# (tests/test_gpu_determinism.py).  FNR_SAMPLE_AHEAD=0: every iteration samples at its own start.
+SAMPLE_AHEAD = os.environ.get("FNR_SAMPLE_AHEAD", "1") != "0"
+
+
+class TrainingSteps:
+    """The training loop's body for one model: batcher.sample -> fused_train_iteration, with the start of iteration
+    i + 1 — fnr_train_prologue (pixels, corrected cameras, rays, level-0 bins, jitters) and the proposal sampler's levels
+    (FruitModel.sample_ahead) — enqueued at the END of iteration i, as soon as the proposal networks' and the cameras'
+    optimiser steps are: with training.OVERLAP_PROPOSAL_BACKWARD on the second HIP stream, underneath the main table's
+    scatter + optimiser step, which they do not depend on.  Same launches on the same values as sampling at the start
+    of iteration i + 1 (counter-based random numbers, schedule flags checked by the model), so the parameters after any
+    number of steps are bit-identical with SAMPLE_AHEAD off.
+
+    camera: (CameraOptimizer, CameraAdam) or None; the batcher is the third member fused_train_iteration wants."""
+
+    def __init__(self, model, optimizer: FusedAdam, batcher, n_rays: int, camera=None, world_size: int = 1):
+        self.model, self.optimizer, self.batcher, self.n_rays = model, optimizer, batcher, int(n_rays)
+        self.camera = (camera[0], camera[1], batcher) if camera is not None else None
+        self.world_size = world_size
+        self.step_idx = 0
+        self._next = None
+
+    def _draw(self, finishing_step: Optional[int]):
+        from .rays import RayBundle
+        o, d, cam, batch = self.batcher.sample(self.n_rays, self.camera[0] if self.camera else None,
+                                               level0=self.model.level0_spec())
+        rb = RayBundle(o, d, None, cam, presampled=self.batcher.last_presample)
+        if finishing_step is not None:
+            self.model.sample_ahead(rb, finishing_step)
+        return rb, batch
+
+    def drop_lookahead(self) -> None:
+        """Forget what was sampled ahead (the proposal networks or the cameras were changed from outside, or the
+        batcher was used in between): the next step() samples at its start.  The draw itself is consumed."""
+        self._next = None
+
+    def step(self, want_metrics: bool = True):
+        if self._next is not None and self._next[0] == self.step_idx:
+            _, rb, batch = self._next
+        else:
+            rb, batch = self._draw(None)
+        self._next = None
+        step = self.step_idx
+
+        def ahead():
+            # On the second stream these tensors come from ITS allocator pool and are consumed on the launch stream by
+            # the next iteration.  No Tensor.record_stream (one event per tensor and free: ~40 barrier packets a step,
+            # measured +6 % step time): a block of either pool is only ever reused by work that its stream enqueues
+            # after waiting for the other one — the second stream starts each iteration's work with a wait on the launch
+            # stream (fork of the proposal backward / the MLP-backward event), the launch stream ends each iteration
+            # with a wait on the second — i.e. after every consumer of the block's previous contents.
+            self._next = (step + 1,) + self._draw(step)
+
+        out = fused_train_iteration(self.model, self.optimizer, rb, batch, step, world_size=self.world_size,
+                                    want_metrics=want_metrics, camera=self.camera,
+                                    ahead=ahead if (SAMPLE_AHEAD and self.model.training) else None)
+        self.step_idx += 1
+        return out

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, steps, mlp_precision, overlap=False, prologue=True):
+def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None):   # None: the product defaults (on)
     import fruitnerf_amd.training as T
     from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
     from fruitnerf_amd.data import synthetic_apple as sa
@@ -26,20 +26,31 @@ def _run(dev, steps, mlp_precision, overlap=False, prologue=True):
     opt = T.FusedAdam(hm)
     cam_opt = CameraOptimizerConfig(mode="SO3xR3").setup(n_train, dev)
     camera = (cam_opt, CameraAdam(cam_opt), batcher)
-    saved, T.OVERLAP_PROPOSAL_BACKWARD = T.OVERLAP_PROPOSAL_BACKWARD, overlap
+    saved = T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD
+    if overlap is not None:
+        T.OVERLAP_PROPOSAL_BACKWARD = overlap
+    if ahead is not None:
+        T.SAMPLE_AHEAD = ahead
     losses = []
     try:
+        if prologue:
+            # what bench.py runs: fnr_train_prologue (the step's random numbers, corrected cameras, rays and level-0 bins
+            # in one launch) and the next step's sampling enqueued at the end of the current one (training.TrainingSteps)
+            loop = T.TrainingSteps(hm, opt, batcher, 4096, camera=(cam_opt, camera[1]))
         for step in range(steps):
-            # prologue: the step's random numbers, corrected cameras, rays and level-0 bins in one launch
-            # (fnr_train_prologue, what bench.py runs); otherwise torch.rand + the separate entry points
-            o, d, cam, batch = batcher.sample(4096, cam_opt, level0=hm.level0_spec() if prologue else None)
-            rb = RayBundle(o, d, None, cam, presampled=batcher.last_presample)
-            ld, md = T.fused_train_iteration(hm, opt, rb, batch, step, camera=camera)
+            if prologue:
+                ld, md = loop.step()
+            else:   # torch.rand + the separate entry points
+                o, d, cam, batch = batcher.sample(4096, cam_opt, level0=None)
+                rb = RayBundle(o, d, None, cam, presampled=batcher.last_presample)
+                ld, md = T.fused_train_iteration(hm, opt, rb, batch, step, camera=camera)
             if step % 20 == 19 or step == steps - 1:
                 losses.append(torch.stack([ld["rgb_loss"], ld["semantics_loss"], ld["interlevel_loss"], md["psnr"],
                                            md["distortion"]]).clone())
+        if prologue and T.SAMPLE_AHEAD:   # every step but the first ran on what the previous one sampled ahead
+            assert hm.__dict__.get("_ahead_used", 0) == steps - 1
     finally:
-        T.OVERLAP_PROPOSAL_BACKWARD = saved
+        T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD = saved
     torch.cuda.synchronize()
     return (hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), cam_opt.pose_adjustment.data.clone(),
             torch.stack(losses))
@@ -83,10 +94,21 @@ def test_paired_proposal_levels_are_the_separate_calls(dev):
         assert torch.equal(x, y)
 
 
+def test_sampling_ahead_is_sampling_at_the_start_of_the_step(dev):
+    """training.SAMPLE_AHEAD: the next iteration's prologue + proposal sampling enqueued at the end of the current one
+    (on the second stream, underneath the table scatter) against every iteration sampling at its own start; with and
+    without the second stream.  120 steps cover the every-step (< 10) and every-other-step proposal update schedule."""
+    ref = _run(dev, 120, "bf16x3", overlap=False, ahead=False)
+    for overlap in (False, True):
+        got = _run(dev, 120, "bf16x3", overlap=overlap, ahead=True)
+        for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), ref, got):
+            assert torch.equal(x, y), f"{name} differ (second stream {overlap})"
+
+
 def test_second_stream_run_is_bit_identical_too(dev):
     """The proposal-network backward on a second HIP stream (FNR_OVERLAP_PROPOSAL_BACKWARD) changes the interleaving of
     kernels, not the arithmetic."""
-    a = _run(dev, 60, "bf16x3", overlap=False)
-    b = _run(dev, 60, "bf16x3", overlap=True)
-    for x, y in zip(a[:4], b[:4]):
+    a = _run(dev, 100, "bf16x3", overlap=False)
+    b = _run(dev, 100, "bf16x3", overlap=True)
+    for x, y in zip(a, b):
         assert torch.equal(x, y)

@@ -381,3 +381,33 @@ def test_bench_roofline_bookkeeping():
     assert e["traffic"] == 8.0e8 and abs(e["traffic_over_algorithmic"] - 8.0e8 / (want * 0.2e-3 * 1e9)) < 1e-3
     l2 = bench.roofline_entry("prop_density_fwd", 1048576, 0.0343, 1, alg)
     assert l2["bound"] == "l2" and l2["peak"] == bench.L2_PEAK_GBS and l2["frac"] < 1.0
+
+
+def test_sampler_look_ahead_is_the_schedule():
+    """ProposalNetworkSampler.updated_after(step) / FruitModel.anneal_at(step + 1) — what FruitModel.sample_ahead assumes
+    about the NEXT iteration while the current one is finishing — against what that iteration then sees
+    (updated_now() after step_cb(step), set_anneal(step + 1)), over the warm-up of the update schedule."""
+    import numpy as np
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig, ProposalNetworkSampler
+    cfg = FruitNerfModelConfig()
+
+    def sched(step):   # fruit_nerf.py:131-136
+        return np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1, cfg.proposal_update_every)
+    s = ProposalNetworkSampler(num_nerf_samples_per_ray=48, num_proposal_samples_per_ray=(256, 96), single_jitter=True,
+                               update_sched=sched)
+    n_updates = 0
+    for step in range(7000):
+        updated = s.updated_now()
+        if updated:
+            s._steps_since_update = 0     # what the forward pass does
+            n_updates += 1
+        predicted = s.updated_after(step)
+        s.step_cb(step)
+        assert predicted == s.updated_now(), step
+    assert 1000 < n_updates < 7000
+
+    class M:   # anneal_at only reads the config
+        config = cfg
+    for step in (0, 1, 10, 500, 999, 1000, 5000):
+        a = FruitModel.anneal_at(M, step)
+        assert 0.0 <= a <= 1.0 and (step < cfg.proposal_weights_anneal_max_num_iters or a == 1.0)

@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').getcwd())   # run from the root of the build under test
 from fruitnerf_amd import _kernels as K   # noqa: E402
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig   # noqa: E402
 from fruitnerf_amd.data.semantics import apple_metadata   # noqa: E402
