@@ -11,12 +11,16 @@ two proposal nets, main field), get_metrics_dict (PSNR + distortion), get_loss_d
 backward, gradient all-reduce over RCCL (N > 1), fused Adam over all 19.4 M parameters, step_cb.
 Every rank draws its own 4096 rays (reference DDP semantics, fruit_pipeline.py:116-118) => weak scaling;
 `value` = N * K * 4096 / max-over-ranks wall time, inputs resident in HBM.
+The loop body is training.TrainingSteps: the pixel sampling + ray generation + proposal sampling of step i + 1 are
+enqueued at the end of step i (second HIP stream, underneath step i's table scatter) — every step still launches each of
+its kernels exactly once, the timed K steps contain K of everything (the first one's sampling was enqueued by the last
+warm-up step, the last one enqueues the sampling of step K + 1).
 
 `python bench.py --gpus N` without a launcher starts the N ranks itself (re-executes under torch.distributed.run,
 the reference's counterpart is nerfstudio's mp.spawn around fruit_pipeline.py:116-118) and fails unless N ranks run.
 
 Extra objects in the JSON line:  roofline (dominant entry point among the HBM- / MFMA-bound ones, chosen by its time
-over the timed window itself, HIP events on the launch stream), cpu_baseline (the oracle's train step on the host cores, rank 0, bounded sample),
+over the timed window itself, HIP events on the stream of the launch, every 5th step, streams serialised on those steps), cpu_baseline (the oracle's train step on the host cores, rank 0, bounded sample),
 breakdown_ms (per entry point, from a short instrumented pass after the timed region), quality (PSNR / IoU on
 held-out views after --quality-steps more steps).
 """
@@ -302,7 +306,7 @@ class MethodRun:
         return self.steps.step(want_metrics)
 
 
-PROFILE_EVERY = 4   # HIP events on the roofline candidates' launches of every 4th step of the timed window
+PROFILE_EVERY = int(os.environ.get("FNR_BENCH_PROFILE_EVERY", "5"))   # HIP events on the roofline candidates' launches of every 5th step of the timed window
 
 
 def timed_window(run, steps, barrier, dist_on, dev):
@@ -313,6 +317,7 @@ def timed_window(run, steps, barrier, dist_on, dev):
     steps, last (loss_dict, metrics))."""
     from fruitnerf_amd import _lib as L
     import fruitnerf_amd.training as T
+    serialize = T.SERIALIZE_STREAMS
     L.profile_enable(True, ops=list(ROOFLINE_OPS))
     barrier()
     torch.cuda.synchronize()
@@ -326,11 +331,11 @@ def timed_window(run, steps, barrier, dist_on, dev):
             # a bracketed launch must have the GPU to itself: on the profiled steps the second stream's launches (proposal
             # backward, ray-gradient reduction, camera step, next step's sampling) run before / after the launch stream's,
             # not next to them (training.SERIALIZE_STREAMS; same results either way)
-            T.SERIALIZE_STREAMS = bool(on)
+            T.SERIALIZE_STREAMS = bool(on) or serialize
             n_prof += on
             last = run.one_step()
     finally:
-        T.SERIALIZE_STREAMS = False
+        T.SERIALIZE_STREAMS = serialize
     run.model.field.flush_deferred_update()   # N > 1: the last step's field collective + optimiser step (training.DEFER_FIELD_UPDATE)
     t_enqueued = time.perf_counter() - t0     # host side done (launches queued); the GPU is still working
     torch.cuda.synchronize()
@@ -526,11 +531,11 @@ def main() -> None:
     # other ranks have left, so no collective may run here) ------------------------------------------------
     nb = 12 if world == 1 else 0
     L.profile_enable(True)
-    _training.SERIALIZE_STREAMS = True      # nothing next to a bracketed launch
+    saved_serialize, _training.SERIALIZE_STREAMS = _training.SERIALIZE_STREAMS, True   # nothing next to a bracketed launch
     for _ in range(nb):
         one_step()
     torch.cuda.synchronize()
-    _training.SERIALIZE_STREAMS = False
+    _training.SERIALIZE_STREAMS = saved_serialize
     recs = L.profile_collect() if nb else []
     L.profile_enable(False)
     breakdown = {}

@@ -582,6 +582,13 @@ class _FieldGradientExchange:
                 self.pending += start_gradient_sync(self.arena, span, self.world)
 
 
+def _second_stream(model, dev):
+    side = model.__dict__.get("_side_stream")
+    if side is None or side.device != dev:
+        side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)   # (a high-priority stream changes nothing: measured)
+    return side
+
+
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
                            ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False,
@@ -651,9 +658,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         up = None   # d_wps is d(loss)/d(density) already (fuse_weights_bwd above)
         if prop_bwd:
             if overlap_proposal_backward:
-                side = model.__dict__.get("_side_stream")
-                if side is None or side.device != dev:
-                    side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+                side = _second_stream(model, dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     _proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources,
@@ -704,9 +709,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             exchange.field_done()
         if tail_on_side:
             if side is None:                       # a step without a proposal backward: the event is the whole fork
-                side = model.__dict__.get("_side_stream")
-                if side is None or side.device != dev:
-                    side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+                side = _second_stream(model, dev)
             with torch.cuda.stream(side):
                 if serialize_streams:
                     side.wait_stream(main)         # behind the scatter instead of underneath it
@@ -770,7 +773,7 @@ OVERLAP_PROPOSAL_BACKWARD = os.environ.get("FNR_OVERLAP_PROPOSAL_BACKWARD", "1")
 # serialize_streams): a step like this gives per-kernel durations that describe one kernel, without switching allocator
 # pools between steps (one-stream and two-stream steps alternating made the caching allocator grow both pools: hipMalloc
 # calls inside bench.py's timed window)
-SERIALIZE_STREAMS = False
+SERIALIZE_STREAMS = os.environ.get("FNR_SERIALIZE_STREAMS") == "1"   # (profiling runs: tools/prof_round.sh)
 # The proposal levels' backward chains next to each other (level 0 on the launch stream, level 1 on a side stream; they
 # share no buffers).  OFF: measured on MI355X (round 3, A/B on one box) the step gets 4 % SLOWER (0.908 -> 0.943 ms) — a
 # cross-stream fork + join costs ~12 us of GPU time per handshake on this stack and the two chains of latency-bound
@@ -820,14 +823,20 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             and model.training and model.proposal_sampler.updated_now():
         prop_opt = optimizer
         done = done + (tuple(spans["proposal_networks"]),)
+    # The look-ahead reads the proposal networks: it may only be enqueued from inside the backward when their step of THIS
+    # iteration is (fused into their backward) or does not happen at all (no gradient -> the optimiser skips the group);
+    # otherwise (unfused configurations, torch-1.13 stepping) it follows optimizer.step() below
+    prop_step_pending = prop_opt is None and (bool(model.training and model.proposal_sampler.updated_now())
+                                              or not optimizer.skip_groups_without_grad)
+    ahead_early = ahead if (ahead is not None and not prop_step_pending) else None
     camera_step = None
-    if exchange is None and (camera is not None or ahead is not None):
+    if exchange is None and (camera is not None or ahead_early is not None):
         def camera_step():   # the datamanager's backward + optimiser step, as soon as it can run; then the look-ahead
             with torch.no_grad():
                 if camera is not None:
                     camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
-                if ahead is not None:
-                    ahead()
+                if ahead_early is not None:
+                    ahead_early()
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads, overlap_proposal_backward=OVERLAP_PROPOSAL_BACKWARD,
                                                      table_adam=table_adam, weight_adam=weight_adam,
@@ -836,6 +845,8 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
     with torch.no_grad():
         if exchange is None:
             optimizer.step(skip=skipped_groups(model, optimizer), done=done)
+            if ahead is not None and ahead_early is None:
+                ahead()
         else:
             pending = list(exchange.pending)
             # the update schedule is a function of the step, identical on every rank: on steps that did not train the

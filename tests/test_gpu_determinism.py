@@ -8,7 +8,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None):   # None: the product defaults (on)
+def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None, torch113=False, fuse_weights=True):
+    # overlap / ahead None: the product defaults (on)
     import fruitnerf_amd.training as T
     from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
     from fruitnerf_amd.data import synthetic_apple as sa
@@ -23,10 +24,11 @@ def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None):   
     torch.manual_seed(0)
     hm = FruitModel(FruitNerfModelConfig(mlp_precision=mlp_precision), apple_metadata(), num_train_data=n_train, device=dev)
     hm.train()
-    opt = T.FusedAdam(hm)
+    opt = T.FusedAdam(hm, skip_groups_without_grad=not torch113)
     cam_opt = CameraOptimizerConfig(mode="SO3xR3").setup(n_train, dev)
     camera = (cam_opt, CameraAdam(cam_opt), batcher)
-    saved = T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD
+    saved = T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD, T.FUSE_WEIGHT_OPTIMIZER
+    T.FUSE_WEIGHT_OPTIMIZER = fuse_weights
     if overlap is not None:
         T.OVERLAP_PROPOSAL_BACKWARD = overlap
     if ahead is not None:
@@ -50,7 +52,7 @@ def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None):   
         if prologue and T.SAMPLE_AHEAD:   # every step but the first ran on what the previous one sampled ahead
             assert hm.__dict__.get("_ahead_used", 0) == steps - 1
     finally:
-        T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD = saved
+        T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD, T.FUSE_WEIGHT_OPTIMIZER = saved
     torch.cuda.synchronize()
     return (hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), cam_opt.pose_adjustment.data.clone(),
             torch.stack(losses))
@@ -103,6 +105,18 @@ def test_sampling_ahead_is_sampling_at_the_start_of_the_step(dev):
         got = _run(dev, 120, "bf16x3", overlap=overlap, ahead=True)
         for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), ref, got):
             assert torch.equal(x, y), f"{name} differ (second stream {overlap})"
+
+
+@pytest.mark.parametrize("config", ["torch113", "unfused"])
+def test_sampling_ahead_waits_for_an_unfused_proposal_step(dev, config):
+    """When the proposal networks' optimiser step is NOT part of their backward (FUSE_WEIGHT_OPTIMIZER off), or happens on
+    every iteration (torch 1.13 semantics: zero gradients still move the parameters through the moments), the look-ahead
+    must follow optimizer.step(): same states as sampling at the start of the next iteration."""
+    kw = dict(torch113=True) if config == "torch113" else dict(fuse_weights=False)
+    ref = _run(dev, 40, "bf16x3", overlap=False, ahead=False, **kw)
+    got = _run(dev, 40, "bf16x3", overlap=True, ahead=True, **kw)
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y)
 
 
 def test_second_stream_run_is_bit_identical_too(dev):

@@ -68,11 +68,15 @@ def find(d, name_part, also=None):
 
 rows = kt(base + 'prof_kernel_trace.txt')
 f, w, sq = pmc(base + 'prof_fetch.txt'), pmc(base + 'prof_write.txt'), pmc(base + 'prof_sq.txt')
-steps = max(n for name, g, n, *_ in rows if 'k_train_prologue' in name or 'k_sample_pixels' in name)
-out = [f'# Round 3 - rocprofv3 of `python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality` (default arithmetic: bf16x3), build {rev}\n',
+steps = max(n for name, g, n, *_ in rows if 'k_train_losses' in name)   # one per training step
+out = [f'# Round 3 - rocprofv3 of `FNR_SERIALIZE_STREAMS=1 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality` (default arithmetic: bf16x3), build {rev}\n',
        f'Collected by `tools/prof_round.sh` on 1xMI355X (gfx950, ROCm 7.2): one `--kernel-trace --stats` pass and three separate '
        f'`--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ counters, each with `--kernel-trace` only), {steps} training steps each (10 '
-       'warm-up + 60 timed + 12 of the per-entry-point breakdown).  Raw aggregates: `profiles/' + tag + '_raw/`; this table: '
+       'warm-up + 60 timed + 12 of the per-entry-point breakdown).  FNR_SERIALIZE_STREAMS=1: the second HIP stream\'s launches '
+       '(proposal-network backward, ray-gradient reduction, camera step, the next step\'s sampling) run before / after the launch '
+       'stream\'s instead of next to them on EVERY step, as bench.py does on the steps it brackets with events — a duration below '
+       'is one kernel with the GPU to itself; `prof_kernel_trace_two_streams.txt` under the raw aggregates is the default run.  '
+       'Raw aggregates: `profiles/' + tag + '_raw/`; this table: '
        '`tools/make_profile_summary.py`.  Times are per STEP (kernel total / steps; the proposal-network backward runs on about '
        'half of the steps of this window).  FETCH_SIZE is doubled per MI355X_MICROARCH.md "HBM" (gfx950 reports half of a wide '
        'streaming read) and, like WRITE_SIZE, given in MB per dispatch (rocprofv3 reports KB).  SQ columns are ratios of '
@@ -154,7 +158,7 @@ for ep, parts in ENTRY.items():
     out.append('| `%s` | %s | %.1f | %s | %s |' % (ep, ', '.join(names), total_b / 1e6, '%.1f' % (alg / 1e6) if alg else '(MFMA-bound: FLOP)',
                                                    '%.2f' % (total_b / alg) if alg else ''))
 json.dump({'source': f'profiles/{tag}_kernel_trace_pmc.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only) of '
-                     '`python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality`, FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM" '
+                     '`FNR_SERIALIZE_STREAMS=1 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality`, FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM" '
                      '(tools/prof_round.sh, tools/make_profile_summary.py)',
            'build': rev, 'entry_points': {'fruit_nerf': traffic}}, open('/root/repo/profiles/pmc_traffic.json', 'w'), indent=1)
 
@@ -175,7 +179,7 @@ out.append('\nDefault line, other fields: cpu_baseline ' + json.dumps(d['cpu_bas
 dbig = line('bench_fruit_nerf_big.log')
 out.append('`fruit_nerf_big` line: quality ' + json.dumps(dbig['quality']) + '.\n')
 big = kt(base + 'prof_kernel_trace_big.txt')
-sb = max(n for name, g, n, *_ in big if 'k_train_prologue' in name or 'k_sample_pixels' in name)
+sb = max(n for name, g, n, *_ in big if 'k_train_losses' in name)
 out.append(f'## `fruit_nerf_big` (8192 rays, samples 512/256/128, T = 2^21): kernel trace of `bench.py --method fruit_nerf_big --steps 40 --warmup 10`, {sb} steps\n')
 out.append('| kernel | grid x | launches/step | us/step | median us |')
 out.append('|---|---|---|---|---|')
