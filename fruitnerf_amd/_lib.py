@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FNR_LIB_PATH") or os.path.join(_HERE, "lib", "libfrui
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 7      # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 8      # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -94,6 +94,7 @@ SIGNATURES = {
     "fnr_profile_enable": (_i, [_i, C.c_uint64]),
     "fnr_profile_pause": (_i, [_i]),
     "fnr_profile_collect": (_i64, [P(C.c_int32), P(C.c_int64), P(C.c_float), _i64]),
+    "fnr_debug_scatter_overflows": (_i, [P(C.c_uint64), _i]),
     "fnr_sample_pixels": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_train_prologue": (_i, [P(fnr_image_set), _vp, _i, _i64, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, _i, _vp, _vp,
                                 _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
@@ -238,6 +239,13 @@ def profile_enable(on: bool, ops=None) -> None:
 
 def profile_pause(paused: bool) -> None:
     check(load().fnr_profile_pause(1 if paused else 0), "profile_pause")
+
+
+def scatter_overflows(reset: bool = False) -> int:
+    """Records of the binned scatter that overflowed their bin's queue since the last reset (fnr_debug_scatter_overflows)."""
+    n = C.c_uint64(0)
+    check(load().fnr_debug_scatter_overflows(C.byref(n), 1 if reset else 0), "debug_scatter_overflows")
+    return int(n.value)
 
 
 def profile_collect(capacity: int = 1 << 20):

@@ -36,6 +36,8 @@ static_assert(SC_MAX_BINS <= SC_EMIT_THREADS, "one bin per thread");
 // two lines and the reservation step alone cost ~150 us per call.
 constexpr int SC_CNT_STRIDE = 32;       // uint32 words between two bins' counters
 
+__device__ unsigned long long g_scatter_overflow_records;   // records that went to the table through global atomics
+
 struct ScatterPlan {
   int log2_rows;         // log2(E)
   int bins_per_level;    // T / E
@@ -364,6 +366,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       queue_r[q] = (unsigned short)row_in_bin;
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
       qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;  // tells the accumulate kernel that the table holds part of the sum
+      atomicAdd(&g_scatter_overflow_records, 1ull);   // fnr_debug_scatter_overflows
       const size_t row = ((size_t)bin << log2_rows) + row_in_bin;
       atomicAdd(table + 2 * row, v.x);
       atomicAdd(table + 2 * row + 1, v.y);
@@ -883,6 +886,18 @@ extern "C" int fnr_debug_emit_phases(unsigned long long* out_host, int reset) {
   return FNR_OK;
 }
 #endif
+
+extern "C" int fnr_debug_scatter_overflows(uint64_t* count_host, int reset) {
+  FNR_CHECK_ARG(count_host, "debug_scatter_overflows: null argument");
+  unsigned long long n = 0;
+  FNR_HIP(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_scatter_overflow_records), sizeof(n)));
+  *count_host = n;
+  if (reset) {
+    n = 0;
+    FNR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_scatter_overflow_records), &n, sizeof(n)));
+  }
+  return FNR_OK;
+}
 
 extern "C" size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
   const ScatterPlan p = scatter_plan(n_samples, n_levels, log2_hashmap_size);

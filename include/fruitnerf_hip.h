@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 7
+#define FNR_ABI_VERSION 8
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -137,9 +137,15 @@ int fnr_device_check(int* cu_count_out, char* name_out, int name_len);
  * 11 weights_bwd, 12 field_mlp_bwd, 13 hash_encode_bwd, 14 prop_density_bwd, 15 adam_step, 16 export_compact. */
 int fnr_profile_enable(int on, uint64_t op_mask);
 /* paused != 0: entry points stop recording events but the records collected so far are kept (bench.py times every
- * fourth step of its timed window: each event pair costs the GPU a ~3 us bubble). */
+ * fifth step of its timed window: each event pair costs the GPU a ~3 us bubble). */
 int fnr_profile_pause(int paused);
 int64_t fnr_profile_collect(int32_t* ops_host, int64_t* units_host, float* ms_host, int64_t capacity);
+/* Diagnostics of the binned scatter (fnr_hash_encode_bwd*, fnr_prop_density_bwd*): records that did not fit their bin's
+ * queue (capacity = 3 x the level's mean) and went to the gradient table through global atomics instead, summed over all
+ * calls since the last reset (synchronises the device).  0 in a healthy configuration; such records make the
+ * gradient's summation order, hence its last bits, depend on timing.  No counterpart in the reference (torch autograd
+ * scatters with atomics throughout). */
+int fnr_debug_scatter_overflows(uint64_t* count_host, int reset);
 
 /* ---- caller side: pixel sampling + ray generation --------------------------------------------- */
 /* The on-device image batch of a datamanager: uint8 images [M,H,W,3], uint8 fruit masks [M,H,W] (1 = fruit),
