@@ -592,7 +592,10 @@ def main() -> None:
                    "trajectory": trajectory,
                    "train_rays_per_s_over_these_steps": round((run.step_idx - s_q) * RAYS_PER_BATCH / max(t_q, 1e-9), 1),
                    "heldout": "5 held-out views x 65 536 random pixels, eval mode; IoU of sigmoid(semantics) > 0.5 vs mask",
-                   "final_train_losses": {k: round(float(v), 6) for k, v in ld.items()}}
+                   "final_train_losses": {k: round(float(v), 6) for k, v in ld.items()},
+                   # records of the binned scatter that overflowed a queue and went through float atomics (their order,
+                   # hence the last bits, would depend on timing) over everything this process has run so far
+                   "scatter_queue_overflows": L.scatter_overflows()}
 
     # ---- secondary metrics: full-image eval rays/s and volume-export samples/s, trained weights ----
     secondary = None

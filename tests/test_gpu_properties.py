@@ -119,6 +119,50 @@ def test_scatter_conserves_the_feature_gradient_full_size(dev):
         assert int((table_grad != 0).any(dim=2).sum()) > 1_000_000
 
 
+def test_scatter_with_overflowing_queues_still_conserves_the_gradient(dev):
+    """One sample per ray, 196 608 rays alternating between two fixed ones: neighbouring samples never share a cell (no run
+    for the emit kernel to pre-sum: 4096 copies of one 48-sample ray leave 8 records per workgroup and level), yet every
+    record of a level lands in the same one or two bins — far beyond the queues' capacity (3 x the level's mean), so the
+    fallback (global atomics into the gradient table, merged by the accumulate kernel) carries most of the call.  The
+    column sums must still match, and fnr_debug_scatter_overflows must report the fallback; it reports none for random
+    rays (training never takes it: tests/diagnostics/scatter_overflows.py, bench.py's quality.scatter_queue_overflows)."""
+    from fruitnerf_amd import _kernels as K, _lib as L
+    m = _full_model(dev)
+    m.train()
+    arena = m.arena()
+    fld = m.field
+    N = 4096 * 48
+    two = _rays(2, dev, seed=5)
+    alt = torch.arange(N, device=dev) % 2
+    rays = K.RaysArg(two.origins[alt].contiguous(), two.directions[alt].contiguous(), torch.full((N, 1), 0.4, device=dev),
+                     torch.full((N, 1), 0.4, device=dev), torch.zeros(N, 1, dtype=torch.long, device=dev))
+    _, eu = K.sample_spaced(rays, 1, 1, None)
+    g = torch.Generator(device=dev).manual_seed(1)
+    d_feats = torch.randn(16, N, 2, device=dev, generator=g) * 1e-3
+    gnet = fld.net_struct(grads=True)
+    want = d_feats.double().sum(dim=1)
+    scale = d_feats.abs().double().sum(dim=1)
+    arena.grads.zero_()
+    L.scatter_overflows(reset=True)
+    K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, eu, 1, d_feats)
+    n_over = L.scatter_overflows(reset=True)
+    table_grad = fld.mlp_base_grid.hash_table.grad.view(16, 1 << 19, 2)
+    got = table_grad.double().sum(dim=1)
+    print(f"[scatter overflow] {n_over} of {16 * N * 8} contributions went through the atomic fallback")
+    assert n_over > 1_000_000
+    assert int((table_grad != 0).any(dim=2).sum()) <= 16 * 16          # two points x 8 corners per level
+    assert float(((got - want).abs() / scale).max()) <= 1e-6
+    # random rays: the same entry point never overflows
+    R, S = 4096, 48
+    rb = _rays(R, dev, seed=9)
+    rays2 = K.RaysArg(rb.origins, rb.directions, torch.full((R, 1), 0.05, device=dev),
+                      torch.full((R, 1), 1000.0, device=dev), rb.camera_indices)
+    _, eu2 = K.sample_spaced(rays2, 1, S, None)
+    arena.grads.zero_()
+    K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays2, eu2, S, d_feats)
+    assert L.scatter_overflows(reset=True) == 0
+
+
 def test_adam_leaves_untouched_parameters_alone_and_is_idempotent_on_zero_grad(dev):
     """Zero gradients with zero moments leave parameters bit-identical (19.4 M-element arena), and a second step
     with zero gradients only decays the moments."""
