@@ -484,9 +484,11 @@ def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_war
 
 
 def prop_density_bwd_pair(nets, grads, warps, rays: RaysArg, euclids, S, feats, d_density, want_position_grad: bool = False,
-                          adam=None):
+                          adam=None, position_ready=None):
     """fnr_prop_density_bwd_pair: both proposal levels of a step (lists of two), their accumulate launches as one.
-    adam = ([table fnr_table_adam x 2], weight fnr_table_adam, gradient arena) or None.  -> [d_position | None] x 2."""
+    adam = ([table fnr_table_adam x 2], weight fnr_table_adam, gradient arena) or None.  -> [d_position | None] x 2.
+    position_ready (torch.cuda.Event): fnr_prop_density_bwd_pair_split — both MLP backwards first, the event recorded on
+    the current stream once the d_position tensors are final, then the scatter."""
     lib = L.load()
     dev = rays.device
     ws, nbytes, clean, d_pos = [], [], [], []
@@ -502,11 +504,17 @@ def prop_density_bwd_pair(nets, grads, warps, rays: RaysArg, euclids, S, feats, 
         t_list, w_adam_s, grad_arena = adam
         t_adams = (PT * 2)(*[C.pointer(t) for t in t_list])
         w_adam = C.byref(w_adam_s)
-    L.check(lib.fnr_prop_density_bwd_pair((PN * 2)(*[C.pointer(n) for n in nets]), (PN * 2)(*[C.pointer(g) for g in grads]),
-                                          (PW * 2)(*[C.pointer(w) for w in warps]), rays.ref, vp(euclids),
-                                          (C.c_int * 2)(*[int(x) for x in S]), vp(feats), vp(d_density), vp(d_pos), t_adams,
-                                          w_adam, L.ptr(grad_arena), vp(ws), (C.c_size_t * 2)(*nbytes),
-                                          (C.c_int * 2)(*clean), L.stream_ptr(dev)), "prop_density_bwd_pair")
+    args = ((PN * 2)(*[C.pointer(n) for n in nets]), (PN * 2)(*[C.pointer(g) for g in grads]),
+            (PW * 2)(*[C.pointer(w) for w in warps]), rays.ref, vp(euclids), (C.c_int * 2)(*[int(x) for x in S]), vp(feats),
+            vp(d_density), vp(d_pos), t_adams, w_adam, L.ptr(grad_arena), vp(ws), (C.c_size_t * 2)(*nbytes),
+            (C.c_int * 2)(*clean), L.stream_ptr(dev))
+    if position_ready is not None:
+        if not position_ready.cuda_event:     # torch creates the HIP event lazily: on its first record
+            position_ready.record(torch.cuda.current_stream(dev))
+        L.check(lib.fnr_prop_density_bwd_pair_split(*args, C.c_void_p(position_ready.cuda_event)),
+                "prop_density_bwd_pair_split")
+    else:
+        L.check(lib.fnr_prop_density_bwd_pair(*args), "prop_density_bwd_pair")
     return d_pos
 
 

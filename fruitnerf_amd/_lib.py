@@ -134,6 +134,9 @@ SIGNATURES = {
     "fnr_prop_density_bwd_pair": (_i, [P(P(fnr_prop_net)), P(P(fnr_prop_net)), P(P(fnr_warp)), P(fnr_rays), P(C.c_void_p),
                                        P(C.c_int), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(P(fnr_table_adam)),
                                        P(fnr_table_adam), _vp, P(C.c_void_p), P(C.c_size_t), P(C.c_int), _vp]),
+    "fnr_prop_density_bwd_pair_split": (_i, [P(P(fnr_prop_net)), P(P(fnr_prop_net)), P(P(fnr_warp)), P(fnr_rays), P(C.c_void_p),
+                                             P(C.c_int), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p), P(P(fnr_table_adam)),
+                                             P(fnr_table_adam), _vp, P(C.c_void_p), P(C.c_size_t), P(C.c_int), _vp, _vp]),
     "fnr_hash_encode_input_grad": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, _vp]),
     "fnr_position_grad_reduce": (_i, [P(fnr_warp), P(fnr_rays), _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fnr_position_grad_reduce_multi": (_i, [_i, P(P(fnr_warp)), P(fnr_rays), P(C.c_void_p), P(C.c_int), P(C.c_int),

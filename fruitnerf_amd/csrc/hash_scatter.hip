@@ -946,7 +946,9 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
                                     const float* d_density, float* d_position, void* workspace,
                                     size_t workspace_bytes, int workspace_clean, void* stream,
                                     const fnr_table_adam* table_adam, const fnr_table_adam* weight_adam,
-                                    const float* grad_arena, AccArgs* defer_acc = nullptr) {
+                                    const float* grad_arena, AccArgs* defer_acc = nullptr, int phase = 0) {
+  // phase 0: the whole backward; 1: MLP backward + weight reduction only (d_feats stay in the workspace, d_position is
+  // complete); 2: the scatter of what phase 1 left (fnr_prop_density_bwd_pair_split)
   FNR_CHECK_ARG(net && grads && warp && rays && euclid_bins && feat_save && d_density && workspace && S > 0,
                 "prop_density_bwd: null argument");
   WeightAdam wa{};
@@ -980,6 +982,7 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
   float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + dfeat_bytes);
   const size_t partial_bytes = (size_t)max_blocks * PROP_PART * sizeof(float);
   FNR_PROF(OP_PROP_BWD, N);
+  if (phase != 2) {
   const GridDev pgrid = make_grid(&net->grid);
   float4* d_xw = reinterpret_cast<float4*>(d_position);
 #define FNR_PROPB_CASE(LL)                                                                                          \
@@ -1012,6 +1015,8 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
     hipLaunchKernelGGL(k_prop_reduce<false>, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), partials,
                        (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1, WeightAdam{});
   FNR_LAUNCH_CHECK();
+  }
+  if (phase == 1) return FNR_OK;
   AccArgs acc;
   const int rce = scatter_emit(&grads->grid, w, src, N, d_feats, 0, L,
                                reinterpret_cast<char*>(workspace) + dfeat_bytes + partial_bytes,
@@ -1069,6 +1074,44 @@ extern "C" int fnr_prop_density_bwd_pair(const fnr_prop_net* const* nets, const 
                                           adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
                                           adam ? grad_arena : nullptr, &acc[q]);
     if (rc) return rc;
+  }
+  const bool first_longer = (long long)S[0] >= (long long)S[1];
+  return scatter_accumulate2(first_longer ? acc[0] : acc[1], first_longer ? acc[1] : acc[0], adam, as_stream(stream));
+}
+
+// fnr_prop_density_bwd_pair with the launches in two groups: both levels' MLP backward + weight reduction first — after
+// them d_position[0..1] are final and `position_ready_event` (a hipEvent_t, optional) is recorded on `stream` — then both
+// levels' emit launches and the joint accumulate.  A caller with a second stream can finish the ray gradients and take
+// the camera optimiser's step next to the ~210 us of scatter that follow.  Same launches, same results.
+extern "C" int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, const fnr_prop_net* const* grads,
+                                               const fnr_warp* const* warps, const fnr_rays* rays,
+                                               const float* const* euclid_bins, const int* S, const float* const* feat_save,
+                                               const float* const* d_density, float* const* d_position,
+                                               const fnr_table_adam* const* table_adam, const fnr_table_adam* weight_adam,
+                                               const float* grad_arena, void* const* workspace, const size_t* workspace_bytes,
+                                               const int* workspace_clean, void* stream, void* position_ready_event) {
+  FNR_CHECK_ARG(nets && grads && warps && rays && euclid_bins && S && feat_save && d_density && d_position && workspace &&
+                    workspace_bytes && workspace_clean,
+                "prop_density_bwd_pair_split: null argument");
+  FNR_CHECK_ARG(nets[0] != nets[1] && grads[0] != grads[1] && workspace[0] != workspace[1],
+                "prop_density_bwd_pair_split: the two levels must have their own network, gradients and workspace");
+  const bool adam = table_adam && table_adam[0] && table_adam[1];
+  FNR_CHECK_ARG(adam || !(table_adam && (table_adam[0] || table_adam[1])), "prop_density_bwd_pair_split: one table_adam missing");
+  if (rays->n_rays == 0) {
+    if (position_ready_event) FNR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(position_ready_event), as_stream(stream)));
+    return FNR_OK;
+  }
+  AccArgs acc[2];
+  for (int phase = 1; phase <= 2; ++phase) {
+    for (int q = 0; q < 2; ++q) {
+      const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
+                                            d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
+                                            adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
+                                            adam ? grad_arena : nullptr, &acc[q], phase);
+      if (rc) return rc;
+    }
+    if (phase == 1 && position_ready_event)
+      FNR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(position_ready_event), as_stream(stream)));
   }
   const bool first_longer = (long long)S[0] >= (long long)S[1];
   return scatter_accumulate2(first_longer ? acc[0] : acc[1], first_longer ? acc[1] : acc[0], adam, as_stream(stream));

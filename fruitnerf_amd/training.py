@@ -186,8 +186,11 @@ class _InterlevelFn(torch.autograd.Function):
 
 def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins: Optional[Tensor],
                        d_directions: Optional[Tensor], level_streams: bool = False,
-                       collect: Optional[list] = None, optimizer: Optional["FusedAdam"] = None) -> None:
+                       collect: Optional[list] = None, optimizer: Optional["FusedAdam"] = None,
+                       position_ready=None) -> bool:
     """Backward of the interlevel loss into the proposal networks (and, when asked, into the rays).
+    position_ready (torch.cuda.Event, with collect): recorded as soon as the collected d_position tensors are final,
+    ahead of the levels' scatter (fnr_prop_density_bwd_pair_split) -> True when it was (the paired path), else False.
     upstream None: d_wps already holds d(loss)/d(density) per level (train_losses(fuse_weights_bwd=True)).
     level_streams: the levels' chains (MLP backward -> weight reduce -> scatter emit -> accumulate; they share nothing when
     every level has its own network) run side by side, level 0 on the current stream and the others on side streams;
@@ -218,7 +221,8 @@ def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins
         d_pos = K.prop_density_bwd_pair([n.prop_struct() for n in nets], [n.prop_struct(grads=True) for n in nets],
                                         [n.warp_struct() for n in nets], rays, [lv["euclid"] for lv, _ in levels],
                                         [lv["S"] for lv, _ in levels], [lv["feats"] for lv, _ in levels],
-                                        [d_wp for _, d_wp in levels], want_position_grad=d_origins is not None, adam=adam)
+                                        [d_wp for _, d_wp in levels], want_position_grad=d_origins is not None, adam=adam,
+                                        position_ready=position_ready if collect is not None else None)
         for net, (lv, _), dp in zip(nets, levels, d_pos):
             if d_origins is None:
                 continue
@@ -226,7 +230,7 @@ def _proposal_backward(model, rctx, d_wps, upstream: Optional[Tensor], d_origins
                 collect.append((net.warp_struct(), lv["euclid"], lv["S"], dp))
             else:
                 K.position_grad_reduce(net.warp_struct(), rays, lv["euclid"], lv["S"], dp, d_origins, d_directions)
-        return
+        return position_ready is not None and collect is not None
     for i, (lv, d_wp) in enumerate(levels):
         net = model.proposal_networks[0 if cfg.use_same_proposal_network else i]
         stream = pool[i - 1] if side_by_side and i > 0 else None
@@ -593,7 +597,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
                            ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False,
                            table_adam=None, weight_adam=None, proposal_optimizer: Optional["FusedAdam"] = None,
-                           after_ray_grads=None, serialize_streams: bool = False):
+                           after_ray_grads=None, serialize_streams: bool = False, ahead=None):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -606,8 +610,9 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
     table_adam: fnr_table_adam of the main hash table (FusedAdam.table_adam_args): its gradient is not materialised,
     the scatter's accumulate kernel applies the optimiser step to the table (single process only).
     after_ray_grads: called once the ray gradients are final (the camera optimiser's backward + step); with
-    overlap_proposal_backward it runs, like the reduction of the ray gradients itself, on the second stream underneath
-    the table scatter, which neither of them depends on.
+    overlap_proposal_backward it runs, like the reduction of the ray gradients itself, next to the table scatter,
+    which neither of them depends on.  ahead: called after it, once the proposal networks' steps are enqueued too
+    (TrainingSteps' look-ahead), on the second stream.
     serialize_streams (with overlap_proposal_backward): the same launches on the same two streams (same allocator pools),
     but each stream waits for everything the other has enqueued — nothing runs concurrently (bench.py: the steps whose
     launches it brackets with HIP events)."""
@@ -656,13 +661,23 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         main = torch.cuda.current_stream(dev)
         side = None
         up = None   # d_wps is d(loss)/d(density) already (fuse_weights_bwd above)
+        # The ray gradients' sources are complete once the MLP backward is (its d_pos) and the proposal chain's MLP
+        # backwards have run; their reduction and the camera optimiser's ~30 us of small launches do not need the
+        # scatters: single process + second stream -> they run next to one
+        tail_on_side = bool(overlap_proposal_backward and ray_grads is not None and exchange is None)
+        sources_early = False   # the proposal chain recorded `pos_ready` ahead of its scatter
         if prop_bwd:
             if overlap_proposal_backward:
                 side = _second_stream(model, dev)
                 side.wait_stream(main)
+                pos_ready = None
+                if tail_on_side and not serialize_streams:
+                    pos_ready = model.__dict__.get("_pos_ready_event")
+                    if pos_ready is None:
+                        pos_ready = model.__dict__["_pos_ready_event"] = torch.cuda.Event()
                 with torch.cuda.stream(side):
-                    _proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources,
-                                       optimizer=proposal_optimizer)
+                    sources_early = bool(_proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources,
+                                                            optimizer=proposal_optimizer, position_ready=pos_ready))
                 if serialize_streams:
                     main.wait_stream(side)
         d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
@@ -686,11 +701,19 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 # fused scatter below may update in place — gather now
                 partial = K.hash_encode_input_grad(net.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
                 field_source = (fld.warp_struct(), fin["euclid"], S, partial)
-        # The ray gradients' sources are complete once the MLP backward is (its d_pos) and the proposal chain has run;
-        # their reduction and the camera optimiser's ~30 us of small launches do not need the scatter (~200 us) that
-        # follows: single process + second stream -> they go underneath it
-        tail_on_side = bool(overlap_proposal_backward and ray_grads is not None and exchange is None)
-        if tail_on_side:
+        if tail_on_side and sources_early:
+            # a step that trains the proposal networks: the second stream is the longer chain (their backward, then the
+            # look-ahead that needs their step AND the cameras'), so the reduction + camera step go to THIS stream, between
+            # the MLP backward and the table scatter, and the look-ahead only waits for them and for the proposal scatter
+            main.wait_event(pos_ready)
+            K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
+            if after_ray_grads is not None:
+                after_ray_grads()
+            mlp_done = model.__dict__.get("_mlp_done_event")
+            if mlp_done is None:
+                mlp_done = model.__dict__["_mlp_done_event"] = torch.cuda.Event()
+            mlp_done.record(main)                  # (here: cameras done)
+        elif tail_on_side:
             mlp_done = model.__dict__.get("_mlp_done_event")
             if mlp_done is None:
                 mlp_done = model.__dict__["_mlp_done_event"] = torch.cuda.Event()
@@ -715,9 +738,12 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                     side.wait_stream(main)         # behind the scatter instead of underneath it
                 else:
                     side.wait_event(mlp_done)
-                K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
-                if after_ray_grads is not None:
-                    after_ray_grads()
+                if not sources_early:
+                    K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
+                    if after_ray_grads is not None:
+                        after_ray_grads()
+                if ahead is not None:
+                    ahead()
             main.wait_stream(side)                 # every local of this call outlives the second stream's launches
             return loss_dict, metrics_dict
         if side is not None:
@@ -732,6 +758,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
         if after_ray_grads is not None:
             after_ray_grads()
+        if ahead is not None:
+            ahead()
     return loss_dict, metrics_dict
 
 
@@ -830,18 +858,16 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
                                               or not optimizer.skip_groups_without_grad)
     ahead_early = ahead if (ahead is not None and not prop_step_pending) else None
     camera_step = None
-    if exchange is None and (camera is not None or ahead_early is not None):
-        def camera_step():   # the datamanager's backward + optimiser step, as soon as it can run; then the look-ahead
+    if exchange is None and camera is not None:
+        def camera_step():   # the datamanager's backward + optimiser step, as soon as it can run
             with torch.no_grad():
-                if camera is not None:
-                    camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
-                if ahead_early is not None:
-                    ahead_early()
+                camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads, overlap_proposal_backward=OVERLAP_PROPOSAL_BACKWARD,
                                                      table_adam=table_adam, weight_adam=weight_adam,
                                                      proposal_optimizer=prop_opt, after_ray_grads=camera_step,
-                                                     serialize_streams=SERIALIZE_STREAMS)
+                                                     serialize_streams=SERIALIZE_STREAMS,
+                                                     ahead=ahead_early if exchange is None else None)
     with torch.no_grad():
         if exchange is None:
             optimizer.step(skip=skipped_groups(model, optimizer), done=done)

@@ -425,6 +425,18 @@ int fnr_prop_density_bwd_pair(const fnr_prop_net* const* nets, const fnr_prop_ne
                               float* const* d_position, const fnr_table_adam* const* table_adam,
                               const fnr_table_adam* weight_adam, const float* grad_arena, void* const* workspace,
                               const size_t* workspace_bytes, const int* workspace_clean, void* stream);
+/* fnr_prop_density_bwd_pair with its launches in two groups: both levels' MLP backward + weight reduction first — after
+ * them d_position[0] and [1] are final, and position_ready_event (a hipEvent_t created by the caller; optional) is
+ * recorded on `stream` — then both levels' emit launches and the joint accumulate (~210 us for `fruit_nerf`).  A caller
+ * with a second stream finishes the ray gradients and takes the camera optimiser's step next to that scatter instead
+ * of behind it.  Same launches on the same inputs: results are those of fnr_prop_density_bwd_pair, bit for bit. */
+int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, const fnr_prop_net* const* grads,
+                                    const fnr_warp* const* warps, const fnr_rays* rays, const float* const* euclid_bins,
+                                    const int* S, const float* const* feat_save, const float* const* d_density,
+                                    float* const* d_position, const fnr_table_adam* const* table_adam,
+                                    const fnr_table_adam* weight_adam, const float* grad_arena, void* const* workspace,
+                                    const size_t* workspace_bytes, const int* workspace_clean, void* stream,
+                                    void* position_ready_event);
 
 /* All of get_loss_dict / get_metrics_dict (fruit_nerf.py:359-372, 396-401: rgb_loss, semantics_loss, interlevel_loss; psnr, distortion) for one training batch in ONE launch:
  * fnr_losses_fwd + fnr_interlevel_fwd for
