@@ -5,10 +5,13 @@ gradients gather their rays by ballot)."""
 import pytest
 import torch
 
+from tests import util
+
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None, torch113=False, fuse_weights=True):
+def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None, torch113=False, fuse_weights=True,
+         eval_after=()):
     # overlap / ahead None: the product defaults (on)
     import fruitnerf_amd.training as T
     from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
@@ -46,11 +49,22 @@ def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None, tor
                 o, d, cam, batch = batcher.sample(4096, cam_opt, level0=None)
                 rb = RayBundle(o, d, None, cam, presampled=batcher.last_presample)
                 ld, md = T.fused_train_iteration(hm, opt, rb, batch, step, camera=camera)
+            if step + 1 in eval_after:   # an eval pass between two iterations (a Trainer's eval_image / bench.py's quality gate)
+                hm.eval()
+                with torch.no_grad():
+                    eo, ed, _, ecam = util.random_rays(2048, n_train, seed=step)
+                    for _ in range(2):   # the first eval render may reset the sampler's update counter, the second not
+                        hm(RayBundle(eo.to(dev), ed.to(dev), None, ecam.to(dev)))
+                hm.train()
             if step % 20 == 19 or step == steps - 1:
                 losses.append(torch.stack([ld["rgb_loss"], ld["semantics_loss"], ld["interlevel_loss"], md["psnr"],
                                            md["distortion"]]).clone())
-        if prologue and T.SAMPLE_AHEAD:   # every step but the first ran on what the previous one sampled ahead
+        if prologue and T.SAMPLE_AHEAD and not eval_after:   # every step but the first ran on what the previous one sampled ahead
             assert hm.__dict__.get("_ahead_used", 0) == steps - 1
+        if prologue and T.SAMPLE_AHEAD and eval_after:
+            # an eval pass resets the sampler's counter when an update was due (nerfstudio does): the look-ahead assumed an
+            # update that the next iteration then does not see, and the model samples again
+            assert steps - 1 - len(eval_after) <= hm.__dict__.get("_ahead_used", 0) <= steps - 1
     finally:
         T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD, T.FUSE_WEIGHT_OPTIMIZER = saved
     torch.cuda.synchronize()
@@ -105,6 +119,16 @@ def test_sampling_ahead_is_sampling_at_the_start_of_the_step(dev):
         got = _run(dev, 120, "bf16x3", overlap=overlap, ahead=True)
         for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), ref, got):
             assert torch.equal(x, y), f"{name} differ (second stream {overlap})"
+
+
+def test_sampling_ahead_survives_eval_passes_between_iterations(dev):
+    """Eval renders between two training iterations change the proposal sampler's update counter (nerfstudio resets it in
+    eval mode too), i.e. the schedule the look-ahead assumed: the model must notice and sample again — same states as
+    without the look-ahead.  Eval passes after steps where an update was due (12, 30) and where it was not (21, 41)."""
+    ref = _run(dev, 60, "bf16x3", overlap=False, ahead=False, eval_after=(12, 21, 30, 41))
+    got = _run(dev, 60, "bf16x3", overlap=True, ahead=True, eval_after=(12, 21, 30, 41))
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("config", ["torch113", "unfused"])
