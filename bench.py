@@ -20,7 +20,7 @@ warm-up step, the last one enqueues the sampling of step K + 1).
 the reference's counterpart is nerfstudio's mp.spawn around fruit_pipeline.py:116-118) and fails unless N ranks run.
 
 Extra objects in the JSON line:  roofline (dominant entry point among the HBM- / MFMA-bound ones, chosen by its time
-over the timed window itself, HIP events on the stream of the launch, every 5th step, streams serialised on those steps), cpu_baseline (the oracle's train step on the host cores, rank 0, bounded sample),
+over the timed window itself, HIP events on the stream of the launch, every 10th step, streams serialised on those steps), cpu_baseline (the oracle's train step on the host cores, rank 0, bounded sample),
 breakdown_ms (per entry point, from a short instrumented pass after the timed region), quality (PSNR / IoU on
 held-out views after --quality-steps more steps).
 """
@@ -306,7 +306,11 @@ class MethodRun:
         return self.steps.step(want_metrics)
 
 
-PROFILE_EVERY = int(os.environ.get("FNR_BENCH_PROFILE_EVERY", "5"))   # HIP events on the roofline candidates' launches of every 5th step of the timed window
+# HIP events on the roofline candidates' launches of every 10th step of the timed window.  Such a step runs its two streams
+# one after the other (training.SERIALIZE_STREAMS) and costs ~0.19 ms more than a normal one (measured: 0.777 ms/step
+# without timed steps, 0.815 with every 5th): every 10th = two timed launches per entry point in the driver's 20-step
+# window, twenty in the default 200-step one, for ~2 % of the reading
+PROFILE_EVERY = int(os.environ.get("FNR_BENCH_PROFILE_EVERY", "10"))
 
 
 def timed_window(run, steps, barrier, dist_on, dev):

@@ -137,7 +137,7 @@ int fnr_device_check(int* cu_count_out, char* name_out, int name_len);
  * 11 weights_bwd, 12 field_mlp_bwd, 13 hash_encode_bwd, 14 prop_density_bwd, 15 adam_step, 16 export_compact. */
 int fnr_profile_enable(int on, uint64_t op_mask);
 /* paused != 0: entry points stop recording events but the records collected so far are kept (bench.py times every
- * fifth step of its timed window: each event pair costs the GPU a ~3 us bubble). */
+ * tenth step of its timed window: each event pair costs the GPU a ~3 us bubble). */
 int fnr_profile_pause(int paused);
 int64_t fnr_profile_collect(int32_t* ops_host, int64_t* units_host, float* ms_host, int64_t capacity);
 /* Diagnostics of the binned scatter (fnr_hash_encode_bwd*, fnr_prop_density_bwd*): records that did not fit their bin's
