@@ -656,8 +656,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         # The proposal-network backward (interlevel loss) and the field backward (rgb + semantic losses) share no
         # buffers.  overlap_proposal_backward=True runs the former on a second HIP stream so that its ~14 small/medium
         # launches fill the gaps and tails of the field kernels (measured: -3 % on the steps that have one); bench.py
-        # turns it off on the steps whose launches it brackets with HIP events (a duration measured while another
-        # stream's kernels share the CUs describes neither kernel).
+        # serialises the two streams on the steps whose launches it brackets with HIP events (serialize_streams: a
+        # duration measured while another stream's kernels share the CUs describes neither kernel).
         main = torch.cuda.current_stream(dev)
         side = None
         up = None   # d_wps is d(loss)/d(density) already (fuse_weights_bwd above)
@@ -709,15 +709,15 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
             if after_ray_grads is not None:
                 after_ray_grads()
-            mlp_done = model.__dict__.get("_mlp_done_event")
-            if mlp_done is None:
-                mlp_done = model.__dict__["_mlp_done_event"] = torch.cuda.Event()
-            mlp_done.record(main)                  # (here: cameras done)
+            tail_ready = model.__dict__.get("_tail_ready_event")
+            if tail_ready is None:
+                tail_ready = model.__dict__["_tail_ready_event"] = torch.cuda.Event()
+            tail_ready.record(main)                # the cameras have taken their step
         elif tail_on_side:
-            mlp_done = model.__dict__.get("_mlp_done_event")
-            if mlp_done is None:
-                mlp_done = model.__dict__["_mlp_done_event"] = torch.cuda.Event()
-            mlp_done.record(main)
+            tail_ready = model.__dict__.get("_tail_ready_event")
+            if tail_ready is None:
+                tail_ready = model.__dict__["_tail_ready_event"] = torch.cuda.Event()
+            tail_ready.record(main)                # the MLP backward (its d_pos) is enqueued
         if exchange is None and table_adam is not None:
             K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, table_adam)
         elif exchange is None:
@@ -737,7 +737,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 if serialize_streams:
                     side.wait_stream(main)         # behind the scatter instead of underneath it
                 else:
-                    side.wait_event(mlp_done)
+                    side.wait_event(tail_ready)
                 if not sources_early:
                     K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
                     if after_ray_grads is not None:
