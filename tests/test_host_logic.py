@@ -411,3 +411,128 @@ def test_sampler_look_ahead_is_the_schedule():
     for step in (0, 1, 10, 500, 999, 1000, 5000):
         a = FruitModel.anneal_at(M, step)
         assert 0.0 <= a <= 1.0 and (step < cfg.proposal_weights_anneal_max_num_iters or a == 1.0)
+
+
+def test_training_steps_draw_and_lookahead_bookkeeping(monkeypatch):
+    """training.TrainingSteps on stubs (no device): iteration i runs on draw i + 1 of the batcher; the look-ahead for
+    iteration i + 1 is made inside iteration i with `finishing step` i; a dropped look-ahead costs its draw and the next
+    step samples at its own start; SAMPLE_AHEAD off / eval mode: no look-ahead at all."""
+    import torch
+    import fruitnerf_amd.training as T
+
+    log = []
+
+    class Model:
+        training = True
+        device = torch.device("cpu")
+
+        def level0_spec(self):
+            return {"S": 4, "near": 0.05, "far": 10.0, "n_jitter": 3}
+
+        def sample_ahead(self, rb, step):
+            log.append(("ahead", step, rb.presampled["draw"]))
+            rb.presampled["ahead"] = {"for": step + 1}
+            return True
+
+    class Batcher:
+        draws = 0
+        last_presample = None
+
+        def sample(self, n, cam, level0=None):
+            assert level0 is not None
+            Batcher.draws += 1
+            self.last_presample = {"draw": Batcher.draws}
+            z = torch.zeros(n, 3)
+            return z, z, torch.zeros(n, 1, dtype=torch.long), {"image": z, "fruit_mask": torch.zeros(n, 1)}
+
+    def fake_iteration(model, optimizer, rb, batch, step, world_size=1, want_metrics=True, camera=None, ahead=None):
+        log.append(("iter", step, rb.presampled["draw"], rb.presampled.get("ahead")))
+        if ahead is not None:
+            ahead()
+        return {}, {}
+
+    monkeypatch.setattr(T, "fused_train_iteration", fake_iteration)
+    monkeypatch.setattr(T, "SAMPLE_AHEAD", True)
+    loop = T.TrainingSteps(Model(), None, Batcher(), 8)
+    loop.step(); loop.step(); loop.step()
+    assert log == [("iter", 0, 1, None), ("ahead", 0, 2), ("iter", 1, 2, {"for": 1}), ("ahead", 1, 3),
+                   ("iter", 2, 3, {"for": 2}), ("ahead", 2, 4)]
+    del log[:]
+    loop.drop_lookahead()                       # draw 4 is gone; iteration 3 samples at its start
+    loop.step()
+    assert log == [("iter", 3, 5, None), ("ahead", 3, 6)]
+    del log[:]
+    monkeypatch.setattr(T, "SAMPLE_AHEAD", False)
+    loop.step(); loop.step()                    # consumes the pending look-ahead, then samples per step
+    assert log == [("iter", 4, 6, {"for": 4}), ("iter", 5, 7, None)]
+    assert loop.step_idx == 6
+
+
+def test_lookahead_is_ordered_after_the_proposal_networks_step(monkeypatch):
+    """fused_train_iteration on stubs: the look-ahead (which reads the proposal networks) is handed to the backward — to be
+    enqueued on the second stream — only when the networks' step of this iteration is fused into their backward or does
+    not happen; when optimizer.step() still has to take it (unfused weights, torch-1.13 stepping without gradients) the
+    look-ahead comes after that call."""
+    import types
+    import torch
+    import fruitnerf_amd.training as T
+
+    log = []
+
+    class Sampler:
+        def __init__(self, updated):
+            self.updated = updated
+
+        def updated_now(self):
+            return self.updated
+
+        def step_cb(self, step):
+            log.append("step_cb")
+
+    def make_model(updated):
+        m = types.SimpleNamespace()
+        m.training = True
+        m.config = types.SimpleNamespace(use_same_proposal_network=False)
+        m.proposal_sampler = Sampler(updated)
+        m.set_anneal = lambda step: None
+        m.arena = lambda: types.SimpleNamespace(group_ranges={"fields": (0, 8), "proposal_networks": (8, 12)})
+        m.field = types.SimpleNamespace(mlp_base_grid=types.SimpleNamespace(hash_table=None))
+        m._last_render_updated = updated
+        return m
+
+    class Opt:
+        def __init__(self, skip):
+            self.skip_groups_without_grad = skip
+
+        def table_adam_args(self, table, group):
+            return object(), (0, 4)
+
+        def weight_adam_args(self, group):
+            return (object(), None), (0, 8)
+
+        def step(self, skip=(), done=()):
+            log.append(("optimizer.step", tuple(skip)))
+
+    def fake_fb(model, rb, batch, jitter, want_metrics, exchange, ray_grads, **kw):
+        log.append(("backward", "fused proposal step" if kw["proposal_optimizer"] is not None else "no fused proposal step"))
+        if kw["ahead"] is not None:
+            kw["ahead"]()
+        return {}, {}
+
+    monkeypatch.setattr(T, "fused_forward_backward", fake_fb)
+    ahead = lambda: log.append("look-ahead")   # noqa: E731
+
+    def run(updated, skip=True, fuse_weights=True):
+        del log[:]
+        monkeypatch.setattr(T, "FUSE_WEIGHT_OPTIMIZER", fuse_weights)
+        T.fused_train_iteration(make_model(updated), Opt(skip), None, None, 7, ahead=ahead)
+        return [e if isinstance(e, str) else e[0] for e in log]
+
+    inside = ["backward", "look-ahead", "optimizer.step", "step_cb"]
+    after = ["backward", "optimizer.step", "look-ahead", "step_cb"]
+    assert run(updated=True) == inside                        # the networks step inside their backward
+    assert run(updated=False) == inside                       # no gradient -> the group is skipped altogether
+    assert run(updated=False, skip=False) == after            # torch 1.13: the group steps on zero gradients
+    assert run(updated=True, skip=False) == inside            # ... but a fused step is a fused step
+    assert run(updated=True, fuse_weights=False) == after     # unfused: optimizer.step() takes the networks' step
+    assert run(updated=False, fuse_weights=False) == inside
