@@ -676,8 +676,9 @@ def main() -> None:
                 return round(args.steps * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
             finally:
                 _T.OVERLAP_PROPOSAL_BACKWARD = saved_flag
-        overlap_modes = {"note": "the headline window (same seeds and step numbers) on a fresh model; 'second_stream': the "
-                                 "proposal-network backward runs on a second HIP stream underneath the field backward",
+        overlap_modes = {"note": "the headline window (same seeds and step numbers) on a fresh model, no event-timed steps; "
+                                 "'second_stream': proposal-network backward, ray-gradient reduction, camera step and the next "
+                                 "step's sampling on the second HIP stream (the default); 'one_stream': everything in-stream",
                          "one_stream": headline_window(False), "second_stream": headline_window(True)}
         # the other arithmetic modes of the field MLPs on the SAME loop (headline mode restored afterwards): bf16x3 is
         # parity grade (tests/test_gpu_bf16.py), bf16 is BASELINE config 2's throughput mode
