@@ -6,6 +6,7 @@ oracle next to HIP     spike_vs_oracle, trained_export_check, golden_big_dbg, go
 timing of the loop     early_steps (per-window step time, host enqueue time, allocator growth from step 0)
 reproducibility        big_determinism (fruit_nerf_big, one / two streams, sampling ahead, eval passes in between),
                        long_divergence (parameter digests every N steps of long runs, across modes and processes),
-                       kernel_stress (one forward + backward on fixed inputs, thousands of times, next to a busy stream)
+                       kernel_stress (one forward + backward on fixed inputs, thousands of times, next to a busy stream),
+                       bench_flow_digest (bench.py's own flow — timed window, breakdown pass, evals — with digests at marks)
 scatter health         scatter_overflows (queue overflows during training: none), overflow_probe (inputs that do overflow)
 """
