@@ -105,9 +105,16 @@ __device__ __forceinline__ float dpp_f32(float old, float v) {
 // row_shr DPP adds gated by those masks (3 VALU per step; the previous per-corner key/flag scan cost ~45 per
 // corner and made this kernel VALU-bound).
 struct RunMasks {
-  bool m1, m2, m4, m8, tail;
+  float g1, g2, g4, g8;   // 1.0f where the lane takes its 1 / 2 / 4 / 8-lanes-left neighbour's partial sum, else 0.0f
+  bool tail;
   bool any_run;  // wave-uniform: some lane continues its left neighbour's run
 };
+// lane i <- lane i - n inside its row of 16, 0 where there is no such lane (bound_ctrl: the combiner can then fold the
+// move into the instruction that uses it)
+template <int CTRL>
+__device__ __forceinline__ float dpp_shr0_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ RunMasks run_structure(uint32_t key_a, uint32_t key_b, int lane) {
   const int j = lane & 15;
   const uint32_t pa = dpp_u32<0x111>(~key_a, key_a), pb = dpp_u32<0x111>(key_b, key_b);  // j == 0: pa != key_a
@@ -117,10 +124,10 @@ __device__ __forceinline__ RunMasks run_structure(uint32_t key_a, uint32_t key_b
   const uint32_t below = row & ((2u << j) - 1u);
   const int dist = j - (31 - __clz((int)below));
   RunMasks m;
-  m.m1 = dist >= 1;
-  m.m2 = dist >= 2;
-  m.m4 = dist >= 4;
-  m.m8 = dist >= 8;
+  m.g1 = dist >= 1 ? 1.0f : 0.0f;
+  m.g2 = dist >= 2 ? 1.0f : 0.0f;
+  m.g4 = dist >= 4 ? 1.0f : 0.0f;
+  m.g8 = dist >= 8 ? 1.0f : 0.0f;
   m.tail = (j == 15) || ((row >> (j + 1)) & 1u);
   m.any_run = ~heads != 0ull;
   return m;
@@ -128,16 +135,90 @@ __device__ __forceinline__ RunMasks run_structure(uint32_t key_a, uint32_t key_b
 __device__ __forceinline__ float run_sum(float v, const RunMasks& m) {
   // the DPP reads are executed by ALL lanes, then gated: inside a divergent branch the disabled source lanes
   // would read as invalid
-  float u;
-  u = dpp_f32<0x111>(0.0f, v);
-  v += m.m1 ? u : 0.0f;
-  u = dpp_f32<0x112>(0.0f, v);
-  v += m.m2 ? u : 0.0f;
-  u = dpp_f32<0x114>(0.0f, v);
-  v += m.m4 ? u : 0.0f;
-  u = dpp_f32<0x118>(0.0f, v);
-  v += m.m8 ? u : 0.0f;
+  // one gated step = v + g * shifted(v): a 0 / 1 gate makes the product exact, so the sums are those of the select form
+  // (finite values); one v_fmac_f32 with a DPP operand per step instead of mov + mov_dpp + cndmask + add
+  v = fmaf(m.g1, dpp_shr0_f32<0x111>(v), v);
+  v = fmaf(m.g2, dpp_shr0_f32<0x112>(v), v);
+  v = fmaf(m.g4, dpp_shr0_f32<0x114>(v), v);
+  v = fmaf(m.g8, dpp_shr0_f32<0x118>(v), v);
   return v;
+}
+
+// All sixteen value streams of a (sample, level) through the four gated steps as 64 v_fmac_f32 with a DPP-shifted source
+// (dst += shifted(dst) * gate; lanes without a source read 0): the compiler's form of the same arithmetic is
+// mov_dpp + fma per step (GCNDPPCombine does not fold a DPP move into v_fmac here).  Inline assembly is outside the
+// hazard recogniser's view: a DPP read needs two wait states after the VALU write of its source, so every step runs over
+// all sixteen registers before the next one starts (distance 16) and the block opens with s_nop 1.
+__device__ __forceinline__ void run_sums16(float (&a)[8], float (&b)[8], const RunMasks& m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %0, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %2, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %3, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %4, %4, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %5, %5, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %6, %6, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %7, %7, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %8, %8, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %9, %9, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %10, %10, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %11, %11, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %12, %12, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %13, %13, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %14, %14, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %15, %15, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %0, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %2, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %3, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %4, %4, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %5, %5, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %6, %6, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %7, %7, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %8, %8, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %9, %9, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %10, %10, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %11, %11, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %12, %12, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %13, %13, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %14, %14, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %15, %15, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %0, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %2, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %3, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %4, %4, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %5, %5, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %6, %6, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %7, %7, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %8, %8, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %9, %9, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %10, %10, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %11, %11, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %12, %12, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %13, %13, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %14, %14, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %15, %15, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %0, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %2, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %3, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %4, %4, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %5, %5, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %6, %6, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %7, %7, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %8, %8, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %9, %9, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %10, %10, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %11, %11, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %12, %12, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %13, %13, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %14, %14, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %15, %15, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]),
+        "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+      : "v"(m.g1), "v"(m.g2), "v"(m.g4), "v"(m.g8));
 }
 
 // Debug build only (make EXTRA=-DFNR_EMIT_TIMING): wave 0 of every emit workgroup adds the shader-clock length of
@@ -240,6 +321,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       vxk[q][k] = valid ? wgt[k] * gf.x : 0.0f;
       vyk[q][k] = valid ? wgt[k] * gf.y : 0.0f;
     }
+#ifdef FNR_EMIT_SCAN_SELECT   // A/B builds (tools/build_variant.sh): the compiler's mov_dpp + fma form of the same sums
     if (rm.any_run) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -247,6 +329,9 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
         vyk[q][k] = run_sum(vyk[q][k], rm);
       }
     }
+#else
+    if (rm.any_run) run_sums16(vxk[q], vyk[q], rm);
+#endif
 #ifdef FNR_EMIT_TIMING
     {
       asm volatile("" ::"v"(vxk[q][0]), "v"(vyk[q][7]));

@@ -394,7 +394,8 @@ class FruitModel(nn.Module):
         else:
             jit = [None] * (n_prop + 1)
         ahead = pre.get("ahead") if pre is not None else None
-        if ahead is not None and ahead["updated"] == updated and ahead["anneal"] == sampler._anneal:
+        if ahead is not None and ahead["updated"] == updated and ahead["anneal"] == sampler._anneal \
+                and ahead.get("param_version", None) in (None, self.lookahead_version()):
             # the proposal levels of these rays were sampled ahead (sample_ahead: enqueued at the end of the previous
             # iteration) under the schedule this pass sees
             levels, spacing, euclid, S = list(ahead["levels"]), ahead["spacing"], ahead["euclid"], ahead["S"]
@@ -479,8 +480,20 @@ class FruitModel(nn.Module):
                          ray_bundle.camera_indices)
         updated, anneal = sampler.updated_after(step), self.anneal_at(step + 1)
         levels, spacing, euclid, S = self._proposal_levels(rays, pre, list(pre["jitter"][:n_prop + 1]), updated, anneal)
-        pre["ahead"] = dict(levels=levels, spacing=spacing, euclid=euclid, S=S, updated=updated, anneal=anneal)
+        pre["ahead"] = dict(levels=levels, spacing=spacing, euclid=euclid, S=S, updated=updated, anneal=anneal,
+                            param_version=self.lookahead_version())
         return True
+
+    def lookahead_version(self) -> tuple:
+        """What a cached look-ahead is tied to besides the schedule: the identity of the parameter arena and torch's
+        version counters of the proposal networks' parameters.  The library's own optimiser steps write through raw
+        pointers and leave the counters alone (the look-ahead is enqueued behind them on purpose); anything torch does to
+        the parameters in between — load_state_dict, an external optimiser's step, `with torch.no_grad(): p.copy_()` —
+        bumps them, and _render / TrainingSteps then sample again instead of training on samples and saved features of
+        the old weights.  (Writes through `p.data` bypass the counters: call TrainingSteps.drop_lookahead().)"""
+        arena = self._arena
+        return (id(arena), None if arena is None else arena.params.data_ptr()) + \
+            tuple(p._version for p in self.proposal_networks.parameters())
 
     def _empty_render(self, ray_bundle: RayBundle) -> Tuple[Dict, RenderContext]:
         dev = ray_bundle.origins.device

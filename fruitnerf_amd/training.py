@@ -593,6 +593,77 @@ def _second_stream(model, dev):
     return side
 
 
+# FNR_STREAM_SAFE=1 (debug): every tensor that crosses between the launch stream and the second stream is ALSO registered
+# with the consuming stream (Tensor.record_stream), so the caching allocator itself refuses to recycle its block before that
+# stream is past it.  The default relies on the fork / join structure instead (see TrainingSteps.step and _ForkJoin below):
+# measured +6 % step time for ~40 extra events a step.  Training must be bit-identical with the switch on and off
+# (tests/test_gpu_determinism.py::test_stream_safe_mode_changes_nothing); a difference would mean a block was recycled
+# under a kernel that still read it.
+STREAM_SAFE = os.environ.get("FNR_STREAM_SAFE") == "1"
+
+
+def _tensors_in(obj, seen, depth=0):
+    if torch.is_tensor(obj):
+        if obj.is_cuda and id(obj) not in seen:
+            seen.add(id(obj))
+            yield obj
+        return
+    if depth > 6 or obj is None or isinstance(obj, (str, bytes, int, float, bool)) or id(obj) in seen:
+        return
+    if isinstance(obj, dict):
+        seen.add(id(obj))
+        for v in obj.values():
+            yield from _tensors_in(v, seen, depth + 1)
+    elif isinstance(obj, (list, tuple)):
+        seen.add(id(obj))
+        for v in obj:
+            yield from _tensors_in(v, seen, depth + 1)
+    elif hasattr(obj, "__dict__") and not isinstance(obj, (torch.nn.Module, type)) and not callable(obj):
+        seen.add(id(obj))
+        for v in vars(obj).values():
+            yield from _tensors_in(v, seen, depth + 1)
+
+
+def crosses_to(stream, *objs) -> int:
+    """STREAM_SAFE: record_stream(stream) on every device tensor reachable from objs (lists, tuples, dicts, RayBundle /
+    RenderContext / RaysArg attributes) -> how many; a no-op (0) otherwise."""
+    if not STREAM_SAFE or stream is None:
+        return 0
+    n = 0
+    for t in _tensors_in(objs, set()):
+        t.record_stream(stream)
+        n += 1
+    return n
+
+
+class _ForkJoin:
+    """The rule that makes two allocator pools safe without record_stream, asserted instead of assumed: every segment of
+    work on the second stream opens with a wait on the launch stream (all of it, or an event recorded on it during THIS
+    call) and the call may not return before the launch stream has waited for the second one — so a block of either pool
+    is only ever reused by work enqueued behind every consumer of its previous contents."""
+
+    def __init__(self, main):
+        self.main, self.open, self.segments, self.joins = main, None, 0, 0
+
+    def fork(self, side, event=None):
+        if event is not None:
+            side.wait_event(event)
+        else:
+            side.wait_stream(self.main)
+        self.open = side
+        self.segments += 1
+
+    def join(self):
+        if self.open is not None:
+            self.main.wait_stream(self.open)
+            self.open = None
+            self.joins += 1
+
+    def check(self):
+        if self.open is not None:
+            raise RuntimeError("fused_forward_backward: returning with unjoined work on the second stream")
+
+
 def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tensor]] = None,
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
                            ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False,
@@ -659,6 +730,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         # serialises the two streams on the steps whose launches it brackets with HIP events (serialize_streams: a
         # duration measured while another stream's kernels share the CUs describes neither kernel).
         main = torch.cuda.current_stream(dev)
+        fj = _ForkJoin(main)
         side = None
         up = None   # d_wps is d(loss)/d(density) already (fuse_weights_bwd above)
         # The ray gradients' sources are complete once the MLP backward is (its d_pos) and the proposal chain's MLP
@@ -669,7 +741,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         if prop_bwd:
             if overlap_proposal_backward:
                 side = _second_stream(model, dev)
-                side.wait_stream(main)
+                fj.fork(side)
+                crosses_to(side, rctx, d_wps, d_o, d_d)
                 pos_ready = None
                 if tail_on_side and not serialize_streams:
                     pos_ready = model.__dict__.get("_pos_ready_event")
@@ -678,6 +751,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 with torch.cuda.stream(side):
                     sources_early = bool(_proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources,
                                                             optimizer=proposal_optimizer, position_ready=pos_ready))
+                crosses_to(main, ray_sources)
                 if serialize_streams:
                     main.wait_stream(side)
         d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
@@ -733,21 +807,21 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         if tail_on_side:
             if side is None:                       # a step without a proposal backward: the event is the whole fork
                 side = _second_stream(model, dev)
+            # behind the scatter (serialize_streams) instead of underneath it
+            fj.fork(side, None if serialize_streams else tail_ready)
+            crosses_to(side, ray_sources, field_source, d_o, d_d, rays)
             with torch.cuda.stream(side):
-                if serialize_streams:
-                    side.wait_stream(main)         # behind the scatter instead of underneath it
-                else:
-                    side.wait_event(tail_ready)
                 if not sources_early:
                     K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
                     if after_ray_grads is not None:
                         after_ray_grads()
                 if ahead is not None:
                     ahead()
-            main.wait_stream(side)                 # every local of this call outlives the second stream's launches
+            fj.join()                              # every local of this call outlives the second stream's launches
+            fj.check()
             return loss_dict, metrics_dict
         if side is not None:
-            main.wait_stream(side)                 # proposal gradients (and their ray-gradient sources) are final
+            fj.join()                              # proposal gradients (and their ray-gradient sources) are final
             for src in ray_sources or ():
                 src[3].record_stream(main)
         elif prop_bwd:
@@ -760,6 +834,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             after_ray_grads()
         if ahead is not None:
             ahead()
+        fj.check()
     return loss_dict, metrics_dict
 
 
@@ -780,6 +855,8 @@ def camera_backward(camera_optimizer, batcher, ray_grads: dict, world_size: int 
 
 def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: dict, world_size: int = 1) -> None:
     """camera_backward() + the camera optimiser's Adam step (one launch in a single process)."""
+    # (the draw may come from the other stream's pool: the look-ahead draws on the second stream, this runs on either)
+    crosses_to(torch.cuda.current_stream(ray_grads["origins"].device), batcher.last_draw, ray_grads)
     if world_size < EXCHANGE_MIN_WORLD and FUSE_CAMERA_OPTIMIZER:
         d = batcher.last_draw
         pose = camera_optimizer.pose_adjustment
@@ -941,6 +1018,7 @@ class TrainingSteps:
         self.world_size = world_size
         self.step_idx = 0
         self._next = None
+        self._next_version = ()
 
     def _draw(self, finishing_step: Optional[int]):
         from .rays import RayBundle
@@ -956,7 +1034,21 @@ class TrainingSteps:
         batcher was used in between): the next step() samples at its start.  The draw itself is consumed."""
         self._next = None
 
+    def _outside_version(self) -> tuple:
+        """Version counters of what the prologue of a look-ahead read besides the proposal networks: the camera poses."""
+        if self.camera is None:
+            return ()
+        pose = getattr(self.camera[0], "pose_adjustment", None)
+        return () if pose is None else (pose.data_ptr(), pose._version)
+
     def step(self, want_metrics: bool = True):
+        if self._next is not None and self._next[0] == self.step_idx and self._next_version != self._outside_version():
+            # the cameras were edited between two steps: the rays drawn ahead used the old poses.  Draw again with the
+            # SAME counter (counter-based random numbers: the same pixels through the new poses — what sampling at the
+            # start of this step would have drawn)
+            self._next = None
+            if getattr(self.batcher, "_offset", 0) > 0:
+                self.batcher._offset -= 1
         if self._next is not None and self._next[0] == self.step_idx:
             _, rb, batch = self._next
         else:
@@ -964,14 +1056,19 @@ class TrainingSteps:
         self._next = None
         step = self.step_idx
 
+        launch_stream = torch.cuda.current_stream(self.model.device)
+
         def ahead():
             # On the second stream these tensors come from ITS allocator pool and are consumed on the launch stream by
             # the next iteration.  No Tensor.record_stream (one event per tensor and free: ~40 barrier packets a step,
             # measured +6 % step time): a block of either pool is only ever reused by work that its stream enqueues
             # after waiting for the other one — the second stream starts each iteration's work with a wait on the launch
             # stream (fork of the proposal backward / the MLP-backward event), the launch stream ends each iteration
-            # with a wait on the second — i.e. after every consumer of the block's previous contents.
+            # with a wait on the second — i.e. after every consumer of the block's previous contents (_ForkJoin asserts
+            # that structure; FNR_STREAM_SAFE=1 registers the tensors with the allocator as well).
             self._next = (step + 1,) + self._draw(step)
+            self._next_version = self._outside_version()
+            crosses_to(launch_stream, self._next, self.batcher.last_draw, getattr(self.batcher, "last_presample", None))
 
         out = fused_train_iteration(self.model, self.optimizer, rb, batch, step, world_size=self.world_size,
                                     want_metrics=want_metrics, camera=self.camera,

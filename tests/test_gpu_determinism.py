@@ -150,3 +150,74 @@ def test_second_stream_run_is_bit_identical_too(dev):
     b = _run(dev, 100, "bf16x3", overlap=True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_stream_safe_mode_changes_nothing(dev):
+    """FNR_STREAM_SAFE (training.STREAM_SAFE): every tensor that crosses between the launch stream and the second stream
+    is also registered with the consuming stream (Tensor.record_stream), so the caching allocator cannot recycle a block
+    under a kernel that still reads it.  The default relies on the fork / join structure alone (training._ForkJoin); if
+    that structure had a hole, the two modes would eventually part ways.  150 steps (every-step and every-other-step
+    proposal updates), eval passes in between; the switch must also have found tensors to register."""
+    import fruitnerf_amd.training as T
+    ref = _run(dev, 150, "bf16x3", eval_after=(12, 41))
+    saved, T.STREAM_SAFE = T.STREAM_SAFE, True
+    counted = []
+    orig = T.crosses_to
+
+    def counting(stream, *objs):
+        n = orig(stream, *objs)
+        counted.append(n)
+        return n
+
+    T.crosses_to = counting
+    try:
+        got = _run(dev, 150, "bf16x3", eval_after=(12, 41))
+    finally:
+        T.STREAM_SAFE, T.crosses_to = saved, orig
+    assert sum(counted) > 150 * 10, "the switch registered no cross-stream tensors"
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), ref, got):
+        assert torch.equal(x, y), f"{name} differ with FNR_STREAM_SAFE"
+
+
+def test_lookahead_is_dropped_when_parameters_change_between_steps(dev):
+    """a cached look-ahead carries the next step's proposal samples and saved proposal features; it is tied to
+    torch's version counters of the proposal networks' parameters and of the camera poses, so a load_state_dict or a pose
+    edit between two TrainingSteps.step calls makes the next step sample again — same states as without the look-ahead."""
+    import fruitnerf_amd.training as T
+
+    def run(ahead):
+        from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+        from fruitnerf_amd.data import synthetic_apple as sa
+        from fruitnerf_amd.data.semantics import apple_metadata
+        from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+        HW, focal, n_train = 96, 1111.0 * 96 / 800, 40
+        scene = sa.make_scene(seed=0, device=dev)
+        c2w = sa.make_cameras(n_train, seed=0, device=dev)
+        data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
+        batcher = sa.PixelBatcher(data, torch.arange(n_train, device=dev), seed=1)
+        torch.manual_seed(0)
+        hm = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=n_train, device=dev)
+        hm.train()
+        opt = T.FusedAdam(hm)
+        cam_opt = CameraOptimizerConfig(mode="SO3xR3").setup(n_train, dev)
+        loop = T.TrainingSteps(hm, opt, batcher, 2048, camera=(cam_opt, CameraAdam(cam_opt)))
+        saved, T.SAMPLE_AHEAD = T.SAMPLE_AHEAD, ahead
+        try:
+            for step in range(16):
+                loop.step()
+                if step == 5:      # a checkpoint reload with different proposal networks
+                    state = {k: (v * 1.01 if k.startswith("proposal_networks") else v) for k, v in hm.state_dict().items()}
+                    hm.load_state_dict(state, strict=True)
+                if step == 9:      # the poses edited from outside
+                    with torch.no_grad():
+                        cam_opt.pose_adjustment.mul_(0.5)
+        finally:
+            T.SAMPLE_AHEAD = saved
+        torch.cuda.synchronize()
+        return hm.arena().params.clone(), opt.exp_avg.clone(), cam_opt.pose_adjustment.data.clone(), hm.__dict__.get("_ahead_used", 0)
+
+    ref = run(False)
+    got = run(True)
+    assert got[3] == 15 - 2, f"look-aheads used: {got[3]} (two of the 15 must have been dropped)"
+    for name, x, y in zip(("parameters", "exp_avg", "camera poses"), ref, got):
+        assert torch.equal(x, y), f"{name} differ: a stale look-ahead was used"

@@ -22,6 +22,12 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 BAR = 1e-4          # north star: RGB + semantic outputs within 1e-4
+# one-step replays at a trained state (end to end: the HIP path samples for itself).  <= 5x what round 3 measured:
+LOSS_REL = 1e-2     # losses / metrics, relative (measured <= 2.5e-3)
+GRAD_L1 = 1e-2      # sum|hip - oracle| / sum|oracle| per parameter tensor (measured <= 2.5e-3)
+GRAD_MAX = 1e-2     # max|hip - oracle| / max|oracle| per parameter tensor (measured <= 1.9e-3)
+RAYS_OFF = 5e-3     # fraction of rays whose origin / direction gradient is off by > 1 % of the largest (measured 0)
+SAME_SAMPLES_GRAD = 5e-4   # every gradient entry within this of max|g| when both sides use the oracle's sample bins
 
 SHAPES = {
     # name: (oracle config factory, rays / step, training steps, optimiser, group lr table)
@@ -205,11 +211,11 @@ def test_fruit_nerf_big_step_at_a_trained_state_matches_the_oracle(dev):
     for k in ld_ref:
         a, r = float(ld[k]), float(ld_ref[k])
         print(f"[trained big] {k}: hip {a:.8e} oracle {r:.8e} rel {abs(a - r) / max(abs(r), 1e-12):.2e}")
-        assert abs(a - r) <= 2e-2 * max(abs(r), 1e-4), k
+        assert abs(a - r) <= LOSS_REL * max(abs(r), 1e-4), k     # measured (round 3): <= 2.5e-3
     for k in md_ref:
         a, r = float(md[k]), float(md_ref[k])
         print(f"[trained big] {k}: hip {a:.8e} oracle {r:.8e}")
-        assert abs(a - r) <= 2e-2 * max(abs(r), 1e-3), k
+        assert abs(a - r) <= LOSS_REL * max(abs(r), 1e-3), k
     named_h = dict(hm.named_parameters())
     for name, p in om.named_parameters():
         ref = p.grad if p.grad is not None else torch.zeros_like(p)
@@ -218,11 +224,118 @@ def test_fruit_nerf_big_step_at_a_trained_state_matches_the_oracle(dev):
         agg = (got - ref).abs().double().sum().item() / max(denom, 1e-30)
         mx = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
         print(f"[trained big] grad {name}: max|ref| {ref.abs().max().item():.3e} max-norm rel {mx:.3e} L1-rel {agg:.3e}")
-        assert denom == 0 and float(got.abs().sum()) == 0 or agg <= 1e-1, f"{name}: aggregate relative gradient error {agg}"
+        # measured (round 3, profiles/r03_raw/gputest_final.log): worst L1 2.5e-3, worst max-norm 1.9e-3 -> bars at ~5x
+        assert denom == 0 and float(got.abs().sum()) == 0 or (agg <= GRAD_L1 and mx <= GRAD_MAX), \
+            f"{name}: gradient error L1-rel {agg} max-norm rel {mx}"
     for name, got_g, ref_g in (("origins", ray_grads["origins"], o_ref.grad), ("directions", ray_grads["directions"], d_ref.grad)):
         diff = (got_g.cpu() - ref_g).abs()
         scale = ref_g.abs().max().item()
         per_ray = diff.max(dim=1)[0]
         off = (per_ray > 1e-2 * scale).float().mean().item()
         print(f"[trained big] d loss / d {name}: max|ref| {scale:.3e} max_err {diff.max().item():.3e} rays off {off:.2%}")
-        assert off <= 0.08, name
+        assert off <= RAYS_OFF, name
+
+
+def _bundle_on_oracle_bins(hm, o, d, cam, oout, updated, anneal):
+    """A HIP RayBundle whose proposal sampling is replaced by the ORACLE's bins at every level (through the look-ahead
+    slot `presampled["ahead"]`, the mechanism TrainingSteps uses): the HIP proposal networks are evaluated on the
+    oracle's level-0 / level-1 bins, their weights are formed by the HIP weights kernel, the inverse-CDF bins it also
+    produces are thrown away in favour of the oracle's.  Both sides then differentiate the losses at IDENTICAL sample
+    positions, so what remains between their gradients is the arithmetic of the backward kernels alone."""
+    from fruitnerf_amd import _kernels as K
+    from fruitnerf_amd.rays import RayBundle
+    dev = o.device
+    cfg = hm.config
+    sampler = hm.proposal_sampler
+    n_prop = sampler.num_proposal_network_iterations
+    R = o.shape[0]
+    rb = hm._collide(RayBundle(o, d, None, cam))
+    rays = K.RaysArg(rb.origins, rb.directions, rb.nears, rb.fars, rb.camera_indices)
+    bins = [tuple(t.to(dev).contiguous() for t in _bins(rs)) for rs in oout["ray_samples_list"]]   # (euclid, spacing)
+    counts = list(sampler.num_proposal_samples_per_ray[:n_prop]) + [sampler.num_nerf_samples_per_ray]
+    zero = torch.zeros(R, device=dev)
+    levels = []
+    with torch.no_grad():
+        for i in range(n_prop):
+            net = hm.proposal_networks[i]
+            euclid, spacing = bins[i]
+            density, feats = K.prop_density_fwd(net.prop_struct(), net.warp_struct(), rays, euclid, counts[i],
+                                                save_feats=updated)
+            weights, depth, _, _ = K.weights_pdf(rays, 1, counts[i], counts[i + 1], density, spacing, euclid, anneal, zero)
+            levels.append(dict(S=counts[i], spacing=spacing, euclid=euclid, density=density, weights=weights, depth=depth,
+                               feats=feats))
+    pre = dict(S0=counts[0], jitter=[zero] * (n_prop + 1), spacing=bins[0][1], euclid=bins[0][0],
+               near=float(cfg.near_plane), far=float(cfg.far_plane),
+               ahead=dict(levels=levels, spacing=bins[-1][1], euclid=bins[-1][0], S=counts[-1], updated=updated,
+                          anneal=anneal))
+    return RayBundle(o, d, None, cam, presampled=pre)
+
+
+@pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
+def test_gradients_on_identical_samples_at_a_trained_state(dev, shape):
+    """The gradient leg of 'field + renderers on IDENTICAL samples' (VERDICT r03, weak #2): one training step (an
+    'updated' one: the proposal networks get gradients too) at the trained state, the oracle sampling for itself and the
+    HIP path differentiating at the oracle's bins.  Bar: every entry of every parameter gradient within 5e-4 of that
+    tensor's max |g| (the round-1 bar of the random-weight tests, now at sharp densities and saturated sigmoids), losses
+    and metrics to 1e-4 relative; the ray gradients (camera optimiser) are reported and held to 5e-3 of their max."""
+    from fruitnerf_amd.training import fused_forward_backward
+    hm, opt, batcher, ocfg, n_train, steps = _trained(dev, shape)
+    hm.train()
+    R = 768 if shape == "fruit_nerf" else 512
+    o, d, cam, batch = batcher.sample(R)
+    jit = [torch.rand(R, 1, device=dev) for _ in range(3)]
+    samp = hm.proposal_sampler
+    hm.set_anneal(steps)
+    samp._steps_since_update = 100
+    state = (samp._step, samp._steps_since_update)
+
+    om = _oracle_of(hm, ocfg, n_train)
+    om.train()
+    om.proposal_sampler._step, om.proposal_sampler._steps_since_update = state
+    om.set_anneal(steps)
+    o_ref, d_ref = o.cpu().clone().requires_grad_(True), d.cpu().clone().requires_grad_(True)
+    out = om(ns.RayBundle(o_ref, d_ref, torch.ones(R, 1), camera_indices=cam.cpu().long()), jitter=[j.cpu() for j in jit])
+    b = {k: v.cpu() for k, v in batch.items()}
+    ld_ref = om.get_loss_dict(out, b)
+    md_ref = om.get_metrics_dict(out, b)
+    sum(ld_ref.values()).backward()
+
+    assert samp.updated_now()
+    rb = _bundle_on_oracle_bins(hm, o, d, cam, out, True, samp._anneal)
+    hm.arena().grads.zero_()
+    used = hm.__dict__.get("_ahead_used", 0)
+    ray_grads = {}
+    ld, md = fused_forward_backward(hm, rb, batch, ray_grads=ray_grads)
+    torch.cuda.synchronize()
+    assert hm.__dict__.get("_ahead_used", 0) == used + 1, "the HIP pass did not run on the oracle's bins"
+    for k in ld_ref:
+        a, r = float(ld[k]), float(ld_ref[k])
+        print(f"[same samples {shape}] {k}: hip {a:.8e} oracle {r:.8e} rel {abs(a - r) / max(abs(r), 1e-12):.2e}")
+        assert abs(a - r) <= 1e-4 * max(abs(r), 1e-4), k
+    for k in md_ref:
+        a, r = float(md[k]), float(md_ref[k])
+        print(f"[same samples {shape}] {k}: hip {a:.8e} oracle {r:.8e}")
+        assert abs(a - r) <= 1e-4 * max(abs(r), 1e-3), k
+    named_h = dict(hm.named_parameters())
+    worst = ("", 0.0)
+    for name, p in om.named_parameters():
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        got = named_h[name].grad.detach().cpu()
+        scale = ref.abs().max().item()
+        mx = (got - ref).abs().max().item() / max(scale, 1e-30)
+        agg = (got - ref).abs().double().sum().item() / max(ref.abs().double().sum().item(), 1e-30)
+        print(f"[same samples {shape}] grad {name}: max|ref| {scale:.3e} max-norm rel {mx:.3e} L1-rel {agg:.3e}")
+        if scale == 0:
+            assert float(got.abs().sum()) == 0, name
+            continue
+        worst = max(worst, (name, mx), key=lambda t: t[1])
+        assert mx <= SAME_SAMPLES_GRAD, f"{name}: {mx:.3e} of max|g| on identical samples"
+    print(f"[same samples {shape}] worst gradient: {worst[0]} {worst[1]:.3e} of max|g| (bar {SAME_SAMPLES_GRAD:g})")
+    for name, got_g, ref_g in (("origins", ray_grads["origins"], o_ref.grad), ("directions", ray_grads["directions"], d_ref.grad)):
+        diff = (got_g.cpu() - ref_g).abs()
+        scale = ref_g.abs().max().item()
+        off = (diff.max(dim=1)[0] > 5e-3 * scale).float().mean().item()
+        print(f"[same samples {shape}] d loss / d {name}: max|ref| {scale:.3e} max_err {diff.max().item():.3e} "
+              f"({diff.max().item() / scale:.2e} of max) rays beyond 5e-3: {off:.2%}")
+        assert off <= RAYS_OFF, name
+    hm.arena().grads.zero_()

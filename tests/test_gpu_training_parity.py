@@ -874,28 +874,30 @@ def test_step_at_a_trained_state_matches_the_oracle(dev):
         # A sample within ~1e-4 of a cell face takes the neighbouring cell's slope (piecewise-linear encoding, see
         # tests/test_golden.py); at a trained state one such sample at a fine level (slope ~ 2048 x table value x d_feat,
         # times t for the direction) can exceed the whole ray's gradient.  A few rays may be off; the rest must match.
-        assert off <= 0.05 and agg <= 5e-2, name
+        assert off <= 5e-3 and agg <= 1e-2, name      # measured (round 3): 0.00 % of rays off, aggregate 9e-5
     for k in ld_ref:
         a, r = float(ld[k]), float(ld_ref[k])
         print(f"[trained state] {k}: hip {a:.8e} oracle {r:.8e}")
         # usually 6 digits; a PDF sample that lands on the other side of a sharp surface (sampler parity is 2e-6, the
         # trained density changes by orders of magnitude within 1e-4) moves one ray's output and the batch mean by ~1e-3
-        assert abs(a - r) <= 2e-2 * max(abs(r), 1e-4), k
+        assert abs(a - r) <= 1e-2 * max(abs(r), 1e-4), k   # measured (round 3): <= 2.5e-3
     for k in md_ref:
         a, r = float(md[k]), float(md_ref[k])
-        assert abs(a - r) <= 2e-2 * max(abs(r), 1e-3), k
+        assert abs(a - r) <= 1e-2 * max(abs(r), 1e-3), k
     _grad_report(om, hm, " trained state")
-    # The trained state differs from run to run (atomics order during the 2500 steps) and its gradients are sums of
-    # large cancelling terms: a few per cent of a small tensor's max is fp32 ordering noise.  Criterion per tensor:
-    # aggregate error sum|hip - oracle| / sum|oracle| <= 10 % (typically 1e-3; the failure this test guards against was
-    # a factor of 1000, and the well-conditioned parity bars live in the random-weight tests above).
+    # Training is bit-reproducible since round 3, so the trained state and these numbers are the same on every run of a
+    # build.  Criterion per tensor, at ~5x what round 3 measured (worst L1-rel 3.7e-4 / max-norm rel 9.4e-4 here, 2.5e-3 /
+    # 1.9e-3 over both trained-state replays, profiles/r03_raw): L1-rel <= 1e-2 AND max-norm rel <= 1e-2 — a kernel
+    # regression of 10x fails.  (The same-samples leg in tests/test_gpu_trained_state.py holds 5e-4 of max |g|.)
     named_h = dict(hm.named_parameters())
     for name, p in om.named_parameters():
         ref = p.grad if p.grad is not None else torch.zeros_like(p)
         got = named_h[name].grad.detach().cpu()
-        denom = ref.abs().sum().item()
-        agg = (got - ref).abs().sum().item() / max(denom, 1e-30)
-        assert denom == 0 and float(got.abs().sum()) == 0 or agg <= 1e-1, f"{name}: aggregate relative gradient error {agg}"
+        denom = ref.abs().double().sum().item()
+        agg = (got - ref).abs().double().sum().item() / max(denom, 1e-30)
+        mx = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert denom == 0 and float(got.abs().sum()) == 0 or (agg <= 1e-2 and mx <= 1e-2), \
+            f"{name}: gradient error L1-rel {agg} max-norm rel {mx}"
 
 
 def test_export_at_a_trained_state_matches_the_oracle(dev):
