@@ -6,10 +6,11 @@ only when `self.training`.  Bins are produced by fnr_sample_spaced.
 Behavioural note (pinned by tests/test_reference_pins.py): the reference builds this sampler inside
 `FruitModel.setup_inference` AFTER `eval_setup()` has put the pipeline in eval mode (scripts/exporter.py:86-94), so the
 new module is still in training mode and the reference's export jitters every bin edge with `torch.rand`
-(single_jitter=False -> t_rand [R, S+1]).  FruitModel.setup_inference here puts the sampler in the MODEL's mode (bin
-centres when evaluating): a deterministic lattice, which is what makes exported point counts reproducible.  The
-as-run behaviour is one call away — `model.proposal_sampler.train()` — and is reproduced exactly when the same jitter
-is supplied (`jitter_fn`; tests/test_gpu_reference_pins.py::test_hip_export_matches_the_reference_export_as_run).
+(single_jitter=False -> t_rand [R, S+1]).  `FruitModel.setup_inference` here does the same by default (round 4); the
+as-run export is reproduced exactly when the same jitter is supplied (`jitter_fn`;
+tests/test_gpu_reference_pins.py::test_hip_export_matches_the_reference_export_as_run).
+`setup_inference(..., deterministic=True)` puts the sampler in eval mode: bin centres, a deterministic lattice whose
+exported point counts are reproducible (and which the fused lattice kernels implement).
 """
 from __future__ import annotations
 

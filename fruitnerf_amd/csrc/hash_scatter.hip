@@ -144,6 +144,11 @@ __device__ __forceinline__ float run_sum(float v, const RunMasks& m) {
   return v;
 }
 
+// MEASURED SLOWER, NOT THE DEFAULT (round 4, same-box A/B, profiles/r04_raw/ab_emit.log: main-field scatter 194.5 -> 202.4 us,
+// 1 M-sample proposal call 91.6 -> 97.5 us with this form; 440 instead of 609 VALU instructions per pair, tools/isa_mix.py).
+// The static count was the wrong model: a DPP-modified VALU instruction does not issue at the plain rate, and the
+// compiler's mov_dpp + fma form interleaves the sixteen independent streams better than this fixed order.  Kept behind
+// -DFNR_EMIT_SCAN_FMAC for the record.
 // All sixteen value streams of a (sample, level) through the four gated steps as 64 v_fmac_f32 with a DPP-shifted source
 // (dst += shifted(dst) * gate; lanes without a source read 0): the compiler's form of the same arithmetic is
 // mov_dpp + fma per step (GCNDPPCombine does not fold a DPP move into v_fmac here).  Inline assembly is outside the
@@ -321,7 +326,9 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       vxk[q][k] = valid ? wgt[k] * gf.x : 0.0f;
       vyk[q][k] = valid ? wgt[k] * gf.y : 0.0f;
     }
-#ifdef FNR_EMIT_SCAN_SELECT   // A/B builds (tools/build_variant.sh): the compiler's mov_dpp + fma form of the same sums
+#ifdef FNR_EMIT_SCAN_FMAC   // A/B builds (tools/build_variant.sh): 64 hand-placed v_fmac_f32_dpp, see run_sums16
+    if (rm.any_run) run_sums16(vxk[q], vyk[q], rm);
+#else
     if (rm.any_run) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -329,8 +336,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
         vyk[q][k] = run_sum(vyk[q][k], rm);
       }
     }
-#else
-    if (rm.any_run) run_sums16(vxk[q], vyk[q], rm);
 #endif
 #ifdef FNR_EMIT_TIMING
     {

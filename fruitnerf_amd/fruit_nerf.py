@@ -212,6 +212,11 @@ class FruitModel(nn.Module):
         assert "semantics" in metadata.keys() and hasattr(metadata["semantics"], "colors"), \
             'FruitModel needs metadata["semantics"] (nerfstudio Semantics: filenames, classes, colors, mask_classes)'
         self.semantics = metadata["semantics"]
+        # the Trainer's GradScaler (fruit_pipeline.py:109; enabled under mixed_precision=True, fruit_nerf_config.py:33).
+        # The kernels compute in fp32 and the fused loop never scales its loss; a host that does scale
+        # (`grad_scaler.scale(loss).backward()`) gets correctly scaled gradients from the autograd path and steps
+        # FusedAdam through training.scaler_step(optimizer, grad_scaler) (unscale inside the Adam kernel, skip on inf).
+        self.grad_scaler = grad_scaler
         self.test_mode = test_mode
         self.config = config
         self.num_train_data = num_train_data
@@ -296,11 +301,19 @@ class FruitModel(nn.Module):
         return self._arena
 
     # ---- reference API -------------------------------------------------------------------------------------
-    def setup_inference(self, render_rgb, num_inference_samples):  # fruit_nerf.py:179-183
+    def setup_inference(self, render_rgb, num_inference_samples, deterministic: bool = False):
+        """fruit_nerf.py:179-183.  The default is the reference AS IT RUNS: the exporter calls eval_setup() first
+        (scripts/exporter.py:86-94) and only then setup_inference(), which builds a fresh UniformSamplerWithNoise — a new
+        nn.Module is in training mode, so the export jitters every bin edge with torch.rand (ray_samplers.py:79-87) and
+        the exported point sets depend on the RNG stream (reproduced exactly given the same numbers: `jitter_fn`,
+        tests/test_gpu_reference_pins.py::test_hip_export_matches_the_reference_export_as_run).
+        deterministic=True: the sampler is put in eval mode (bin centres) — the lattice for which "identical exported
+        point counts" is a meaningful bar, and the one the fused lattice kernels (fnr_hash_encode_lattice) implement."""
         self.render_rgb = render_rgb
         self.num_inference_samples = num_inference_samples
         self.proposal_sampler = UniformSamplerWithNoise(num_samples=self.num_inference_samples, single_jitter=False)
-        self.proposal_sampler.train(self.training)
+        if deterministic:
+            self.proposal_sampler.eval()
         self.field.spatial_distortion = None
 
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:  # fruit_nerf.py:185-189

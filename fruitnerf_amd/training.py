@@ -481,6 +481,35 @@ class FusedAdam:
                               self.betas[0], self.betas[1], self.eps, grad_scale, True, weight_decay=self.weight_decay)
 
 
+def scaler_step(optimizer: "FusedAdam", grad_scaler, skip=(), done=()) -> bool:
+    """`grad_scaler.step(optimizer)` for FusedAdam (Nerfstudio's Trainer, mixed_precision=True:
+    `grad_scaler.scale(loss).backward()` -> `optimizers.optimizer_scaler_step_all(grad_scaler)` -> `grad_scaler.update()`,
+    fruit_nerf_config.py:33, fruit_pipeline.py:109).  A scaled loss reaches the arena as scaled gradients (the autograd
+    Functions multiply by their upstream gradient), so the step unscales inside the Adam kernel (grad_scale = 1 / scale)
+    and, as torch.amp.GradScaler does, is skipped altogether when a gradient is not finite; the inf check is recorded
+    with the scaler so that its own `update()` grows / backs off the scale.  -> whether the step was taken.
+    The HIP kernels compute in fp32, so loss scaling protects nothing here — it is honoured, not needed; the fused loop
+    (fused_train_iteration) never scales."""
+    if grad_scaler is None or not grad_scaler.is_enabled():
+        optimizer.step(skip=skip, done=done)
+        return True
+    grads = optimizer.arena.grads
+    scale = float(grad_scaler.get_scale())                      # host sync, like GradScaler.step's found_inf.item()
+    found_inf = (~torch.isfinite(grads).all()).to(torch.float32).reshape(1)
+    try:   # what GradScaler.unscale_ / step record per optimiser, so that update() sees this inf check
+        from torch.amp.grad_scaler import OptState
+        state = grad_scaler._per_optimizer_states[id(optimizer)]
+        state["found_inf_per_device"] = {grads.device: found_inf}
+        state["stage"] = OptState.STEPPED
+    except Exception as exc:   # pragma: no cover - a torch version with another GradScaler layout
+        raise RuntimeError("FusedAdam cannot record its inf check with this torch.amp.GradScaler: " + repr(exc))
+    if bool(found_inf.item()):
+        optimizer.arena.zero_grad()                             # the step is skipped; scheduler ticks are the Trainer's
+        return False
+    optimizer.step(grad_scale=1.0 / scale, skip=skip, done=done)
+    return True
+
+
 def skipped_groups(model, optimizer: Optional["FusedAdam"] = None) -> tuple:
     """Parameter groups that got no gradient in the last training render (the proposal networks on steps that did not
     'update' them) — empty when the optimiser steps such groups anyway (FusedAdam.skip_groups_without_grad=False)."""
@@ -532,16 +561,27 @@ def sync_gradients(arena, world_size: int) -> float:
 
 
 def train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, world_size: int = 1,
-                    jitter: Optional[List[Tensor]] = None, want_metrics: bool = True):
-    """One Trainer.train_iteration for the hot path."""
+                    jitter: Optional[List[Tensor]] = None, want_metrics: bool = True, grad_scaler=None):
+    """One Trainer.train_iteration for the hot path.  grad_scaler (default: the one the model was
+    constructed with, fruit_pipeline.py:109): the loss is scaled before backward and the optimiser step goes through
+    scaler_step(), as Nerfstudio's Trainer does under mixed_precision=True."""
+    if grad_scaler is None:
+        grad_scaler = getattr(model, "grad_scaler", None)
+    scaling = grad_scaler is not None and grad_scaler.is_enabled()
     model.set_anneal(step)                                     # BEFORE_TRAIN_ITERATION callback
     outputs = model(ray_bundle, jitter=jitter)
     metrics_dict = model.get_metrics_dict(outputs, batch) if want_metrics else {}
     loss_dict = model.get_loss_dict(outputs, batch, metrics_dict)
     loss = sum(loss_dict.values())                             # functools.reduce(torch.add, loss_dict.values())
-    loss.backward()
+    (grad_scaler.scale(loss) if scaling else loss).backward()
     scale = sync_gradients(model.arena(), world_size)
-    optimizer.step(grad_scale=scale, skip=skipped_groups(model, optimizer))
+    if scaling:
+        if world_size >= EXCHANGE_MIN_WORLD:
+            raise NotImplementedError("loss scaling with the gradient exchange: use the fused loop (it never scales)")
+        scaler_step(optimizer, grad_scaler, skip=skipped_groups(model, optimizer))
+        grad_scaler.update()
+    else:
+        optimizer.step(grad_scale=scale, skip=skipped_groups(model, optimizer))
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
 
@@ -1056,7 +1096,7 @@ class TrainingSteps:
         self._next = None
         step = self.step_idx
 
-        launch_stream = torch.cuda.current_stream(self.model.device)
+        launch_stream = torch.cuda.current_stream(self.model.device) if STREAM_SAFE else None
 
         def ahead():
             # On the second stream these tensors come from ITS allocator pool and are consumed on the launch stream by
@@ -1068,7 +1108,8 @@ class TrainingSteps:
             # that structure; FNR_STREAM_SAFE=1 registers the tensors with the allocator as well).
             self._next = (step + 1,) + self._draw(step)
             self._next_version = self._outside_version()
-            crosses_to(launch_stream, self._next, self.batcher.last_draw, getattr(self.batcher, "last_presample", None))
+            crosses_to(launch_stream, self._next, getattr(self.batcher, "last_draw", None),
+                       getattr(self.batcher, "last_presample", None))
 
         out = fused_train_iteration(self.model, self.optimizer, rb, batch, step, world_size=self.world_size,
                                     want_metrics=want_metrics, camera=self.camera,

@@ -25,7 +25,7 @@ em = FruitModel(copy.deepcopy(hm.config), apple_metadata(), num_train_data=n_tra
 em.load_state_dict(hm.state_dict(), strict=True); em.eval()
 class P: pass
 pipe = P(); pipe.model = em; pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=4096)
-em.setup_inference(True, N)
+em.setup_inference(True, N, deterministic=True)
 aabb = ((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5))
 n_rays = pipe.datamanager.setup_inference(aabb=aabb, num_points=N)
 got = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})

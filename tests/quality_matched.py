@@ -167,7 +167,7 @@ def main():
                 pass
             pipe = _Pipe()
             pipe.model, pipe.datamanager = em, ExportDataManager(dev, eval_num_rays_per_batch=32768)
-            em.setup_inference(True, N_EXP)
+            em.setup_inference(True, N_EXP, deterministic=True)
             n_rays = pipe.datamanager.setup_inference(aabb=aabb, num_points=N_EXP)
             sets = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})
             pts = sets["semantic"]["points"]

@@ -262,7 +262,7 @@ def test_export_counts_and_points_identical(dev, shape):
         pipe = Pipe()
         pipe.model = hm
         pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=333)
-        hm.setup_inference(True, N)
+        hm.setup_inference(True, N, deterministic=True)
         num_rays = pipe.datamanager.setup_inference(aabb=aabb, num_points=N)
         if not fused:
             pipe.datamanager.export_lattice = None

@@ -241,7 +241,7 @@ def test_export_is_invariant_to_the_ray_batch_size(dev, fused):
         pipe = Pipe()
         pipe.model = m
         pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=per_batch)
-        m.setup_inference(True, N)
+        m.setup_inference(True, N, deterministic=True)
         n_rays = pipe.datamanager.setup_inference(aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), num_points=N)
         if not fused:
             pipe.datamanager.export_lattice = None

@@ -311,7 +311,11 @@ def test_gradients_on_identical_samples_at_a_trained_state(dev, shape):
     for k in ld_ref:
         a, r = float(ld[k]), float(ld_ref[k])
         print(f"[same samples {shape}] {k}: hip {a:.8e} oracle {r:.8e} rel {abs(a - r) / max(abs(r), 1e-12):.2e}")
-        assert abs(a - r) <= 1e-4 * max(abs(r), 1e-4), k
+        # 1e-4 relative + 5e-8 absolute: at a trained state the semantic loss is a MEAN of 6e-7 .. 6e-5 over rays whose
+        # logits sit at +-15 .. 30, where the two BCE-with-logits formulas (torch: (1 - z) x + m + log(e^-m + e^(-x-m));
+        # HIP: max(x, 0) - x z + log1p(e^-|x|)) round intermediates of size |x|: ~1e-6 per saturated ray (measured
+        # round 4: |hip - oracle| = 1.2e-8 .. 1.7e-8 on the mean, rgb and interlevel losses 3e-7 .. 5e-7 relative)
+        assert abs(a - r) <= 1e-4 * abs(r) + 5e-8, k
     for k in md_ref:
         a, r = float(md[k]), float(md_ref[k])
         print(f"[same samples {shape}] {k}: hip {a:.8e} oracle {r:.8e}")

@@ -934,7 +934,7 @@ def test_export_at_a_trained_state_matches_the_oracle(dev):
     pipe = Pipe()
     pipe.model = em
     pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=1000)
-    em.setup_inference(True, N)
+    em.setup_inference(True, N, deterministic=True)
     aabb = ((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5))
     n_rays = pipe.datamanager.setup_inference(aabb=aabb, num_points=N)
     got = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})

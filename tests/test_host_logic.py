@@ -536,3 +536,93 @@ def test_lookahead_is_ordered_after_the_proposal_networks_step(monkeypatch):
     assert run(updated=True, skip=False) == inside            # ... but a fused step is a fused step
     assert run(updated=True, fuse_weights=False) == after     # unfused: optimizer.step() takes the networks' step
     assert run(updated=False, fuse_weights=False) == inside
+
+
+def test_method_config_entry_points_resolve_and_match_the_reference_table():
+    """pyproject.toml's `nerfstudio.method_configs` entry points (reference pyproject.toml:24-27) name objects that exist
+    in fruitnerf_amd.fruit_nerf_config, and the three method tables carry the reference's hyper-parameters
+    (fruit_nerf_config.py:27-164): batch sizes, iteration counts, optimisers + schedulers per group, camera optimiser,
+    the model fields FruitModel forwards to FruitField."""
+    import importlib
+    import os
+    import tomli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "pyproject.toml"), "rb") as f:
+        proj = tomli.load(f)
+    eps = proj["project"]["entry-points"]["nerfstudio.method_configs"]
+    assert sorted(eps) == ["fruit_nerf", "fruit_nerf_big", "fruit_nerf_huge"]
+    for method, target in eps.items():
+        mod, attr = target.split(":")
+        spec = getattr(importlib.import_module(mod), attr)
+        cfg = spec.config
+        name = cfg["method_name"] if isinstance(cfg, dict) else cfg.method_name
+        assert name == method
+        assert spec.description.startswith("Base config for FruitNeRF")
+    from fruitnerf_amd import fruit_nerf_config as FC
+    base, big, huge = (FC.METHODS[k] for k in ("fruit_nerf", "fruit_nerf_big", "fruit_nerf_huge"))
+    assert [m["datamanager"]["train_num_rays_per_batch"] for m in (base, big, huge)] == [4096, 8192, 16384]
+    assert [m["trainer"]["max_num_iterations"] for m in (base, big, huge)] == [30000, 100000, 100000]
+    assert all(m["trainer"]["mixed_precision"] for m in (base, big, huge))
+    assert base["optimizers"]["fields"] == dict(algorithm="adam", lr=1e-2, eps=1e-15,
+                                                scheduler=dict(kind="exponential_decay", lr_final=1e-4, max_steps=200000))
+    assert big["optimizers"]["proposal_networks"] == dict(algorithm="radam", lr=1e-2, eps=1e-15, scheduler=None)
+    assert big["optimizers"]["fields"]["scheduler"]["max_steps"] == 50000
+    assert base["camera_optimizer"]["weight_decay"] == 1e-2 and big["camera_optimizer"]["weight_decay"] == 1e-3
+    assert big["camera_optimizer"]["scheduler"] is None and huge["camera_optimizer"]["scheduler"]["lr_final"] == 6e-5
+    mc = FC.model_config("fruit_nerf_big")
+    assert (mc.num_nerf_samples_per_ray, mc.num_proposal_samples_per_ray, mc.geo_feat_dim, mc.hidden_dim_semantics,
+            mc.num_layers_semantic, mc.max_res, mc.log2_hashmap_size, mc.proposal_weights_anneal_max_num_iters) == \
+        (128, (512, 256), 30, 128, 3, 4096, 21, 5000)
+    mh = FC.model_config("fruit_nerf_huge")
+    assert [a["num_levels"] for a in mh.proposal_net_args_list] == [5, 7] and mh.max_res == 8192
+    assert FC.model_config("fruit_nerf").max_res == 2048 and FC.model_config("fruit_nerf").eval_num_rays_per_chunk == 1 << 15
+    # bench.py reads its method table from here
+    import bench
+    assert bench.METHODS["fruit_nerf_big"]["groups"] == FC.group_schedules("fruit_nerf_big")
+    assert bench.METHODS["fruit_nerf"]["rays"] == 4096 and bench.METHODS["fruit_nerf_huge"]["samples"] == (512, 512, 64)
+
+
+def test_scaler_step_unscales_skips_on_inf_and_feeds_the_scalers_update():
+    """training.scaler_step: what `grad_scaler.step(optimizer)` means for FusedAdam — gradients of a scaled loss are
+    unscaled inside the step (grad_scale = 1 / scale), a non-finite gradient skips the step and zeroes the gradients, and
+    the inf check is visible to GradScaler.update() (scale backs off after an inf, grows after `growth_interval` clean
+    steps)."""
+    import torch
+    import fruitnerf_amd.training as T
+
+    class Arena:
+        def __init__(self):
+            self.grads = torch.zeros(8)
+
+        def zero_grad(self):
+            self.grads.zero_()
+
+    class Opt:
+        def __init__(self):
+            self.arena = Arena()
+            self.calls = []
+
+        def step(self, grad_scale=1.0, skip=(), done=()):
+            self.calls.append((grad_scale, tuple(skip)))
+
+    opt = Opt()
+    assert T.scaler_step(opt, None, skip=("proposal_networks",)) and opt.calls == [(1.0, ("proposal_networks",))]
+    scaler = torch.amp.GradScaler("cpu", init_scale=1024.0, growth_interval=2)
+    loss = torch.ones(1, requires_grad=True).sum()
+    scaler.scale(loss)                        # initialises the scale tensor, as a Trainer's scale(loss).backward() does
+    opt.arena.grads.fill_(1024.0)
+    assert T.scaler_step(opt, scaler)
+    assert opt.calls[-1] == (1.0 / 1024.0, ())
+    scaler.update()
+    assert scaler.get_scale() == 1024.0
+    opt.arena.grads[3] = float("inf")
+    n = len(opt.calls)
+    assert not T.scaler_step(opt, scaler)
+    assert len(opt.calls) == n and float(opt.arena.grads.abs().sum()) == 0.0
+    scaler.update()
+    assert scaler.get_scale() == 512.0       # backoff_factor 0.5
+    for _ in range(2):
+        opt.arena.grads.fill_(1.0)
+        assert T.scaler_step(opt, scaler)
+        scaler.update()
+    assert scaler.get_scale() == 1024.0      # growth after growth_interval clean steps

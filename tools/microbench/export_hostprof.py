@@ -11,7 +11,7 @@ N = 256
 m = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev, test_mode="export"); m.eval()
 class P: pass
 pipe = P(); pipe.model = m; pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=32768)
-m.setup_inference(True, N)
+m.setup_inference(True, N, deterministic=True)
 for it in range(10):
     n_rays = pipe.datamanager.setup_inference(aabb=((-1., -1., -1.), (1., 1., 1.)), num_points=N)
     pr = cProfile.Profile()

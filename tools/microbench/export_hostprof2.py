@@ -18,7 +18,7 @@ N = 256
 m = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev, test_mode="export"); m.eval()
 class P: pass
 pipe = P(); pipe.model = m; pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=32768)
-m.setup_inference(True, N)
+m.setup_inference(True, N, deterministic=True)
 marks = []
 side = torch.cuda.Stream()
 orig_read, orig_compact = E._read_counts, E.K.export_compact

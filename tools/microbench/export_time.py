@@ -16,7 +16,7 @@ passes = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 m = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=90, device=dev, test_mode="export"); m.eval()
 class P: pass
 pipe = P(); pipe.model = m; pipe.datamanager = ExportDataManager(dev, eval_num_rays_per_batch=32768)
-m.setup_inference(True, N)
+m.setup_inference(True, N, deterministic=True)
 gc_runs = []
 gc.callbacks.append(lambda phase, info: gc_runs.append((phase, info["generation"])) if phase == "stop" else None)
 for it in range(passes):
