@@ -254,6 +254,38 @@ def counting_stage_bench(dev, cpu: bool):
     return out
 
 
+def count_fruits_end_to_end(emodel, pipe, sample_volume, scene, dev, n_side: int = 512):
+    """The reference's whole counting pipeline on the trained field: bin-centre export of an n_side^3 lattice, then
+    Clustering.count = cluster (GPU: radius-outlier removal, voxel down-sampling, DBSCAN) -> merge_small_clusters ->
+    split_large_cluster (alpha-shape volume test against a sphere template of the scene's mean fruit radius, ICP / Ward
+    hypotheses scored by Hausdorff distance), scored against the scene's fruit centres (clustering_base.py:463-509).
+    Front-end parameters scale with the lattice pitch as in the first-stage count."""
+    from fruitnerf_amd.clustering import Clustering, PointCloud
+    t0 = time.perf_counter()
+    emodel.setup_inference(True, n_side, deterministic=True)
+    n_rays = pipe.datamanager.setup_inference(aabb=((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), num_points=n_side)
+    sets = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})
+    pts = sets["semantic"]["points"]
+    t_export = time.perf_counter() - t0
+    if pts.shape[0] < 5:
+        return None
+    pitch = 2.0 / n_side * 2.0
+    fruit = scene.is_fruit.cpu().numpy()
+    centres = scene.centers.cpu().numpy()[fruit].astype(np.float64) * 2.0          # export coordinates: x2 (exporter_utils.py:190-191)
+    radius = float(scene.radii.cpu().numpy()[fruit].mean()) * 2.0
+    cl = Clustering(template_path=None, voxel_size_down_sample=pitch / 4, remove_outliers_nb_points=2,
+                    remove_outliers_radius=1.8 * pitch, min_samples=4, apple_template_size=1.0,
+                    cluster_merge_distance=0.04, gt_cluster=centres, gt_count=int(scene.n_fruits), template_radius=radius)
+    t1 = time.perf_counter()
+    count = cl.count(PointCloud(pts, None, dev), eps=1.8 * pitch)
+    return {"count": int(count), "first_stage": int(cl.counter - cl.fuse_counter), "additional": int(cl.additional_count),
+            "pruned": int(cl.prune_counter), "true_positive": int(cl.true_positive), "false_positive": int(cl.false_positive),
+            "false_negative": int(cl.false_negative), "precision": round(cl.precision, 4), "recall": round(cl.recall, 4),
+            "F1": round(cl.F1, 4), "scene_fruits": int(scene.n_fruits), "lattice": f"{n_side}^3",
+            "semantic_points": int(pts.shape[0]), "template": f"sphere, radius {radius:.4f} (mean fruit radius x 2)",
+            "export_s": round(t_export, 3), "counting_s": round(time.perf_counter() - t1, 3)}
+
+
 class MethodRun:
     """Model + optimisers + camera optimiser + pixel batcher of one reference method on the shared synthetic scene."""
 
@@ -700,6 +732,10 @@ def main() -> None:
             fc = FruitClustering(voxel_size_down_sample=spacing / 4, remove_outliers_nb_points=2,
                                  remove_outliers_radius=1.8 * spacing, cluster_merge_distance=0.04)
             fruit_count = fc.first_stage_count(PointCloud(pts, None, dev), eps=1.8 * spacing, min_samples=4)
+        # the END-TO-END count (BASELINE config 5, clustering_base.py:513-538): export -> cluster -> merge_small_clusters
+        # -> split_large_cluster on a 512^3 lattice (the second stage's alpha = 100 surface needs points closer than
+        # ~0.01: the reference's clouds sit on a 1 mm voxel grid, a 256^3 lattice has a pitch of 0.0156)
+        full_count = count_fruits_end_to_end(emodel, pipe, sample_volume, scene, dev, n_side=512)
         counting = counting_stage_bench(dev, cpu=not args.no_cpu_baseline)
         secondary = {"train_rays_per_s_by_proposal_backward_stream": overlap_modes,
                      "train_rays_per_s_by_mlp_precision": mlp_modes,
@@ -713,8 +749,9 @@ def main() -> None:
                                       "per-batch D2H of the point lists)",
                      "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()},
                      "fruit_count_first_stage_on_semantic_export": fruit_count, "fruit_count_scene": scene.n_fruits,
-                     "counting_front_end": counting}
-        if quality is not None:   # the north star's count gate: first-stage count of the exported semantic set vs the scene
+                     "fruit_count_end_to_end": full_count, "counting_front_end": counting}
+        if quality is not None:   # the north star's count gate: the counting stage's result on the exported semantic set
+            quality["fruit_count"] = None if full_count is None else full_count["count"]
             quality["fruit_count_first_stage"] = fruit_count
             quality["fruit_count_scene"] = scene.n_fruits
         model.train()

@@ -664,6 +664,39 @@ def cloud_voxel_down_sample(xyz: Tensor, rgb: Optional[Tensor], voxel_size: floa
     return xyz_out[:m], (None if rgb_out is None else rgb_out[:m])
 
 
+# ---- eval-image metrics ------------------------------------------------------------------------------
+
+
+_GAUSS11 = None
+
+
+def ssim_window() -> "C.Array":
+    """The 11 float32 weights of torchmetrics' default SSIM window (gaussian, sigma 1.5), evaluated with torch on the
+    host exactly as torchmetrics.functional.image.helper._gaussian does (arange((1 - k) / 2, (1 + k) / 2), exp, / sum)."""
+    global _GAUSS11
+    if _GAUSS11 is None:
+        dist = torch.arange((1 - 11) / 2, (1 + 11) / 2, 1, dtype=torch.float32)
+        g = torch.exp(-torch.pow(dist / 1.5, 2) / 2)
+        _GAUSS11 = (C.c_float * 11)(*(g / g.sum()).tolist())
+    return _GAUSS11
+
+
+def image_metrics(rgb: Tensor, image: Tensor, semantics: Optional[Tensor] = None, mask: Optional[Tensor] = None) -> Tensor:
+    """fnr_image_metrics on [H,W,3] images (+ [H,W] logits / mask) -> 8 doubles on the device (see the header)."""
+    lib = L.load()
+    L.require_gpu_tensor(rgb, "rgb")
+    H, W = int(rgb.shape[0]), int(rgb.shape[1])
+    rgb, image = _f32c(rgb), _f32c(image)
+    sem = None if semantics is None else _f32c(semantics.reshape(H, W))
+    msk = None if mask is None else _f32c(mask.reshape(H, W))
+    out = torch.empty(8, dtype=torch.float64, device=rgb.device)
+    nbytes = lib.fnr_image_metrics_workspace_bytes(H, W)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=rgb.device)
+    L.check(lib.fnr_image_metrics(H, W, L.ptr(rgb), L.ptr(image), L.ptr(sem), L.ptr(msk), ssim_window(), L.ptr(out),
+                                  L.ptr(ws), ws.numel(), L.stream_ptr(rgb.device)), "image_metrics")
+    return out
+
+
 # ---- caller side -------------------------------------------------------------------------------------
 
 

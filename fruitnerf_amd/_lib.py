@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FNR_LIB_PATH") or os.path.join(_HERE, "lib", "libfrui
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 8      # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 9      # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -159,6 +159,8 @@ SIGNATURES = {
     "fnr_camera_pose_grad": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_camera_pose_grad_adam": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, P(fnr_table_adam),
                                        _vp]),
+    "fnr_image_metrics_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "fnr_image_metrics": (_i, [_i, _i, _vp, _vp, _vp, _vp, P(C.c_float), _vp, _vp, C.c_size_t, _vp]),
     "fnr_export_workspace_bytes": (C.c_size_t, [_i64]),
     "fnr_export_compact": (_i, [P(fnr_lattice), _i64, _i64, _vp, _i64, _vp, _vp, _vp, P(_vp), P(_vp), _i64, _vp, _vp,
                                 _vp]),

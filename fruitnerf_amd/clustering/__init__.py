@@ -1,2 +1,2 @@
-"""Front-end of the fruit counting stage (reference: /root/reference/clustering/clustering_base.py:118-258)."""
-from .clustering_base import FruitClustering, PointCloud  # noqa: F401
+"""The fruit counting stage (reference: /root/reference/clustering/clustering_base.py, run_clustering.py)."""
+from .clustering_base import Clustering, FruitClustering, PointCloud  # noqa: F401

@@ -177,27 +177,6 @@ class RenderContext:
     ray_bundle: Optional[object] = None   # the caller's RayBundle (its origins / directions may carry autograd history)
 
 
-def _ssim(a: Tensor, b: Tensor, sigma: float = 1.5, ksize: int = 11, k1: float = 0.01, k2: float = 0.03) -> Tensor:
-    """torchmetrics.functional.structural_similarity_index_measure defaults (gaussian 11x11, sigma 1.5,
-    data_range 1.0): reflect-pad by 5, depthwise gaussian filtering of a, b, a^2, b^2, ab, SSIM map cropped by the
-    pad, mean.  a, b: [1, C, H, W] in [0, 1]."""
-    C_ = a.shape[1]
-    dist = torch.arange((1 - ksize) / 2, (1 + ksize) / 2, 1, device=a.device, dtype=a.dtype)
-    g = torch.exp(-((dist / sigma) ** 2) / 2)
-    g = (g / g.sum())[:, None]
-    kernel = (g @ g.t())[None, None].expand(C_, 1, ksize, ksize)
-    pad = (ksize - 1) // 2
-    ap = torch.nn.functional.pad(a, (pad, pad, pad, pad), mode="reflect")
-    bp = torch.nn.functional.pad(b, (pad, pad, pad, pad), mode="reflect")
-    stack = torch.cat([ap, bp, ap * ap, bp * bp, ap * bp])
-    out = torch.nn.functional.conv2d(stack, kernel, groups=C_)
-    mu_a, mu_b, e_aa, e_bb, e_ab = out.split(a.shape[0])
-    c1, c2 = k1 ** 2, k2 ** 2
-    s_aa, s_bb, s_ab = e_aa - mu_a * mu_a, e_bb - mu_b * mu_b, e_ab - mu_a * mu_b
-    ssim = ((2 * mu_a * mu_b + c1) * (2 * s_ab + c2)) / ((mu_a * mu_a + mu_b * mu_b + c1) * (s_aa + s_bb + c2))
-    return ssim[..., pad:-pad, pad:-pad].mean()
-
-
 class FruitModel(nn.Module):
     config: FruitNerfModelConfig
 
@@ -645,42 +624,38 @@ class FruitModel(nn.Module):
 
     @torch.no_grad()
     def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
-        """fruit_nerf.py:403-458 (eval images; not the hot path — plain torch ops on the model's device).
+        """fruit_nerf.py:403-458 on the device: one entry point (fnr_image_metrics, csrc/image_metrics.hip) for everything
+        the reference computes with torchmetrics, no per-metric torch launches and ONE host read of eight sums.
 
         PSNR and SSIM (torchmetrics defaults: 11x11 gaussian, sigma 1.5, data_range 1) and the reference's IoU
         (fruit_nerf.py:449-453): `F.softmax(outputs["semantics"])` WITHOUT a dim on the [H,W,1] map — torch's legacy
         implicit dim for a 3-D tensor is 0, so the softmax runs over image ROWS, every value is ~1/H < 0.5, and
         BinaryJaccardIndex (threshold 0.5) sees an all-False prediction: "iou" is ~0 whatever the model learned.
         Reproduced as is under "iou"; "iou_sigmoid" additionally reports the meaningful sigmoid(semantics) > 0.5 IoU.
+        Pinned against the float64 restatement oracle/image_metrics.py (tests/test_gpu_properties.py).
         Not built: LPIPS (needs pretrained weights; reported as nan) and the matplotlib colormaps of
         nerfstudio.utils.colormaps (accumulation / depth images are returned as raw single-channel maps)."""
         dev = self.device
         image = batch["image"].to(dev)
-        rgb = torch.clamp(outputs["rgb"].to(dev), min=0, max=1)
+        raw_rgb = outputs["rgb"].to(dev)
+        rgb = torch.clamp(raw_rgb, min=0, max=1)
         acc = outputs["accumulation"].to(dev)
         depth = outputs["depth"].to(dev)
         images_dict = {"img": torch.cat([image, rgb], dim=1), "accumulation": acc, "depth": depth}
-        img_c = torch.moveaxis(image, -1, 0)[None, ...]
-        rgb_c = torch.moveaxis(rgb, -1, 0)[None, ...]
-        mse = torch.mean((img_c - rgb_c) ** 2)
-        psnr = -10.0 * torch.log10(mse)
-        metrics_dict = {"psnr": float(psnr.item()), "ssim": float(_ssim(img_c, rgb_c)), "lpips": float("nan")}
         for i in range(self.config.num_proposal_iterations):
             images_dict[f"prop_depth_{i}"] = outputs[f"prop_depth_{i}"].to(dev)
-        images_dict["semantics_colormap"] = torch.sigmoid(outputs["semantics"].to(dev))
+        sem = outputs["semantics"].to(dev)
+        images_dict["semantics_colormap"] = torch.sigmoid(sem)
         mask = batch["fruit_mask"].to(dev)
         images_dict["fruit_mask"] = mask.repeat(1, 1, 3)
-        sem = outputs["semantics"].to(dev)
-        tgt = mask[..., 0] > 0.5
-
-        def jaccard(pred):
-            inter = (pred & tgt).sum().float()
-            union = (pred | tgt).sum().float()
-            return float((inter / union.clamp_min(1.0)).item())   # torchmetrics: 0 when the union is empty
-
-        implicit_dim = 0 if sem.dim() in (0, 1, 3) else 1        # torch.nn.functional._get_softmax_dim
-        metrics_dict["iou"] = jaccard(torch.softmax(sem, dim=implicit_dim)[..., 0] > 0.5)
-        metrics_dict["iou_sigmoid"] = jaccard(torch.sigmoid(sem)[..., 0] > 0.5)
+        if sem.dim() != 3 or sem.shape[-1] != 1:
+            raise ValueError("get_image_metrics_and_images expects the [H, W, 1] semantics map of a full-image render")
+        sums = K.image_metrics(raw_rgb, image, sem[..., 0], mask[..., 0]).tolist()   # the one device -> host read
+        sse, ssim_sum, inter_sig, union_sig, inter_row, union_row, n_ssim, n_sse = sums
+        metrics_dict = {"psnr": float(-10.0 * np.log10(sse / n_sse)), "ssim": float(ssim_sum / n_ssim),
+                        "lpips": float("nan"),
+                        "iou": float(inter_row / max(union_row, 1.0)),     # torchmetrics: 0 when the union is empty
+                        "iou_sigmoid": float(inter_sig / max(union_sig, 1.0))}
         return metrics_dict, images_dict
 
     # ---- losses / metrics ----------------------------------------------------------------------------------------

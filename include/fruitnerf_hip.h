@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 8
+#define FNR_ABI_VERSION 9
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -558,6 +558,23 @@ int fnr_cloud_dbscan(const double* xyz, int64_t n, const double* lo, const doubl
 int fnr_cloud_voxel_down_sample(const double* xyz, const double* rgb, int64_t n, const double* min_bound,
                                 const double* max_bound, double voxel_size, double* xyz_out, double* rgb_out,
                                 int32_t* n_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- eval-image metrics ------------------------------------------------------------------------ */
+/* FruitModel.get_image_metrics_and_images (fruit_nerf/fruit_nerf.py:403-458) on the device: everything the reference
+ * computes with torchmetrics on a rendered [H, W, 3] image, as raw sums (the host forms the four ratios):
+ *   PSNR(data_range 1, :427): squared error of clamp(rgb, 0, 1) (:408) against the image;
+ *   SSIM (:428; torchmetrics defaults: 11 x 11 gaussian, sigma 1.5, k1 0.01, k2 0.03): the mean over the
+ *        (H - 10) x (W - 10) x 3 interior values of the valid-window SSIM map (torchmetrics pads by 5 and crops the
+ *        padded border away again); gauss11: HOST array of the 11 normalised float32 window weights;
+ *   IoU  (:449-453): BinaryJaccardIndex(threshold 0.5) of `F.softmax(semantics)` — no dim given: on the [H, W, 1] map
+ *        torch's implicit dim is 0, a softmax over image ROWS — and of sigmoid(semantics), each against mask > 0.5.
+ * rgb / image: [H][W][3]; semantics (logits) / mask: [H][W], nullable together.
+ * out: 8 doubles (device) = { squared error, SSIM sum, intersection | union of sigmoid > 0.5, intersection | union of the
+ * row softmax > 0.5, number of SSIM values, number of squared-error terms }.
+ * workspace: >= fnr_image_metrics_workspace_bytes(H, W) bytes, caller-owned.  H, W > 10. */
+size_t fnr_image_metrics_workspace_bytes(int H, int W);
+int fnr_image_metrics(int H, int W, const float* rgb, const float* image, const float* semantics, const float* mask,
+                      const float* gauss11, double* out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

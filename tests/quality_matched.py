@@ -149,9 +149,15 @@ def main():
         spacing = 2.0 / N_EXP * 2.0
         kw = dict(nb_points=2, radius=1.8 * spacing, voxel_size=spacing / 4, eps=1.8 * spacing, min_samples=4)
         aabb = ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
-        from fruitnerf_amd.clustering import FruitClustering
-        fc = FruitClustering(voxel_size_down_sample=kw["voxel_size"], remove_outliers_nb_points=kw["nb_points"],
-                             remove_outliers_radius=kw["radius"], cluster_merge_distance=0.04)
+        from fruitnerf_amd.clustering import Clustering
+        fruit = scene.is_fruit.cpu().numpy()
+        fc = Clustering(template_path=None, voxel_size_down_sample=kw["voxel_size"], remove_outliers_nb_points=kw["nb_points"],
+                        remove_outliers_radius=kw["radius"], min_samples=kw["min_samples"], apple_template_size=1.0,
+                        cluster_merge_distance=0.04, gt_cluster=scene.centers.cpu().numpy()[fruit].astype(np.float64) * 2.0,
+                        gt_count=int(scene.n_fruits), template_radius=float(scene.radii.cpu().numpy()[fruit].mean()) * 2.0)
+        fc.alpha_surface = min(100.0, 0.6 / spacing)   # the reference's 100 presumes a 1 mm voxel grid
+        fc.icp_max_correspondence_distance = max(0.01, 1.5 * spacing)
+        full = None
         if hip:
             import copy
             from fruitnerf_amd.clustering import PointCloud
@@ -171,8 +177,10 @@ def main():
             n_rays = pipe.datamanager.setup_inference(aabb=aabb, num_points=N_EXP)
             sets = sample_volume(pipe, n_rays, transform_json={"scale": 1.0})
             pts = sets["semantic"]["points"]
-            count = fc.first_stage_count(PointCloud(pts, None, dev), eps=kw["eps"], min_samples=kw["min_samples"]) \
-                if pts.shape[0] >= 5 else 0
+            count = 0
+            if pts.shape[0] >= 5:
+                full = fc.count(PointCloud(pts, None, dev), eps=kw["eps"])
+                count = fc.counter - fc.fuse_counter
         else:
             from oracle import cloud as ocl
             emo = fo.FruitModel(ocfg, num_train_data=n_train, test_mode="export")
@@ -185,14 +193,16 @@ def main():
             if pts.shape[0] >= 5:
                 X, _, labels = ocl.cluster_front_end(pts, None, kw["nb_points"], kw["radius"], kw["voxel_size"], kw["eps"],
                                                      kw["min_samples"])
-                fc.merge_small_clusters(X, None, labels)
+                Xs, ls = fc.merge_small_clusters(X, None, labels)
                 count = fc.counter - fc.fuse_counter
+                full = fc.split_large_cluster(Xs, None, ls)
         import hashlib
         rec = {"export_lattice": f"{N_EXP}^3", "export_points": {k: int(v["points"].shape[0]) for k, v in sets.items()},
                "export_points_sha1": {k: hashlib.sha1(np.ascontiguousarray(
                    (v["points"].cpu().numpy() if torch.is_tensor(v["points"]) else v["points"]).astype(np.float64)).tobytes()).hexdigest()
                    for k, v in sets.items()},
-               "fruit_count_first_stage": int(count), "fruit_count_scene": int(scene.n_fruits)}
+               "fruit_count": None if full is None else int(full), "fruit_count_first_stage": int(count),
+               "fruit_count_scene": int(scene.n_fruits)}
         results["count"] = rec
         print(json.dumps(rec), flush=True)
 

@@ -92,3 +92,51 @@ def test_merge_small_clusters_host_logic():
     assert fc.counter == 3 and fc.fuse_counter == 1 and len(Xs) == 2
     assert len(Xs[0]) == 50 and len(Xs[1]) == 25 and set(ls[1]) == {1}
     assert np.allclose(fc.cluster_center[0], (a.mean(0) + b.mean(0)) / 2)
+
+
+def test_second_stage_geometry_matches_the_oracle_restatements():
+    """fruitnerf_amd.clustering.shapes (vectorised circumradii + KD-tree nearest neighbours + SciPy Ward tree) against the
+    oracle's loop / brute-force restatements of alphashape, Open3D's ICP and surface sampling, hausdorff, and against
+    scikit-learn's AgglomerativeClustering itself."""
+    import numpy as np
+    from sklearn.cluster import AgglomerativeClustering
+    from fruitnerf_amd.clustering import shapes as S
+    from oracle import cloud as oc
+    rng = np.random.default_rng(1)
+    p = rng.normal(size=(1200, 3))
+    p = 0.08 * p / np.linalg.norm(p, axis=1, keepdims=True) * rng.random((1200, 1)) ** (1 / 3)
+    for alpha in (10, 40):
+        a, b = oc.alphashape_3d(p, alpha, seed=3), S.alpha_shape(p, alpha)
+        assert abs(a.volume - b.volume) <= 1e-12 and np.array_equal(a.faces, b.faces)
+        assert abs(b.volume - 4 / 3 * np.pi * 0.08 ** 3) <= 0.2 * 4 / 3 * np.pi * 0.08 ** 3      # a ball, roughly
+        v, f = b.vertices, b.faces        # closed, outward-wound surface: the divergence theorem gives the same volume
+        assert abs(np.einsum("ij,ij->i", v[f[:, 0]], np.cross(v[f[:, 1]], v[f[:, 2]])).sum() / 6 - b.volume) <= 1e-12
+    assert np.array_equal(a.sample_points_uniformly(300).points, b.sample_points_uniformly(300, seed=3))
+    assert S.alpha_shape(p[:3], 10).volume == 0.0 and S.alpha_shape(p, 1e6).faces.shape[0] == 0
+    A, B = p[:300], p[300:800] + 0.01
+    assert abs(oc.hausdorff_distance(A, B) - S.hausdorff_distance(A, B)) <= 1e-15
+    # ICP: a scaled, shifted copy of a sphere template; both loops must land on the same similarity transform
+    t = S.sphere_template(0.08, 800)
+    tgt = oc.O3dPointCloud()
+    tgt.points = 1.04 * t + np.array([0.01, 0.003, -0.002])
+    src = oc.O3dPointCloud()
+    src.points = t
+    init = np.eye(4)
+    init[:3, 3] = [0.005, 0.0, 0.0]
+
+    class Est:
+        with_scaling = True
+
+    class Crit:
+        max_iteration, relative_fitness, relative_rmse = 2000, 1e-6, 1e-6
+
+    ro = oc.registration_icp(src, tgt, 0.01, init, Est(), Crit())
+    rs = S.registration_icp(t, tgt.points, 0.01, init, with_scaling=True, max_iteration=2000)
+    assert np.abs(ro.transformation - rs.transformation).max() <= 1e-9 and abs(ro.fitness - rs.fitness) <= 1e-12
+    assert abs(rs.transformation[0, 0] - 1.04) <= 1e-6 and rs.fitness == 1.0
+    # Ward: the same partition as scikit-learn's AgglomerativeClustering (numbering aside)
+    blobs3 = np.vstack([t + c for c in ([0, 0, 0], [0.2, 0, 0], [0, 0.25, 0.05])])
+    for k in (2, 3, 5):
+        ours, theirs = S.ward_labels(blobs3, k), AgglomerativeClustering(n_clusters=k).fit_predict(blobs3)
+        pairs = {(a, b) for a, b in zip(ours.tolist(), theirs.tolist())}
+        assert len(pairs) == k == len(set(ours.tolist()))

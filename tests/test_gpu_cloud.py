@@ -177,3 +177,51 @@ def test_large_cloud_invariants(dev):
     keys = torch.floor((x - (x.amin(0) - 0.002)) / 0.004).to(torch.int64)
     assert vx.shape[0] == torch.unique(keys, dim=0).shape[0]
     assert float(vx.amin()) >= float(x.amin()) and float(vx.amax()) <= float(x.amax())
+
+
+def test_end_to_end_count_matches_the_cpu_pipeline(dev):
+    """Clustering.count (clustering_base.py:513-538: cluster -> merge_small_clusters -> split_large_cluster) on a lattice
+    cloud of fruits, two of them touching: the GPU front-end (radius-outlier removal, voxel down-sampling, DBSCAN) feeding
+    the host second stage must give the count the all-CPU pipeline gives, with the same per-cluster decisions, and find
+    every fruit.  CPU leg: SciPy's KD-tree for the radius counts (1.8 h is not a lattice distance, so `<` and `<=` agree),
+    voxels of h / 4 hold one lattice point each (the down-sampled cloud is the cleaned cloud in ascending (z, y, x)
+    order), scikit-learn's DBSCAN — the reference's own call — then the same second stage."""
+    from scipy.spatial import cKDTree
+    from fruitnerf_amd.clustering import Clustering, PointCloud
+    rng = np.random.default_rng(3)
+    h, r = 0.009, 0.08
+    centres = np.array([[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.0, 0.5, 0.0], [0.5, 0.5, 0.1],            # singles
+                        [-0.5, 0.0, 0.0], [-0.5 + 1.5 * r, 0.0, 0.0],                                  # a touching pair
+                        [0.0, -0.5, 0.0]])
+    k = int(np.ceil(r / h))
+    g = np.stack(np.meshgrid(*[np.arange(-k, k + 1)] * 3, indexing="ij"), -1).reshape(-1, 3) * h
+    ball = g[(g * g).sum(1) <= r * r]
+    parts = [np.round(c / h) * h + ball for c in centres]
+    crumb = g[(g * g).sum(1) <= (0.3 * r) ** 2] + np.round(np.array([0.3, -0.5, 0.0]) / h) * h         # far too small: pruned
+    X = np.unique(np.concatenate(parts + [crumb, np.round(rng.uniform(-1, 1, (300, 3)) / h) * h]), axis=0)
+    rng.shuffle(X)
+    kw = dict(voxel_size_down_sample=h / 4, remove_outliers_nb_points=2, remove_outliers_radius=1.8 * h, min_samples=4,
+              apple_template_size=1.0, cluster_merge_distance=0.04, gt_cluster=centres, gt_count=len(centres),
+              template_radius=r)
+    cl = Clustering(template_path=None, **kw)
+    cl.alpha_surface = 60.0                            # 1 / 60 > the lattice cell's circumradius (0.87 h)
+    count = cl.count(PointCloud(X, None, dev), eps=1.8 * h, seed=2)
+    ref = Clustering(template_path=None, **kw)
+    ref.alpha_surface = 60.0
+    keep = cKDTree(X).query_ball_point(X, 1.8 * h, return_length=True) > 2
+    Xo = X[keep]
+    Xo = Xo[np.lexsort((Xo[:, 0], Xo[:, 1], Xo[:, 2]))]
+    labels = oc.dbscan(Xo, 1.8 * h, 4)
+    assert np.array_equal(Xo, cl.pcd_downsampled_cleaned.points.cpu().numpy())
+    Xs, ls = ref.merge_small_clusters(Xo, None, labels)
+    want = ref.split_large_cluster(Xs, None, ls, seed=2)
+    print(f"[count] gpu front-end {count} cpu front-end {want}; first stage {cl.counter - cl.fuse_counter}, additional "
+          f"{cl.additional_count}, pruned {cl.prune_counter}; TP {cl.true_positive} FP {cl.false_positive} FN {cl.false_negative}")
+    assert count == want
+    assert [d["fruits"] for d in cl.cluster_decisions] == [d["fruits"] for d in ref.cluster_decisions]
+    assert (cl.counter, cl.fuse_counter, cl.additional_count, cl.prune_counter) == \
+        (ref.counter, ref.fuse_counter, ref.additional_count, ref.prune_counter)
+    assert cl.prune_counter == 1                       # the crumb
+    # every fruit is found; the touching pair is the one cluster the template hypotheses may over-split (the reference's
+    # Hausdorff score prefers three or four small-error templates to two there)
+    assert cl.true_positive == len(centres) and cl.false_negative == 0 and len(centres) <= count <= len(centres) + 2

@@ -205,6 +205,13 @@ def test_full_image_eval_and_image_metrics(dev):
     metrics, images = m.get_image_metrics_and_images(out, batch)
     assert set(metrics) == {"psnr", "ssim", "lpips", "iou", "iou_sigmoid"}
     assert 0 < metrics["psnr"] < 60 and -1 <= metrics["ssim"] <= 1
+    # every metric against the float64 restatement of torchmetrics' algorithm (oracle/image_metrics.py)
+    from oracle import image_metrics as oim
+    want_all = oim.image_metrics(out["rgb"].cpu().numpy(), batch["image"].numpy(), out["semantics"].cpu().numpy(),
+                                 batch["fruit_mask"].numpy())
+    print("[image metrics]", metrics, want_all)
+    assert abs(metrics["ssim"] - want_all["ssim"]) <= 1e-5 and abs(metrics["psnr"] - want_all["psnr"]) <= 1e-4
+    assert abs(metrics["iou"] - want_all["iou"]) <= 1e-9 and abs(metrics["iou_sigmoid"] - want_all["iou_sigmoid"]) <= 1e-9
     # the reference's quirk (fruit_nerf.py:451): F.softmax without dim on [H,W,1] runs over image rows (implicit dim 0)
     sem, tgt = out["semantics"].cpu(), batch["fruit_mask"][..., 0] > 0.5
     pred = torch.softmax(sem, dim=0)[..., 0] > 0.5
@@ -294,3 +301,34 @@ def test_train_prologue_is_the_separate_launches(dev):
         rays = K.RaysArg(o, d, torch.full((R, 1), 0.05, device=dev), torch.full((R, 1), 1000.0, device=dev), cam)
         spacing, euclid = K.sample_spaced(rays, 1, S0, out["jitter"][0])
         assert torch.equal(out["spacing"], spacing) and torch.equal(out["euclid"], euclid)
+
+
+@pytest.mark.parametrize("shape", [(11, 11), (64, 75), (203, 131)])
+def test_image_metrics_kernel_matches_the_float64_oracle(dev, shape):
+    """fnr_image_metrics (csrc/image_metrics.hip) on synthetic images with structure (smooth ramps + noise, a prediction
+    with out-of-range values so that the clamp matters, saturated and near-zero logits): SSIM within 1e-5 and PSNR within
+    1e-4 dB of the float64 restatement of torchmetrics' algorithm, both IoUs exact; (11, 11) is the smallest image with an
+    SSIM value (one window), the others have ragged 32 x 32 tiles."""
+    import numpy as np
+    from fruitnerf_amd import _kernels as K
+    from oracle import image_metrics as oim
+    H, W = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    image = torch.stack([0.5 + 0.4 * torch.sin(6 * xx + 2 * yy), yy * xx, 0.3 + 0.2 * torch.cos(9 * yy)], dim=-1)
+    image = (image + 0.05 * torch.rand(H, W, 3, generator=g)).clamp(0, 1)
+    rgb = image + 0.15 * torch.randn(H, W, 3, generator=g)          # leaves [0, 1]: the metrics see clamp(rgb)
+    sem = 8.0 * torch.randn(H, W, 1, generator=g)
+    mask = (torch.rand(H, W, 1, generator=g) > 0.6).float()
+    sums = K.image_metrics(rgb.to(dev), image.to(dev), sem.to(dev)[..., 0], mask.to(dev)[..., 0]).tolist()
+    want = oim.image_metrics(rgb.numpy(), image.numpy(), sem.numpy(), mask.numpy())
+    got = {"psnr": -10.0 * np.log10(sums[0] / sums[7]), "ssim": sums[1] / sums[6],
+           "iou_sigmoid": sums[2] / max(sums[3], 1.0), "iou": sums[4] / max(sums[5], 1.0)}
+    print(f"[image metrics {H}x{W}]", got, want)
+    assert sums[6] == 3 * (H - 10) * (W - 10) and sums[7] == 3 * H * W
+    assert abs(got["ssim"] - want["ssim"]) <= 1e-5
+    assert abs(got["psnr"] - want["psnr"]) <= 1e-4
+    assert got["iou"] == pytest.approx(want["iou"], abs=1e-12) and got["iou_sigmoid"] == pytest.approx(want["iou_sigmoid"], abs=1e-12)
+    # without semantics: only the image sums
+    sums2 = K.image_metrics(rgb.to(dev), image.to(dev)).tolist()
+    assert sums2[0] == sums[0] and sums2[1] == sums[1] and sums2[2:6] == [0.0, 0.0, 0.0, 0.0]

@@ -167,3 +167,38 @@ def test_median_depth_is_the_weighted_median_of_the_sample_midpoints():
     mids = (t[:, :-1] + t[:, 1:]) / 2
     want = np.array([ind.weighted_median(mids[r], w[r]) for r in range(R)])
     assert np.abs(got - want).max() < 1e-6
+
+
+def test_image_metrics_oracle_against_an_independent_ssim():
+    """oracle/image_metrics.py (separable filtering of the reflect-padded images, then the crop) against the definition
+    evaluated another way: a full 121-tap 2-D convolution (scipy) of the UNPADDED images restricted to the windows that fit
+    — torchmetrics' pad-then-crop leaves exactly those.  Plus the closed forms: SSIM(a, a) = 1, SSIM of two constant images
+    = (2 ab + c1) / (a^2 + b^2 + c1), and the window is normalised and symmetric."""
+    import numpy as np
+    from scipy.signal import convolve2d
+    from oracle import image_metrics as om
+    g = om.gaussian_window()
+    assert g.dtype == np.float32 and abs(float(g.sum(dtype=np.float64)) - 1.0) < 1e-6 and np.array_equal(g, g[::-1])
+    rng = np.random.default_rng(0)
+    a = rng.random((40, 37, 3))
+    b = np.clip(a + 0.1 * rng.standard_normal(a.shape), 0, 1)
+    assert abs(om.ssim(a, a) - 1.0) < 1e-12
+    w = np.outer(g.astype(np.float64), g.astype(np.float64))
+
+    def f(x):
+        return np.stack([convolve2d(x[..., c], w, mode="valid") for c in range(3)])
+
+    mu_a, mu_b = f(a), f(b)
+    saa, sbb, sab = f(a * a) - mu_a ** 2, f(b * b) - mu_b ** 2, f(a * b) - mu_a * mu_b
+    m = ((2 * mu_a * mu_b + 1e-4) * (2 * sab + 9e-4)) / ((mu_a ** 2 + mu_b ** 2 + 1e-4) * (saa + sbb + 9e-4))
+    assert m.shape == (3, 30, 27) and abs(om.ssim(a, b) - float(m.mean())) < 1e-12
+    ca, cb = np.full((20, 20, 3), 0.3), np.full((20, 20, 3), 0.7)
+    # (the float32 window sums to 1 within 1e-7, so the 'variances' of a constant image are ~1e-8 against c2 = 9e-4)
+    assert abs(om.ssim(ca, cb) - (2 * 0.3 * 0.7 + 1e-4) / (0.09 + 0.49 + 1e-4)) < 2e-5
+    assert abs(om.psnr(ca, cb) - 10 * np.log10(1 / 0.16)) < 1e-9
+    sem = np.ones((12, 11, 1))
+    sem[2, 1, 0] = 10.0                                   # dominates its COLUMN: the row softmax is > 0.5 only there
+    mask = np.zeros((12, 11, 1))
+    mask[2, 1, 0] = mask[0, 0, 0] = 1.0
+    r = om.image_metrics(np.zeros((12, 11, 3)) + 0.5, np.zeros((12, 11, 3)) + 0.5 + 1e-3, sem, mask)
+    assert r["iou"] == 0.5 and r["iou_sigmoid"] == 2 / 132    # sigmoid(1) > 0.5 everywhere

@@ -304,3 +304,38 @@ def test_reference_export_counts_depend_on_its_sampler_noise():
     a = [g[f"as_run::{s}::points"].shape[0] for s in ("semantic_colormap", "semantic", "density")]
     b = [g[f"centres::{s}::points"].shape[0] for s in ("semantic_colormap", "semantic", "density")]
     assert a != b
+
+
+def test_second_counting_stage_matches_the_reference_split_large_cluster():
+    """clustering/clustering_base.py:260-511 — the reference's own merge_small_clusters + split_large_cluster were executed
+    over the oracle's restatements of alphashape / Open3D ICP / hausdorff (tests/golden/make_reference_split_golden.py);
+    fruitnerf_amd.clustering (its own alpha shapes, KD-tree ICP and Hausdorff, SciPy Ward tree) must reach the same count
+    through the same decisions: first-stage counters, which clusters are split / pruned, the six hypothesis distances of
+    every split cluster, the final count and detection rate."""
+    import time
+    from fruitnerf_amd.clustering import FruitClustering
+    from fruitnerf_amd.clustering import shapes
+    from tests.golden.make_reference_split_golden import make_scene
+    g = np.load(os.path.join(os.path.dirname(PINS), "reference_split.npz"))
+    X, labels = make_scene()
+    fc = FruitClustering(cluster_merge_distance=0.04)
+    fc.set_template(shapes.sphere_template(float(g["template_radius"]), int(g["template_points"])))
+    fc.gt_count = 11
+    assert abs(fc.fruit_alpha_shape_.volume - float(g["template_volume"])) <= 1e-12
+    t0 = time.time()
+    Xs, ls = fc.merge_small_clusters(X, None, labels)
+    assert (fc.counter, fc.fuse_counter, len(Xs)) == (int(g["counter"]), int(g["fuse_counter"]), int(g["n_merged_clusters"]))
+    assert [len(c) for c in Xs] == g["merged_sizes"].tolist()
+    count = fc.split_large_cluster(Xs, None, ls, seed=int(g["seed"]))
+    print(f"[second stage] count {count} (reference {int(g['count'])}) in {time.time() - t0:.1f} s; decisions "
+          f"{[d['fruits'] for d in fc.cluster_decisions]}")
+    got = np.array([d["distances"] for d in fc.cluster_decisions if "distances" in d])
+    want = g["hypothesis_distances"]
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-9
+    assert [int(np.argmin(r)) + 1 for r in want] == [d["fruits"] for d in fc.cluster_decisions if "distances" in d]
+    assert count == int(g["count"]) == fc.counter - fc.fuse_counter + fc.additional_count - fc.prune_counter
+    assert fc.prune_counter == 2 and abs(fc.detection_rate - float(g["detection_rate"])) <= 1e-12
+    # the reference's own summary lines
+    text = str(g["stdout"])
+    assert f"Second stage clustering count: {count}" in text
+    assert f"First clustering stage count after fused (tiny) clusters: {fc.counter - fc.fuse_counter}" in text
