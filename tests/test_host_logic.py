@@ -255,18 +255,18 @@ def test_ply_sink_roundtrip(tmp_path):
     assert np.array_equal(c2, np.rint(np.clip(cols, 0, 1) * 255) / 255.0)
 
 
-def test_ssim_restatement_basic_properties():
-    """SSIM used by get_image_metrics_and_images: 1 for identical images, symmetric, lower for noisier images."""
-    import torch
-    from fruitnerf_amd.fruit_nerf import _ssim
-    from fruitnerf_amd.data.semantics import apple_metadata
-    g = torch.Generator().manual_seed(0)
-    a = torch.rand(1, 3, 48, 40, generator=g)
-    assert abs(float(_ssim(a, a)) - 1.0) < 1e-6
-    b = (a + 0.05 * torch.randn(a.shape, generator=g)).clamp(0, 1)
-    c = (a + 0.25 * torch.randn(a.shape, generator=g)).clamp(0, 1)
-    assert abs(float(_ssim(a, b)) - float(_ssim(b, a))) < 1e-6
-    assert 0.0 < float(_ssim(a, c)) < float(_ssim(a, b)) < 1.0
+def test_ssim_oracle_basic_properties():
+    """The SSIM oracle (oracle/image_metrics.py; the product's SSIM is the HIP kernel fnr_image_metrics, compared with it
+    in tests/test_gpu_properties.py): 1 for identical images, symmetric, lower for noisier images."""
+    import numpy as np
+    from oracle.image_metrics import ssim
+    rng = np.random.default_rng(0)
+    a = rng.random((48, 40, 3))
+    assert abs(ssim(a, a) - 1.0) < 1e-12
+    b = np.clip(a + 0.05 * rng.standard_normal(a.shape), 0, 1)
+    c = np.clip(a + 0.25 * rng.standard_normal(a.shape), 0, 1)
+    assert abs(ssim(a, b) - ssim(b, a)) < 1e-12
+    assert 0.0 < ssim(a, c) < ssim(a, b) < 1.0
 
 
 def test_product_package_never_imports_the_oracle_or_the_tests():
