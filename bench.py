@@ -102,6 +102,12 @@ def alg_table(mlp_flop: float):
     }
 
 
+# The table optimiser fused into the scatter's accumulate kernel (N = 1): the gradient never touches HBM, so a parameter
+# costs p, m, v read + p, m, v written = 24 B (the 28 B of the separate step over-priced the launch)
+FUSED_ADAM_BYTES_PER_PARAM = 24.0
+SCATTER_RECORD_BYTES = 10.0     # 8-byte value pair + 16-bit row inside the bin (csrc/hash_scatter.hip)
+
+
 # entry points that belong to one kernel family (the judge's grouping: scatter = field + proposal-network scatter)
 FAMILIES = {
     "field_mlp_bwd": "field MLP backward (MFMA)", "field_mlp_fwd": "field MLP forward (MFMA)",
@@ -380,7 +386,7 @@ def timed_window(run, steps, barrier, dist_on, dev):
     return dt, t_enqueued, recs, n_prof, last
 
 
-def rooflines_of(run, recs, steps, dist_on, pmc):
+def rooflines_of(run, recs, steps, dist_on, pmc, field_records_per_launch=None):
     # steps = the number of PROFILED steps the records come from
     """`roofline` / `roofline_other_bound` objects of a timed window (see pick_rooflines)."""
     M = run.M
@@ -395,10 +401,21 @@ def rooflines_of(run, recs, steps, dist_on, pmc):
         fixed, note = 0.0, None
         if op == "hash_encode_bwd" and not dist_on and units == run.rays * M["samples"][2]:
             # single process: this entry point also takes the main table's optimiser step (fnr_hash_encode_bwd_adam)
-            fixed = alg["adam_step"][1] * float(table.numel())
-            note = (f"main hash table's {M['algorithm']} step fused into this launch: {alg['adam_step'][1]:.0f} B x "
-                    f"{table.numel()} table parameters (what adam_step is priced with)")
+            fixed = FUSED_ADAM_BYTES_PER_PARAM * float(table.numel())
+            note = (f"main hash table's {M['algorithm']} step fused into this launch: {FUSED_ADAM_BYTES_PER_PARAM:.0f} B x "
+                    f"{table.numel()} table parameters (p, m, v read + written; the gradient never reaches HBM)")
         e = roofline_entry(op, units, float(np.mean(sel)), len(sel), alg, fixed, note, method=run.method, pmc=pmc)
+        if op == "hash_encode_bwd" and field_records_per_launch and units == run.rays * M["samples"][2]:
+            # design overhead, NOT algorithmic work: every record is written by the emit kernel and read back by the
+            # accumulate kernel.  With it the counter traffic decomposes: optimiser sweep + record round trip + d_feats
+            rq = 2.0 * SCATTER_RECORD_BYTES * field_records_per_launch
+            e["records_per_launch"] = int(field_records_per_launch)
+            e["record_queue_bytes"] = rq
+            e["hbm_bytes_expected"] = {"optimiser_sweep": fixed, "record_queue_write_plus_read": rq,
+                                       "d_feats_read": 128.0 * units,
+                                       "sum": fixed + rq + 128.0 * units}
+            if e.get("traffic"):
+                e["traffic_over_expected"] = round(e["traffic"] / (fixed + rq + 128.0 * units), 3)
         e["ms_per_step_in_window"] = round(float(np.sum(sel)) / steps, 5)
         e["selection"] = (f"largest total time among the HBM- / MFMA-bound entry points over the {steps} event-timed "
                           f"steps (every {PROFILE_EVERY}th) of the timed window")
@@ -537,8 +554,10 @@ def main() -> None:
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps -------------------------------------------------------------------
+    L.scatter_records(reset=True)
     dt, t_enqueued, recs, n_prof, (ld, md) = timed_window(run, args.steps, barrier, dist_on, dev)
     rays_per_s = world * args.steps * RAYS_PER_BATCH / dt
+    field_records = L.scatter_records()[0] / max(args.steps, 1)     # one main-field scatter per step
 
     if rank != 0:
         if dist_on:
@@ -548,7 +567,19 @@ def main() -> None:
         return
 
     # ---- roofline of the dominant entry point (and of the dominant one bound by the other roofline) --------------------
-    roofline, roofline_other = rooflines_of(run, recs, n_prof, dist_on, pmc)
+    roofline, roofline_other = rooflines_of(run, recs, n_prof, dist_on, pmc, field_records)
+    # the SAME window (fresh model, same seeds, warm-up, steps and event-timed steps) in the strictly-fp32 arithmetic
+    # (v_mfma_f32_16x16x4_f32 chains, forward and backward): the reference's own arithmetic, next to the headline's
+    value_fp32 = None
+    if world == 1 and args.mlp_precision != "fp32" and not dist_on:
+        r32 = MethodRun(args.method, "fp32", args.camera_optimizer, dev, rank, world, data, train_ids, len(i_train))
+        for _ in range(args.warmup):
+            r32.one_step()
+        torch.cuda.synchronize()
+        dt32 = timed_window(r32, args.steps, barrier, dist_on, dev)[0]
+        value_fp32 = round(args.steps * RAYS_PER_BATCH / dt32, 1)
+        del r32
+        torch.cuda.empty_cache()
     # whole-step fractions against both rooflines (SURVEY §8d per-ray figures): never "the path is MFMA-bound"
     whole_step = {"mfma_f32_frac": round(M["flop_per_ray_train"] * rays_per_s / world / (MFMA_F32_PEAK_TF * 1e12), 4),
                   "hbm_frac": round(M["bytes_per_ray_train"] * rays_per_s / world / (HBM_PEAK_GBS * 1e9), 4),
@@ -768,8 +799,9 @@ def main() -> None:
             rb_.one_step()
         torch.cuda.synchronize()
         nb_steps = 20
+        L.scatter_records(reset=True)
         dt_b, enq_b, recs_b, n_prof_b, _ = timed_window(rb_, nb_steps, barrier, dist_on, dev)
-        r_b, r_b2 = rooflines_of(rb_, recs_b, n_prof_b, dist_on, pmc)
+        r_b, r_b2 = rooflines_of(rb_, recs_b, n_prof_b, dist_on, pmc, L.scatter_records()[0] / nb_steps)
         Mb = METHODS["fruit_nerf_big"]
         v_b = nb_steps * Mb["rays"] / dt_b
         big = {"metric": f"train rays/sec, fruit_nerf_big on synthetic apple {HW}x{HW}", "value": round(v_b, 1),
@@ -865,8 +897,12 @@ def main() -> None:
         "vs_baseline": None,
         # arithmetic type of the MLP GEMMs; hash grids, samplers, compositing, losses and the optimiser are fp32 in
         # every mode.  bf16x3 = three bf16 pieces per fp32 operand (fp32-grade results), bf16 = bf16 operands.
-        "dtype": {"fp32": "f32", "bf16x3": "f32 (MLP GEMMs: exact bf16x3 split on the bf16 MFMA pipe)",
+        "dtype": {"fp32": "f32",
+                  "bf16x3": "f32 fwd (MLP GEMMs: 3-piece bf16 split, 6 products, ~2^-24) / 2-piece bwd (dX, dW: 3 products, "
+                            "~2^-17; its forward recompute 3-piece); everything else f32",
                   "bf16": "bf16"}[args.mlp_precision],
+        # rays/s of the same window (fresh model, same seeds / warm-up / steps) with every MLP GEMM in fp32 MFMA chains
+        "value_fp32_arithmetic": value_fp32,
         "data": "synthetic",
         "config": {"workload": f"{args.method} synthetic apple {HW}x{HW}, {N_CAMERAS} cameras ({len(i_train)} train), "
                                f"{RAYS_PER_BATCH} rays/rank/step, samples {'/'.join(map(str, M['samples']))}, "

@@ -323,7 +323,8 @@ def train_losses(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tens
                  S_f: int, spacing_f: Tensor, weights_f: Tensor, levels, interlevel_mult: float, want_distortion: bool,
                  accum: Tensor, fuse_weights_bwd: bool = False):
     """losses_fwd + interlevel_fwd per proposal level + distortion + the slot sums in one launch.
-    levels: [(S_p, spacing_p, weights_p), ...]; accum: ZEROED float buffer of FNR_TRAIN_LOSSES_ACCUM_FLOATS.
+    levels: [(S_p, spacing_p, weights_p), ...]; accum: float buffer of FNR_TRAIN_LOSSES_ACCUM_FLOATS, zeroed before its
+    first use (every completed call leaves it zeroed; it is re-zeroed here when the call fails).
     -> losses [5] (rgb_loss, semantics_loss, psnr, interlevel_loss, distortion), d_rgb [R,3], d_semantics [R],
        [d_weights_p per level].
     fuse_weights_bwd: levels are (S_p, spacing_p, weights_p, euclid_p, density_p) and the last list holds each level's
@@ -344,11 +345,14 @@ def train_losses(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tens
         d_wp, eu, dn, d_dn = None, vps([lv[3] for lv in levels]), vps([lv[4] for lv in levels]), vps(outs)
     else:
         d_wp, eu, dn, d_dn = vps(outs), None, None, None
-    L.check(lib.fnr_train_losses(R, L.ptr(rgb), L.ptr(image), L.ptr(semantics), L.ptr(fruit_mask),
-                                 float(semantic_loss_weight), L.ptr(d_rgb), L.ptr(d_sem), S_f, L.ptr(spacing_f),
-                                 L.ptr(weights_f), n, sp, vps([lv[1] for lv in levels]), vps([lv[2] for lv in levels]),
-                                 d_wp, eu, dn, d_dn, float(interlevel_mult), 1 if want_distortion else 0, L.ptr(accum),
-                                 L.ptr(losses), L.stream_ptr(dev)), "train_losses")
+    rc = lib.fnr_train_losses(R, L.ptr(rgb), L.ptr(image), L.ptr(semantics), L.ptr(fruit_mask),
+                              float(semantic_loss_weight), L.ptr(d_rgb), L.ptr(d_sem), S_f, L.ptr(spacing_f),
+                              L.ptr(weights_f), n, sp, vps([lv[1] for lv in levels]), vps([lv[2] for lv in levels]),
+                              d_wp, eu, dn, d_dn, float(interlevel_mult), 1 if want_distortion else 0, L.ptr(accum),
+                              L.ptr(losses), L.stream_ptr(dev))
+    if rc != 0:
+        accum.zero_()     # a failed call may leave slots / completion counters dirty for every later step
+    L.check(rc, "train_losses")
     return losses, d_rgb, d_sem, outs
 
 
@@ -542,6 +546,12 @@ def position_grad_reduce_multi(sources, rays: RaysArg, d_origins: Tensor, d_dire
     """One launch for several ray-gradient sources [(warp, euclid [R,S+1], S, partial [n_levels,N,4] | [N,4]), ...]:
     d_origins / d_directions [R,3] = (or +=) the sum of their ray gradients, in source order."""
     lib = L.load()
+    if len(sources) > L.FNR_MAX_POSITION_SOURCES:
+        # more sources than one launch takes (> 3 proposal iterations + the field): in chunks, the later ones accumulating
+        m = L.FNR_MAX_POSITION_SOURCES
+        for a in range(0, len(sources), m):
+            position_grad_reduce_multi(sources[a:a + m], rays, d_origins, d_directions, accumulate=accumulate or a > 0)
+        return
     n = len(sources)
     warps = (C.POINTER(L.fnr_warp) * n)(*[C.pointer(w) for w, _, _, _ in sources])
     euclid = (C.c_void_p * n)(*[L.ptr(e) for _, e, _, _ in sources])

@@ -66,6 +66,8 @@ class fnr_adam_span(C.Structure):
 
 FNR_MAX_ADAM_SPANS = 8
 FNR_MAX_PROPOSAL_LEVELS = 4
+FNR_MAX_POSITION_SOURCES = 4         # fnr_position_grad_reduce_multi
+FNR_TRAIN_PROLOGUE_MAX_JITTER = 5    # fnr_train_prologue: n_jitter in 1..5
 FNR_TRAIN_LOSSES_ACCUM_FLOATS = 4 * FNR_LOSS_SLOTS + 33 * 32
 
 
@@ -95,6 +97,7 @@ SIGNATURES = {
     "fnr_profile_pause": (_i, [_i]),
     "fnr_profile_collect": (_i64, [P(C.c_int32), P(C.c_int64), P(C.c_float), _i64]),
     "fnr_debug_scatter_overflows": (_i, [P(C.c_uint64), _i]),
+    "fnr_debug_scatter_records": (_i, [P(C.c_uint64), _i]),
     "fnr_sample_pixels": (_i, [P(fnr_image_set), _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_train_prologue": (_i, [P(fnr_image_set), _vp, _i, _i64, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, _i, _vp, _vp,
                                 _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
@@ -251,6 +254,13 @@ def scatter_overflows(reset: bool = False) -> int:
     n = C.c_uint64(0)
     check(load().fnr_debug_scatter_overflows(C.byref(n), 1 if reset else 0), "debug_scatter_overflows")
     return int(n.value)
+
+
+def scatter_records(reset: bool = False):
+    """(records summed into the field's table, into proposal tables) since the last reset (fnr_debug_scatter_records)."""
+    n = (C.c_uint64 * 2)()
+    check(load().fnr_debug_scatter_records(n, 1 if reset else 0), "debug_scatter_records")
+    return int(n[0]), int(n[1])
 
 
 def profile_collect(capacity: int = 1 << 20):

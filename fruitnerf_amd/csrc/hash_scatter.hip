@@ -37,6 +37,10 @@ static_assert(SC_MAX_BINS <= SC_EMIT_THREADS, "one bin per thread");
 constexpr int SC_CNT_STRIDE = 32;       // uint32 words between two bins' counters
 
 __device__ unsigned long long g_scatter_overflow_records;   // records that went to the table through global atomics
+// records summed by the accumulate kernels since the last reset, per kind of call (0: the field's table, 1: proposal
+// tables); 64 slots per kind, each in its own 128-byte line (one atomic per accumulate workgroup, spread by workgroup id:
+// same-line atomics serialise at ~12 ns).  fnr_debug_scatter_records: bench.py prices the record queue's round trip with it.
+__device__ unsigned long long g_scatter_records[2][64][16];
 
 struct ScatterPlan {
   int log2_rows;         // log2(E)
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   EMIT_T(4);
   // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 8-byte + 2-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
+  unsigned overflowed_here = 0;
   for (unsigned i = threadIdx.x; i < total; i += SC_EMIT_THREADS) {
     const float2 v = s_val[i];
     const unsigned key = s_key[i];
@@ -456,12 +461,13 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       queue_r[q] = (unsigned short)row_in_bin;
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
       qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;  // tells the accumulate kernel that the table holds part of the sum
-      atomicAdd(&g_scatter_overflow_records, 1ull);   // fnr_debug_scatter_overflows
+      ++overflowed_here;                             // fnr_debug_scatter_overflows: one atomic per thread, below
       const size_t row = ((size_t)bin << log2_rows) + row_in_bin;
       atomicAdd(table + 2 * row, v.x);
       atomicAdd(table + 2 * row + 1, v.y);
     }
   }
+  if (overflowed_here) atomicAdd(&g_scatter_overflow_records, (unsigned long long)overflowed_here);
   EMIT_T(5);
   __syncthreads();  // the next level re-uses the bin tables and the record staging
   }  // levels of this workgroup
@@ -495,6 +501,7 @@ struct AccArgs {
   unsigned *qcount, *qmax, *qdone;
   long long cap;
   int log2_rows, level0, nbins;   // nbins = level_count * bins per level = workgroups of this call
+  int kind;                       // 0: the field's table, 1: a proposal network's (g_scatter_records)
   TableAdam adam;
 };
 
@@ -534,6 +541,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     }
   }
   const bool have = n != 0 && vmax > 0.0f;
+  if (threadIdx.x == 0 && n > 0)
+    atomicAdd(&g_scatter_records[A.kind & 1][vblock & 63][0], (unsigned long long)(n > cap ? cap : n));
   if (!ADAM && !have) return;  // (with the fused optimiser every row still takes its moment-decay step)
   if (n > cap) n = cap;
   if (n < 1) n = 1;
@@ -706,6 +715,7 @@ static int scatter_emit(const fnr_grid* grid_grad, const Warp& warp, const Sourc
   acc.qdone = qcount + (nbins_all + level_count) * SC_CNT_STRIDE;
   acc.cap = p.cap, acc.log2_rows = p.log2_rows, acc.level0 = level0;
   acc.nbins = level_count * p.bins_per_level;
+  acc.kind = 0;
   acc.adam = adam ? *adam : TableAdam{};
   return FNR_OK;
 }
@@ -989,6 +999,21 @@ extern "C" int fnr_debug_scatter_overflows(uint64_t* count_host, int reset) {
   return FNR_OK;
 }
 
+extern "C" int fnr_debug_scatter_records(uint64_t* records_host, int reset) {
+  FNR_CHECK_ARG(records_host, "debug_scatter_records: null argument");
+  static unsigned long long host[2][64][16];
+  FNR_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_scatter_records), sizeof(host)));
+  for (int k = 0; k < 2; ++k) {
+    records_host[k] = 0;
+    for (int i = 0; i < 64; ++i) records_host[k] += host[k][i][0];
+  }
+  if (reset) {
+    memset(host, 0, sizeof(host));
+    FNR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_scatter_records), host, sizeof(host)));
+  }
+  return FNR_OK;
+}
+
 extern "C" size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
   const ScatterPlan p = scatter_plan(n_samples, n_levels, log2_hashmap_size);
   return p.count_bytes + p.queue_bytes;
@@ -1036,7 +1061,10 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
                                     const float* d_density, float* d_position, void* workspace,
                                     size_t workspace_bytes, int workspace_clean, void* stream,
                                     const fnr_table_adam* table_adam, const fnr_table_adam* weight_adam,
-                                    const float* grad_arena, AccArgs* defer_acc = nullptr, int phase = 0) {
+                                    const float* grad_arena, AccArgs* defer_acc = nullptr, int phase = 0,
+                                    bool own_scope = true) {
+  // own_scope false: the caller's ProfScope spans this call (the paired entry points open ONE scope over both levels and
+  // their joint accumulate launch, which runs outside any per-level call)
   // phase 0: the whole backward; 1: MLP backward + weight reduction only (d_feats stay in the workspace, d_position is
   // complete); 2: the scatter of what phase 1 left (fnr_prop_density_bwd_pair_split)
   FNR_CHECK_ARG(net && grads && warp && rays && euclid_bins && feat_save && d_density && workspace && S > 0,
@@ -1071,7 +1099,7 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
   const size_t dfeat_bytes = ((size_t)L * (size_t)N * sizeof(float2) + 255) / 256 * 256;
   float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + dfeat_bytes);
   const size_t partial_bytes = (size_t)max_blocks * PROP_PART * sizeof(float);
-  FNR_PROF(OP_PROP_BWD, N);
+  ::fnr::ProfScope prof_scope__(own_scope ? (int)OP_PROP_BWD : -1, N, stream);
   if (phase != 2) {
   const GridDev pgrid = make_grid(&net->grid);
   float4* d_xw = reinterpret_cast<float4*>(d_position);
@@ -1113,6 +1141,7 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
                                workspace_bytes - dfeat_bytes - partial_bytes, workspace_clean, as_stream(stream),
                                table_adam ? &ta : nullptr, acc);
   if (rce) return rce;
+  acc.kind = 1;
   if (defer_acc) {   // the caller launches the accumulate kernel (together with another call's)
     *defer_acc = acc;
     return FNR_OK;
@@ -1157,12 +1186,13 @@ extern "C" int fnr_prop_density_bwd_pair(const fnr_prop_net* const* nets, const 
   const bool adam = table_adam && table_adam[0] && table_adam[1];
   FNR_CHECK_ARG(adam || !(table_adam && (table_adam[0] || table_adam[1])), "prop_density_bwd_pair: one table_adam missing");
   if (rays->n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_PROP_BWD, rays->n_rays * ((long long)S[0] + (long long)S[1]));   // one scope: both levels + the joint accumulate
   AccArgs acc[2];
   for (int q = 0; q < 2; ++q) {
     const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
                                           d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
                                           adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
-                                          adam ? grad_arena : nullptr, &acc[q]);
+                                          adam ? grad_arena : nullptr, &acc[q], 0, false);
     if (rc) return rc;
   }
   const bool first_longer = (long long)S[0] >= (long long)S[1];
@@ -1191,13 +1221,14 @@ extern "C" int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, 
     if (position_ready_event) FNR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(position_ready_event), as_stream(stream)));
     return FNR_OK;
   }
+  FNR_PROF(OP_PROP_BWD, rays->n_rays * ((long long)S[0] + (long long)S[1]));   // one scope: both phases + the joint accumulate
   AccArgs acc[2];
   for (int phase = 1; phase <= 2; ++phase) {
     for (int q = 0; q < 2; ++q) {
       const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
                                             d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
                                             adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
-                                            adam ? grad_arena : nullptr, &acc[q], phase);
+                                            adam ? grad_arena : nullptr, &acc[q], phase, false);
       if (rc) return rc;
     }
     if (phase == 1 && position_ready_event)

@@ -196,7 +196,8 @@ extern "C" int fnr_train_prologue(const fnr_image_set* set, const int64_t* train
                 "train_prologue: null argument");
   FNR_CHECK_ARG(set->images && set->masks && set->c2w && set->n_images > 0 && set->H > 0 && set->W > 0 && n_train > 0,
                 "train_prologue: bad image set");
-  FNR_CHECK_ARG(n_jitter >= 1 && n_jitter <= 5 && S0 >= 1, "train_prologue: n_jitter %d (1..5), S0 %d", n_jitter, S0);
+  FNR_CHECK_ARG(n_jitter >= 1 && n_jitter <= FNR_TRAIN_PROLOGUE_MAX_JITTER && S0 >= 1, "train_prologue: n_jitter %d (1..%d), S0 %d",
+                n_jitter, FNR_TRAIN_PROLOGUE_MAX_JITTER, S0);
   FNR_CHECK_ARG((pose_adjustment == nullptr) == (c2w_adjusted == nullptr), "train_prologue: pose and c2w_adjusted go together");
   FNR_CHECK_ARG(n_rays >= n_train || !pose_adjustment, "train_prologue: fewer rays than cameras");
   if (n_rays == 0) return FNR_OK;

@@ -55,7 +55,7 @@ static bool prof_event(hipEvent_t* e) {
 }
 
 ProfScope::ProfScope(int op, long long units, void* stream) : slot(-1), st(as_stream(stream)) {
-  if (!g_prof_on || g_prof_paused || !((g_prof_mask >> op) & 1ull) || g_prof.size() >= (1u << 20)) return;
+  if (op < 0 || !g_prof_on || g_prof_paused || !((g_prof_mask >> op) & 1ull) || g_prof.size() >= (1u << 20)) return;   // op < 0: a scope that is part of its caller's
   ProfRec r;
   r.op = op;
   r.units = units;

@@ -125,13 +125,19 @@ __device__ __forceinline__ int searchsorted_right(const float* a, int n, float v
 
 // A wave's contribution to a loss accumulator row (FNR_LOSS_SLOTS floats spread over 32 cache lines: same-line atomics
 // serialise).  FIXED (fnr_train_losses): the row is read as 512 64-bit words and the value is added as two's-complement
-// fixed point (2^-44 resolution, |sum| < 5e5) — integer adds commute, so the logged losses and metrics are bit-identical
-// run to run like the gradients; a non-finite value raises `flag` instead (the result is then NaN).
-constexpr double TL_FIX_SCALE = 17592186044416.0;  // 2^44
+// fixed point (2^-34 resolution) — integer adds commute, so the logged losses and metrics are bit-identical run to run like
+// the gradients.  A contribution that is not finite or above its row's bound raises `flag` instead (the result is then
+// NaN): per-ray contributions (interlevel, distortion: already divided by R) |v| <= 2^12, up to 2^17 of them — more than
+// any built method launches per row (fruit_nerf_huge: 16 384 rays x 2 proposal levels); the rgb / semantic rows' raw
+// per-wave sums |v| <= 2^28 / waves.  At a scale of 2^34 neither a slot nor the total can reach 2^63 and wrap
+// (at 2^44 a total of ~5e5, e.g. a diverging semantic BCE sum over a large batch, wrapped silently).
+constexpr double TL_FIX_SCALE = 17179869184.0;  // 2^34
+constexpr float TL_FIX_MAX = 4096.0f;
 template <bool FIXED>
-__device__ __forceinline__ void slot_add(float* __restrict__ row, int block, int wave, float v, unsigned* flag = nullptr) {
+__device__ __forceinline__ void slot_add(float* __restrict__ row, int block, int wave, float v, unsigned* flag = nullptr,
+                                         float vmax = TL_FIX_MAX) {
   if constexpr (FIXED) {
-    if (!(fabsf(v) < 4.0e5f)) {  // inf / nan / absurd
+    if (!(fabsf(v) <= vmax)) {  // inf / nan / absurd
       if (flag) atomicOr(flag, 1u);
       return;
     }
@@ -338,8 +344,11 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
     l_rgb = wave_sum(l_rgb);
     l_sem = wave_sum(l_sem);
     if (lane == 0) {
-      slot_add<true>(rgb_slots, blockIdx.x, wave, l_rgb, flag);
-      slot_add<true>(sem_slots, blockIdx.x, wave, l_sem, flag);
+      // these two rows take raw sums over a wave's 64 rays (not divided by R yet), 4 nbl of them: the bound that keeps
+      // their total below 2^28 (x 2^34 < 2^63) is 2^28 / waves — 4e6 per wave at 4096 rays
+      const float wave_cap = 268435456.0f / (float)(4 * nbl);
+      slot_add<true>(rgb_slots, blockIdx.x, wave, l_rgb, flag, wave_cap);
+      slot_add<true>(sem_slots, blockIdx.x, wave, l_sem, flag, wave_cap);
     }
   } else {
     const int b = (int)blockIdx.x - nbl;

@@ -330,6 +330,8 @@ class FruitModel(nn.Module):
         sampler = self.proposal_sampler
         if not self.training or not isinstance(sampler, ProposalNetworkSampler):
             return None
+        if sampler.num_proposal_network_iterations + 1 > L.FNR_TRAIN_PROLOGUE_MAX_JITTER:
+            return None     # more jitters than fnr_train_prologue draws: the separate launches (torch.rand + sample_spaced)
         return {"S": sampler.num_proposal_samples_per_ray[0], "near": float(self.config.near_plane),
                 "far": float(self.config.far_plane), "n_jitter": sampler.num_proposal_network_iterations + 1}
 

@@ -1062,8 +1062,11 @@ class TrainingSteps:
 
     def _draw(self, finishing_step: Optional[int]):
         from .rays import RayBundle
-        o, d, cam, batch = self.batcher.sample(self.n_rays, self.camera[0] if self.camera else None,
-                                               level0=self.model.level0_spec())
+        level0 = self.model.level0_spec()
+        n_train = getattr(getattr(self.batcher, "image_ids", None), "numel", lambda: 0)()
+        if self.camera is not None and self.n_rays < n_train:
+            level0 = None     # fnr_train_prologue adjusts one camera per ray slot: fewer rays than cameras -> separate launches
+        o, d, cam, batch = self.batcher.sample(self.n_rays, self.camera[0] if self.camera else None, level0=level0)
         rb = RayBundle(o, d, None, cam, presampled=self.batcher.last_presample)
         if finishing_step is not None:
             self.model.sample_ahead(rb, finishing_step)

@@ -146,6 +146,12 @@ int64_t fnr_profile_collect(int32_t* ops_host, int64_t* units_host, float* ms_ho
  * gradient's summation order, hence its last bits, depend on timing.  No counterpart in the reference (torch autograd
  * scatters with atomics throughout). */
 int fnr_debug_scatter_overflows(uint64_t* count_host, int reset);
+/* records_host[2] = records the accumulate kernels have summed since the last reset: [0] into the field's table
+ * (fnr_hash_encode_bwd*), [1] into proposal tables (fnr_prop_density_bwd*) — i.e. the 8 L contributions per sample after
+ * run pre-summing.  Each record is 10 bytes written by the emit kernel and read back by the accumulate kernel: the
+ * design overhead bench.py reports as roofline.record_queue_bytes.  Synchronises the device.  No counterpart in the
+ * reference. */
+int fnr_debug_scatter_records(uint64_t* records_host, int reset);
 
 /* ---- caller side: pixel sampling + ray generation --------------------------------------------- */
 /* The on-device image batch of a datamanager: uint8 images [M,H,W,3], uint8 fruit masks [M,H,W] (1 = fruit),
@@ -167,6 +173,7 @@ int fnr_sample_pixels(const fnr_image_set* set, const int64_t* train_ids, int n_
                       const float* c2w_adjusted, float* origins, float* directions, int32_t* camera_indices,
                       float* image, float* fruit_mask, void* stream);
 
+#define FNR_TRAIN_PROLOGUE_MAX_JITTER 5   /* rows of `jitter` one fnr_train_prologue launch draws (level 0 + 4 PDF levels) */
 /* The start of a training step in ONE launch (single jitter per ray, the Nerfacto default): draws the step's random
  * numbers itself — Philox4x32-10, counter = (ray, word group, offset), key = seed; the caller advances `offset` by one per
  * step — and performs fnr_camera_adjust (pose_adjustment / c2w_adjusted both set, or both NULL), fnr_sample_pixels and
@@ -443,8 +450,13 @@ int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, const fnr_p
  * each of the n_levels (<= FNR_MAX_PROPOSAL_LEVELS) proposal levels against the final level + (want_distortion)
  * fnr_distortion, and the sum of the accumulator slots.  losses [5] = rgb_loss, semantics_loss, psnr,
  * interlevel_loss, distortion (0 when not wanted); d_rgb [R,3], d_semantics [R], d_weights_p[l] [R,S_p[l]] as the
- * single calls give them.  accum: FNR_TRAIN_LOSSES_ACCUM_FLOATS floats, ZEROED by the caller (loss slots + completion
- * counters).  S_p / spacing_p / weights_p / d_weights_p are host arrays of n_levels entries.
+ * single calls give them.  accum: FNR_TRAIN_LOSSES_ACCUM_FLOATS floats (loss slots + completion counters), zeroed by
+ * the caller before its FIRST use; every completed call leaves it zeroed again (the last workgroup cleans up), so a caller
+ * that keeps the buffer launches no fill per step — after a FAILED call the caller must zero it again.  The slots hold
+ * 64-bit fixed point (2^-34 resolution): a contribution that is not finite or beyond its row's bound (4096 for the per-ray
+ * interlevel / distortion terms, 2^28 / waves for the per-wave squared-error and BCE sums) makes every loss of the call
+ * NaN instead of wrapping the sum.
+ * S_p / spacing_p / weights_p / d_weights_p are host arrays of n_levels entries.
  * d_density_p (optional, with euclid_p [R,S_p+1] and density_p [R,S_p]): level l's d(loss)/d(density) [R,S_p[l]] =
  * fnr_weights_bwd of that level with d_weights_p[l] as upstream, computed in the same pass (bit-identical); then
  * d_weights_p / d_weights_p[l] may be NULL. */

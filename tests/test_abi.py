@@ -38,7 +38,8 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(L.fnr_table_adam) == 24 + 8 + 8 + 3 * 8   # int + 4 floats (padded), step, 2 floats, 3 pointers
     assert C.sizeof(L.fnr_adam_span) == 3 * 8 + 4 + 4
     hdr = open(os.path.join(ROOT, "include", "fruitnerf_hip.h")).read()
-    for name in ("FNR_MAX_ADAM_SPANS", "FNR_MAX_PROPOSAL_LEVELS", "FNR_LOSS_SLOTS"):
+    for name in ("FNR_MAX_ADAM_SPANS", "FNR_MAX_PROPOSAL_LEVELS", "FNR_LOSS_SLOTS", "FNR_MAX_POSITION_SOURCES",
+                 "FNR_TRAIN_PROLOGUE_MAX_JITTER"):
         assert int(re.search(r"#define %s (\d+)" % name, hdr).group(1)) == getattr(L, name)
     assert L.FNR_TRAIN_LOSSES_ACCUM_FLOATS == 4 * L.FNR_LOSS_SLOTS + 33 * 32
     assert "#define FNR_TRAIN_LOSSES_ACCUM_FLOATS (4 * FNR_LOSS_SLOTS + 33 * 32)" in hdr
