@@ -776,7 +776,11 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         # The ray gradients' sources are complete once the MLP backward is (its d_pos) and the proposal chain's MLP
         # backwards have run; their reduction and the camera optimiser's ~30 us of small launches do not need the
         # scatters: single process + second stream -> they run next to one
-        tail_on_side = bool(overlap_proposal_backward and ray_grads is not None and exchange is None)
+        # ... and with a gradient exchange the same segment holds what follows the collectives of the small groups
+        # (after_ray_grads = fused_train_iteration's exchange_tail: pose gradient + its all-reduce, the proposal networks'
+        # all-reduce, their waits and optimiser steps), so that N > 1 keeps the schedule N = 1 has
+        tail_on_side = bool(overlap_proposal_backward and ((ray_grads is not None and exchange is None) or
+                                                           (exchange is not None and after_ray_grads is not None)))
         sources_early = False   # the proposal chain recorded `pos_ready` ahead of its scatter
         if prop_bwd:
             if overlap_proposal_backward:
@@ -784,7 +788,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 fj.fork(side)
                 crosses_to(side, rctx, d_wps, d_o, d_d)
                 pos_ready = None
-                if tail_on_side and not serialize_streams:
+                if tail_on_side and not serialize_streams and exchange is None:
                     pos_ready = model.__dict__.get("_pos_ready_event")
                     if pos_ready is None:
                         pos_ready = model.__dict__["_pos_ready_event"] = torch.cuda.Event()
@@ -832,31 +836,50 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             if tail_ready is None:
                 tail_ready = model.__dict__["_tail_ready_event"] = torch.cuda.Event()
             tail_ready.record(main)                # the MLP backward (its d_pos) is enqueued
-        if exchange is None and table_adam is not None:
-            K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, table_adam)
-        elif exchange is None:
-            K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
-        else:
-            n_lv = int(gnet.grid.n_levels)
-            per = -(-n_lv // max(1, exchange.level_groups))
-            for lb in range(0, n_lv, per):
-                cnt = min(per, n_lv - lb)
-                K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, lb, cnt)
-                exchange.levels_done(lb, cnt)      # this slice of the gradient table is final: all-reduce it now
-            exchange.field_done()
-        if tail_on_side:
+        def scatter():
+            if exchange is None and table_adam is not None:
+                K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, table_adam)
+            elif exchange is None:
+                K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats)
+            else:
+                n_lv = int(gnet.grid.n_levels)
+                per = -(-n_lv // max(1, exchange.level_groups))
+                for lb in range(0, n_lv, per):
+                    cnt = min(per, n_lv - lb)
+                    K.hash_encode_bwd(gnet.grid, fld.warp_struct(), rays, fin["euclid"], S, d_feats, lb, cnt)
+                    exchange.levels_done(lb, cnt)      # this slice of the gradient table is final: all-reduce it now
+                exchange.field_done()
+
+        def tail():
             if side is None:                       # a step without a proposal backward: the event is the whole fork
-                side = _second_stream(model, dev)
+                side_ = _second_stream(model, dev)
+            else:
+                side_ = side
             # behind the scatter (serialize_streams) instead of underneath it
-            fj.fork(side, None if serialize_streams else tail_ready)
-            crosses_to(side, ray_sources, field_source, d_o, d_d, rays)
-            with torch.cuda.stream(side):
+            fj.fork(side_, None if serialize_streams else tail_ready)
+            crosses_to(side_, ray_sources, field_source, d_o, d_d, rays)
+            with torch.cuda.stream(side_):
                 if not sources_early:
-                    K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
+                    if ray_grads is not None:
+                        K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
                     if after_ray_grads is not None:
                         after_ray_grads()
                 if ahead is not None:
                     ahead()
+
+        if tail_on_side and exchange is not None and not serialize_streams:
+            # Gradient exchange: the second stream's segment is ENQUEUED FIRST — its collectives (proposal networks, poses:
+            # 10.5 MB + 2 KB) then sit ahead of the field's 67 MB on the communicator's stream, which runs them in issue
+            # order, instead of waiting behind it; on the GPU the segment still runs next to the scatter (it only waits
+            # for the MLP backward's event)
+            tail()
+            scatter()
+            fj.join()
+            fj.check()
+            return loss_dict, metrics_dict
+        scatter()
+        if tail_on_side:
+            tail()
             fj.join()                              # every local of this call outlives the second stream's launches
             fj.check()
             return loss_dict, metrics_dict
@@ -979,32 +1002,49 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
         def camera_step():   # the datamanager's backward + optimiser step, as soon as it can run
             with torch.no_grad():
                 camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
+    lrs = None
+    if exchange is not None:
+        # The exchange path's counterpart of the single-process tail (round 4): everything that follows the collectives of
+        # the SMALL groups — the proposal networks' 10.5 MB on the steps that train them, the 2 KB pose gradient — runs in
+        # the second stream's segment of fused_forward_backward (their all-reduces are issued there, ahead of the field's
+        # 67 MB; their waits, 1 / world + optimiser steps and the look-ahead follow on that stream), next to the table
+        # scatter.  The update schedule is a function of the step, identical on every rank: on steps that do not train the
+        # proposal networks their gradients are zero everywhere, their exchange is skipped and — as in the reference
+        # (grad = None -> torch.optim skips them) — so is their optimiser step.
+        prop_updated = bool(model.training and model.proposal_sampler.updated_now())    # what _render is about to see
+        prop_stepped = prop_updated or not optimizer.skip_groups_without_grad
+        lrs = optimizer.begin_step(skip=() if prop_stepped else ("proposal_networks",))
+        scale = 1.0 / world_size
+
+        def camera_step():   # noqa: F811  (exchange_tail)
+            with torch.no_grad():
+                small = start_gradient_sync(arena, spans["proposal_networks"], world_size) if prop_updated else []
+                cam_work, cam_scale = (camera_backward(camera[0], camera[2], ray_grads, world_size)
+                                       if camera is not None else (None, 1.0))
+                for a, b, work in small:
+                    work.wait()                                # the stream this runs on waits for this bucket only
+                    optimizer.step_span(a, b, lrs["proposal_networks"], scale, group="proposal_networks")
+                if prop_stepped and not prop_updated:   # torch < 2.0 semantics: zero gradients everywhere, still a step
+                    pa, pb = spans["proposal_networks"]
+                    optimizer.step_span(pa, pb, lrs["proposal_networks"], scale, group="proposal_networks")
+                if camera is not None:
+                    if cam_work is not None:
+                        cam_work.wait()
+                    camera[1].step(grad_scale=cam_scale)
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads, overlap_proposal_backward=OVERLAP_PROPOSAL_BACKWARD,
                                                      table_adam=table_adam, weight_adam=weight_adam,
                                                      proposal_optimizer=prop_opt, after_ray_grads=camera_step,
                                                      serialize_streams=SERIALIZE_STREAMS,
-                                                     ahead=ahead_early if exchange is None else None)
+                                                     ahead=ahead_early if exchange is None else ahead)
     with torch.no_grad():
         if exchange is None:
             optimizer.step(skip=skipped_groups(model, optimizer), done=done)
             if ahead is not None and ahead_early is None:
                 ahead()
         else:
-            pending = list(exchange.pending)
-            # the update schedule is a function of the step, identical on every rank: on steps that did not train the
-            # proposal networks their gradients are zero everywhere and the 10.5 MB exchange is skipped
-            prop_updated = bool(getattr(model, "_last_render_updated", True))
-            prop_stepped = prop_updated or not optimizer.skip_groups_without_grad
-            if prop_updated:
-                pending += start_gradient_sync(arena, spans["proposal_networks"], world_size)
-            # collectives run in issue order on the communicator's stream: the 2 KB pose-gradient exchange goes LAST so
-            # that nothing on the compute stream waits behind the big buckets before their own Adam launches
-            cam_work, cam_scale = (camera_backward(camera[0], camera[2], ray_grads, world_size)
-                                   if camera is not None else (None, 1.0))
-            # ... and, as in the reference (grad = None -> torch.optim skips them), neither is their optimiser step
-            lrs = optimizer.begin_step(skip=() if prop_stepped else ("proposal_networks",))
-            scale = 1.0 / world_size
+            assert prop_updated == bool(getattr(model, "_last_render_updated", True)), "proposal update schedule"
+            pending = list(exchange.pending)                   # the field's buckets (issued behind the scatter)
             deferred = []
             for a, b, work in pending:
                 name = "fields" if a >= spans["fields"][0] else "proposal_networks"
@@ -1013,9 +1053,6 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
                     continue
                 work.wait()                                    # the compute stream waits for this bucket only
                 optimizer.step_span(a, b, lrs[name], scale, group=name)
-            if prop_stepped and not prop_updated:   # torch < 2.0 semantics: zero gradients everywhere, still a step
-                pa, pb = spans["proposal_networks"]
-                optimizer.step_span(pa, pb, lrs["proposal_networks"], scale, group="proposal_networks")
             if deferred:
                 lr_f, step_f = lrs["fields"], optimizer.group_steps["fields"]
 
@@ -1025,12 +1062,6 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
                             work.wait()
                             optimizer.step_span(a, b, lr_f, scale, group="fields", step=step_f)
                 model.field.defer_update(finish)
-            if camera is not None:
-                if cam_work is not None:
-                    cam_work.wait()
-                camera[1].step(grad_scale=cam_scale)
-            if ahead is not None:
-                ahead()
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
 

@@ -136,3 +136,84 @@ def test_exchange_path_step_is_the_single_process_step(dev):
     # second step: its inputs (the MLP weights) already differ in the last bits between ANY two runs
     for x, y in zip(s2, e2):
         assert float((x - y).abs().mean()) <= 1e-4 * float(x.abs().mean()) + 1e-9
+
+
+def test_exchange_path_keeps_the_two_stream_schedule(dev):
+    """Round 4: with a gradient exchange the second stream's segment carries what the single process has there — the
+    ray-gradient reduction, the pose gradient and its all-reduce, the proposal networks' all-reduce, their waits and
+    optimiser steps, and the look-ahead — and is enqueued AHEAD of the table scatter so that the small collectives precede
+    the field's 67 MB on the communicator's stream.  TrainingSteps over a one-rank RCCL group against the single process:
+    same states after 8 steps (update and non-update steps), every step but the first ran on a look-ahead, and the order
+    of the all-reduce calls is small groups first."""
+    import torch.distributed as dist
+    import fruitnerf_amd.training as T
+    from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+    from fruitnerf_amd.data import synthetic_apple as sa
+    n_cam, HW, focal, R, steps = 8, 64, 90.0, 512, 14
+    cfg = util.small_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, num_images=n_cam, seed=21)
+    scene = sa.make_scene(seed=0)
+    c2w = sa.make_cameras(n_cam, seed=0)
+    data = {k: (v.to(dev) if torch.is_tensor(v) else v)
+            for k, v in sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal).items()}
+
+    def run(world_arg, log=None):
+        hm = util.make_hip_like(om, dev)
+        hm.train()
+        opt = T.FusedAdam(hm)
+        cam = CameraOptimizerConfig(mode="SO3xR3").setup(n_cam, dev)
+        batcher = sa.PixelBatcher(data, torch.arange(n_cam, device=dev), seed=3)
+        loop = T.TrainingSteps(hm, opt, batcher, R, camera=(cam, CameraAdam(cam)), world_size=world_arg)
+        for step in range(steps):
+            if log is not None:
+                log.append(("step", step, bool(hm.proposal_sampler.updated_now())))
+            loop.step()
+        hm.field.flush_deferred_update()
+        torch.cuda.synchronize()
+        table = hm.field.mlp_base_grid.hash_table
+        a, n = [(off, k) for _, p, off, k in hm.arena().entries if p is table][0]
+        return (hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), cam.pose_adjustment.data.clone(),
+                hm.__dict__.get("_ahead_used", 0), (a, a + n))
+
+    single = run(1)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29643", rank=0, world_size=1, device_id=dev)
+    old, old_defer = T.EXCHANGE_MIN_WORLD, T.DEFER_FIELD_UPDATE
+    T.EXCHANGE_MIN_WORLD, T.DEFER_FIELD_UPDATE = 1, True
+    log = []
+    real = dist.all_reduce
+
+    def spy(tensor, *a, **k):
+        log.append(("all_reduce", int(tensor.numel())))
+        return real(tensor, *a, **k)
+
+    dist.all_reduce = spy
+    try:
+        exch = run(1, log)
+    finally:
+        dist.all_reduce = real
+        T.EXCHANGE_MIN_WORLD, T.DEFER_FIELD_UPDATE = old, old_defer
+        if created:
+            dist.destroy_process_group()
+    assert single[4] == exch[4] == steps - 1, "every step but the first runs on what the previous one sampled ahead"
+    a, b = single[5]
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), single[:3], exch[:3]):
+        assert torch.equal(x[a:b], y[a:b]), f"hash table {name}"
+        assert float((x - y).abs().max()) <= 1e-6 * max(1.0, float(x.abs().max())), name
+    assert torch.equal(single[3], exch[3]), "camera poses"
+    # per step: [proposal networks (update steps only)], poses (n_cam x 6), then the field group — the largest — last
+    i = 0
+    seen_update = seen_plain = False
+    while i < len(log):
+        assert log[i][0] == "step"
+        updated = log[i][2]
+        calls = []
+        i += 1
+        while i < len(log) and log[i][0] == "all_reduce":
+            calls.append(log[i][1])
+            i += 1
+        assert len(calls) == (3 if updated else 2), (updated, calls)
+        assert calls[-1] == max(calls) and calls[-2] == n_cam * 6, calls
+        seen_update, seen_plain = seen_update or updated, seen_plain or not updated
+    assert seen_update and seen_plain
