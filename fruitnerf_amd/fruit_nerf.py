@@ -242,6 +242,9 @@ class FruitModel(nn.Module):
                     HashMLPDensityField(self.scene_aabb, spatial_distortion=scene_contraction, **args))
             self.density_fns.extend([network.density_fn for network in self.proposal_networks])
 
+        import functools
+
+        @functools.lru_cache(maxsize=8192)     # (a pure function of the step, asked several times per iteration)
         def update_schedule(step):  # fruit_nerf.py:131-136
             return np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]),
                            1, cfg.proposal_update_every)
@@ -486,8 +489,10 @@ class FruitModel(nn.Module):
         bumps them, and _render / TrainingSteps then sample again instead of training on samples and saved features of
         the old weights.  (Writes through `p.data` bypass the counters: call TrainingSteps.drop_lookahead().)"""
         arena = self._arena
-        return (id(arena), None if arena is None else arena.params.data_ptr()) + \
-            tuple(p._version for p in self.proposal_networks.parameters())
+        cached = self.__dict__.get("_lookahead_params")
+        if cached is None or cached[0] is not arena:     # (module traversal per call cost ~45 us of host time per step)
+            cached = self.__dict__["_lookahead_params"] = (arena, list(self.proposal_networks.parameters()))
+        return (id(arena), None if arena is None else arena.params.data_ptr()) + tuple(p._version for p in cached[1])
 
     def _empty_render(self, ray_bundle: RayBundle) -> Tuple[Dict, RenderContext]:
         dev = ray_bundle.origins.device

@@ -194,11 +194,13 @@ def test_end_to_end_count_matches_the_cpu_pipeline(dev):
                         [-0.5, 0.0, 0.0], [-0.5 + 1.5 * r, 0.0, 0.0],                                  # a touching pair
                         [0.0, -0.5, 0.0]])
     k = int(np.ceil(r / h))
-    g = np.stack(np.meshgrid(*[np.arange(-k, k + 1)] * 3, indexing="ij"), -1).reshape(-1, 3) * h
-    ball = g[(g * g).sum(1) <= r * r]
-    parts = [np.round(c / h) * h + ball for c in centres]
-    crumb = g[(g * g).sum(1) <= (0.3 * r) ** 2] + np.round(np.array([0.3, -0.5, 0.0]) / h) * h         # far too small: pruned
-    X = np.unique(np.concatenate(parts + [crumb, np.round(rng.uniform(-1, 1, (300, 3)) / h) * h]), axis=0)
+    gi = np.stack(np.meshgrid(*[np.arange(-k, k + 1)] * 3, indexing="ij"), -1).reshape(-1, 3)          # lattice INDICES
+    ball = gi[((gi * h) ** 2).sum(1) <= r * r]
+    parts = [np.round(c / h).astype(np.int64) + ball for c in centres]
+    crumb = gi[((gi * h) ** 2).sum(1) <= (0.3 * r) ** 2] + np.round(np.array([0.3, -0.5, 0.0]) / h).astype(np.int64)   # pruned
+    clutter = np.round(rng.uniform(-1, 1, (300, 3)) / h).astype(np.int64)
+    # unique in index space: the touching balls share lattice nodes, and two float sums for one node may differ in an ulp
+    X = np.unique(np.concatenate(parts + [crumb, clutter]), axis=0).astype(np.float64) * h
     rng.shuffle(X)
     kw = dict(voxel_size_down_sample=h / 4, remove_outliers_nb_points=2, remove_outliers_radius=1.8 * h, min_samples=4,
               apple_template_size=1.0, cluster_merge_distance=0.04, gt_cluster=centres, gt_count=len(centres),

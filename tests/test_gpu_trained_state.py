@@ -322,10 +322,16 @@ def test_gradients_on_identical_samples_at_a_trained_state(dev, shape):
         assert abs(a - r) <= 1e-4 * max(abs(r), 1e-3), k
     named_h = dict(hm.named_parameters())
     worst = ("", 0.0)
+    ref_grads = {name: (p.grad if p.grad is not None else torch.zeros_like(p)) for name, p in om.named_parameters()}
     for name, p in om.named_parameters():
-        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        ref = ref_grads[name]
         got = named_h[name].grad.detach().cpu()
         scale = ref.abs().max().item()
+        if ref.numel() == 1 and name.endswith(".bias"):
+            # a scalar output bias is ONE sum of signed per-sample terms (d loss / d out) that nearly cancel (|g| ~ 1e-6
+            # where the layer's weight gradient, the same terms weighted by O(1) activations, is ~5e-5): its own magnitude
+            # is not the scale of its rounding error, the layer's weight gradient is
+            scale = max(scale, ref_grads[name[:-len("bias")] + "weight"].abs().max().item())
         mx = (got - ref).abs().max().item() / max(scale, 1e-30)
         agg = (got - ref).abs().double().sum().item() / max(ref.abs().double().sum().item(), 1e-30)
         print(f"[same samples {shape}] grad {name}: max|ref| {scale:.3e} max-norm rel {mx:.3e} L1-rel {agg:.3e}")
