@@ -609,6 +609,8 @@ class _FieldGradientExchange:
         self.per_level = self.table_n // self.n_levels
         self.f0, self.f1 = self.arena.group_ranges["fields"]
         self.head_sent = self.tail_sent = False
+        self.hold = False          # True: levels_done / field_done only note their spans; issue() starts the collectives
+        self.held = []
 
     def levels_done(self, level_begin: int, level_count: int) -> None:
         a = self.table_off + level_begin * self.per_level
@@ -617,7 +619,17 @@ class _FieldGradientExchange:
             a, self.head_sent = self.f0, True
         if level_begin + level_count == self.n_levels and not self.tail_sent:
             b, self.tail_sent = self.f1, True
-        self.pending += start_gradient_sync(self.arena, (a, b), self.world, bucket_elems=max(GRAD_BUCKET_ELEMS, b - a))
+        if self.hold:
+            self.held.append(((a, b), max(GRAD_BUCKET_ELEMS, b - a)))
+        else:
+            self.pending += start_gradient_sync(self.arena, (a, b), self.world, bucket_elems=max(GRAD_BUCKET_ELEMS, b - a))
+
+    def issue(self) -> None:
+        """Start the collectives of the spans noted while `hold` was set (in order)."""
+        for span, bucket in self.held:
+            self.pending += start_gradient_sync(self.arena, span, self.world, bucket_elems=bucket)
+        self.held = []
+        self.hold = False
 
     def field_done(self) -> None:
         """Whatever of the group no level collective carried (nothing when all levels went through levels_done)."""
@@ -625,13 +637,33 @@ class _FieldGradientExchange:
                 ([] if self.tail_sent else [(self.table_off + self.table_n, self.f1)])
         for span in spans:
             if span[1] > span[0]:
-                self.pending += start_gradient_sync(self.arena, span, self.world)
+                if self.hold:
+                    self.held.append((span, GRAD_BUCKET_ELEMS))
+                else:
+                    self.pending += start_gradient_sync(self.arena, span, self.world)
+
+
+# HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), round robin in creation order.
+# In a single process the second stream lands on its own queue; once RCCL has created its streams it may land on the
+# LAUNCH stream's queue, and then nothing overlaps (round 4, rocprofv3 kernel trace of the one-rank RCCL run,
+# profiles/r04_raw/kt_exchange_step.txt: every kernel of both streams on queue 0, the second stream's 150 us segment run
+# ahead of the table scatter instead of next to it).  A stream of another priority gets a hardware queue of its own:
+# "high" is the default when a process group exists and GPU_MAX_HW_QUEUES is below 8, "normal" otherwise.  Measured on
+# the one-rank RCCL run (round 4, ms/step): colliding queues 0.989, high priority 0.930, GPU_MAX_HW_QUEUES=8 with normal
+# priority 0.887 (bench.py exports that for multi-rank runs; a host application should too), single
+# process 0.795.  FNR_SIDE_STREAM_PRIORITY = high | normal overrides.
+SIDE_STREAM_PRIORITY = os.environ.get("FNR_SIDE_STREAM_PRIORITY", "auto")
 
 
 def _second_stream(model, dev):
     side = model.__dict__.get("_side_stream")
     if side is None or side.device != dev:
-        side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)   # (a high-priority stream changes nothing: measured)
+        want = SIDE_STREAM_PRIORITY
+        if want == "auto":
+            import torch.distributed as dist
+            queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)      # (HIP reads it when the runtime starts)
+            want = "high" if (dist.is_available() and dist.is_initialized() and queues < 8) else "normal"
+        side = model.__dict__["_side_stream"] = torch.cuda.Stream(device=dev, priority=-1 if want == "high" else 0)
     return side
 
 
@@ -710,7 +742,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                            want_metrics: bool = True, exchange: Optional[_FieldGradientExchange] = None,
                            ray_grads: Optional[dict] = None, overlap_proposal_backward: bool = False,
                            table_adam=None, weight_adam=None, proposal_optimizer: Optional["FusedAdam"] = None,
-                           after_ray_grads=None, serialize_streams: bool = False, ahead=None):
+                           after_ray_grads=None, serialize_streams: bool = False, ahead=None, exchange_finish=None):
     """model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> sum -> backward without the autograd engine:
     the same kernels in the same order, called directly.
 
@@ -852,30 +884,42 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                     exchange.levels_done(lb, cnt)      # this slice of the gradient table is final: all-reduce it now
                 exchange.field_done()
 
-        def tail():
+        def tail(first=True, last=True):
+            """The second stream's segment; with a gradient exchange in two parts: first = up to the issue of the small
+            collectives (after_ray_grads), last = their waits + optimiser steps (exchange_finish) and the look-ahead."""
             if side is None:                       # a step without a proposal backward: the event is the whole fork
                 side_ = _second_stream(model, dev)
             else:
                 side_ = side
-            # behind the scatter (serialize_streams) instead of underneath it
-            fj.fork(side_, None if serialize_streams else tail_ready)
-            crosses_to(side_, ray_sources, field_source, d_o, d_d, rays)
+            if first:
+                # behind the scatter (serialize_streams) instead of underneath it
+                fj.fork(side_, None if serialize_streams else tail_ready)
+                crosses_to(side_, ray_sources, field_source, d_o, d_d, rays)
             with torch.cuda.stream(side_):
-                if not sources_early:
+                if first and not sources_early:
                     if ray_grads is not None:
                         K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
                     if after_ray_grads is not None:
                         after_ray_grads()
-                if ahead is not None:
-                    ahead()
+                if last:
+                    if exchange_finish is not None:
+                        exchange_finish()
+                    if ahead is not None:
+                        ahead()
 
-        if tail_on_side and exchange is not None and not serialize_streams:
-            # Gradient exchange: the second stream's segment is ENQUEUED FIRST — its collectives (proposal networks, poses:
-            # 10.5 MB + 2 KB) then sit ahead of the field's 67 MB on the communicator's stream, which runs them in issue
-            # order, instead of waiting behind it; on the GPU the segment still runs next to the scatter (it only waits
-            # for the MLP backward's event)
-            tail()
+        if tail_on_side and exchange is not None and not serialize_streams and exchange.level_groups <= 1:
+            # Gradient exchange, host order (the host is only ~0.2 ms ahead of the GPU on this path, so what it enqueues
+            # first matters): (1) the scatter's launches — the critical chain; (2) the second stream's segment up to the
+            # ISSUE of the small collectives (proposal networks 10.5 MB, poses 2 KB), so that they precede the field's
+            # 67 MB on the communicator's stream, which runs collectives in issue order; (3) the field's collective — the
+            # scatter is still running on the GPU; (4) the small groups' waits + optimiser steps and the look-ahead.
+            # (Enqueueing the whole segment before the scatter left the launch stream idle for ~60 us per step, round 4
+            # kernel trace profiles/r04_raw/kt_exchange_high_step.txt.)
+            exchange.hold = True
             scatter()
+            tail(first=True, last=False)
+            exchange.issue()
+            tail(first=False, last=True)
             fj.join()
             fj.check()
             return loss_dict, metrics_dict
@@ -897,6 +941,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
         if after_ray_grads is not None:
             after_ray_grads()
+        if exchange_finish is not None:
+            exchange_finish()
         if ahead is not None:
             ahead()
         fj.check()
@@ -1004,7 +1050,7 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
         def camera_step():   # the datamanager's backward + optimiser step, as soon as it can run
             with torch.no_grad():
                 camera_backward_and_step(camera[0], camera[1], camera[2], ray_grads, world_size)
-    lrs = None
+    lrs = exchange_finish = None
     if exchange is not None:
         # The exchange path's counterpart of the single-process tail (round 4): everything that follows the collectives of
         # the SMALL groups — the proposal networks' 10.5 MB on the steps that train them, the 2 KB pose gradient — runs in
@@ -1018,18 +1064,24 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
         lrs = optimizer.begin_step(skip=() if prop_stepped else ("proposal_networks",))
         scale = 1.0 / world_size
 
-        def camera_step():   # noqa: F811  (exchange_tail)
+        small_groups = {}
+
+        def camera_step():   # noqa: F811  (the exchange path's first half of the tail: issue the small collectives)
             with torch.no_grad():
-                small = start_gradient_sync(arena, spans["proposal_networks"], world_size) if prop_updated else []
-                cam_work, cam_scale = (camera_backward(camera[0], camera[2], ray_grads, world_size)
+                small_groups["prop"] = start_gradient_sync(arena, spans["proposal_networks"], world_size) if prop_updated else []
+                small_groups["cam"] = (camera_backward(camera[0], camera[2], ray_grads, world_size)
                                        if camera is not None else (None, 1.0))
-                for a, b, work in small:
+
+        def exchange_finish():   # ... second half: their waits, 1 / world + optimiser steps
+            with torch.no_grad():
+                for a, b, work in small_groups["prop"]:
                     work.wait()                                # the stream this runs on waits for this bucket only
                     optimizer.step_span(a, b, lrs["proposal_networks"], scale, group="proposal_networks")
                 if prop_stepped and not prop_updated:   # torch < 2.0 semantics: zero gradients everywhere, still a step
                     pa, pb = spans["proposal_networks"]
                     optimizer.step_span(pa, pb, lrs["proposal_networks"], scale, group="proposal_networks")
                 if camera is not None:
+                    cam_work, cam_scale = small_groups["cam"]
                     if cam_work is not None:
                         cam_work.wait()
                     camera[1].step(grad_scale=cam_scale)
@@ -1038,7 +1090,8 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
                                                      table_adam=table_adam, weight_adam=weight_adam,
                                                      proposal_optimizer=prop_opt, after_ray_grads=camera_step,
                                                      serialize_streams=SERIALIZE_STREAMS,
-                                                     ahead=ahead_early if exchange is None else ahead)
+                                                     ahead=ahead_early if exchange is None else ahead,
+                                                     exchange_finish=exchange_finish if exchange is not None else None)
     with torch.no_grad():
         if exchange is None:
             optimizer.step(skip=skipped_groups(model, optimizer), done=done)
