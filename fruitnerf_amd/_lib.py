@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FNR_LIB_PATH") or os.path.join(_HERE, "lib", "libfrui
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 9      # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 10     # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -56,7 +56,7 @@ class fnr_field_net(C.Structure):
 class fnr_table_adam(C.Structure):
     _fields_ = [("algorithm", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("step", C.c_int64), ("grad_scale", C.c_float), ("weight_decay", C.c_float),
-                ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p)]
+                ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("touched", C.c_void_p)]
 
 
 class fnr_adam_span(C.Structure):

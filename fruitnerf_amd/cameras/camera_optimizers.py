@@ -106,7 +106,7 @@ class CameraAdam:
         p = self.opt.pose_adjustment
         return L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], c.eps,
                                 self.step_count, grad_scale, c.weight_decay, L.ptr(p.data), L.ptr(self.exp_avg),
-                                L.ptr(self.exp_avg_sq))
+                                L.ptr(self.exp_avg_sq), None)
 
     def step(self, grad_scale: float = 1.0) -> None:
         from ..training import exponential_decay_lr

@@ -316,6 +316,7 @@ struct TableAdam {
   float2 *p, *m, *v;  // the table's slices of the parameter / exp_avg / exp_avg_sq arenas, [L << log2_T] rows
   float lr, b1, b2, eps, bc1, bc2_sqrt, rect, grad_scale, weight_decay;
   int radam;
+  unsigned* touched;  // one bit per pair of rows: ever received a gradient (nullable; fnr_table_adam.touched)
 };
 __device__ __forceinline__ void table_adam_update(const TableAdam& a, float g, float& P, float& M, float& V) {
   float gr = g * a.grad_scale;
@@ -361,6 +362,8 @@ static inline int make_table_adam(const fnr_table_adam* a, TableAdam& t) {
   t.v = reinterpret_cast<float2*>(a->exp_avg_sq);
   t.lr = a->lr, t.b1 = a->beta1, t.b2 = a->beta2, t.eps = a->eps, t.grad_scale = a->grad_scale, t.weight_decay = a->weight_decay;
   t.radam = a->algorithm;
+  t.touched = a->touched;
+  FNR_CHECK_ARG(!a->touched || a->weight_decay == 0.0f, "table adam: sparse-touch skipping needs weight_decay = 0");
   const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step);
   const double b2t = pow((double)a->beta2, (double)a->step);
   const double bc2 = 1.0 - b2t;

@@ -599,12 +599,21 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
       float4* P4 = reinterpret_cast<float4*>(adam.p + row0);
       float4* M4 = reinterpret_cast<float4*>(adam.m + row0);
       float4* V4 = reinterpret_cast<float4*>(adam.v + row0);
+      // sparse-touch skipping: a pair of rows that never received a gradient (bit clear) and receives none now has
+      // m = v = 0 and a zero update — its 48 bytes in + 48 out are skipped.  Bins are >= 64 rows here (32 pairs a word).
+      unsigned* tw = (adam.touched && rows >= 64) ? adam.touched + (row0 >> 6) : nullptr;
       // (Two iterations' parameters / moments in flight per thread — 96 B instead of 48 — changes nothing: 194.3 vs 194.9 us
       //  for the whole entry point, same-box A/B, profiles/r04_raw/ab_sweep.log.  The sweep is not latency-bound.)
       for (int e4 = threadIdx.x; e4 < (rows >> 1); e4 += blockDim.x) {
-        float4 P = P4[e4], M = M4[e4], V = V4[e4];
         const long long a0 = (long long)s_acc[4 * e4], a1 = (long long)s_acc[4 * e4 + 1],
                         a2 = (long long)s_acc[4 * e4 + 2], a3 = (long long)s_acc[4 * e4 + 3];
+        if (tw) {
+          const bool now = (a0 | a1 | a2 | a3) != 0;
+          const bool ever = (tw[e4 >> 5] >> (e4 & 31)) & 1u;
+          if (!now && !ever) continue;
+          if (!ever) atomicOr(&tw[e4 >> 5], 1u << (e4 & 31));   // first gradient of this pair (once per pair, ever)
+        }
+        float4 P = P4[e4], M = M4[e4], V = V4[e4];
         const float g0 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a0 * inv) : 0.0f;
         const float g1 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a1 * inv) : 0.0f;
         const float g2 = (a2 != 0 || a3 != 0) ? 0.0f + (float)((double)a2 * inv) : 0.0f;

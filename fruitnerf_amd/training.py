@@ -346,6 +346,9 @@ def exponential_decay_lr(step: int, lr_init: float, lr_final: float, max_steps: 
 
 
 L_MAX_ADAM_SPANS = 8   # include/fruitnerf_hip.h: FNR_MAX_ADAM_SPANS
+# fnr_table_adam.touched: the fused table steps skip pairs of rows that never received a gradient (their update is exactly
+# zero).  FNR_SPARSE_TOUCH=0 sweeps every row (A/B; results are bit-identical either way, tests/test_gpu_training_parity.py)
+SPARSE_TOUCH_SKIPPING = os.environ.get("FNR_SPARSE_TOUCH", "1") != "0"
 
 
 class FusedAdam:
@@ -376,6 +379,10 @@ class FusedAdam:
                                    for name in self.arena.group_ranges}
         self.step_count = 0                                   # scheduler steps (every iteration, every group)
         self.group_steps = {name: 0 for name in self.arena.group_ranges}   # optimiser steps a group actually took
+        # sparse-touch skipping of the fused table steps (fnr_table_adam.touched): one bit per pair of table rows, "ever
+        # received a gradient", per hash table; valid while it covers every pair with a non-zero moment (true from zero
+        # moments on; rebuild_touched() after loading moments from elsewhere)
+        self._touched: Dict[int, Tensor] = {}
 
     def current_lr(self, name: str) -> float:
         g = self.groups[name]
@@ -399,6 +406,25 @@ class FusedAdam:
         return {name: (exponential_decay_lr(self.step_count - 1, g["lr"], g["lr_final"], g["max_steps"])
                        if g.get("lr_final") is not None else g["lr"]) for name, g in self.groups.items()}
 
+    def touched_bitmap(self, table: Tensor, a: int, n: int) -> Optional[Tensor]:
+        """The persistent pair bitmap of `table` (arena span [a, a + n)); None when skipping does not apply."""
+        if not SPARSE_TOUCH_SKIPPING or self.weight_decay != 0.0 or n % 128 != 0:
+            return None
+        bm = self._touched.get(id(table))
+        if bm is None or bm.device != self.arena.params.device:
+            # from the moments (all zero at construction): bit i of word i / 32 = "pair i has a non-zero moment"
+            m, v = self.exp_avg[a:a + n].view(-1, 4), self.exp_avg_sq[a:a + n].view(-1, 4)
+            ever = ((m != 0) | (v != 0)).any(dim=1).view(-1, 32)           # [n / 128 words, 32 pairs]
+            words = (ever.to(torch.int64) << torch.arange(32, device=ever.device, dtype=torch.int64)).sum(dim=1)
+            bm = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()   # same 32 bits
+            self._touched[id(table)] = bm
+        return bm
+
+    def rebuild_touched(self) -> None:
+        """Forget the bitmaps: they are rebuilt from the moments at the next fused table step (after exp_avg / exp_avg_sq
+        were loaded or edited from outside)."""
+        self._touched.clear()
+
     def table_adam_args(self, table: Tensor, group: str = "fields", grad_scale: float = 1.0):
         """fnr_table_adam for the NEXT update of `table` (a parameter of `group` that lives in the arena): learning
         rate and step count as begin_step() will set them — the fused scatter (fnr_hash_encode_bwd_adam) runs before
@@ -414,7 +440,7 @@ class FusedAdam:
         args = L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], self.eps,
                                 self.group_steps[group] + 1, grad_scale, self.weight_decay,
                                 L.ptr(self.arena.params[a:a + n]), L.ptr(self.exp_avg[a:a + n]),
-                                L.ptr(self.exp_avg_sq[a:a + n]))
+                                L.ptr(self.exp_avg_sq[a:a + n]), L.ptr(self.touched_bitmap(table, a, n)))
         return args, (a, a + n)
 
     def weight_adam_args(self, group: str = "fields", grad_scale: float = 1.0):
@@ -427,7 +453,7 @@ class FusedAdam:
               if g.get("lr_final") is not None else g["lr"])
         args = L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], self.eps,
                                 self.group_steps[group] + 1, grad_scale, self.weight_decay,
-                                L.ptr(self.arena.params), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq))
+                                L.ptr(self.arena.params), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), None)
         return (args, self.arena.grads), tuple(self.arena.group_ranges[group])
 
     def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0, group: Optional[str] = None,

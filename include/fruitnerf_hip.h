@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 9
+#define FNR_ABI_VERSION 10
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -374,7 +374,14 @@ int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const f
  * exp_avg_sq are the TABLE's slices [n_levels << log2_hashmap_size, 2] of the caller's arenas, `step` is the
  * optimiser's step count of this update (>= 1), grad_scale / weight_decay as in fnr_adam_step.  The gradient table
  * (grid_grad->table) is left as it was (zero): it is only read where an overflowed queue spilled into it.  Results are
- * bit-identical to fnr_hash_encode_bwd followed by fnr_adam_step / fnr_radam_step on the table's span. */
+ * bit-identical to fnr_hash_encode_bwd followed by fnr_adam_step / fnr_radam_step on the table's span.
+ * touched (optional, table entry points only; weight_decay must be 0): persistent bitmap owned by the caller, one bit per
+ * PAIR of table rows (4 floats; bit i of word i / 32, index relative to `params`), zeroed when the moments are zero: "some
+ * row of this pair has ever received a gradient".  A pair whose bit is clear and which receives no gradient now has
+ * exp_avg = exp_avg_sq = 0, so torch's update of it is exactly zero (m = v = 0 stay, p - lr / bc1 * (0 / eps) = p) and
+ * its 24 B per parameter are neither read nor written ("sparse-touch skipping"): every level is hashed,
+ * so the coarse levels only ever use (res + 1)^3 of their 2^T rows — 27 % of the `fruit_nerf` table never moves.  The
+ * kernel sets the bits of the pairs it touches.  NULL: every row is swept.  Results are bit-identical either way. */
 typedef struct fnr_table_adam {
   int32_t algorithm;
   float lr, beta1, beta2, eps;
@@ -383,6 +390,7 @@ typedef struct fnr_table_adam {
   float* params;
   float* exp_avg;
   float* exp_avg_sq;
+  uint32_t* touched;
 } fnr_table_adam;
 int fnr_hash_encode_bwd_adam(const fnr_grid* grid_grad, const fnr_warp* warp, const fnr_rays* rays,
                              const float* euclid_bins, int S, const float* d_feats, void* workspace,

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/fruitnerf_hip.h but not exported"
         assert name in L.SIGNATURES, f"{name} has no ctypes signature in fruitnerf_amd/_lib.py"
     assert set(L.SIGNATURES) == set(declared)
-    assert lib.fnr_abi_version() == L.ABI_VERSION == 9
+    assert lib.fnr_abi_version() == L.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_header_sizes():
@@ -35,7 +35,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(L.fnr_lattice) == 16 + 3 * 8  # 3 ints padded to 16
     assert C.sizeof(L.fnr_prop_net) == C.sizeof(L.fnr_grid) + 8 + 4 * 8
     assert C.sizeof(L.fnr_field_net) == C.sizeof(L.fnr_grid) + 8 * 4 + (4 + 8 + 2 + 6 + 1) * 8 + 8  # + mlp_mode (padded)
-    assert C.sizeof(L.fnr_table_adam) == 24 + 8 + 8 + 3 * 8   # int + 4 floats (padded), step, 2 floats, 3 pointers
+    assert C.sizeof(L.fnr_table_adam) == 24 + 8 + 8 + 4 * 8   # int + 4 floats (padded), step, 2 floats, 4 pointers
     assert C.sizeof(L.fnr_adam_span) == 3 * 8 + 4 + 4
     hdr = open(os.path.join(ROOT, "include", "fruitnerf_hip.h")).read()
     for name in ("FNR_MAX_ADAM_SPANS", "FNR_MAX_PROPOSAL_LEVELS", "FNR_LOSS_SLOTS", "FNR_MAX_POSITION_SOURCES",
@@ -62,7 +62,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     rc = lib.fnr_train_losses(16, None, None, None, None, 1.0, None, None, 48, None, None, 0, None, None, None, None, None,
                               None, None, 1.0, 1, None, None, None)
     assert rc == -1 and b"train_losses" in lib.fnr_last_error()
-    adam = L.fnr_table_adam(2, 1e-2, 0.9, 0.999, 1e-8, 1, 1.0, 0.0, 1, 1, 1)        # algorithm 2 does not exist
+    adam = L.fnr_table_adam(2, 1e-2, 0.9, 0.999, 1e-8, 1, 1.0, 0.0, 1, 1, 1, None)        # algorithm 2 does not exist
     grid = L.fnr_grid()
     grid.n_levels, grid.log2_hashmap_size = 16, 19
     rc = lib.fnr_hash_encode_bwd_adam(C.byref(grid), C.byref(L.fnr_warp()), C.byref(rays), 1, 4, 1, 1, 1 << 30, 0,

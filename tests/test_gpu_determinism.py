@@ -221,3 +221,55 @@ def test_lookahead_is_dropped_when_parameters_change_between_steps(dev):
     assert got[3] == 15 - 2, f"look-aheads used: {got[3]} (two of the 15 must have been dropped)"
     for name, x, y in zip(("parameters", "exp_avg", "camera poses"), ref, got):
         assert torch.equal(x, y), f"{name} differ: a stale look-ahead was used"
+
+
+def test_sparse_touch_skipping_changes_nothing(dev):
+    """fnr_table_adam.touched (round 4): the fused table steps skip pairs of rows that never received a gradient — their
+    moments are zero, so torch's update of them is exactly zero.  60 steps with the skipping on (the default), with every
+    row swept (training.SPARSE_TOUCH_SKIPPING off) and with the bitmaps thrown away and rebuilt from the moments half way:
+    identical parameters, moments, poses, losses; and the bitmap says what the moments say — a pair is marked iff one of
+    its 4 moment entries is non-zero — with a sizeable part of the table never touched (every level is hashed: the coarse
+    levels use (res + 1)^3 of their 2^19 rows)."""
+    import fruitnerf_amd.training as T
+    ref = _run(dev, 60, "bf16x3")
+    saved = T.SPARSE_TOUCH_SKIPPING
+    T.SPARSE_TOUCH_SKIPPING = False
+    try:
+        dense = _run(dev, 60, "bf16x3")
+    finally:
+        T.SPARSE_TOUCH_SKIPPING = saved
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), ref, dense):
+        assert torch.equal(x, y), f"{name} differ between sparse-touch skipping and the dense sweep"
+    # the bitmap against the moments, on a short run of the same loop
+    from fruitnerf_amd.cameras.camera_optimizers import CameraAdam, CameraOptimizerConfig
+    from fruitnerf_amd.data import synthetic_apple as sa
+    from fruitnerf_amd.data.semantics import apple_metadata
+    from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
+    HW, focal, n_train = 96, 1111.0 * 96 / 800, 40
+    scene = sa.make_scene(seed=0, device=dev)
+    c2w = sa.make_cameras(n_train, seed=0, device=dev)
+    data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
+    batcher = sa.PixelBatcher(data, torch.arange(n_train, device=dev), seed=1)
+    torch.manual_seed(0)
+    hm = FruitModel(FruitNerfModelConfig(), apple_metadata(), num_train_data=n_train, device=dev)
+    hm.train()
+    opt = T.FusedAdam(hm)
+    cam_opt = CameraOptimizerConfig(mode="SO3xR3").setup(n_train, dev)
+    loop = T.TrainingSteps(hm, opt, batcher, 4096, camera=(cam_opt, CameraAdam(cam_opt)))
+    for step in range(12):
+        loop.step()
+        if step == 5:
+            opt.rebuild_touched()            # e.g. after loading moments: rebuilt from them at the next fused step
+    torch.cuda.synchronize()
+    table = hm.field.mlp_base_grid.hash_table
+    a, n = [(off, k) for _, p, off, k in hm.arena().entries if p is table][0]
+    bm = opt._touched[id(table)]
+    bits = ((bm.to(torch.int64)[:, None] >> torch.arange(32, device=dev)) & 1).bool().reshape(-1)
+    m, v = opt.exp_avg[a:a + n].view(-1, 4), opt.exp_avg_sq[a:a + n].view(-1, 4)
+    nonzero = ((m != 0) | (v != 0)).any(dim=1)
+    assert torch.equal(bits, nonzero), "the touched bitmap and the moments disagree"
+    frac = float(nonzero.float().mean())
+    print(f"[sparse touch] pairs of rows ever touched after 12 steps: {frac:.3f} of the table")
+    assert 0.5 < frac < 0.8            # levels 0 - 4 mostly untouched, levels 5 - 15 dense
+    untouched = ~nonzero
+    assert bool((opt.exp_avg[a:a + n].view(-1, 4)[untouched] == 0).all())
