@@ -69,7 +69,8 @@ def find(d, name_part, also=None):
 rows = kt(base + 'prof_kernel_trace.txt')
 f, w, sq = pmc(base + 'prof_fetch.txt'), pmc(base + 'prof_write.txt'), pmc(base + 'prof_sq.txt')
 steps = max(n for name, g, n, *_ in rows if 'k_train_losses' in name)   # one per training step
-out = [f'# Round 3 - rocprofv3 of `FNR_SERIALIZE_STREAMS=1 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality` (default arithmetic: bf16x3), build {rev}\n',
+round_no = tag[1:].lstrip("0")
+out = [f'# Round {round_no} - rocprofv3 of `FNR_SERIALIZE_STREAMS=1 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality` (default arithmetic: bf16x3), build {rev}\n',
        f'Collected by `tools/prof_round.sh` on 1xMI355X (gfx950, ROCm 7.2): one `--kernel-trace --stats` pass and three separate '
        f'`--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ counters, each with `--kernel-trace` only), {steps} training steps each (10 '
        'warm-up + 60 timed + 12 of the per-entry-point breakdown).  FNR_SERIALIZE_STREAMS=1: the second HIP stream\'s launches '
@@ -135,7 +136,8 @@ out.append('## HBM traffic per entry-point launch (counters: FETCH_SIZE x 2 + WR
 out.append('| entry point | kernels | counter MB / launch | algorithmic MB / launch (bench.py) | counter / algorithmic |')
 out.append('|---|---|---|---|---|')
 bench = line('bench_fruit_nerf.log')
-ALG = {'hash_encode_bwd[196608]': (2 * 1024.0 + 128.0) * 196608 + 28.0 * 16777216, 'hash_encode_fwd[196608]': (1024.0 + 128.0) * 196608}
+ALG = {'hash_encode_bwd[196608]': (2 * 1024.0 + 128.0) * 196608 + 24.0 * 16777216,   # fused sweep: p, m, v read + written
+       'hash_encode_fwd[196608]': (1024.0 + 128.0) * 196608}
 for ep, parts in ENTRY.items():
     total_b, names = 0.0, []
     ok = True

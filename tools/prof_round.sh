@@ -2,7 +2,7 @@
 # on the GPU box: everything profiles/r03_* is made from.  usage: bash tools/prof_round.sh [round tag, default r03]
 # bench lines (default arithmetic, fp32, fruit_nerf_big), rocprofv3 kernel trace + the three PMC passes (separate runs:
 # FETCH_SIZE | WRITE_SIZE | SQ counters, each with --kernel-trace only) of ONE bench command, kernel trace of fruit_nerf_big.
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p /root/repo/gpurun_out/$TAG
 OUT=/root/repo/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
