@@ -1,0 +1,96 @@
+"""Is the proposal networks' backward itself reproducible?  Round 4's per-step records (digest_perstep.py) put the rare
+divergence of long `fruit_nerf_big` runs into ONE place, three times out of three: proposal network 0's hash table changes
+first, alone.  This repeats that step's call in isolation, thousands of times from one restored state on fixed inputs:
+  pair   fnr_prop_density_bwd_pair(+adam): both levels' MLP backward, weight reduce, emit, joint accumulate + optimiser step
+  scatter  fnr_hash_encode_bwd on proposal network 0's grid with FIXED d_feats: emit + accumulate only -> gradient table
+and counts the repetitions whose result (integer checksum of tables / moments / gradient table) differs from the first.
+`--load` runs a bandwidth-heavy copy loop on another stream at the same time (the training step's field scatter does).
+usage: scatter_repeat.py [pair|scatter] [iterations] [--load]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+from fruitnerf_amd import _kernels as K  # noqa: E402
+from fruitnerf_amd.data.semantics import apple_metadata  # noqa: E402
+from fruitnerf_amd.fruit_nerf import FruitModel  # noqa: E402
+from fruitnerf_amd import fruit_nerf_config as FC  # noqa: E402
+from fruitnerf_amd.training import FusedAdam  # noqa: E402
+from tests import util  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "pair"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+load = "--load" in sys.argv
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+R = 8192
+model = FruitModel(FC.model_config("fruit_nerf_big"), apple_metadata(), num_train_data=90, device=dev)
+model.train()
+arena = model.arena()
+opt = FusedAdam(model, algorithm="radam", group_lr=FC.group_schedules("fruit_nerf_big"))
+with torch.no_grad():     # trained-like tables and weights (uniform random features, O(1) densities)
+    for net in model.proposal_networks:
+        net.encoding.hash_table.uniform_(-0.5, 0.5)
+        net.mlp_base[1].layers[1].bias.add_(1.0)
+o, d, _, cam = util.random_rays(R, 90, seed=3)
+rays = K.RaysArg(o.to(dev), d.to(dev), torch.full((R, 1), 0.05, device=dev), torch.full((R, 1), 1000.0, device=dev), cam.to(dev))
+nets = list(model.proposal_networks)
+S = [512, 256]
+jit = torch.rand(R, device=dev)
+spacing, euclid0 = K.sample_spaced(rays, 1, S[0], jit)
+dens0, feats0 = K.prop_density_fwd(nets[0].prop_struct(), nets[0].warp_struct(), rays, euclid0, S[0], save_feats=True)
+w0, _, spacing1, euclid1 = K.weights_pdf(rays, 1, S[0], S[1], dens0, spacing, euclid0, 1.0, torch.rand(R, device=dev))
+dens1, feats1 = K.prop_density_fwd(nets[1].prop_struct(), nets[1].warp_struct(), rays, euclid1, S[1], save_feats=True)
+g = torch.Generator(device=dev).manual_seed(5)
+dd = [1e-4 * torch.randn(R, S[0], device=dev, generator=g), 1e-4 * torch.randn(R, S[1], device=dev, generator=g)]
+a, b = arena.group_ranges["proposal_networks"]
+state = (arena.params[a:b].clone(), opt.exp_avg[a:b].clone().normal_(0, 1e-4), opt.exp_avg_sq[a:b].clone().uniform_(1e-10, 1e-8))
+opt.group_steps["proposal_networks"] = 700       # a mid-training RAdam step (rectified)
+torch.cuda.synchronize()
+
+
+def checksum(*ts):
+    return torch.stack([t.view(torch.int32).sum(dtype=torch.int64) for t in ts])
+
+
+side = torch.cuda.Stream(device=dev)
+big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev) if load else None
+big_b = torch.empty_like(big_a) if load else None
+bad = torch.zeros(1, dtype=torch.int64, device=dev)
+first = None
+bad_iters = []
+t0 = time.time()
+for it in range(iters):
+    if load and it % 4 == 0:
+        with torch.cuda.stream(side):
+            big_b.copy_(big_a)
+    if mode == "pair":
+        arena.params[a:b].copy_(state[0])
+        opt.exp_avg[a:b].copy_(state[1])
+        opt.exp_avg_sq[a:b].copy_(state[2])
+        opt._touched.clear() if it == 0 else None
+        t_adams = [opt.table_adam_args(n.encoding.hash_table, "proposal_networks")[0] for n in nets]
+        (w_adam, grad_arena), _ = opt.weight_adam_args("proposal_networks")
+        K.prop_density_bwd_pair([n.prop_struct() for n in nets], [n.prop_struct(grads=True) for n in nets],
+                                [n.warp_struct() for n in nets], rays, [euclid0, euclid1], S, [feats0, feats1], dd,
+                                want_position_grad=True, adam=(t_adams, w_adam, grad_arena))
+        cs = checksum(arena.params[a:b], opt.exp_avg[a:b], opt.exp_avg_sq[a:b])
+    else:
+        gnet = nets[0].prop_struct(grads=True)
+        nets[0].encoding.hash_table.grad.zero_()
+        if it == 0:
+            d_feats = 1e-4 * torch.randn(5, R * S[0], 2, device=dev, generator=g)
+        K.hash_encode_bwd(gnet.grid, nets[0].warp_struct(), rays, euclid0, S[0], d_feats)
+        cs = checksum(nets[0].encoding.hash_table.grad)
+    if first is None:
+        first = cs.clone()
+    else:
+        bad += (cs != first).any().to(torch.int64)
+    if (it + 1) % 2000 == 0:
+        nb = int(bad.item())
+        print(f"{mode}{' +load' if load else ''}: {it + 1} repetitions, {nb} differ from the first; {time.time() - t0:.0f} s", flush=True)
+        if nb and len(bad_iters) < 5:
+            bad_iters.append(it + 1)
+print(f"RESULT {mode}{' +load' if load else ''}: {int(bad.item())} of {iters} repetitions differ")
