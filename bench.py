@@ -282,18 +282,25 @@ def count_fruits_end_to_end(emodel, pipe, sample_volume, scene, dev, n_side: int
         return None
     pitch = 2.0 / n_side * 2.0
     fruit = scene.is_fruit.cpu().numpy()
-    centres = scene.centers.cpu().numpy()[fruit].astype(np.float64) * 2.0          # export coordinates: x2 (exporter_utils.py:190-191)
-    radius = float(scene.radii.cpu().numpy()[fruit].mean()) * 2.0
+    # Exported coordinates ARE scene coordinates: the export model normalises a lattice point p of the [-1, 1]^3 box by
+    # the box ((p + 1) / 2 = (2p + 2) / 4, fruit_field.py:169-175 without spatial distortion), i.e. it reads the field
+    # where training put the scene point 2p ((contract(x) + 2) / 4), and the exporter's closing x2
+    # (exporter_utils.py:190-191) restores exactly that.  Hence centres and radii unscaled, lattice pitch x2.
+    centres = scene.centers.cpu().numpy()[fruit].astype(np.float64)
+    radius = float(scene.radii.cpu().numpy()[fruit].mean())
     cl = Clustering(template_path=None, voxel_size_down_sample=pitch / 4, remove_outliers_nb_points=2,
                     remove_outliers_radius=1.8 * pitch, min_samples=4, apple_template_size=1.0,
                     cluster_merge_distance=0.04, gt_cluster=centres, gt_count=int(scene.n_fruits), template_radius=radius)
+    if os.environ.get("FNR_BENCH_DUMP_CLOUD"):          # diagnostics: the cloud the count runs on, for offline inspection
+        np.savez_compressed(os.environ["FNR_BENCH_DUMP_CLOUD"], points=pts.detach().cpu().numpy() if hasattr(pts, "detach")
+                            else np.asarray(pts), centres=centres, radii=scene.radii.cpu().numpy()[fruit], pitch=pitch)
     t1 = time.perf_counter()
     count = cl.count(PointCloud(pts, None, dev), eps=1.8 * pitch)
     return {"count": int(count), "first_stage": int(cl.counter - cl.fuse_counter), "additional": int(cl.additional_count),
             "pruned": int(cl.prune_counter), "true_positive": int(cl.true_positive), "false_positive": int(cl.false_positive),
             "false_negative": int(cl.false_negative), "precision": round(cl.precision, 4), "recall": round(cl.recall, 4),
             "F1": round(cl.F1, 4), "scene_fruits": int(scene.n_fruits), "lattice": f"{n_side}^3",
-            "semantic_points": int(pts.shape[0]), "template": f"sphere, radius {radius:.4f} (mean fruit radius x 2)",
+            "semantic_points": int(pts.shape[0]), "template": f"sphere, radius {radius:.4f} (the scene's mean fruit radius)",
             "export_s": round(t_export, 3), "counting_s": round(time.perf_counter() - t1, 3)}
 
 
