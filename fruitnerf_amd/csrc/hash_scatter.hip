@@ -460,7 +460,11 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       queue_v[q] = v;
       queue_r[q] = (unsigned short)row_in_bin;
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
+#ifdef FNR_SCATTER_ATOMIC_COUNTERS
+      atomicMax(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], 1u);
+#else
       qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;  // tells the accumulate kernel that the table holds part of the sum
+#endif
       ++overflowed_here;                             // fnr_debug_scatter_overflows: one atomic per thread, below
       const size_t row = ((size_t)bin << log2_rows) + row_in_bin;
       atomicAdd(table + 2 * row, v.x);
@@ -524,21 +528,39 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   const int gbin = A.nbins - 1 - vblock;  // (level - level0) * bins + bin
   const int lrel = gbin / bins, bin = gbin - lrel * bins;
   const int level = level0 + lrel;
+#ifdef FNR_SCATTER_ATOMIC_COUNTERS
+  // A/B build (tools/build_variant.sh): the counters are written by agent-scope atomics in the emit
+  // kernel — read and reset them at the same scope instead of through plain accesses (which the memory model allows
+  // across a kernel boundary; these are the only small lines every step rewrites and every XCD's L2 keeps)
+  long long n = __hip_atomic_load(&qcount[(size_t)gbin * SC_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float vmax = __uint_as_float(__hip_atomic_load(&qmax[(size_t)lrel * SC_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const bool overflowed = __hip_atomic_load(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+#else
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
   const float vmax = __uint_as_float(qmax[(size_t)lrel * SC_CNT_STRIDE]);  // largest |value| of the whole level
   // some emit workgroup overflowed a queue of this level and added records to the gradient table with atomics
   const bool overflowed = qmax[(size_t)lrel * SC_CNT_STRIDE + 1] != 0u;
+#endif
   // every thread has its copy: put the counters back to zero, so the NEXT call on this workspace needs no memset
   // launch (the caller says so with workspace_clean = 1).  The level's max is shared by its `bins` workgroups: the
   // last of them to have read it clears it.
   __syncthreads();
   if (threadIdx.x == 0) {
+#ifdef FNR_SCATTER_ATOMIC_COUNTERS
+    __hip_atomic_store(&qcount[(size_t)gbin * SC_CNT_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (atomicAdd(&qdone[(size_t)lrel * SC_CNT_STRIDE], 1u) == (unsigned)bins - 1u) {
+      __hip_atomic_store(&qmax[(size_t)lrel * SC_CNT_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&qdone[(size_t)lrel * SC_CNT_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#else
     qcount[(size_t)gbin * SC_CNT_STRIDE] = 0u;
     if (atomicAdd(&qdone[(size_t)lrel * SC_CNT_STRIDE], 1u) == (unsigned)bins - 1u) {
       qmax[(size_t)lrel * SC_CNT_STRIDE] = 0u;
       qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 0u;
       qdone[(size_t)lrel * SC_CNT_STRIDE] = 0u;
     }
+#endif
   }
   const bool have = n != 0 && vmax > 0.0f;
   if (threadIdx.x == 0 && n > 0)

@@ -4,8 +4,12 @@ first, alone.  This repeats that step's call in isolation, thousands of times fr
   pair   fnr_prop_density_bwd_pair(+adam): both levels' MLP backward, weight reduce, emit, joint accumulate + optimiser step
   scatter  fnr_hash_encode_bwd on proposal network 0's grid with FIXED d_feats: emit + accumulate only -> gradient table
 and counts the repetitions whose result (integer checksum of tables / moments / gradient table) differs from the first.
-`--load` runs a bandwidth-heavy copy loop on another stream at the same time (the training step's field scatter does).
-usage: scatter_repeat.py [pair|scatter] [iterations] [--load]"""
+`--load` runs a bandwidth-heavy copy loop on another stream at the same time; `--field` (round 4's follow-up: the copy loop
+never reproduced the event, and 44 one-stream training runs did not either) runs the training step's own neighbour
+instead: the pair goes to a SECOND stream as fnr_prop_density_bwd_pair_split (event after the MLP backwards, as in
+training.fused_forward_backward) while the launch stream runs the FIELD's scatter + fused optimiser
+(fnr_hash_encode_bwd_adam: the same k_scatter_emit code object, its own workspace) on fixed inputs.
+usage: scatter_repeat.py [pair|scatter] [iterations] [--load|--field]"""
 import sys
 import time
 
@@ -23,6 +27,7 @@ from tests import util  # noqa: E402
 mode = sys.argv[1] if len(sys.argv) > 1 else "pair"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 load = "--load" in sys.argv
+field_load = "--field" in sys.argv
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 R = 8192
@@ -56,6 +61,14 @@ def checksum(*ts):
 
 
 side = torch.cuda.Stream(device=dev)
+if field_load:     # the field's scatter on fixed inputs: 48 samples per ray, all 16 levels, fused table optimiser
+    fld = model.field
+    S_f = 48
+    _, euclid_f = K.sample_spaced(rays, 1, S_f, torch.rand(R, device=dev))
+    d_feats_f = 1e-4 * torch.randn(fld.net_struct().grid.n_levels, R * S_f, 2, device=dev, generator=g)
+    fa, fb = arena.group_ranges["fields"]
+    pos_ready = torch.cuda.Event()
+    main = torch.cuda.current_stream(dev)
 big_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev) if load else None
 big_b = torch.empty_like(big_a) if load else None
 bad = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -73,9 +86,19 @@ for it in range(iters):
         opt._touched.clear() if it == 0 else None
         t_adams = [opt.table_adam_args(n.encoding.hash_table, "proposal_networks")[0] for n in nets]
         (w_adam, grad_arena), _ = opt.weight_adam_args("proposal_networks")
-        K.prop_density_bwd_pair([n.prop_struct() for n in nets], [n.prop_struct(grads=True) for n in nets],
-                                [n.warp_struct() for n in nets], rays, [euclid0, euclid1], S, [feats0, feats1], dd,
-                                want_position_grad=True, adam=(t_adams, w_adam, grad_arena))
+        pair_args = ([n.prop_struct() for n in nets], [n.prop_struct(grads=True) for n in nets],
+                     [n.warp_struct() for n in nets], rays, [euclid0, euclid1], S, [feats0, feats1], dd)
+        if field_load:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                d_pos = K.prop_density_bwd_pair(*pair_args, want_position_grad=True, adam=(t_adams, w_adam, grad_arena),
+                                                position_ready=pos_ready)
+            main.wait_event(pos_ready)
+            f_adam = opt.table_adam_args(fld.mlp_base_grid.hash_table, "fields")[0]
+            K.hash_encode_bwd_adam(fld.net_struct(grads=True).grid, fld.warp_struct(), rays, euclid_f, S_f, d_feats_f, f_adam)
+            main.wait_stream(side)
+        else:
+            K.prop_density_bwd_pair(*pair_args, want_position_grad=True, adam=(t_adams, w_adam, grad_arena))
         cs = checksum(arena.params[a:b], opt.exp_avg[a:b], opt.exp_avg_sq[a:b])
     else:
         gnet = nets[0].prop_struct(grads=True)
@@ -90,7 +113,7 @@ for it in range(iters):
         bad += (cs != first).any().to(torch.int64)
     if (it + 1) % 2000 == 0:
         nb = int(bad.item())
-        print(f"{mode}{' +load' if load else ''}: {it + 1} repetitions, {nb} differ from the first; {time.time() - t0:.0f} s", flush=True)
+        print(f"{mode}{' +load' if load else ' +field' if field_load else ''}: {it + 1} repetitions, {nb} differ from the first; {time.time() - t0:.0f} s", flush=True)
         if nb and len(bad_iters) < 5:
             bad_iters.append(it + 1)
-print(f"RESULT {mode}{' +load' if load else ''}: {int(bad.item())} of {iters} repetitions differ")
+print(f"RESULT {mode}{' +load' if load else ' +field' if field_load else ''}: {int(bad.item())} of {iters} repetitions differ")
