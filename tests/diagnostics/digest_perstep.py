@@ -5,6 +5,7 @@ MLPs; camera poses).  Run 0 is the reference; a run that leaves it prints the fi
 which columns.  Reading: losses differ first -> that step's forward saw different inputs (rays / look-ahead) or is itself
 nondeterministic; a single span first -> the kernels that write it.
 usage: digest_perstep.py [method] [runs] [steps]"""
+import os
 import sys
 import time
 
@@ -28,6 +29,25 @@ c2w = sa.make_cameras(bench.N_CAMERAS, seed=0, device=dev)
 data = sa.render_dataset(scene, c2w, H=HW, W=HW, fx=focal, fy=focal)
 i_train, i_eval = bench.split_indices(bench.N_CAMERAS, bench.TRAIN_SPLIT)
 COLS = ["rgb_loss", "semantics_loss", "interlevel_loss"]
+# FNR_DIGEST_WS=1: also a checksum per step of what the proposal networks' MLP backward left for the scatter — the d_feats
+# region at the head of each level's persistent workspace (unchanged on steps that do not train the networks).  At an event
+# step it tells "the scatter's INPUT already differed" (k_prop_bwd's output, or memory corrupted after it) from "emit /
+# accumulate went wrong on equal inputs".
+WS_DIGEST = os.environ.get("FNR_DIGEST_WS") == "1"
+
+
+def workspace_views(run):
+    from fruitnerf_amd import _kernels as K
+    out = []
+    samples = run.model.config.num_proposal_samples_per_ray
+    for q, net in enumerate(run.model.proposal_networks):
+        cands = [t for key, t in K._SCATTER_WS.items() if key[4] == f"prop{q}"]
+        if not cands:
+            return None
+        ws = max(cands, key=lambda t: t.numel())
+        nbytes = int(net.prop_struct().grid.n_levels) * run.rays * int(samples[q]) * 8
+        out.append((f"prop{q}.d_feats", ws[:nbytes]))
+    return out
 
 
 def spans_of(run):
@@ -85,6 +105,10 @@ def one_run():
     L.profile_collect()
     L.profile_enable(False)
     sp = spans_of(run)
+    if WS_DIGEST:
+        wv = workspace_views(run)
+        assert wv is not None, "the paired proposal backward has not run yet"
+        sp = sp + wv
     names = COLS + [n for n, _ in sp]
     rec = torch.zeros(steps, len(names), dtype=torch.int64, device=dev)
     while run.step_idx < steps:
