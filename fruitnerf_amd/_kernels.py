@@ -421,20 +421,48 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
     return d_feats
 
 
-_SCATTER_WS = {}
+class _WorkspaceCache:
+    """Persistent scatter workspaces, keyed by (device, stream, size, entry point): LRU, at most `per_tag` buffers per
+    (device, entry point).  A training loop uses one key per entry point for its whole life; a process that builds many
+    models in sequence (each with its own second stream out of torch's pool of 32) would otherwise keep up to 32 x the
+    multi-GB queues alive.  Evicting is always safe: the buffer is only dropped from the cache (a caller that comes back
+    for it allocates a new one and says workspace_clean = 0)."""
+
+    def __init__(self, per_tag: int = 2):
+        self.per_tag = per_tag
+        self.entries = {}          # key -> buffer; dict order = recency (oldest first)
+
+    def get(self, key, make):
+        """-> (buffer, clean): clean = 1 when the buffer has been used by these kernels before (counters left zeroed)."""
+        buf = self.entries.pop(key, None)
+        if buf is not None:
+            self.entries[key] = buf
+            return buf, 1
+        same = [k for k in self.entries if (k[0], k[1], k[4]) == (key[0], key[1], key[4])]
+        for k in same[:max(0, len(same) - self.per_tag + 1)]:
+            del self.entries[k]
+        buf = self.entries[key] = make()
+        return buf, 0
+
+    # dict-like views for diagnostics
+    def items(self):
+        return self.entries.items()
+
+    def __len__(self):
+        return len(self.entries)
+
+    def clear(self):
+        self.entries.clear()
+
+
+_SCATTER_WS = _WorkspaceCache()
 
 
 def _scatter_workspace(dev, nbytes: int, tag: str):
     """Persistent scatter workspace per (device, stream, size, entry point) -> (buffer, clean flag).  The kernels leave
     the queue counters zeroed, so after its first use the buffer needs no memset launch (workspace_clean = 1)."""
     key = (dev.type, dev.index, L.stream_ptr(dev), nbytes, tag)
-    ws = _SCATTER_WS.get(key)
-    if ws is None:
-        if len(_SCATTER_WS) > 32:
-            _SCATTER_WS.clear()
-        ws = _SCATTER_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        return ws, 0
-    return ws, 1
+    return _SCATTER_WS.get(key, lambda: torch.empty(nbytes, dtype=torch.uint8, device=dev))
 
 
 def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,

@@ -41,7 +41,11 @@ def workspace_views(run):
     out = []
     samples = run.model.config.num_proposal_samples_per_ray
     for q, net in enumerate(run.model.proposal_networks):
-        cands = [t for key, t in K._SCATTER_WS.items() if key[4] == f"prop{q}"]
+        # the workspace of THIS run: keyed by its model's second stream (round-4 call 14 took the first run's buffer
+        # for every run — each model has its own stream out of torch's pool — and compared frozen bytes)
+        side = run.model.__dict__.get("_side_stream")
+        cands = [t for key, t in K._SCATTER_WS.items()
+                 if key[4] == f"prop{q}" and side is not None and key[2] == side.cuda_stream]
         if not cands:
             return None
         ws = max(cands, key=lambda t: t.numel())

@@ -626,3 +626,30 @@ def test_scaler_step_unscales_skips_on_inf_and_feeds_the_scalers_update():
         assert T.scaler_step(opt, scaler)
         scaler.update()
     assert scaler.get_scale() == 1024.0      # growth after growth_interval clean steps
+
+
+def test_scatter_workspace_cache_is_bounded_per_entry_point():
+    """_kernels._WorkspaceCache: LRU, at most two buffers per (device, entry point); a hit reports the buffer as clean, a
+    miss (first use, or after eviction) as not clean."""
+    from fruitnerf_amd._kernels import _WorkspaceCache
+    made = []
+
+    def make():
+        made.append(object())
+        return made[-1]
+
+    c = _WorkspaceCache(per_tag=2)
+    k = lambda stream, tag, n=64: ("cuda", 0, stream, n, tag)     # noqa: E731
+    b1, clean = c.get(k(1, "prop0"), make)
+    assert clean == 0 and c.get(k(1, "prop0"), make) == (b1, 1)
+    b2, _ = c.get(k(2, "prop0"), make)
+    assert len(c) == 2 and c.get(k(1, "prop0"), make) == (b1, 1)        # 1 is now the most recent
+    b3, clean = c.get(k(3, "prop0"), make)                               # evicts stream 2 (least recent), keeps 1
+    assert clean == 0 and len(c) == 2
+    assert c.get(k(1, "prop0"), make) == (b1, 1)
+    assert c.get(k(2, "prop0"), make)[1] == 0                           # gone: a new buffer, not clean
+    c.get(k(7, "field"), make)                                           # other entry points are counted separately
+    c.get(k(7, "prop1"), make)
+    assert len(c) == 4
+    c.get(k(1, "prop0", n=128), make)                                    # another size of the same entry point counts too
+    assert sum(1 for key, _ in c.items() if key[4] == "prop0") == 2
