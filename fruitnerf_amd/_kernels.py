@@ -6,6 +6,7 @@ device.  No arithmetic happens here.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -458,11 +459,18 @@ class _WorkspaceCache:
 _SCATTER_WS = _WorkspaceCache()
 
 
+# FNR_SCATTER_MEMSET=1 (hunt switch): never tell the library that the counters were left clean — every
+# scatter call then zeroes its counter block with a hipMemsetAsync ahead of the emit kernel instead of relying on the
+# previous call's accumulate kernel having put them back to zero (~3 us per call).
+SCATTER_MEMSET_EVERY_CALL = os.environ.get("FNR_SCATTER_MEMSET") == "1"
+
+
 def _scatter_workspace(dev, nbytes: int, tag: str):
     """Persistent scatter workspace per (device, stream, size, entry point) -> (buffer, clean flag).  The kernels leave
     the queue counters zeroed, so after its first use the buffer needs no memset launch (workspace_clean = 1)."""
     key = (dev.type, dev.index, L.stream_ptr(dev), nbytes, tag)
-    return _SCATTER_WS.get(key, lambda: torch.empty(nbytes, dtype=torch.uint8, device=dev))
+    buf, clean = _SCATTER_WS.get(key, lambda: torch.empty(nbytes, dtype=torch.uint8, device=dev))
+    return buf, (0 if SCATTER_MEMSET_EVERY_CALL else clean)
 
 
 def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,

@@ -42,6 +42,23 @@ __device__ unsigned long long g_scatter_overflow_records;   // records that went
 // same-line atomics serialise at ~12 ns).  fnr_debug_scatter_records: bench.py prices the record queue's round trip with it.
 __device__ unsigned long long g_scatter_records[2][64][16];
 
+// Hunt build only (tools/build_variant.sh seen -DFNR_SCATTER_DEBUG_SEEN): what the kernels of the LAST call
+// of each kind saw — per accumulate workgroup the queue count and the level maximum it read (its scalar loads), per emit
+// level the records the emit workgroups placed (atomics).  slot 0: the field's call, 1 / 2: the first / second proposal
+// level of a paired call.  tests/diagnostics/digest_perstep.py checksums this block every step (fnr_debug_scatter_seen_copy):
+// at an event step it tells "the accumulate kernel read other counters than the emit kernel left" from "equal counters,
+// other records".
+#ifdef FNR_SCATTER_DEBUG_SEEN
+constexpr int SEEN_SLOTS = 3, SEEN_BINS = 4096;
+struct ScatterSeen {
+  unsigned acc_n[SEEN_SLOTS][SEEN_BINS];       // qcount as read by the accumulate workgroup of (level, bin)
+  unsigned acc_vmax[SEEN_SLOTS][SEEN_BINS];    // qmax (float bits) as read by it
+  unsigned long long emit_records[SEEN_SLOTS][FNR_MAX_LEVELS];   // records placed by the emit kernel, per level
+  unsigned long long emit_calls[SEEN_SLOTS];   // emit launches so far (the harness resets the block per step)
+};
+__device__ ScatterSeen g_scatter_seen;
+#endif
+
 struct ScatterPlan {
   int log2_rows;         // log2(E)
   int bins_per_level;    // T / E
@@ -253,7 +270,11 @@ template <class Source, bool PAIRS>
 __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, Warp warp, Source src, long long N,
                                                       const float2* __restrict__ d_feats, float2* __restrict__ queue_v,
                                                       unsigned short* __restrict__ queue_r, unsigned* __restrict__ qcount, unsigned* __restrict__ qmax,
-                                                      long long cap, int log2_rows, int level0, int level_count, int lpb) {
+                                                      long long cap, int log2_rows, int level0, int level_count, int lpb
+#ifdef FNR_SCATTER_DEBUG_SEEN
+                                                      , int seen_slot
+#endif
+                                                      ) {
   // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs.
   // A workgroup takes its 512 samples through `lpb` consecutive levels: the sample position and its warp are computed
   // once, and the next level's feature gradient is loaded while the current level is processed (the wait for the first
@@ -400,6 +421,9 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
 #pragma unroll
   for (int w = 0; w < SC_EMIT_THREADS / 64; ++w) total += s_wsum[w];
   unsigned run = woff + incl - tsum;
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  if (threadIdx.x == 0 && total) atomicAdd(&g_scatter_seen.emit_records[seen_slot][lrel], (unsigned long long)total);
+#endif
 #pragma unroll
   for (int t = 0; t < SC_BINS_PER_THREAD; ++t) {
     const int i = threadIdx.x * SC_BINS_PER_THREAD + t;
@@ -507,6 +531,9 @@ struct AccArgs {
   int log2_rows, level0, nbins;   // nbins = level_count * bins per level = workgroups of this call
   int kind;                       // 0: the field's table, 1: a proposal network's (g_scatter_records)
   TableAdam adam;
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  int seen_slot;                  // g_scatter_seen slot of this call
+#endif
 };
 
 // s_acc: [rows][2] two's-complement fixed point in DYNAMIC LDS, 16 bytes per row of the bin (128 KiB for the main
@@ -545,6 +572,12 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   // launch (the caller says so with workspace_clean = 1).  The level's max is shared by its `bins` workgroups: the
   // last of them to have read it clears it.
   __syncthreads();
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  if (threadIdx.x == blockDim.x - 1 && gbin < SEEN_BINS) {   // (the LAST wave's copy: the one furthest from thread 0's stores)
+    g_scatter_seen.acc_n[A.seen_slot][gbin] = (unsigned)n;
+    g_scatter_seen.acc_vmax[A.seen_slot][gbin] = __float_as_uint(vmax);
+  }
+#endif
   if (threadIdx.x == 0) {
 #ifdef FNR_SCATTER_ATOMIC_COUNTERS
     __hip_atomic_store(&qcount[(size_t)gbin * SC_CNT_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -697,6 +730,13 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate2(AccArgs a, AccArgs
   else accumulate_bin<ADAM>(b, (int)blockIdx.x - a.nbins, s_acc);
 }
 
+#ifdef FNR_SCATTER_DEBUG_SEEN
+#define FNR_SEEN_ARG(x) , x
+static int g_seen_slot_next = 0;   // host: the slot of the next scatter_emit (set by the entry points; 0 = the field's call)
+#else
+#define FNR_SEEN_ARG(x)
+#endif
+
 // emit of one scatter call -> the arguments its accumulate launch needs
 template <class Source>
 static int scatter_emit(const fnr_grid* grid_grad, const Warp& warp, const Source& src, long long N,
@@ -736,12 +776,15 @@ static int scatter_emit(const fnr_grid* grid_grad, const Warp& warp, const Sourc
   } else if (pairs)
     hipLaunchKernelGGL((k_scatter_emit<Source, true>), dim3((unsigned)chunks, gy), dim3(SC_EMIT_THREADS),
                        0, st, gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap,
-                       p.log2_rows, level0, level_count, lpb);
+                       p.log2_rows, level0, level_count, lpb FNR_SEEN_ARG(g_seen_slot_next));
   else
     hipLaunchKernelGGL((k_scatter_emit<Source, false>), dim3((unsigned)chunks, gy), dim3(SC_EMIT_THREADS),
                        0, st, gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap,
-                       p.log2_rows, level0, level_count, lpb);
+                       p.log2_rows, level0, level_count, lpb FNR_SEEN_ARG(g_seen_slot_next));
   FNR_LAUNCH_CHECK();
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  acc.seen_slot = g_seen_slot_next;
+#endif
   acc.grid = gd;
   acc.queue_v = queue_v, acc.queue_r = queue_r, acc.qcount = qcount;
   acc.qmax = qcount + nbins_all * SC_CNT_STRIDE;
@@ -1047,6 +1090,20 @@ extern "C" int fnr_debug_scatter_records(uint64_t* records_host, int reset) {
   return FNR_OK;
 }
 
+#ifdef FNR_SCATTER_DEBUG_SEEN
+// Hunt build only (not in include/fruitnerf_hip.h): device-to-device copy of g_scatter_seen into `dst` on `stream`, then
+// (reset != 0) the block is zeroed on the same stream.  -> bytes copied, or 0 if `dst_bytes` is too small.
+extern "C" size_t fnr_debug_scatter_seen_copy(void* dst, size_t dst_bytes, int reset, void* stream) {
+  if (!dst || dst_bytes < sizeof(ScatterSeen)) return 0;
+  void* src = nullptr;
+  if (hipGetSymbolAddress(&src, HIP_SYMBOL(g_scatter_seen)) != hipSuccess) return 0;
+  if (hipMemcpyAsync(dst, src, sizeof(ScatterSeen), hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess) return 0;
+  if (reset && hipMemsetAsync(src, 0, sizeof(ScatterSeen), as_stream(stream)) != hipSuccess) return 0;
+  return sizeof(ScatterSeen);
+}
+extern "C" size_t fnr_debug_scatter_seen_bytes() { return sizeof(ScatterSeen); }
+#endif
+
 extern "C" size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
   const ScatterPlan p = scatter_plan(n_samples, n_levels, log2_hashmap_size);
   return p.count_bytes + p.queue_bytes;
@@ -1222,10 +1279,16 @@ extern "C" int fnr_prop_density_bwd_pair(const fnr_prop_net* const* nets, const 
   FNR_PROF(OP_PROP_BWD, rays->n_rays * ((long long)S[0] + (long long)S[1]));   // one scope: both levels + the joint accumulate
   AccArgs acc[2];
   for (int q = 0; q < 2; ++q) {
+#ifdef FNR_SCATTER_DEBUG_SEEN
+    g_seen_slot_next = 1 + q;
+#endif
     const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
                                           d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
                                           adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
                                           adam ? grad_arena : nullptr, &acc[q], 0, false);
+#ifdef FNR_SCATTER_DEBUG_SEEN
+    g_seen_slot_next = 0;
+#endif
     if (rc) return rc;
   }
   const bool first_longer = (long long)S[0] >= (long long)S[1];
@@ -1258,10 +1321,16 @@ extern "C" int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, 
   AccArgs acc[2];
   for (int phase = 1; phase <= 2; ++phase) {
     for (int q = 0; q < 2; ++q) {
+#ifdef FNR_SCATTER_DEBUG_SEEN
+      g_seen_slot_next = 1 + q;
+#endif
       const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
                                             d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
                                             adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
                                             adam ? grad_arena : nullptr, &acc[q], phase, false);
+#ifdef FNR_SCATTER_DEBUG_SEEN
+      g_seen_slot_next = 0;
+#endif
       if (rc) return rc;
     }
     if (phase == 1 && position_ready_event)

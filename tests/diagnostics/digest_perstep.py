@@ -34,6 +34,24 @@ COLS = ["rgb_loss", "semantics_loss", "interlevel_loss"]
 # step it tells "the scatter's INPUT already differed" (k_prop_bwd's output, or memory corrupted after it) from "emit /
 # accumulate went wrong on equal inputs".
 WS_DIGEST = os.environ.get("FNR_DIGEST_WS") == "1"
+# Per-BIN checksums of both proposal tables every step (always on: two reductions per step): at an event step they name the
+# (level, accumulate bin) whose rows differ — one bin (a queue count), a whole level (the level's maximum, i.e. the
+# fixed-point scale), or scattered rows (records).
+# FNR_DIGEST_SEEN=1 (needs the `seen` library variant: tools/build_variant.sh seen -DFNR_SCATTER_DEBUG_SEEN, FNR_LIB_PATH):
+# what the scatter kernels of the step saw — the queue count and level maximum every accumulate workgroup of the two
+# proposal levels READ, and the records the emit kernels PLACED per level — is copied out of the library every step.
+SEEN_DIGEST = os.environ.get("FNR_DIGEST_SEEN") == "1"
+PROP_BIN_ROWS = 4096        # rows per accumulate bin of a 2^17-row proposal table (hash_scatter.hip: scatter_plan)
+SEEN_SLOTS, SEEN_BINS, MAX_LEVELS = 3, 4096, 16
+
+
+def seen_views(buf):
+    """The library's ScatterSeen block (hash_scatter.hip) as tensors: acc_n, acc_vmax [3, 4096] int32, emit_records [3, 16] int64."""
+    words = SEEN_SLOTS * SEEN_BINS
+    acc_n = buf[:4 * words].view(torch.int32).view(SEEN_SLOTS, SEEN_BINS)
+    acc_v = buf[4 * words:8 * words].view(torch.int32).view(SEEN_SLOTS, SEEN_BINS)
+    emit = buf[8 * words:8 * words + 8 * SEEN_SLOTS * MAX_LEVELS].view(torch.int64).view(SEEN_SLOTS, MAX_LEVELS)
+    return acc_n, acc_v, emit
 
 
 def workspace_views(run):
@@ -115,25 +133,110 @@ def one_run():
         sp = sp + wv
     names = COLS + [n for n, _ in sp]
     rec = torch.zeros(steps, len(names), dtype=torch.int64, device=dev)
+    tables = [t for n, t in sp if n.endswith(".table") and n.startswith("prop")]
+    nbin = [t.numel() // (2 * PROP_BIN_ROWS) for t in tables]
+    bins = torch.zeros(steps, len(tables), max(nbin), dtype=torch.int64, device=dev)
+    seen = seen_buf = None
+    if SEEN_DIGEST:
+        import ctypes as C
+        lib = L.load()
+        lib.fnr_debug_scatter_seen_bytes.restype = C.c_size_t
+        lib.fnr_debug_scatter_seen_copy.restype = C.c_size_t
+        lib.fnr_debug_scatter_seen_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        nb = int(lib.fnr_debug_scatter_seen_bytes())
+        seen_buf = torch.zeros((nb + 7) // 8 * 8, dtype=torch.uint8, device=dev)
+        # per step, slots 1 and 2 (the two proposal levels): counts and maxima of their bins, records placed per level
+        seen = {"n": torch.zeros(steps, 2, max(nbin), dtype=torch.int32, device=dev),
+                "vmax": torch.zeros(steps, 2, max(nbin), dtype=torch.int32, device=dev),
+                "emit": torch.zeros(steps, 2, MAX_LEVELS, dtype=torch.int64, device=dev)}
+        assert lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev)) == nb   # reset
     while run.step_idx < steps:
         i = run.step_idx
         ld, _ = run.one_step(want_metrics=False)
         rec[i, 0:3] = torch.stack([ld[k] for k in COLS]).view(torch.int32).to(torch.int64)
         for c, (_, t) in enumerate(sp):
             rec[i, 3 + c] = t.view(torch.int32).sum(dtype=torch.int64)
+        for q, t in enumerate(tables):
+            bins[i, q, :nbin[q]] = t.view(torch.int32).view(nbin[q], -1).sum(dim=1, dtype=torch.int64)
+        if seen is not None:
+            lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev))
+            acc_n, acc_v, emit = seen_views(seen_buf)
+            seen["n"][i] = acc_n[1:3, :max(nbin)]
+            seen["vmax"][i] = acc_v[1:3, :max(nbin)]
+            seen["emit"][i] = emit[1:3]
         if run.step_idx in eval_at:
             eval_pass(run.model)
-    return names, rec.cpu()
+    extra = {"bins": bins.cpu(), "nbin": nbin}
+    if seen is not None:
+        extra["seen"] = {k: v.cpu() for k, v in seen.items()}
+    return names, rec.cpu(), extra
+
+
+def explain(step, extra, ref_extra):
+    """What the finer records say about the first differing step."""
+    b, rb = extra["bins"][step], ref_extra["bins"][step]
+    for q in range(b.shape[0]):
+        nb = extra["nbin"][q]
+        bad = (b[q, :nb] != rb[q, :nb]).nonzero().flatten().tolist()
+        if not bad:
+            continue
+        per_level = nb // 5 if nb % 5 == 0 else nb
+        where = [(g // per_level, g % per_level) for g in bad]
+        print(f"      prop{q}.table: {len(bad)} of {nb} bins differ; (level, bin): {where[:24]}{' ...' if len(where) > 24 else ''}",
+              flush=True)
+        print(f"         deltas: {[int(b[q, g] - rb[q, g]) for g in bad[:12]]}", flush=True)
+    if "seen" not in extra:
+        return
+    sn, rn = extra["seen"], ref_extra["seen"]
+    for q in range(2):
+        nb = extra["nbin"][q]
+        dn = (sn["n"][step, q, :nb] != rn["n"][step, q, :nb]).nonzero().flatten().tolist()
+        dv = (sn["vmax"][step, q, :nb] != rn["vmax"][step, q, :nb]).nonzero().flatten().tolist()
+        de = (sn["emit"][step, q] != rn["emit"][step, q]).nonzero().flatten().tolist()
+        # the accumulate kernel indexes its bins as gbin = level * bins_per_level + bin, like the table's
+        print(f"      prop{q} scatter: counts READ differ in bins {dn[:16]} ({[(int(sn['n'][step, q, g]), int(rn['n'][step, q, g])) for g in dn[:8]]}), "
+              f"maxima READ differ in bins {dv[:16]}, records PLACED differ at levels {de}", flush=True)
+        tot_n = [int(sn["n"][step, q, lv * (nb // 5):(lv + 1) * (nb // 5)].sum()) for lv in range(5)] if nb % 5 == 0 else []
+        print(f"         records placed per level {sn['emit'][step, q, :5].tolist()} vs counts read per level {tot_n}", flush=True)
 
 
 print(f"{method}: {runs} runs x {steps} steps, a record per step; overlap {T.OVERLAP_PROPOSAL_BACKWARD} ahead {T.SAMPLE_AHEAD} "
       f"stream_safe {T.STREAM_SAFE} sparse_touch {T.SPARSE_TOUCH_SKIPPING}", flush=True)
 ref = None
 t0 = time.time()
+def self_check(k, extra):
+    """Needs no reference run: within one step the counts the accumulate workgroups READ must add up, level by level, to the
+    records the emit kernel PLACED (no queue overflowed: bench's overflow counter), and the bins of a level must all have
+    read the same level maximum."""
+    if "seen" not in extra:
+        return
+    sn = extra["seen"]
+    for q in range(2):
+        nb = extra["nbin"][q]
+        if nb % 5:
+            continue
+        per = nb // 5
+        n = sn["n"][:, q, :nb].to(torch.int64).view(-1, 5, per)
+        placed = sn["emit"][:, q, :5]
+        bad = (n.sum(dim=2) != placed).any(dim=1).nonzero().flatten().tolist()
+        v = sn["vmax"][:, q, :nb].view(-1, 5, per)
+        uneven = (v != v[:, :, :1]).any(dim=2).any(dim=1).nonzero().flatten().tolist()
+        if bad or uneven:
+            print(f"run {k}: prop{q} SELF-CHECK: counts read != records placed at steps {bad[:8]}; "
+                  f"bins of one level read different maxima at steps {uneven[:8]}", flush=True)
+            for st in bad[:2]:
+                print(f"      step {st}: placed {placed[st].tolist()} read {n[st].sum(dim=1).tolist()}", flush=True)
+            for st in uneven[:2]:
+                lv = (v[st] != v[st, :, :1]).any(dim=1).nonzero().flatten().tolist()
+                print(f"      step {st}: levels {lv}: maxima (bits) {[sorted(set(v[st, l].tolist())) for l in lv]}", flush=True)
+
+
+ref_extra = None
 for k in range(runs):
-    names, rec = one_run()
+    names, rec, extra = one_run()
+    self_check(k, extra)
     if ref is None:
-        ref = rec
+        ref, ref_extra = rec, extra
         print(f"run 0: reference ({rec.shape[0]} steps x {names}); {time.time() - t0:.0f} s", flush=True)
         continue
     diff = rec != ref
@@ -148,3 +251,4 @@ for k in range(runs):
             for n, a, b in zip(names, rec[r].tolist(), ref[r].tolist()):
                 if a != b:
                     print(f"      {n}: {a} vs {b} (delta {a - b})", flush=True)
+            explain(r, extra, ref_extra)
