@@ -1,0 +1,8 @@
+#!/bin/bash
+# The library variants tools/r05_hunt.sh selects through FNR_LIB_PATH — build them HERE (CPU container: hipcc cross-compiles)
+# before the gpurun call; the .so files travel with the snapshot.
+set -e
+cd "$(dirname "$0")/.."
+bash tools/build_variant.sh seen -DFNR_SCATTER_DEBUG_SEEN
+bash tools/build_variant.sh atomic_counters -DFNR_SCATTER_ATOMIC_COUNTERS
+bash tools/build_variant.sh rmw_counters -DFNR_SCATTER_RMW_COUNTERS

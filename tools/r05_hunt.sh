@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 5, first GPU call: the two-stream divergence hunt with the instruments written (on CPU) at the end of round 4.
+# (build the variants on the CPU side first: bash tools/build_hunt_variants.sh)
 # usage: bash tools/r05_hunt.sh <leg> [runs]   legs: seen | atomic | rmw | memset | unpaired | base
 #   seen     the `seen` library variant (-DFNR_SCATTER_DEBUG_SEEN): every step the harness copies out what the proposal
 #            scatters' accumulate workgroups READ (queue count, level maximum) and what their emit kernels PLACED, checks
