@@ -50,13 +50,27 @@ __device__ unsigned long long g_scatter_records[2][64][16];
 // other records".
 #ifdef FNR_SCATTER_DEBUG_SEEN
 constexpr int SEEN_SLOTS = 3, SEEN_BINS = 4096;
+constexpr int SEEN_HBINS = 32, SEEN_HQ = SEEN_HBINS * 8;   // bins per level / (level, bin) pairs of a proposal call
 struct ScatterSeen {
   unsigned acc_n[SEEN_SLOTS][SEEN_BINS];       // qcount as read by the accumulate workgroup of (level, bin)
   unsigned acc_vmax[SEEN_SLOTS][SEEN_BINS];    // qmax (float bits) as read by it
   unsigned long long emit_records[SEEN_SLOTS][FNR_MAX_LEVELS];   // records placed by the emit kernel, per level
   unsigned long long emit_calls[SEEN_SLOTS];   // emit launches so far (the harness resets the block per step)
+  // proposal calls (slots 1, 2; <= SEEN_HBINS bins a level x <= 8 levels): an ORDER-INDEPENDENT checksum of the records of
+  // every bin — the sum over its records of seen_record_hash(row, value pair) — as the emit kernel WROTE them into the queue
+  // and as the accumulate kernel READ them back.  Equal sums: the queue came back as written.
+  unsigned long long emit_sum[2][SEEN_HQ];
+  unsigned long long acc_sum[2][SEEN_HQ];
 };
 __device__ ScatterSeen g_scatter_seen;
+__device__ __forceinline__ unsigned long long seen_record_hash(unsigned row, float vx, float vy) {
+  unsigned long long h = ((unsigned long long)__float_as_uint(vx) << 32) | (unsigned long long)__float_as_uint(vy);
+  h ^= (unsigned long long)(row + 1u) * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 32;
+  return h;
+}
 #endif
 
 struct ScatterPlan {
@@ -286,6 +300,9 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   __shared__ unsigned s_base[SC_MAX_BINS];  // per-bin start inside the global queue
   __shared__ unsigned s_max;                // max |value| emitted by this workgroup (float bits; order-preserving for >= 0)
   __shared__ unsigned s_wsum[SC_EMIT_THREADS / 64];
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  __shared__ unsigned long long s_hsum[SEEN_HBINS];   // (256 B: three workgroups still fit a CU)
+#endif
 #ifdef FNR_EMIT_TIMING
   unsigned long long t_phase__ = __builtin_readcyclecounter();
   unsigned t_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -314,6 +331,10 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     s_cnt[i] = 0;
   }
   if (threadIdx.x == 0) s_max = 0;
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  const bool seen_hash = seen_slot >= 1 && bins <= SEEN_HBINS && level_count <= 8;
+  if (seen_hash && threadIdx.x < SEEN_HBINS) s_hsum[threadIdx.x] = 0ull;
+#endif
   __syncthreads();
   EMIT_T(0);
   const int scaling = grid.scalings[level];
@@ -483,6 +504,9 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       const size_t q = ((size_t)lrel * bins + bin) * cap + slot;
       queue_v[q] = v;
       queue_r[q] = (unsigned short)row_in_bin;
+#ifdef FNR_SCATTER_DEBUG_SEEN
+      if (seen_hash) atomicAdd(&s_hsum[bin], seen_record_hash(row_in_bin, v.x, v.y));
+#endif
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
 #if defined(FNR_SCATTER_ATOMIC_COUNTERS) || defined(FNR_SCATTER_RMW_COUNTERS)
       atomicMax(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], 1u);
@@ -497,6 +521,13 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   if (overflowed_here) atomicAdd(&g_scatter_overflow_records, (unsigned long long)overflowed_here);
   EMIT_T(5);
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  if (seen_hash) {
+    __syncthreads();
+    if (threadIdx.x < bins && s_hsum[threadIdx.x] != 0ull)
+      atomicAdd(&g_scatter_seen.emit_sum[seen_slot - 1][lrel * SEEN_HBINS + threadIdx.x], s_hsum[threadIdx.x]);
+  }
+#endif
   __syncthreads();  // the next level re-uses the bin tables and the record staging
   }  // levels of this workgroup
 #ifdef FNR_EMIT_TIMING
@@ -659,6 +690,12 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   const float4* qv2 = reinterpret_cast<const float4*>(qv);
   const ushort2* qr2 = reinterpret_cast<const ushort2*>(qr);
   const long long np = n >> 1;  // full pairs
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  unsigned long long hsum = 0ull;
+#define FNR_SEEN_HASH(row, vx, vy) hsum += seen_record_hash((row), (vx), (vy))
+#else
+#define FNR_SEEN_HASH(row, vx, vy) do { } while (0)
+#endif
   long long i = threadIdx.x;
   for (; i + 3 * (long long)blockDim.x < np; i += 4 * (long long)blockDim.x) {  // 8 loads (8 records) in flight per thread
     float4 v[4];
@@ -672,6 +709,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     for (int u = 0; u < 4; ++u) {
       acc_record(s_acc, row[u].x, make_float2(v[u].x, v[u].y), scale);
       acc_record(s_acc, row[u].y, make_float2(v[u].z, v[u].w), scale);
+      FNR_SEEN_HASH(row[u].x, v[u].x, v[u].y);
+      FNR_SEEN_HASH(row[u].y, v[u].z, v[u].w);
     }
   }
   for (; i < np; i += blockDim.x) {
@@ -679,8 +718,18 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     const ushort2 row = qr2[i];
     acc_record(s_acc, row.x, make_float2(v.x, v.y), scale);
     acc_record(s_acc, row.y, make_float2(v.z, v.w), scale);
+    FNR_SEEN_HASH(row.x, v.x, v.y);
+    FNR_SEEN_HASH(row.y, v.z, v.w);
   }
-  if ((n & 1) && threadIdx.x == 0) acc_record(s_acc, qr[n - 1], qv[n - 1], scale);
+  if ((n & 1) && threadIdx.x == 0) {
+    acc_record(s_acc, qr[n - 1], qv[n - 1], scale);
+    FNR_SEEN_HASH(qr[n - 1], qv[n - 1].x, qv[n - 1].y);
+  }
+#undef FNR_SEEN_HASH
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  if (A.seen_slot >= 1 && bins <= SEEN_HBINS && A.nbins <= 8 * bins && hsum != 0ull)
+    atomicAdd(&g_scatter_seen.acc_sum[A.seen_slot - 1][lrel * SEEN_HBINS + bin], hsum);
+#endif
   __syncthreads();
   float2* dst = grid.table + ((size_t)level << grid.log2_T) + (size_t)bin * rows;
   if constexpr (ADAM) {

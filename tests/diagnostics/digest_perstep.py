@@ -50,8 +50,13 @@ def seen_views(buf):
     words = SEEN_SLOTS * SEEN_BINS
     acc_n = buf[:4 * words].view(torch.int32).view(SEEN_SLOTS, SEEN_BINS)
     acc_v = buf[4 * words:8 * words].view(torch.int32).view(SEEN_SLOTS, SEEN_BINS)
-    emit = buf[8 * words:8 * words + 8 * SEEN_SLOTS * MAX_LEVELS].view(torch.int64).view(SEEN_SLOTS, MAX_LEVELS)
-    return acc_n, acc_v, emit
+    o = 8 * words
+    emit = buf[o:o + 8 * SEEN_SLOTS * MAX_LEVELS].view(torch.int64).view(SEEN_SLOTS, MAX_LEVELS)
+    o += 8 * SEEN_SLOTS * MAX_LEVELS + 8 * SEEN_SLOTS          # emit_records, emit_calls
+    hq = 32 * 8                                               # SEEN_HQ: (level, bin) pairs of a proposal call
+    emit_sum = buf[o:o + 8 * 2 * hq].view(torch.int64).view(2, hq)
+    acc_sum = buf[o + 8 * 2 * hq:o + 16 * 2 * hq].view(torch.int64).view(2, hq)
+    return acc_n, acc_v, emit, emit_sum, acc_sum
 
 
 def workspace_views(run):
@@ -119,11 +124,12 @@ def one_run():
     torch.cuda.synchronize()
     bench.timed_window(run, 200, lambda: None, False, dev)
     L.profile_enable(True)
+    serialize_was = T.SERIALIZE_STREAMS      # (FNR_SERIALIZE_STREAMS=1: the hunt's `serial` leg keeps it for the whole run)
     T.SERIALIZE_STREAMS = True
     for _ in range(12):
         run.one_step()
     torch.cuda.synchronize()
-    T.SERIALIZE_STREAMS = False
+    T.SERIALIZE_STREAMS = serialize_was
     L.profile_collect()
     L.profile_enable(False)
     sp = spans_of(run)
@@ -148,7 +154,10 @@ def one_run():
         # per step, slots 1 and 2 (the two proposal levels): counts and maxima of their bins, records placed per level
         seen = {"n": torch.zeros(steps, 2, max(nbin), dtype=torch.int32, device=dev),
                 "vmax": torch.zeros(steps, 2, max(nbin), dtype=torch.int32, device=dev),
-                "emit": torch.zeros(steps, 2, MAX_LEVELS, dtype=torch.int64, device=dev)}
+                "emit": torch.zeros(steps, 2, MAX_LEVELS, dtype=torch.int64, device=dev),
+                # order-independent checksums of every bin's records: as written by emit / as read back by accumulate
+                "emit_sum": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev),
+                "acc_sum": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev)}
         assert lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev)) == nb   # reset
     while run.step_idx < steps:
         i = run.step_idx
@@ -160,10 +169,12 @@ def one_run():
             bins[i, q, :nbin[q]] = t.view(torch.int32).view(nbin[q], -1).sum(dim=1, dtype=torch.int64)
         if seen is not None:
             lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev))
-            acc_n, acc_v, emit = seen_views(seen_buf)
+            acc_n, acc_v, emit, emit_sum, acc_sum = seen_views(seen_buf)
             seen["n"][i] = acc_n[1:3, :max(nbin)]
             seen["vmax"][i] = acc_v[1:3, :max(nbin)]
             seen["emit"][i] = emit[1:3]
+            seen["emit_sum"][i] = emit_sum
+            seen["acc_sum"][i] = acc_sum
         if run.step_idx in eval_at:
             eval_pass(run.model)
     extra = {"bins": bins.cpu(), "nbin": nbin}
@@ -196,6 +207,10 @@ def explain(step, extra, ref_extra):
         # the accumulate kernel indexes its bins as gbin = level * bins_per_level + bin, like the table's
         print(f"      prop{q} scatter: counts READ differ in bins {dn[:16]} ({[(int(sn['n'][step, q, g]), int(rn['n'][step, q, g])) for g in dn[:8]]}), "
               f"maxima READ differ in bins {dv[:16]}, records PLACED differ at levels {de}", flush=True)
+        dw = (sn["emit_sum"][step, q] != rn["emit_sum"][step, q]).nonzero().flatten().tolist()
+        dr = (sn["acc_sum"][step, q] != rn["acc_sum"][step, q]).nonzero().flatten().tolist()
+        print(f"         record checksums vs the reference run: WRITTEN differ at (level, bin) {[(w // 32, w % 32) for w in dw[:12]]}, "
+              f"READ BACK differ at {[(w // 32, w % 32) for w in dr[:12]]}", flush=True)
         tot_n = [int(sn["n"][step, q, lv * (nb // 5):(lv + 1) * (nb // 5)].sum()) for lv in range(5)] if nb % 5 == 0 else []
         print(f"         records placed per level {sn['emit'][step, q, :5].tolist()} vs counts read per level {tot_n}", flush=True)
 
@@ -221,6 +236,13 @@ def self_check(k, extra):
         bad = (n.sum(dim=2) != placed).any(dim=1).nonzero().flatten().tolist()
         v = sn["vmax"][:, q, :nb].view(-1, 5, per)
         uneven = (v != v[:, :, :1]).any(dim=2).any(dim=1).nonzero().flatten().tolist()
+        # (level, bin) pairs whose records came back from the queue with another checksum than they were written with
+        torn = (sn["emit_sum"][:, q] != sn["acc_sum"][:, q]).any(dim=1).nonzero().flatten().tolist()
+        if torn:
+            st = torn[0]
+            where = (sn["emit_sum"][st, q] != sn["acc_sum"][st, q]).nonzero().flatten().tolist()
+            print(f"run {k}: prop{q} SELF-CHECK: records read back != records written at steps {torn[:8]}; "
+                  f"step {st}: (level, bin) {[(w // 32, w % 32) for w in where[:16]]}", flush=True)
         if bad or uneven:
             print(f"run {k}: prop{q} SELF-CHECK: counts read != records placed at steps {bad[:8]}; "
                   f"bins of one level read different maxima at steps {uneven[:8]}", flush=True)

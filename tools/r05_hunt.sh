@@ -1,34 +1,46 @@
 #!/bin/bash
 # Round 5, first GPU call: the two-stream divergence hunt with the instruments written (on CPU) at the end of round 4.
 # (build the variants on the CPU side first: bash tools/build_hunt_variants.sh)
-# usage: bash tools/r05_hunt.sh <leg> [runs]   legs: seen | atomic | rmw | memset | unpaired | base
-#   seen     the `seen` library variant (-DFNR_SCATTER_DEBUG_SEEN): every step the harness copies out what the proposal
-#            scatters' accumulate workgroups READ (queue count, level maximum) and what their emit kernels PLACED, checks
-#            them against each other inside the run (self_check: needs no reference run) and names the (level, bin) of
-#            the table that differs at an event step
-#   atomic   the `atomic_counters` variant: counters read / reset with agent-scope atomics (vector path, past L1 and the
-#            scalar cache) — events gone => the scalar-load path of the counters is the mechanism
-#   rmw      the `rmw_counters` variant: every counter access in every kernel is a device-scope atomic read-modify-write
-#            (exchange / max-with-0 by thread 0, broadcast through LDS): no cached copy of a counter line is ever read —
-#            past the scalar cache, L1 AND the XCD's L2
-#   memset   default library, FNR_SCATTER_MEMSET=1: counters zeroed by a memset node per call instead of self-cleaning
-#   unpaired default library, FNR_PAIR_PROPOSAL_LEVELS=0: one accumulate launch per proposal level
-#   base     the same hunt on `fruit_nerf` (never hunted at this length: 3000 steps x runs)
+# usage: bash tools/r05_hunt.sh <leg> [runs]
+# Every leg runs tests/diagnostics/digest_perstep.py on a `seen` build of the library (-DFNR_SCATTER_DEBUG_SEEN): each step
+# the harness copies out, for both proposal scatters, (a) the queue count and level maximum every accumulate workgroup READ,
+# (b) the records every emit level PLACED, (c) an order-independent checksum of every bin's records as WRITTEN by the emit
+# kernel and as READ BACK by the accumulate kernel.  Inside each run (no reference needed) it checks (a) against (b), the
+# bins of a level against each other, and (c) written against read back; against the reference run it compares per-bin
+# checksums of both proposal tables and (c).  Reading an event:
+#   counts read != records placed, or uneven maxima   -> the counter path (scalar loads of words that atomics wrote)
+#   counters fine, records read back != written       -> the queue came back different (cache maintenance / lost stores)
+#   both fine, WRITTEN differs from the reference run -> the emit kernel's input (d_feats / positions): FNR_DIGEST_WS=1 next
+#   all equal to the reference, table differs         -> the sweep (parameter / moment reads, LDS sums, the update)
+# legs:
+#   seen      default counter code
+#   atomic    counters read / reset with agent-scope atomic loads / stores (vector path, past L1 and the scalar cache)
+#   rmw       every counter access a device-scope atomic read-modify-write (past the XCD's L2 too)
+#   memset    default counter code, FNR_SCATTER_MEMSET=1: counters zeroed by a memset node per call
+#   unpaired  FNR_PAIR_PROPOSAL_LEVELS=0: one accumulate launch per proposal level
+#   serial    FNR_SERIALIZE_STREAMS=1: both streams, both allocator pools, both hardware queues — nothing concurrent
+#   onestream FNR_OVERLAP_PROPOSAL_BACKWARD=0: one stream (round 4: 0 of 44 runs; is that still so under AMD_OPT_FLUSH=0?)
+#   base      the same hunt on `fruit_nerf` (no kernel of its step uses scratch memory; fruit_nerf_big's semantic backward
+#             spills 34 registers) — never hunted at this length
 # AMD_OPT_FLUSH=0 everywhere: the setting with twice the event rate (round 4: 5 of 49 runs).  ~15 s per run.
 cd /root/repo; mkdir -p gpurun_out/r05
-export TMPDIR=/tmp AMD_OPT_FLUSH=0
+export TMPDIR=/tmp AMD_OPT_FLUSH=0 FNR_DIGEST_SEEN=1
 LEG=${1:-seen}; RUNS=${2:-36}
-V=fruitnerf_amd/lib/variants
+V=$PWD/fruitnerf_amd/lib/variants
+M=fruit_nerf_big; LIB=seen; ENV=""
 case $LEG in
-  seen)     ENV="FNR_LIB_PATH=$PWD/$V/seen/libfruitnerf_hip.so FNR_DIGEST_SEEN=1"; M=fruit_nerf_big ;;
-  atomic)   ENV="FNR_LIB_PATH=$PWD/$V/atomic_counters/libfruitnerf_hip.so"; M=fruit_nerf_big ;;
-  rmw)      ENV="FNR_LIB_PATH=$PWD/$V/rmw_counters/libfruitnerf_hip.so"; M=fruit_nerf_big ;;
-  memset)   ENV="FNR_SCATTER_MEMSET=1"; M=fruit_nerf_big ;;
-  unpaired) ENV="FNR_PAIR_PROPOSAL_LEVELS=0"; M=fruit_nerf_big ;;
-  base)     ENV=""; M=fruit_nerf ;;
+  seen)      ;;
+  atomic)    LIB=seen_atomic ;;
+  rmw)       LIB=seen_rmw ;;
+  memset)    ENV="FNR_SCATTER_MEMSET=1" ;;
+  unpaired)  ENV="FNR_PAIR_PROPOSAL_LEVELS=0" ;;
+  serial)    ENV="FNR_SERIALIZE_STREAMS=1" ;;
+  onestream) ENV="FNR_OVERLAP_PROPOSAL_BACKWARD=0" ;;
+  base)      M=fruit_nerf ;;
   *) echo "unknown leg $LEG"; exit 2 ;;
 esac
+test -f $V/$LIB/libfruitnerf_hip.so || { echo "missing $V/$LIB: run tools/build_hunt_variants.sh on the CPU side"; exit 2; }
 LOG=gpurun_out/r05/hunt_$LEG.log
-( time env $ENV timeout $((RUNS * 17 + 120)) python tests/diagnostics/digest_perstep.py $M $RUNS 3000 ) > $LOG 2>&1
+( time env FNR_LIB_PATH=$V/$LIB/libfruitnerf_hip.so $ENV timeout $((RUNS * 17 + 120)) python tests/diagnostics/digest_perstep.py $M $RUNS 3000 ) > $LOG 2>&1
 grep -E "DIFFERS|SELF-CHECK|   step|      |overlap" $LOG | cut -c1-400 | head -60
 echo "identical runs: $(grep -c identical $LOG)"; tail -3 $LOG | cut -c1-200
