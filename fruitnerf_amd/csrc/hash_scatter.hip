@@ -61,6 +61,9 @@ struct ScatterSeen {
   // and as the accumulate kernel READ them back.  Equal sums: the queue came back as written.
   unsigned long long emit_sum[2][SEEN_HQ];
   unsigned long long acc_sum[2][SEEN_HQ];
+  // ... and a position-weighted checksum of the bin's fixed-point gradient sums as the sweep found them in LDS (equal
+  // records read back + another value here = the LDS accumulation itself lost or doubled an add)
+  unsigned long long acc_grad[2][SEEN_HQ];
 };
 __device__ ScatterSeen g_scatter_seen;
 __device__ __forceinline__ unsigned long long seen_record_hash(unsigned row, float vx, float vy) {
@@ -732,6 +735,13 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
 #endif
   __syncthreads();
   float2* dst = grid.table + ((size_t)level << grid.log2_T) + (size_t)bin * rows;
+#ifdef FNR_SCATTER_DEBUG_SEEN
+  if (A.seen_slot >= 1 && bins <= SEEN_HBINS && A.nbins <= 8 * bins) {
+    unsigned long long gsum = 0ull;
+    for (int e = threadIdx.x; e < 2 * rows; e += blockDim.x) gsum += s_acc[e] * (unsigned long long)(2 * e + 1);
+    if (gsum != 0ull) atomicAdd(&g_scatter_seen.acc_grad[A.seen_slot - 1][lrel * SEEN_HBINS + bin], gsum);
+  }
+#endif
   if constexpr (ADAM) {
     const size_t row0 = ((size_t)level << grid.log2_T) + (size_t)bin * rows;
     // Two rows per thread through 16-byte loads / stores: this phase moves two thirds of the kernel's bytes (24 B in +

@@ -56,7 +56,8 @@ def seen_views(buf):
     hq = 32 * 8                                               # SEEN_HQ: (level, bin) pairs of a proposal call
     emit_sum = buf[o:o + 8 * 2 * hq].view(torch.int64).view(2, hq)
     acc_sum = buf[o + 8 * 2 * hq:o + 16 * 2 * hq].view(torch.int64).view(2, hq)
-    return acc_n, acc_v, emit, emit_sum, acc_sum
+    acc_grad = buf[o + 16 * 2 * hq:o + 24 * 2 * hq].view(torch.int64).view(2, hq)
+    return acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad
 
 
 def workspace_views(run):
@@ -157,7 +158,9 @@ def one_run():
                 "emit": torch.zeros(steps, 2, MAX_LEVELS, dtype=torch.int64, device=dev),
                 # order-independent checksums of every bin's records: as written by emit / as read back by accumulate
                 "emit_sum": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev),
-                "acc_sum": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev)}
+                "acc_sum": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev),
+                # checksum of every bin's fixed-point gradient sums as the optimiser sweep found them in LDS
+                "acc_grad": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev)}
         assert lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev)) == nb   # reset
     while run.step_idx < steps:
         i = run.step_idx
@@ -169,7 +172,8 @@ def one_run():
             bins[i, q, :nbin[q]] = t.view(torch.int32).view(nbin[q], -1).sum(dim=1, dtype=torch.int64)
         if seen is not None:
             lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev))
-            acc_n, acc_v, emit, emit_sum, acc_sum = seen_views(seen_buf)
+            acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad = seen_views(seen_buf)
+            seen["acc_grad"][i] = acc_grad
             seen["n"][i] = acc_n[1:3, :max(nbin)]
             seen["vmax"][i] = acc_v[1:3, :max(nbin)]
             seen["emit"][i] = emit[1:3]
@@ -209,8 +213,10 @@ def explain(step, extra, ref_extra):
               f"maxima READ differ in bins {dv[:16]}, records PLACED differ at levels {de}", flush=True)
         dw = (sn["emit_sum"][step, q] != rn["emit_sum"][step, q]).nonzero().flatten().tolist()
         dr = (sn["acc_sum"][step, q] != rn["acc_sum"][step, q]).nonzero().flatten().tolist()
+        dg = (sn["acc_grad"][step, q] != rn["acc_grad"][step, q]).nonzero().flatten().tolist()
         print(f"         record checksums vs the reference run: WRITTEN differ at (level, bin) {[(w // 32, w % 32) for w in dw[:12]]}, "
-              f"READ BACK differ at {[(w // 32, w % 32) for w in dr[:12]]}", flush=True)
+              f"READ BACK differ at {[(w // 32, w % 32) for w in dr[:12]]}; gradient sums in LDS differ at "
+              f"{[(w // 32, w % 32) for w in dg[:12]]}", flush=True)
         tot_n = [int(sn["n"][step, q, lv * (nb // 5):(lv + 1) * (nb // 5)].sum()) for lv in range(5)] if nb % 5 == 0 else []
         print(f"         records placed per level {sn['emit'][step, q, :5].tolist()} vs counts read per level {tot_n}", flush=True)
 

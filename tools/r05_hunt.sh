@@ -11,7 +11,8 @@
 #   counts read != records placed, or uneven maxima   -> the counter path (scalar loads of words that atomics wrote)
 #   counters fine, records read back != written       -> the queue came back different (cache maintenance / lost stores)
 #   both fine, WRITTEN differs from the reference run -> the emit kernel's input (d_feats / positions): FNR_DIGEST_WS=1 next
-#   all equal to the reference, table differs         -> the sweep (parameter / moment reads, LDS sums, the update)
+#   records equal, gradient sums in LDS differ        -> the LDS accumulation (ds_add_u64) lost or doubled an add
+#   all equal to the reference, table differs         -> the sweep (parameter / moment reads, the update itself)
 # legs:
 #   seen      default counter code
 #   atomic    counters read / reset with agent-scope atomic loads / stores (vector path, past L1 and the scalar cache)
