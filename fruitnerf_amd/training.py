@@ -588,6 +588,78 @@ def sync_gradients(arena, world_size: int) -> float:
     return 1.0 / world_size
 
 
+# The field group's optimiser step SHARDED over the ranks ("reduce-scatter + sharded Adam + all-gather"): with
+# N ranks every rank all-reduces the field's 67 MB gradient and then runs the SAME 16.8 M-parameter Adam sweep (40 B per
+# parameter: 670 MB of HBM traffic, ~110 us) as every other rank.  Sharded, the gradient is REDUCE-SCATTERED (the first half
+# of a ring all-reduce), each rank takes the optimiser step of its 1/N of the span only (sweep / N; its moments are the
+# only ones that stay current: optimiser state / N as well), the rest of its local gradient is zeroed, and the updated
+# parameters are ALL-GATHERED in place (the second half of the all-reduce): the same bytes on the links, (N - 1) / N of
+# the sweep saved per rank, and the ranks' parameters are identical by construction instead of by determinism.  Same
+# arithmetic per element as the all-reduce path.  Opt-in (FNR_SHARDED_FIELD_OPTIMIZER=1) until it has run on real peers:
+# CPU-tested on gloo (tests/test_distributed_cpu.py), which implements both collectives in place.
+SHARDED_FIELD_OPTIMIZER = os.environ.get("FNR_SHARDED_FIELD_OPTIMIZER") == "1"
+SHARD_ALIGN = 1024    # elements: every rank's shard starts on a 4 KiB boundary of the span
+
+
+class _ShardedSpan:
+    """One reduce-scattered span of the gradient arena: [a, main_b) is split into `world` equal shards, this rank owns
+    [my_a, my_b); [main_b, b) (fewer than world * SHARD_ALIGN elements) is all-reduced like before (`tail`)."""
+
+    def __init__(self, a, b, main_b, my_a, my_b, work, tail):
+        self.a, self.b, self.main_b, self.my_a, self.my_b, self.work, self.tail = a, b, main_b, my_a, my_b, work, tail
+
+    def finish(self, optimizer: "FusedAdam", lr: float, scale: float, group: str, step: Optional[int] = None) -> None:
+        """Wait for the shard's sum, take its optimiser step, zero what this rank does not own, start the all-gather of
+        the updated parameters and make the current stream wait for it (the host does not block)."""
+        import torch.distributed as dist
+        arena = optimizer.arena
+        if self.work is not None:
+            self.work.wait()
+            optimizer.step_span(self.my_a, self.my_b, lr, scale, group=group, step=step)   # (zeroes the gradient it consumes)
+            if self.my_a > self.a:
+                arena.grads[self.a:self.my_a].zero_()
+            if self.main_b > self.my_b:
+                arena.grads[self.my_b:self.main_b].zero_()
+            gathered = dist.all_gather_into_tensor(arena.params[self.a:self.main_b], arena.params[self.my_a:self.my_b],
+                                                   async_op=True)
+        else:
+            gathered = None
+        for ta, tb, twork in self.tail:
+            twork.wait()
+            optimizer.step_span(ta, tb, lr, scale, group=group, step=step)
+        if gathered is not None:
+            gathered.wait()
+
+
+def start_sharded_gradient_sync(arena, span, world_size: int, rank: Optional[int] = None) -> list:
+    """Reduce-scatter(SUM) of arena.grads[span], in place (a rank's output is its own slice of the input: RCCL's and
+    gloo's in-place form) -> [_ShardedSpan]."""
+    import torch.distributed as dist
+    if rank is None:
+        rank = dist.get_rank()
+    a, b = span
+    shard = ((b - a) // world_size) // SHARD_ALIGN * SHARD_ALIGN
+    main_b = a + shard * world_size
+    work = None
+    my_a = my_b = a
+    if shard > 0:
+        my_a, my_b = a + rank * shard, a + (rank + 1) * shard
+        work = dist.reduce_scatter_tensor(arena.grads[my_a:my_b], arena.grads[a:main_b], op=dist.ReduceOp.SUM, async_op=True)
+    tail = start_gradient_sync(arena, (main_b, b), world_size) if b > main_b else []
+    return [_ShardedSpan(a, b, main_b, my_a, my_b, work, tail)]
+
+
+def finish_exchange_entry(optimizer: "FusedAdam", entry, lr: float, scale: float, group: str, step: Optional[int] = None) -> None:
+    """Wait for one pending collective of the gradient exchange and apply what follows it: an all-reduced bucket
+    (a, b, work) takes its optimiser step on every rank; a _ShardedSpan see there."""
+    if isinstance(entry, _ShardedSpan):
+        entry.finish(optimizer, lr, scale, group, step)
+        return
+    a, b, work = entry
+    work.wait()                                    # the stream this runs on waits for this bucket only
+    optimizer.step_span(a, b, lr, scale, group=group, step=step)
+
+
 def train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: int, world_size: int = 1,
                     jitter: Optional[List[Tensor]] = None, want_metrics: bool = True, grad_scaler=None):
     """One Trainer.train_iteration for the hot path.  grad_scaler (default: the one the model was
@@ -648,12 +720,17 @@ class _FieldGradientExchange:
         if self.hold:
             self.held.append(((a, b), max(GRAD_BUCKET_ELEMS, b - a)))
         else:
-            self.pending += start_gradient_sync(self.arena, (a, b), self.world, bucket_elems=max(GRAD_BUCKET_ELEMS, b - a))
+            self.pending += self._start((a, b), max(GRAD_BUCKET_ELEMS, b - a))
+
+    def _start(self, span, bucket_elems: int) -> list:
+        if SHARDED_FIELD_OPTIMIZER:
+            return start_sharded_gradient_sync(self.arena, span, self.world)
+        return start_gradient_sync(self.arena, span, self.world, bucket_elems=bucket_elems)
 
     def issue(self) -> None:
         """Start the collectives of the spans noted while `hold` was set (in order)."""
         for span, bucket in self.held:
-            self.pending += start_gradient_sync(self.arena, span, self.world, bucket_elems=bucket)
+            self.pending += self._start(span, bucket)
         self.held = []
         self.hold = False
 
@@ -666,7 +743,7 @@ class _FieldGradientExchange:
                 if self.hold:
                     self.held.append((span, GRAD_BUCKET_ELEMS))
                 else:
-                    self.pending += start_gradient_sync(self.arena, span, self.world)
+                    self.pending += self._start(span, GRAD_BUCKET_ELEMS)
 
 
 # HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), round robin in creation order.
@@ -1127,21 +1204,20 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
             assert prop_updated == bool(getattr(model, "_last_render_updated", True)), "proposal update schedule"
             pending = list(exchange.pending)                   # the field's buckets (issued behind the scatter)
             deferred = []
-            for a, b, work in pending:
+            for entry in pending:
+                a = entry.a if isinstance(entry, _ShardedSpan) else entry[0]
                 name = "fields" if a >= spans["fields"][0] else "proposal_networks"
                 if DEFER_FIELD_UPDATE and name == "fields":
-                    deferred.append((a, b, work))
+                    deferred.append(entry)
                     continue
-                work.wait()                                    # the compute stream waits for this bucket only
-                optimizer.step_span(a, b, lrs[name], scale, group=name)
+                finish_exchange_entry(optimizer, entry, lrs[name], scale, name)   # the compute stream waits for this bucket only
             if deferred:
                 lr_f, step_f = lrs["fields"], optimizer.group_steps["fields"]
 
                 def finish(deferred=deferred, lr_f=lr_f, step_f=step_f, scale=scale):
                     with torch.no_grad():
-                        for a, b, work in deferred:
-                            work.wait()
-                            optimizer.step_span(a, b, lr_f, scale, group="fields", step=step_f)
+                        for entry in deferred:
+                            finish_exchange_entry(optimizer, entry, lr_f, scale, "fields", step=step_f)
                 model.field.defer_update(finish)
     model.proposal_sampler.step_cb(step)                       # AFTER_TRAIN_ITERATION callback
     return loss_dict, metrics_dict
