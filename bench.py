@@ -929,7 +929,8 @@ def main() -> None:
                    # N=1: the main table's optimiser step runs inside the scatter's accumulate kernel (its launches are
                    # the hash_encode_bwd entry; no gradient table is written or re-read); N>1: separate step after RCCL
                    "table_optimizer": "fused into hash_encode_bwd" if not dist_on else
-                   ("separate (after the exchange" + (", deferred to the next step's field encode)" if _training.DEFER_FIELD_UPDATE else ")")),
+                   ("separate (after the exchange" + (", deferred to the next step's field encode)" if _training.DEFER_FIELD_UPDATE else ")") +
+                    (f", sharded over the {world} ranks: reduce-scatter + own shard's step + all-gather" if _training.SHARDED_FIELD_OPTIMIZER else "")),
                    "streams": (f"2: proposal-network backward underneath the field backward; ray-gradient reduction, camera "
                                f"step and the next step's rays + proposal sampling underneath the table scatter (serialised "
                                f"on every {PROFILE_EVERY}th step, whose launches are timed)"
