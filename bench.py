@@ -505,6 +505,11 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if os.environ.get("FNR_BENCH_MAIN_PRIORITY") == "high":
+        # A/B knob (round 5): the LAUNCH stream is a high-priority stream instead of the default one, the training loop's
+        # second stream stays normal — when both hardware queues have workgroups ready the dispatcher takes the launch
+        # stream's first (the step's critical chain); same launches, same results
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1282,6 +1282,17 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
   long long blocks = (N + 255) / 256;
   const long long max_blocks = 3ll * device_cu_count();  // 3 x 46 KiB LDS per CU; fewer workgroups = fewer dW atomics
   if (blocks > max_blocks) blocks = max_blocks;
+  {
+    // A/B knob (round 5): FNR_PROP_BWD_WGS_PER_CU = 1 | 2 caps the PERSISTENT workgroups of k_prop_bwd below the three a CU
+    // holds.  On a second stream the kernel fills every CU for its whole 75 - 140 us and the launch stream's short kernels
+    // wait for it to END (kernel trace of the two-stream step, profiles/r04_raw/prof_step_timeline_two_streams.txt:
+    // k_color_ray_grads 11 -> 75 us, the base backward 50 -> 95 us next to it); with fewer resident workgroups it runs
+    // longer itself but leaves wave slots and LDS to the other queue.  Same partial sums per workgroup, summed by
+    // k_prop_reduce in workgroup order: the weight gradients change in the last bits with the workgroup count.
+    static const int cap_per_cu = [] { const char* e = getenv("FNR_PROP_BWD_WGS_PER_CU"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 3) ? v : 3; }();
+    const long long capped = (long long)cap_per_cu * device_cu_count();
+    if (blocks > capped) blocks = capped;
+  }
   Warp w = make_warp(warp);
   const float2* fs = reinterpret_cast<const float2*>(feat_save);
   float2* d_feats = reinterpret_cast<float2*>(workspace);
