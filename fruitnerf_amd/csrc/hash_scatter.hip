@@ -64,6 +64,9 @@ struct ScatterSeen {
   // ... and a position-weighted checksum of the bin's fixed-point gradient sums as the sweep found them in LDS (equal
   // records read back + another value here = the LDS accumulation itself lost or doubled an add)
   unsigned long long acc_grad[2][SEEN_HQ];
+  // ... and of the parameters and moments the fused optimiser sweep READ for the bin's rows (the arena was equal at the end
+  // of the previous step + another value here = the sweep read something else than what was there)
+  unsigned long long acc_pmv[2][SEEN_HQ];
 };
 __device__ ScatterSeen g_scatter_seen;
 __device__ __forceinline__ unsigned long long seen_record_hash(unsigned row, float vx, float vy) {
@@ -758,6 +761,9 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
       unsigned* tw = (adam.touched && rows >= 64) ? adam.touched + (row0 >> 6) : nullptr;
       // (Two iterations' parameters / moments in flight per thread — 96 B instead of 48 — changes nothing: 194.3 vs 194.9 us
       //  for the whole entry point, same-box A/B, profiles/r04_raw/ab_sweep.log.  The sweep is not latency-bound.)
+#ifdef FNR_SCATTER_DEBUG_SEEN
+      unsigned long long pmv_sum = 0ull;
+#endif
       for (int e4 = threadIdx.x; e4 < (rows >> 1); e4 += blockDim.x) {
         const long long a0 = (long long)s_acc[4 * e4], a1 = (long long)s_acc[4 * e4 + 1],
                         a2 = (long long)s_acc[4 * e4 + 2], a3 = (long long)s_acc[4 * e4 + 3];
@@ -768,6 +774,11 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
           if (!ever) atomicOr(&tw[e4 >> 5], 1u << (e4 & 31));   // first gradient of this pair (once per pair, ever)
         }
         float4 P = P4[e4], M = M4[e4], V = V4[e4];
+#ifdef FNR_SCATTER_DEBUG_SEEN
+        pmv_sum += seen_record_hash((unsigned)(4 * e4), P.x, P.y) + seen_record_hash((unsigned)(4 * e4 + 1), P.z, P.w) +
+                   seen_record_hash((unsigned)(4 * e4 + 2), M.x, M.y) + seen_record_hash((unsigned)(4 * e4 + 3), M.z, M.w) +
+                   3ull * seen_record_hash((unsigned)(4 * e4), V.x, V.y) + 5ull * seen_record_hash((unsigned)(4 * e4 + 1), V.z, V.w);
+#endif
         const float g0 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a0 * inv) : 0.0f;
         const float g1 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a1 * inv) : 0.0f;
         const float g2 = (a2 != 0 || a3 != 0) ? 0.0f + (float)((double)a2 * inv) : 0.0f;
@@ -780,6 +791,10 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
         M4[e4] = M;
         V4[e4] = V;
       }
+#ifdef FNR_SCATTER_DEBUG_SEEN
+      if (A.seen_slot >= 1 && bins <= SEEN_HBINS && A.nbins <= 8 * bins && pmv_sum != 0ull)
+        atomicAdd(&g_scatter_seen.acc_pmv[A.seen_slot - 1][lrel * SEEN_HBINS + bin], pmv_sum);
+#endif
       return;
     }
     for (int e2 = threadIdx.x; e2 < rows; e2 += blockDim.x) {

@@ -57,7 +57,8 @@ def seen_views(buf):
     emit_sum = buf[o:o + 8 * 2 * hq].view(torch.int64).view(2, hq)
     acc_sum = buf[o + 8 * 2 * hq:o + 16 * 2 * hq].view(torch.int64).view(2, hq)
     acc_grad = buf[o + 16 * 2 * hq:o + 24 * 2 * hq].view(torch.int64).view(2, hq)
-    return acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad
+    acc_pmv = buf[o + 24 * 2 * hq:o + 32 * 2 * hq].view(torch.int64).view(2, hq)
+    return acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad, acc_pmv
 
 
 def workspace_views(run):
@@ -160,7 +161,9 @@ def one_run():
                 "emit_sum": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev),
                 "acc_sum": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev),
                 # checksum of every bin's fixed-point gradient sums as the optimiser sweep found them in LDS
-                "acc_grad": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev)}
+                "acc_grad": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev),
+                # checksum of the parameters and moments the fused optimiser sweep read for every bin's rows
+                "acc_pmv": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev)}
         assert lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev)) == nb   # reset
     while run.step_idx < steps:
         i = run.step_idx
@@ -172,8 +175,9 @@ def one_run():
             bins[i, q, :nbin[q]] = t.view(torch.int32).view(nbin[q], -1).sum(dim=1, dtype=torch.int64)
         if seen is not None:
             lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev))
-            acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad = seen_views(seen_buf)
+            acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad, acc_pmv = seen_views(seen_buf)
             seen["acc_grad"][i] = acc_grad
+            seen["acc_pmv"][i] = acc_pmv
             seen["n"][i] = acc_n[1:3, :max(nbin)]
             seen["vmax"][i] = acc_v[1:3, :max(nbin)]
             seen["emit"][i] = emit[1:3]
@@ -216,7 +220,9 @@ def explain(step, extra, ref_extra):
         dg = (sn["acc_grad"][step, q] != rn["acc_grad"][step, q]).nonzero().flatten().tolist()
         print(f"         record checksums vs the reference run: WRITTEN differ at (level, bin) {[(w // 32, w % 32) for w in dw[:12]]}, "
               f"READ BACK differ at {[(w // 32, w % 32) for w in dr[:12]]}; gradient sums in LDS differ at "
-              f"{[(w // 32, w % 32) for w in dg[:12]]}", flush=True)
+              f"{[(w // 32, w % 32) for w in dg[:12]]}; parameters / moments READ by the sweep differ at "
+              f"{[(w // 32, w % 32) for w in (sn['acc_pmv'][step, q] != rn['acc_pmv'][step, q]).nonzero().flatten().tolist()[:12]]}",
+              flush=True)
         tot_n = [int(sn["n"][step, q, lv * (nb // 5):(lv + 1) * (nb // 5)].sum()) for lv in range(5)] if nb % 5 == 0 else []
         print(f"         records placed per level {sn['emit'][step, q, :5].tolist()} vs counts read per level {tot_n}", flush=True)
 

@@ -12,7 +12,9 @@
 #   counters fine, records read back != written       -> the queue came back different (cache maintenance / lost stores)
 #   both fine, WRITTEN differs from the reference run -> the emit kernel's input (d_feats / positions): FNR_DIGEST_WS=1 next
 #   records equal, gradient sums in LDS differ        -> the LDS accumulation (ds_add_u64) lost or doubled an add
-#   all equal to the reference, table differs         -> the sweep (parameter / moment reads, the update itself)
+#   parameters / moments READ by the sweep differ     -> the sweep read something else than the arena held at the end of
+#                                                        the previous step (its checksums were equal): stale parameter lines
+#   all equal to the reference, table differs         -> the update arithmetic or its stores
 # legs:
 #   seen      default counter code
 #   atomic    counters read / reset with agent-scope atomic loads / stores (vector path, past L1 and the scalar cache)
