@@ -473,6 +473,20 @@ def _scatter_workspace(dev, nbytes: int, tag: str):
     return buf, (0 if SCATTER_MEMSET_EVERY_CALL else clean)
 
 
+def _forget_scatter_workspaces(dev) -> None:
+    """A scatter entry point failed: its launches may have been enqueued in part (emit without accumulate), which leaves
+    queue counters that the next call — told workspace_clean = 1 — would add to.  Drop every cached workspace of the
+    device; the next calls allocate new ones and zero their counters."""
+    for k in [k for k, _ in _SCATTER_WS.items() if (k[0], k[1]) == (dev.type, dev.index)]:
+        del _SCATTER_WS.entries[k]
+
+
+def _scatter_check(rc: int, what: str, dev) -> None:
+    if rc != 0:
+        _forget_scatter_workspaces(dev)
+    L.check(rc, what)
+
+
 def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
                     d_feats: Tensor, level_begin: int = 0, level_count: Optional[int] = None) -> None:
     """Scatter the feature gradients of levels [level_begin, level_begin + level_count) (default: all) into the
@@ -482,9 +496,9 @@ def hash_encode_bwd(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, eucl
         level_count = grid_grad.n_levels - level_begin
     nbytes = lib.fnr_hash_scatter_workspace_bytes(rays.n * S, level_count, grid_grad.log2_hashmap_size)
     ws, clean = _scatter_workspace(rays.device, nbytes, "field")
-    L.check(lib.fnr_hash_encode_bwd(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
-                                    level_begin, level_count, L.ptr(ws), nbytes, clean, L.stream_ptr(rays.device)),
-            "hash_encode_bwd")
+    _scatter_check(lib.fnr_hash_encode_bwd(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
+                                           level_begin, level_count, L.ptr(ws), nbytes, clean, L.stream_ptr(rays.device)),
+                   "hash_encode_bwd", rays.device)
 
 
 def hash_encode_bwd_adam(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor, S: int,
@@ -494,9 +508,9 @@ def hash_encode_bwd_adam(grid_grad: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg,
     lib = L.load()
     nbytes = lib.fnr_hash_scatter_workspace_bytes(rays.n * S, grid_grad.n_levels, grid_grad.log2_hashmap_size)
     ws, clean = _scatter_workspace(rays.device, nbytes, "field")
-    L.check(lib.fnr_hash_encode_bwd_adam(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
-                                         L.ptr(ws), nbytes, clean, C.byref(adam), L.stream_ptr(rays.device)),
-            "hash_encode_bwd_adam")
+    _scatter_check(lib.fnr_hash_encode_bwd_adam(C.byref(grid_grad), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
+                                                L.ptr(ws), nbytes, clean, C.byref(adam), L.stream_ptr(rays.device)),
+                   "hash_encode_bwd_adam", rays.device)
 
 
 def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, euclid: Tensor,
@@ -511,15 +525,15 @@ def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_war
     d_pos = torch.empty(rays.n * S, 4, device=rays.device) if want_position_grad else None
     if adam is not None:
         t_adam, w_adam, grad_arena = adam
-        L.check(lib.fnr_prop_density_bwd_adam(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
-                                              L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), C.byref(t_adam),
-                                              C.byref(w_adam), L.ptr(grad_arena), L.ptr(ws), nbytes, clean,
-                                              L.stream_ptr(rays.device)), "prop_density_bwd_adam")
+        _scatter_check(lib.fnr_prop_density_bwd_adam(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
+                                                     L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), C.byref(t_adam),
+                                                     C.byref(w_adam), L.ptr(grad_arena), L.ptr(ws), nbytes, clean,
+                                                     L.stream_ptr(rays.device)), "prop_density_bwd_adam", rays.device)
         return d_pos
-    L.check(lib.fnr_prop_density_bwd(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
-                                     L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), L.ptr(ws), nbytes, clean,
-                                     L.stream_ptr(rays.device)),
-            "prop_density_bwd")
+    _scatter_check(lib.fnr_prop_density_bwd(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
+                                            L.ptr(feats), L.ptr(d_density), L.ptr(d_pos), L.ptr(ws), nbytes, clean,
+                                            L.stream_ptr(rays.device)),
+                   "prop_density_bwd", rays.device)
     return d_pos
 
 
@@ -551,10 +565,10 @@ def prop_density_bwd_pair(nets, grads, warps, rays: RaysArg, euclids, S, feats, 
     if position_ready is not None:
         if not position_ready.cuda_event:     # torch creates the HIP event lazily: on its first record
             position_ready.record(torch.cuda.current_stream(dev))
-        L.check(lib.fnr_prop_density_bwd_pair_split(*args, C.c_void_p(position_ready.cuda_event)),
-                "prop_density_bwd_pair_split")
+        _scatter_check(lib.fnr_prop_density_bwd_pair_split(*args, C.c_void_p(position_ready.cuda_event)),
+                       "prop_density_bwd_pair_split", dev)
     else:
-        L.check(lib.fnr_prop_density_bwd_pair(*args), "prop_density_bwd_pair")
+        _scatter_check(lib.fnr_prop_density_bwd_pair(*args), "prop_density_bwd_pair", dev)
     return d_pos
 
 

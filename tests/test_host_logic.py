@@ -653,3 +653,25 @@ def test_scatter_workspace_cache_is_bounded_per_entry_point():
     assert len(c) == 4
     c.get(k(1, "prop0", n=128), make)                                    # another size of the same entry point counts too
     assert sum(1 for key, _ in c.items() if key[4] == "prop0") == 2
+
+
+def test_a_failed_scatter_call_drops_the_cached_workspaces():
+    """A scatter entry point that fails may have enqueued its emit launch without the accumulate launch that puts the
+    queue counters back to zero: every cached workspace of that device is dropped, so that the next call zeroes its own."""
+    import pytest as _pytest
+    import torch as _torch
+    from fruitnerf_amd import _kernels as K
+    saved = dict(K._SCATTER_WS.entries)
+    try:
+        K._SCATTER_WS.clear()
+        K._SCATTER_WS.entries[("cuda", 0, 11, 64, "field")] = object()
+        K._SCATTER_WS.entries[("cuda", 0, 12, 64, "prop0")] = object()
+        K._SCATTER_WS.entries[("cuda", 1, 11, 64, "field")] = object()
+        K._scatter_check(0, "ok", _torch.device("cuda", 0))                       # success: nothing is dropped
+        assert len(K._SCATTER_WS) == 3
+        with _pytest.raises(RuntimeError):
+            K._scatter_check(3, "hash_encode_bwd", _torch.device("cuda", 0))      # failure: device 0's buffers go, then it raises
+        assert [k for k, _ in K._SCATTER_WS.items()] == [("cuda", 1, 11, 64, "field")]
+    finally:
+        K._SCATTER_WS.clear()
+        K._SCATTER_WS.entries.update(saved)
