@@ -4,7 +4,7 @@
 #   FNR_PROP_BWD_WGS_PER_CU = 1 | 2   fewer persistent workgroups of the proposal backward (second stream)
 #   FNR_BENCH_MAIN_PRIORITY = high    the launch stream on a high-priority hardware queue
 cd /root/repo; mkdir -p gpurun_out/r05; export TMPDIR=/tmp
-run() { env "$@" python bench.py --no-cpu-baseline --no-quality 2>/dev/null | python -c "
+run() { env "$@" python bench.py --no-cpu-baseline --no-quality --no-big 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$*', d['value'], d['ms_per_step'])"; }
 for rep in 1 2; do
