@@ -6,7 +6,7 @@ V=$PWD/fruitnerf_amd/lib/variants
 run() { label=$1; shift; env "$@" python bench.py --no-cpu-baseline --no-quality --no-big ${METHOD:+--method $METHOD} 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline']
-print('$label ${METHOD:-fruit_nerf}', d['value'], d['ms_per_step'], r['kernel'], r.get('us_per_launch', r.get('achieved')))"; }
+print('$label ${METHOD:-fruit_nerf}', d['value'], d['ms_per_step'], r['kernel'], r.get('avg_launch_ms'))"; }
 for METHOD in "" fruit_nerf_big; do
   for rep in 1 2; do
     run default A=1
