@@ -67,6 +67,10 @@ struct ScatterSeen {
   // ... and of the parameters and moments the fused optimiser sweep READ for the bin's rows (the arena was equal at the end
   // of the previous step + another value here = the sweep read something else than what was there)
   unsigned long long acc_pmv[2][SEEN_HQ];
+  // acc_n / acc_vmax hold the LARGEST value any wave of the workgroup read, these the complement of the SMALLEST: they differ
+  // from ~acc_n / ~acc_vmax exactly when the waves of one workgroup did not all read the same counter
+  unsigned acc_n_minc[SEEN_SLOTS][SEEN_BINS];
+  unsigned acc_vmax_minc[SEEN_SLOTS][SEEN_BINS];
 };
 __device__ ScatterSeen g_scatter_seen;
 __device__ __forceinline__ unsigned long long seen_record_hash(unsigned row, float vx, float vy) {
@@ -616,9 +620,11 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   const bool overflowed = s_bcast[2] != 0u;
   __syncthreads();   // everyone has its copy: thread 0 may go on (and the accumulator may be zeroed below)
 #ifdef FNR_SCATTER_DEBUG_SEEN
-  if (threadIdx.x == blockDim.x - 1 && gbin < SEEN_BINS) {
-    g_scatter_seen.acc_n[A.seen_slot][gbin] = (unsigned)n;
-    g_scatter_seen.acc_vmax[A.seen_slot][gbin] = __float_as_uint(vmax);
+  if ((threadIdx.x & 63) == 0 && gbin < SEEN_BINS) {
+    atomicMax(&g_scatter_seen.acc_n[A.seen_slot][gbin], (unsigned)n);
+    atomicMax(&g_scatter_seen.acc_n_minc[A.seen_slot][gbin], ~(unsigned)n);
+    atomicMax(&g_scatter_seen.acc_vmax[A.seen_slot][gbin], __float_as_uint(vmax));
+    atomicMax(&g_scatter_seen.acc_vmax_minc[A.seen_slot][gbin], ~__float_as_uint(vmax));
   }
 #endif
   if (threadIdx.x == 0) {
@@ -638,20 +644,50 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   long long n = __hip_atomic_load(&qcount[(size_t)gbin * SC_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float vmax = __uint_as_float(__hip_atomic_load(&qmax[(size_t)lrel * SC_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   const bool overflowed = __hip_atomic_load(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+#elif defined(FNR_SCATTER_NO_COUNTER_WAIT)
+  // hunt build `seen_nowait`: the code as it shipped until the end of round 4 — no wait ahead of the barrier — with the
+  // loads FORCED onto the vector path (an opaque zero in a VGPR makes the address non-uniform for the compiler): which
+  // path the compiler picks for these uniform loads changes with the surrounding code (the shipped build had vector loads
+  // in the first call's copy of k_scatter_accumulate2<true> only; this instrumented build gets scalar loads everywhere),
+  // and the hazard only exists on the vector path
+  unsigned vzero = 0u;
+  asm volatile("" : "+v"(vzero));
+  long long n = qcount[(size_t)gbin * SC_CNT_STRIDE + vzero];
+  const float vmax = __uint_as_float(qmax[(size_t)lrel * SC_CNT_STRIDE + vzero]);
+  const bool overflowed = qmax[(size_t)lrel * SC_CNT_STRIDE + 1 + vzero] != 0u;
 #else
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
   const float vmax = __uint_as_float(qmax[(size_t)lrel * SC_CNT_STRIDE]);  // largest |value| of the whole level
   // some emit workgroup overflowed a queue of this level and added records to the gradient table with atomics
   const bool overflowed = qmax[(size_t)lrel * SC_CNT_STRIDE + 1] != 0u;
 #endif
-  // every thread has its copy: put the counters back to zero, so the NEXT call on this workspace needs no memset
+  // EVERY WAVE MUST HOLD ITS COPIES BEFORE ANYONE MAY RESET A COUNTER.  The loads above are uniform, and the compiler is free
+  // to issue them as scalar loads or as vector loads; a workgroup barrier on gfx950 only waits for LDS / scalar traffic
+  // (lgkmcnt), NOT for outstanding vector loads (the workgroup-scope fence of __syncthreads omits vmcnt(0)).  In
+  // k_scatter_accumulate2<true> the FIRST call's copy of this function (proposal network 0) got VECTOR loads: its waves
+  // passed the barrier with the count / maximum still in flight, thread 0 then reset the count and counted the workgroup in
+  // on `qdone` — and the last workgroup of the level to arrive (any CU, any XCD) reset the level's maximum while loads of it
+  // were still on their way somewhere else.  A wave whose load was overtaken read 0, took its share of the bin's queue
+  // (a sixteenth) for empty and dropped it: the rare two-stream divergence of long fruit_nerf_big runs (DESIGN 2 round 4 (c);
+  // found by reading the ISA at the end of round 4: `s_barrier` ahead of `s_waitcnt vmcnt(1)` in that one code path, scalar
+  // loads + `s_waitcnt lgkmcnt(0)` ahead of the barrier in the second call's copy and in k_scatter_accumulate).  The
+  // counters are inputs of the wait: the compiler has to have them in registers before it, whatever loads it chose.
+#ifndef FNR_SCATTER_NO_COUNTER_WAIT   // (hunt build `seen_nowait`: the code as it was, to reproduce the events)
+  {
+    const unsigned seen_n = (unsigned)n, seen_max = __float_as_uint(vmax), seen_ovf = overflowed ? 1u : 0u;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(seen_n), "v"(seen_max), "v"(seen_ovf) : "memory");
+  }
+#endif
+  // now every thread has its copy: put the counters back to zero, so the NEXT call on this workspace needs no memset
   // launch (the caller says so with workspace_clean = 1).  The level's max is shared by its `bins` workgroups: the
-  // last of them to have read it clears it.
+  // last of them to have read it (its own increment of `qdone` follows its waves' loads) clears it.
   __syncthreads();
 #ifdef FNR_SCATTER_DEBUG_SEEN
-  if (threadIdx.x == blockDim.x - 1 && gbin < SEEN_BINS) {   // (the LAST wave's copy: the one furthest from thread 0's stores)
-    g_scatter_seen.acc_n[A.seen_slot][gbin] = (unsigned)n;
-    g_scatter_seen.acc_vmax[A.seen_slot][gbin] = __float_as_uint(vmax);
+  if ((threadIdx.x & 63) == 0 && gbin < SEEN_BINS) {   // every wave's copy: largest and (complemented) smallest
+    atomicMax(&g_scatter_seen.acc_n[A.seen_slot][gbin], (unsigned)n);
+    atomicMax(&g_scatter_seen.acc_n_minc[A.seen_slot][gbin], ~(unsigned)n);
+    atomicMax(&g_scatter_seen.acc_vmax[A.seen_slot][gbin], __float_as_uint(vmax));
+    atomicMax(&g_scatter_seen.acc_vmax_minc[A.seen_slot][gbin], ~__float_as_uint(vmax));
   }
 #endif
   if (threadIdx.x == 0) {

@@ -58,7 +58,11 @@ def seen_views(buf):
     acc_sum = buf[o + 8 * 2 * hq:o + 16 * 2 * hq].view(torch.int64).view(2, hq)
     acc_grad = buf[o + 16 * 2 * hq:o + 24 * 2 * hq].view(torch.int64).view(2, hq)
     acc_pmv = buf[o + 24 * 2 * hq:o + 32 * 2 * hq].view(torch.int64).view(2, hq)
-    return acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad, acc_pmv
+    o += 32 * 2 * hq
+    # complements of the SMALLEST count / maximum any wave of the workgroup read (acc_n / acc_v hold the largest)
+    n_minc = buf[o:o + 4 * words].view(torch.int32).view(SEEN_SLOTS, SEEN_BINS)
+    v_minc = buf[o + 4 * words:o + 8 * words].view(torch.int32).view(SEEN_SLOTS, SEEN_BINS)
+    return acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad, acc_pmv, n_minc, v_minc
 
 
 def workspace_views(run):
@@ -163,7 +167,10 @@ def one_run():
                 # checksum of every bin's fixed-point gradient sums as the optimiser sweep found them in LDS
                 "acc_grad": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev),
                 # checksum of the parameters and moments the fused optimiser sweep read for every bin's rows
-                "acc_pmv": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev)}
+                "acc_pmv": torch.zeros(steps, 2, 256, dtype=torch.int64, device=dev),
+                # smallest count / maximum any wave of the bin's workgroup read ("n" / "vmax" are the largest)
+                "n_min": torch.zeros(steps, 2, max(nbin), dtype=torch.int32, device=dev),
+                "vmax_min": torch.zeros(steps, 2, max(nbin), dtype=torch.int32, device=dev)}
         assert lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev)) == nb   # reset
     while run.step_idx < steps:
         i = run.step_idx
@@ -175,7 +182,9 @@ def one_run():
             bins[i, q, :nbin[q]] = t.view(torch.int32).view(nbin[q], -1).sum(dim=1, dtype=torch.int64)
         if seen is not None:
             lib.fnr_debug_scatter_seen_copy(L.ptr(seen_buf), seen_buf.numel(), 1, L.stream_ptr(dev))
-            acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad, acc_pmv = seen_views(seen_buf)
+            acc_n, acc_v, emit, emit_sum, acc_sum, acc_grad, acc_pmv, n_minc, v_minc = seen_views(seen_buf)
+            seen["n_min"][i] = ~n_minc[1:3, :max(nbin)]
+            seen["vmax_min"][i] = ~v_minc[1:3, :max(nbin)]
             seen["acc_grad"][i] = acc_grad
             seen["acc_pmv"][i] = acc_pmv
             seen["n"][i] = acc_n[1:3, :max(nbin)]
@@ -255,6 +264,20 @@ def self_check(k, extra):
             where = (sn["emit_sum"][st, q] != sn["acc_sum"][st, q]).nonzero().flatten().tolist()
             print(f"run {k}: prop{q} SELF-CHECK: records read back != records written at steps {torn[:8]}; "
                   f"step {st}: (level, bin) {[(w // 32, w % 32) for w in where[:16]]}", flush=True)
+        # THE mechanism found at the end of round 4 (hash_scatter.hip, accumulate_bin): the waves of one accumulate workgroup
+        # read DIFFERENT values of the bin's count or of the level's maximum — a reset store (this workgroup's thread 0, or
+        # the level's last workgroup) overtook a wave's load that the workgroup barrier had not waited for
+        ran = sn["n"][:, q, :nb] != 0           # (steps that trained the networks; an all-zero row has min = ~0 = -1)
+        split_n = ((sn["n"][:, q, :nb] != sn["n_min"][:, q, :nb]) & ran)
+        split_v = ((sn["vmax"][:, q, :nb] != sn["vmax_min"][:, q, :nb]) & ran)
+        split = (split_n | split_v).any(dim=1).nonzero().flatten().tolist()
+        if split:
+            st = split[0]
+            wn, wv = split_n[st].nonzero().flatten().tolist(), split_v[st].nonzero().flatten().tolist()
+            print(f"run {k}: prop{q} SELF-CHECK: the WAVES of a workgroup read different counters at steps {split[:8]}; "
+                  f"step {st}: count differs in bins {wn[:8]} "
+                  f"({[(int(sn['n_min'][st, q, g]), int(sn['n'][st, q, g])) for g in wn[:4]]}), maximum (bits) in bins {wv[:8]} "
+                  f"({[(int(sn['vmax_min'][st, q, g]), int(sn['vmax'][st, q, g])) for g in wv[:4]]})", flush=True)
         if bad or uneven:
             print(f"run {k}: prop{q} SELF-CHECK: counts read != records placed at steps {bad[:8]}; "
                   f"bins of one level read different maxima at steps {uneven[:8]}", flush=True)
