@@ -1,0 +1,53 @@
+"""Properties of the COMPILED scatter kernels that no functional test can see (hipcc cross-compiles without a GPU).
+
+Round 4's rare divergence of long two-stream runs was a missing wait: `accumulate_bin` reads its queue counters, passes a
+workgroup barrier and lets thread 0 reset them — but on gfx950 neither the barrier nor the workgroup-scope fence of
+`__syncthreads()` waits for outstanding VECTOR loads, and hipcc had issued the counter loads as vector loads in one inlined
+copy of `k_scatter_accumulate2<true>` (`s_barrier` ahead of `s_waitcnt vmcnt`).  A wave could read a counter after its reset.
+The fix is an explicit `s_waitcnt vmcnt(0) lgkmcnt(0)` (inline assembly, counters as inputs) ahead of that barrier; this
+test keeps it there, in every copy of the function, whatever loads the compiler picks."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "fruitnerf_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def scatter_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "hash_scatter.s"
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffp-contract=off",
+           "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "hash_scatter.hip")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    return out.read_text().split("\n")
+
+
+def _kernel(lines, mangled_prefix):
+    """The instructions of the kernel whose label starts with `mangled_prefix` (label line .. s_endpgm)."""
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix) and ":" in l)
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return [l.strip() for l in lines[start:end + 1]]
+
+
+@pytest.mark.parametrize("name,copies", [("_ZN3fnr20k_scatter_accumulateILb1EEE", 1), ("_ZN3fnr20k_scatter_accumulateILb0EEE", 1),
+                                         ("_ZN3fnr21k_scatter_accumulate2ILb1EEE", 2), ("_ZN3fnr21k_scatter_accumulate2ILb0EEE", 2)])
+def test_counter_loads_are_waited_for_ahead_of_the_reset_barrier(scatter_asm, name, copies):
+    body = _kernel(scatter_asm, name)
+    waits = [i for i, l in enumerate(body) if l.startswith("s_waitcnt vmcnt(0) lgkmcnt(0)") and body[i - 1].startswith(";;#ASMSTART")]
+    assert len(waits) == copies, f"{name}: {len(waits)} explicit counter waits for {copies} inlined copies of accumulate_bin"
+    for w in waits:
+        # the next barrier follows within a few instructions, with no memory instruction in between ...
+        nxt = next(i for i in range(w, len(body)) if body[i].startswith("s_barrier"))
+        between = [l for l in body[w + 1:nxt] if l and not l.startswith(";")]
+        assert len(between) <= 6 and not any(re.match(r"(global|buffer|flat|scratch)_", l) for l in between), between
+        # ... and every counter load of this copy sits ahead of the wait: the first store / atomic to global memory (the
+        # reset, the qdone increment) comes after the barrier
+        first_write = next(i for i in range(w, len(body)) if re.match(r"global_(store|atomic)", body[i]))
+        assert first_write > nxt
