@@ -644,12 +644,13 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   long long n = __hip_atomic_load(&qcount[(size_t)gbin * SC_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float vmax = __uint_as_float(__hip_atomic_load(&qmax[(size_t)lrel * SC_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   const bool overflowed = __hip_atomic_load(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-#elif defined(FNR_SCATTER_NO_COUNTER_WAIT)
-  // hunt build `seen_nowait`: the code as it shipped until the end of round 4 — no wait ahead of the barrier — with the
-  // loads FORCED onto the vector path (an opaque zero in a VGPR makes the address non-uniform for the compiler): which
-  // path the compiler picks for these uniform loads changes with the surrounding code (the shipped build had vector loads
-  // in the first call's copy of k_scatter_accumulate2<true> only; this instrumented build gets scalar loads everywhere),
-  // and the hazard only exists on the vector path
+#elif defined(FNR_SCATTER_FORCE_VECTOR_LOADS)
+  // hunt builds: the counter loads FORCED onto the vector path (an opaque zero in a VGPR makes the address non-uniform for
+  // the compiler).  Which path the compiler picks for these uniform loads changes with the surrounding code — the shipped
+  // build had vector loads in the first call's copy of k_scatter_accumulate2<true> only, the instrumented builds get scalar
+  // loads everywhere — and the hazard only exists on the vector path.  `seen_nowait` (+ FNR_SCATTER_NO_COUNTER_WAIT)
+  // is the code as it shipped until the end of round 4, in its hazardous form, in BOTH copies: it must reproduce the
+  // events; `seen_vec` is the fix under the same loads: it must not.
   unsigned vzero = 0u;
   asm volatile("" : "+v"(vzero));
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE + vzero];

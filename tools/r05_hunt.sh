@@ -18,9 +18,11 @@
 # THE MECHANISM WAS FOUND BY READING THE ISA AFTER THIS KIT WAS WRITTEN (hash_scatter.hip, accumulate_bin; DESIGN 2 round 4
 # (c)): in k_scatter_accumulate2<true>'s copy for proposal network 0 the counter loads are vector loads that the workgroup
 # barrier does not wait for, so a reset store can overtake them.  The first two legs are the proof to collect:
-#   nowait    the code AS IT WAS (-DFNR_SCATTER_NO_COUNTER_WAIT): expect events (round 4: 5 of 49 runs), each with
-#             "the WAVES of a workgroup read different counters" from the self-check at the event step
-#   seen      the fixed default (every wave waits for its counter loads ahead of the barrier): expect NO event, no self-check line
+#   nowait    the code AS IT WAS, no wait ahead of the barrier, with the counter loads forced onto the vector path in both
+#             copies (the instrumented builds would otherwise get harmless scalar loads): expect events (round 4: 5 of 49
+#             runs with ONE hazardous copy), each with "the WAVES of a workgroup read different counters" at its step
+#   vec       the FIX under the same forced vector loads: expect NO event, no self-check line
+#   seen      the fixed default as the compiler builds it: expect NO event either
 # further legs (kept from before the finding):
 #   atomic    counters read / reset with agent-scope atomic loads / stores (vector path, past L1 and the scalar cache)
 #   rmw       every counter access a device-scope atomic read-modify-write (past the XCD's L2 too)
@@ -39,6 +41,7 @@ M=fruit_nerf_big; LIB=seen; ENV=""
 case $LEG in
   seen)      ;;
   nowait)    LIB=seen_nowait ;;
+  vec)       LIB=seen_vec ;;
   atomic)    LIB=seen_atomic ;;
   rmw)       LIB=seen_rmw ;;
   memset)    ENV="FNR_SCATTER_MEMSET=1" ;;
