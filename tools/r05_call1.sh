@@ -3,7 +3,8 @@
 #   1. the GPU suite on the tree that ends round 4 (the accumulate kernels wait for their counter loads now);
 #   2. the unvalidated legs written without a GPU (sharded optimiser step over a one-rank RCCL group), non-fatal;
 #   3. the default bench line (the fix costs a wait per accumulate workgroup: compare with round 4's 5.43 M rays/s);
-#   4. the proof of the divergence's mechanism: leg nowait (old code, hazardous loads: expect events + "WAVES ... read
+#   4. the hazard in isolation (tools/microbench/barrier_load_race.hip: stale counter reads with / without the wait);
+#   5. the proof of the divergence's mechanism: leg nowait (old code, hazardous loads: expect events + "WAVES ... read
 #      different counters"), leg vec (the fix under the same loads: expect none).
 # gpurun --timeout 1500 -- bash tools/r05_call1.sh
 cd /root/repo; mkdir -p gpurun_out/r05; export TMPDIR=/tmp
@@ -17,5 +18,7 @@ import json
 d = json.loads(open('gpurun_out/r05/bench_1.log').read())
 print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('avg_launch_ms'))
 P
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench/barrier_load_race.hip -o /tmp/barrier_load_race 2>/dev/null && \
+  timeout 240 /tmp/barrier_load_race 100000 | tee gpurun_out/r05/barrier_load_race.log   # the hazard in isolation (4 x ~10 s)
 bash tools/r05_hunt.sh nowait 24
 bash tools/r05_hunt.sh vec 24
