@@ -673,6 +673,12 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   // found by reading the ISA at the end of round 4: `s_barrier` ahead of `s_waitcnt vmcnt(1)` in that one code path, scalar
   // loads + `s_waitcnt lgkmcnt(0)` ahead of the barrier in the second call's copy and in k_scatter_accumulate).  The
   // counters are inputs of the wait: the compiler has to have them in registers before it, whatever loads it chose.
+#ifdef FNR_ACC_ZERO_EARLY
+  // A/B build (tools/build_variant.sh zero_early -DFNR_ACC_ZERO_EARLY): the accumulator is zeroed HERE, while the counter
+  // loads are in flight — it does not depend on them — and the barrier below covers it, so the second barrier (and the
+  // load latency the wait exposes) goes: one barrier and ~1 us less per accumulate workgroup
+  for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0ull;
+#endif
 #ifndef FNR_SCATTER_NO_COUNTER_WAIT   // (hunt build `seen_nowait`: the code as it was, to reproduce the events)
   {
     const unsigned seen_n = (unsigned)n, seen_max = __float_as_uint(vmax), seen_ovf = overflowed ? 1u : 0u;
@@ -722,8 +728,10 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   int S = 62 - nb - e;
   if (S > 1000) S = 1000;
   const double scale = ldexp(1.0, S), inv = ldexp(1.0, -S);
+#if !defined(FNR_ACC_ZERO_EARLY) || defined(FNR_SCATTER_RMW_COUNTERS)
   for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0ull;
   __syncthreads();
+#endif
   if (!have) n = 0;
   const float2* qv = queue_v + (size_t)gbin * cap;
   const unsigned short* qr = queue_r + (size_t)gbin * cap;

@@ -10,3 +10,4 @@ bash tools/build_variant.sh seen_atomic "-DFNR_SCATTER_DEBUG_SEEN -DFNR_SCATTER_
 bash tools/build_variant.sh seen_rmw "-DFNR_SCATTER_DEBUG_SEEN -DFNR_SCATTER_RMW_COUNTERS"
 bash tools/build_variant.sh atomic_counters -DFNR_SCATTER_ATOMIC_COUNTERS
 bash tools/build_variant.sh rmw_counters -DFNR_SCATTER_RMW_COUNTERS
+bash tools/build_variant.sh zero_early -DFNR_ACC_ZERO_EARLY    # A/B only (tools/r05_ab_counters.sh): accumulator zeroed while the counter loads fly, one barrier fewer

@@ -13,5 +13,6 @@ for METHOD in "" fruit_nerf_big; do
     run atomic FNR_LIB_PATH=$V/atomic_counters/libfruitnerf_hip.so
     run rmw FNR_LIB_PATH=$V/rmw_counters/libfruitnerf_hip.so
     run memset FNR_SCATTER_MEMSET=1
+    run zero_early FNR_LIB_PATH=$V/zero_early/libfruitnerf_hip.so
   done
 done | tee gpurun_out/r05/ab_counters.log
