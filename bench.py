@@ -673,7 +673,12 @@ def main() -> None:
                    "final_train_losses": {k: round(float(v), 6) for k, v in ld.items()},
                    # records of the binned scatter that overflowed a queue and went through float atomics (their order,
                    # hence the last bits, would depend on timing) over everything this process has run so far
-                   "scatter_queue_overflows": L.scatter_overflows()}
+                   "scatter_queue_overflows": L.scatter_overflows(),
+                   # integer sum of the bit patterns of every parameter after these steps: two runs of this command on
+                   # any box must print the same number (training is deterministic: fixed-point scatter sums, ordered
+                   # reductions, counter-based random numbers) — the visible form of the reproducibility claim, and the
+                   # quickest detector of a defect like round 4's (one differing step changes it)
+                   "parameter_checksum": int(model.arena().params.view(torch.int32).sum(dtype=torch.int64))}
 
     # ---- secondary metrics: full-image eval rays/s and volume-export samples/s, trained weights ----
     secondary = None
