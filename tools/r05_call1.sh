@@ -6,7 +6,7 @@
 #   4. the hazard in isolation (tools/microbench/barrier_load_race.hip: stale counter reads with / without the wait);
 #   5. the proof of the divergence's mechanism: leg nowait (old code, hazardous loads: expect events + "WAVES ... read
 #      different counters"), leg vec (the fix under the same loads: expect none).
-# gpurun --timeout 1500 -- bash tools/r05_call1.sh
+# gpurun --timeout 1800 -- bash tools/r05_call1.sh   (suite 2 min, bench 2, microbenchmark 1, two hunt legs of 24 runs ~8 min each)
 cd /root/repo; mkdir -p gpurun_out/r05; export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider -x > gpurun_out/r05/tests_1.log 2>&1
 echo "gpu tests rc $?"; grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/r05/tests_1.log | tail -5
@@ -20,5 +20,5 @@ print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'
 P
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench/barrier_load_race.hip -o /tmp/barrier_load_race 2>/dev/null && \
   timeout 240 /tmp/barrier_load_race 100000 | tee gpurun_out/r05/barrier_load_race.log   # the hazard in isolation (4 x ~10 s)
-bash tools/r05_hunt.sh nowait 24
-bash tools/r05_hunt.sh vec 24
+bash tools/r05_hunt.sh nowait 22
+bash tools/r05_hunt.sh vec 22

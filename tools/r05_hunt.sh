@@ -53,6 +53,6 @@ case $LEG in
 esac
 test -f $V/$LIB/libfruitnerf_hip.so || { echo "missing $V/$LIB: run tools/build_hunt_variants.sh on the CPU side"; exit 2; }
 LOG=gpurun_out/r05/hunt_$LEG.log
-( time env FNR_LIB_PATH=$V/$LIB/libfruitnerf_hip.so $ENV timeout $((RUNS * 17 + 120)) python tests/diagnostics/digest_perstep.py $M $RUNS 3000 ) > $LOG 2>&1
+( time env FNR_LIB_PATH=$V/$LIB/libfruitnerf_hip.so $ENV timeout $((RUNS * 22 + 120)) python tests/diagnostics/digest_perstep.py $M $RUNS 3000 ) > $LOG 2>&1
 grep -E "DIFFERS|SELF-CHECK|   step|      |overlap" $LOG | cut -c1-400 | head -60
 echo "identical runs: $(grep -c identical $LOG)"; tail -3 $LOG | cut -c1-200
