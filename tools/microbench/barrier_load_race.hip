@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
   qmax = qcount + (size_t)LEVELS * BINS * STRIDE;
   qdone = qmax + (size_t)LEVELS * STRIDE;
   (void)hipMalloc(&stale, 16);
-  const size_t nload = (size_t)1 << 26;   // 1 GiB in, 1 GiB out per launch of the background stream
+  const size_t nload = (size_t)1 << 24;   // 256 MiB in, 256 MiB out per launch of the background stream (~0.1 ms)
   float4 *la, *lb;
   (void)hipMalloc(&la, nload * sizeof(float4));
   (void)hipMalloc(&lb, nload * sizeof(float4));
