@@ -3,7 +3,8 @@
 // divergence, in isolation, with the scatter's counter protocol:
 //   set    (the emit kernel's role)  qcount[g] = g + 1, qmax[l] = 1.0f — with device-scope atomics, like the emit kernel
 //   read   (accumulate_bin's role)   every thread of a 1024-thread workgroup loads its bin's count and its level's maximum
-//          through the VECTOR path (an opaque zero in a VGPR), [WAIT: s_waitcnt vmcnt(0)], __syncthreads(), thread 0
+//          through the VECTOR path (an opaque zero in a VGPR; third mode: provably uniform address = scalar loads),
+//          [WAIT: s_waitcnt vmcnt(0)], __syncthreads(), thread 0
 //          resets the count and counts the workgroup in on qdone[l]; the level's last workgroup resets the maximum.
 //          Every wave then checks what it read: a 0 where g + 1 / 1.0f was set = a reset overtook the load.
 // A second stream streams a few GB through HBM meanwhile (the training step's other stream, in spirit).
@@ -21,14 +22,15 @@ __global__ void k_set(unsigned* qcount, unsigned* qmax) {
   if (g < LEVELS) atomicMax(&qmax[(size_t)g * STRIDE], 0x3f800000u);
 }
 
-template <bool WAIT>
+template <bool WAIT, bool VEC>
 __global__ __launch_bounds__(1024) void k_read(unsigned* qcount, unsigned* qmax, unsigned* qdone,
                                                unsigned long long* stale /* [2]: counts, maxima */) {
   extern __shared__ unsigned long long lds[];   // 64 KiB like the proposal tables' accumulate workgroups: two per CU
   const int gbin = LEVELS * BINS - 1 - (int)blockIdx.x;
   const int lrel = gbin / BINS;
   unsigned vzero = 0u;
-  asm volatile("" : "+v"(vzero));               // the address is not uniform for the compiler: vector loads
+  if (VEC) asm volatile("" : "+v"(vzero));      // the address is not uniform for the compiler: vector loads
+  // (!VEC: a provably uniform address — hipcc issues scalar loads, which the barrier's lgkmcnt(0) does wait for)
   const unsigned n = qcount[(size_t)gbin * STRIDE + vzero];
   const unsigned vmax = qmax[(size_t)lrel * STRIDE + vzero];
   if (WAIT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(n), "v"(vmax) : "memory");
@@ -74,23 +76,26 @@ int main(int argc, char** argv) {
   hipStream_t s0, s1;
   (void)hipStreamCreate(&s0);
   (void)hipStreamCreate(&s1);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_read<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_read<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  for (int wait = 0; wait < 2; ++wait)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_read<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_read<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_read<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  for (int wait = 0; wait < 3; ++wait)     // 0: vector loads, no wait (the hazard); 1: vector loads + wait (the fix); 2: scalar loads, no wait
     for (int load = 0; load < 2; ++load) {
       (void)hipMemset(stale, 0, 16);
       (void)hipDeviceSynchronize();
       for (int r = 0; r < rounds; ++r) {
         if (load && (r % 8) == 0) hipLaunchKernelGGL(k_stream, dim3(4096), dim3(256), 0, s1, la, lb, nload);
         hipLaunchKernelGGL(k_set, dim3(1), dim3(256), 0, s0, qcount, qmax);
-        if (wait) hipLaunchKernelGGL(k_read<true>, dim3(LEVELS * BINS), dim3(1024), 65536, s0, qcount, qmax, qdone, stale);
-        else hipLaunchKernelGGL(k_read<false>, dim3(LEVELS * BINS), dim3(1024), 65536, s0, qcount, qmax, qdone, stale);
+        if (wait == 1) hipLaunchKernelGGL((k_read<true, true>), dim3(LEVELS * BINS), dim3(1024), 65536, s0, qcount, qmax, qdone, stale);
+        else if (wait == 0) hipLaunchKernelGGL((k_read<false, true>), dim3(LEVELS * BINS), dim3(1024), 65536, s0, qcount, qmax, qdone, stale);
+        else hipLaunchKernelGGL((k_read<false, false>), dim3(LEVELS * BINS), dim3(1024), 65536, s0, qcount, qmax, qdone, stale);
       }
       (void)hipDeviceSynchronize();
       unsigned long long h[2];
       (void)hipMemcpy(h, stale, 16, hipMemcpyDeviceToHost);
-      printf("wait ahead of the barrier: %-3s  second stream streaming: %-3s  %d rounds x %d workgroups x 16 waves: stale counts %llu, "
-             "stale maxima %llu\n", wait ? "yes" : "no", load ? "yes" : "no", rounds, LEVELS * BINS, h[0], h[1]);
+      printf("%-34s second stream streaming: %-3s  %d rounds x %d workgroups x 16 waves: stale counts %llu, stale maxima %llu\n",
+             wait == 0 ? "vector loads, no wait (hazard):" : wait == 1 ? "vector loads + wait (the fix):" : "scalar loads, no explicit wait:",
+             load ? "yes" : "no", rounds, LEVELS * BINS, h[0], h[1]);
       fflush(stdout);
     }
   return 0;

@@ -19,6 +19,6 @@ d = json.loads(open('gpurun_out/r05/bench_1.log').read())
 print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('avg_launch_ms'))
 P
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench/barrier_load_race.hip -o /tmp/barrier_load_race 2>/dev/null && \
-  timeout 300 /tmp/barrier_load_race 400000 | tee gpurun_out/r05/barrier_load_race.log   # the hazard in isolation (4 x ~10 s; round 4 saw ~1.6e-8 stale reads per wave and launch)
+  timeout 300 /tmp/barrier_load_race 400000 | tee gpurun_out/r05/barrier_load_race.log   # the hazard in isolation (6 x ~10 s; round 4 saw ~1.6e-8 stale reads per wave and launch)
 bash tools/r05_hunt.sh nowait 22
 bash tools/r05_hunt.sh vec 22
