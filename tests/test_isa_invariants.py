@@ -51,3 +51,17 @@ def test_counter_loads_are_waited_for_ahead_of_the_reset_barrier(scatter_asm, na
         # reset, the qdone increment) comes after the barrier
         first_write = next(i for i in range(w, len(body)) if re.match(r"global_(store|atomic)", body[i]))
         assert first_write > nxt
+
+
+def test_scatter_kernels_use_no_scratch_and_keep_three_emit_workgroups_per_cu(scatter_asm):
+    """Resource facts DESIGN 4 relies on: no scatter kernel spills (scratch would also make them the only scratch users of the
+    `fruit_nerf` step), and the emit kernel's static LDS lets three workgroups share a CU's 160 KiB."""
+    text = "\n".join(scatter_asm)
+    meta = re.findall(r"\.group_segment_fixed_size:\s*(\d+)\s*\n(?:.*\n)*?\s*\.name:\s*(\S+)\s*\n(?:.*\n)*?\s*\.private_segment_fixed_size:\s*(\d+)"
+                      r"(?:.*\n)*?\s*\.vgpr_spill_count:\s*(\d+)", text)
+    kernels = {name: (int(lds), int(scratch), int(spill)) for lds, name, scratch, spill in meta if name.startswith("_ZN3fnr")}
+    assert len(kernels) >= 20, sorted(kernels)
+    for name, (lds, scratch, spill) in kernels.items():
+        assert scratch == 0 and spill == 0, (name, scratch, spill)
+        if "k_scatter_emit" in name:
+            assert 3 * ((lds + 511) // 512 * 512) <= 160 * 1024, (name, lds)
