@@ -50,7 +50,11 @@ def test_bench_gpus_2_starts_two_ranks(dev):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["steps"] == 4 and d["value"] > 0
     assert d["config"]["table_optimizer"].startswith("separate")
-    assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["kernel"] in ("hash_encode_bwd", "field_mlp_bwd")
+    # WHICH entry point a 4-step window with two ranks interleaving on one device measures as the slowest is timing, not
+    # function: only the shape of the roofline object is asserted here
+    sys.path.insert(0, ROOT)
+    import bench
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["kernel"] in bench.ROOFLINE_OPS
 
 
 def test_exchange_path_step_is_the_single_process_step(dev):
