@@ -454,6 +454,18 @@ def spawn_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _group_report(dev) -> dict:
+    """{"world_size", "backend", "devices"} of the default process group: devices = distinct (host, device index) pairs the
+    ranks report (2 ranks on one device in the one-GPU self-test; N on a real node).  A collective: every rank calls it."""
+    import socket
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    mine = f"{socket.gethostname()}:{dev.index if dev.index is not None else 0}"
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    return {"world_size": world, "backend": str(dist.get_backend()), "devices": len(set(seen))}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -518,6 +530,7 @@ def main() -> None:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    group_report = _group_report(dev) if dist_on else None
 
     from fruitnerf_amd import _lib as L
     from fruitnerf_amd.data import synthetic_apple as sa
@@ -945,6 +958,9 @@ def main() -> None:
                                f"step and the next step's rays + proposal sampling underneath the table scatter (serialised "
                                f"on every {PROFILE_EVERY}th step, whose launches are timed)"
                                if _training.OVERLAP_PROPOSAL_BACKWARD else "1"),
+                   # what the process group itself reports (so that a SCALE line can be checked against the launcher):
+                   # ranks of the group, its backend ("nccl" is RCCL on ROCm) and the distinct devices they run on
+                   "rccl_ranks": group_report,
                    "exchange": None if not dist_on else f"{_training.EXCHANGE_LEVEL_GROUPS} field collective(s) per step + proposal networks on update steps + poses",
                    "device": info["arch"], "setup_s": round(setup_s, 1)},
         "roofline": roofline,

@@ -260,8 +260,9 @@ class FruitClustering:
 
 class Clustering(FruitClustering):
     """run_clustering.py:21-67: FruitClustering + the fruit template and the evaluation inputs.  template_path: a PLY of
-    the template (Open3D-readable binary layout); None or unreadable (the reference's *_template.ply are Git-LFS pointers
-    in its repository snapshot) -> a sphere of `template_radius` (shapes.sphere_template).  The template is scaled by
+    the template (Open3D-readable binary layout); None or a Git-LFS pointer file (the reference's *_template.ply in its
+    repository snapshot) -> a sphere of `template_radius` (shapes.sphere_template), `template_fallback` True; any other
+    unreadable file raises.  The template is scaled by
     apple_template_size about the origin, then centred (:41-43)."""
 
     def __init__(self, template_path: Union[str, Path, None] = None, voxel_size_down_sample: float = 0.00005,
@@ -273,12 +274,18 @@ class Clustering(FruitClustering):
                          remove_outliers_radius=remove_outliers_radius, cluster_merge_distance=cluster_merge_distance)
         self.template_path = template_path
         self.min_samples = min_samples
+        # The sphere stands in ONLY for "no template given" and for a Git-LFS pointer file (what the reference's
+        # *_template.ply are in its repository snapshot); a missing, mistyped or corrupt file raises like the reference's
+        # o3d.io.read_point_cloud + asserts would: the template's volume drives the split and prune thresholds, so a silent
+        # substitute would give plausible but wrong counts.
         template = None
+        self.template_fallback = True
         if template_path is not None:
-            try:
-                template, _ = ply.read_point_cloud(str(template_path))
-            except Exception:
-                template = None
+            with open(str(template_path), "rb") as f:            # FileNotFoundError for a mistyped path
+                head = f.read(64)
+            if not head.startswith(b"version https://git-lfs"):
+                template, _ = ply.read_point_cloud(str(template_path))     # raises on a corrupt PLY
+                self.template_fallback = False
         if template is None:
             template = shapes.sphere_template(template_radius)
         self.set_template(np.asarray(template, dtype=np.float64) * apple_template_size)

@@ -842,6 +842,11 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
 #endif
       return;
     }
+    // (row-by-row sweep: unaligned spans, and levels some queue of which overflowed.  It visits every row, but it has to
+    //  keep the sparse-touch bitmap valid for the wide sweeps of later steps: a row that gets its first gradient here
+    //  leaves with non-zero moments, so its pair's bit is set — without it the next wide sweep would skip the pair and
+    //  freeze its moments)
+    unsigned* tw1 = (adam.touched && rows >= 64) ? adam.touched + (row0 >> 6) : nullptr;
     for (int e2 = threadIdx.x; e2 < rows; e2 += blockDim.x) {
       const long long ax = (long long)s_acc[2 * e2], ay = (long long)s_acc[2 * e2 + 1];
       // the gradient exactly as the unfused path leaves it in the table: existing entry (zero, or what overflowed
@@ -854,6 +859,10 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
       if (ax != 0 || ay != 0) {
         g.x += (float)((double)ax * inv);
         g.y += (float)((double)ay * inv);
+      }
+      if (tw1 && (ax != 0 || ay != 0 || g.x != 0.0f || g.y != 0.0f)) {
+        const int pair = e2 >> 1;
+        if (!((tw1[pair >> 5] >> (pair & 31)) & 1u)) atomicOr(&tw1[pair >> 5], 1u << (pair & 31));
       }
       float2 P = adam.p[row0 + e2], M = adam.m[row0 + e2], V = adam.v[row0 + e2];
       table_adam_update(adam, g.x, P.x, M.x, V.x);
@@ -1236,7 +1245,10 @@ extern "C" int fnr_debug_scatter_overflows(uint64_t* count_host, int reset) {
 
 extern "C" int fnr_debug_scatter_records(uint64_t* records_host, int reset) {
   FNR_CHECK_ARG(records_host, "debug_scatter_records: null argument");
-  static unsigned long long host[2][64][16];
+  // the accumulate kernels run on the caller's (non-blocking) streams, which a symbol copy does not order against:
+  // drain the device first.  Stack buffer (16 KB): callable from several host threads.
+  FNR_HIP(hipDeviceSynchronize());
+  unsigned long long host[2][64][16];
   FNR_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_scatter_records), sizeof(host)));
   for (int k = 0; k < 2; ++k) {
     records_host[k] = 0;

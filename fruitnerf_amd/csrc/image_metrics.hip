@@ -2,7 +2,9 @@
 // (/root/reference/fruit_nerf/fruit_nerf.py:403-458) computes with torchmetrics on [H, W, C] images:
 //   * PSNR(data_range = 1): squared error over every pixel and channel of clamp(rgb, 0, 1) vs the image;
 //   * SSIM (torchmetrics structural_similarity_index_measure defaults: 11 x 11 gaussian window, sigma 1.5, k1 0.01,
-//     k2 0.03, data_range 1): reflect-pad by 5, filter a, b, a^2, b^2, ab with the window, SSIM map, CROP the padded
+//     k2 0.03, data_range None — the reference calls `self.ssim(image, rgb)` (:176,:424) without one, so torchmetrics
+//     takes max(preds.max() - preds.min(), target.max() - target.min()) of the two images it is given: found on the
+//     device by k_image_range, c1 / c2 = (k * range)^2 read by the SSIM kernel from the workspace): reflect-pad by 5, filter a, b, a^2, b^2, ab with the window, SSIM map, CROP the padded
 //     border away again and take the mean — i.e. the mean over the (H - 10) x (W - 10) interior pixels of the
 //     valid-window SSIM map; the padding never reaches a kept pixel.  Separable here (row pass into LDS, column pass);
 //   * BinaryJaccardIndex(threshold 0.5) of sigmoid(semantics) against the mask, and of the reference's
@@ -41,12 +43,13 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
 
 // one workgroup: a 32 x 32 tile of the interior SSIM map of one channel -> partial[block] = sum of the tile's SSIM values
 __global__ __launch_bounds__(IM_THREADS) void k_image_ssim(int H, int W, const float* __restrict__ rgb,
-                                                           const float* __restrict__ image, Gauss11 g, float c1, float c2,
-                                                           double* __restrict__ partial) {
+                                                           const float* __restrict__ image, Gauss11 g,
+                                                           const float* __restrict__ c12, double* __restrict__ partial) {
   __shared__ float s_a[IM_IN][IM_IN + 1], s_b[IM_IN][IM_IN + 1];
   __shared__ float s_h[5][IM_IN][IM_TILE + 1];
   __shared__ double s_red[IM_THREADS / 64];
   const int c = blockIdx.z;
+  const float c1 = c12[0], c2 = c12[1];                                // (k1 * data_range)^2, (k2 * data_range)^2: k_image_range_finish
   const int oy0 = blockIdx.y * IM_TILE, ox0 = blockIdx.x * IM_TILE;   // interior coordinates: pixel (oy + 5, ox + 5)
   const int OH = H - 2 * IM_PAD, OW = W - 2 * IM_PAD;
   for (int i = threadIdx.x; i < IM_IN * IM_IN; i += IM_THREADS) {
@@ -96,6 +99,51 @@ __global__ __launch_bounds__(IM_THREADS) void k_image_ssim(int H, int W, const f
   }
   const double t = block_sum(acc, s_red);
   if (threadIdx.x == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+}
+
+// data_range = None of torchmetrics: value ranges of the image and of clamp(rgb, 0, 1), partial[block] = {min a, max a, min b, max b}
+__global__ __launch_bounds__(IM_THREADS) void k_image_range(long long n_val, const float* __restrict__ rgb,
+                                                            const float* __restrict__ image, float* __restrict__ partial) {
+  __shared__ float s_mm[IM_THREADS / 64][4];
+  float lo_a = __builtin_inff(), hi_a = -__builtin_inff(), lo_b = __builtin_inff(), hi_b = -__builtin_inff();
+  for (long long i = (long long)blockIdx.x * IM_THREADS + threadIdx.x; i < n_val; i += (long long)gridDim.x * IM_THREADS) {
+    const float a = image[i], b = fminf(fmaxf(rgb[i], 0.0f), 1.0f);
+    lo_a = fminf(lo_a, a), hi_a = fmaxf(hi_a, a), lo_b = fminf(lo_b, b), hi_b = fmaxf(hi_b, b);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo_a = fminf(lo_a, __shfl_xor(lo_a, d, 64)), hi_a = fmaxf(hi_a, __shfl_xor(hi_a, d, 64));
+    lo_b = fminf(lo_b, __shfl_xor(lo_b, d, 64)), hi_b = fmaxf(hi_b, __shfl_xor(hi_b, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    float* m = s_mm[threadIdx.x >> 6];
+    m[0] = lo_a, m[1] = hi_a, m[2] = lo_b, m[3] = hi_b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < IM_THREADS / 64; ++w)
+      lo_a = fminf(lo_a, s_mm[w][0]), hi_a = fmaxf(hi_a, s_mm[w][1]), lo_b = fminf(lo_b, s_mm[w][2]), hi_b = fmaxf(hi_b, s_mm[w][3]);
+    float* o = partial + 4 * blockIdx.x;
+    o[0] = lo_a, o[1] = hi_a, o[2] = lo_b, o[3] = hi_b;
+  }
+}
+
+// one wave: the partial ranges -> c12 = {(0.01 * range)^2, (0.03 * range)^2}, c12[2] = range
+__global__ __launch_bounds__(64) void k_image_range_finish(const float* __restrict__ partial, int n, float* __restrict__ c12) {
+  float lo_a = __builtin_inff(), hi_a = -__builtin_inff(), lo_b = __builtin_inff(), hi_b = -__builtin_inff();
+  for (int i = threadIdx.x; i < n; i += 64)
+    lo_a = fminf(lo_a, partial[4 * i]), hi_a = fmaxf(hi_a, partial[4 * i + 1]), lo_b = fminf(lo_b, partial[4 * i + 2]),
+    hi_b = fmaxf(hi_b, partial[4 * i + 3]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo_a = fminf(lo_a, __shfl_xor(lo_a, d, 64)), hi_a = fmaxf(hi_a, __shfl_xor(hi_a, d, 64));
+    lo_b = fminf(lo_b, __shfl_xor(lo_b, d, 64)), hi_b = fmaxf(hi_b, __shfl_xor(hi_b, d, 64));
+  }
+  if (threadIdx.x == 0) {
+    const float range = fmaxf(hi_a - lo_a, hi_b - lo_b);
+    const float k1r = 0.01f * range, k2r = 0.03f * range;
+    c12[0] = k1r * k1r, c12[1] = k2r * k2r, c12[2] = range;
+  }
 }
 
 // per pixel: squared error over the three channels; sigmoid(semantics) > 0.5 against mask > 0.5
@@ -177,7 +225,9 @@ extern "C" size_t fnr_image_metrics_workspace_bytes(int H, int W) {
   if (H <= 0 || W <= 0) return 0;
   const int OH = H - 2 * IM_PAD, OW = W - 2 * IM_PAD;
   const long long tiles = (OH > 0 && OW > 0) ? 3ll * ((OH + IM_TILE - 1) / IM_TILE) * ((OW + IM_TILE - 1) / IM_TILE) : 0;
-  return (size_t)(tiles + 3ll * pixel_blocks((long long)H * W) + 2ll * ((W + IM_THREADS - 1) / IM_THREADS)) * sizeof(double);
+  // + the value-range partials (4 floats per pixel block) and {c1, c2, range, -} of the SSIM
+  return (size_t)(tiles + 3ll * pixel_blocks((long long)H * W) + 2ll * ((W + IM_THREADS - 1) / IM_THREADS) +
+                  2ll * pixel_blocks((long long)H * W) + 2) * sizeof(double);
 }
 
 extern "C" int fnr_image_metrics(int H, int W, const float* rgb, const float* image, const float* semantics,
@@ -196,9 +246,14 @@ extern "C" int fnr_image_metrics(int H, int W, const float* rgb, const float* im
   double* p_ssim = reinterpret_cast<double*>(workspace);
   double* p_pix = p_ssim + n_ssim;
   double* p_col = p_pix + 3 * n_pb;
+  float* p_range = reinterpret_cast<float*>(p_col + 2 * ((W + IM_THREADS - 1) / IM_THREADS));   // [n_pb][4]
+  float* c12 = p_range + 4 * n_pb;
   hipStream_t st = as_stream(stream);
-  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;     // (k1 * data_range)^2, (k2 * data_range)^2
-  hipLaunchKernelGGL(k_image_ssim, tiles, dim3(IM_THREADS), 0, st, H, W, rgb, image, g, c1, c2, p_ssim);
+  hipLaunchKernelGGL(k_image_range, dim3((unsigned)n_pb), dim3(IM_THREADS), 0, st, 3ll * H * W, rgb, image, p_range);
+  FNR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_image_range_finish, dim3(1), dim3(64), 0, st, p_range, n_pb, c12);
+  FNR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_image_ssim, tiles, dim3(IM_THREADS), 0, st, H, W, rgb, image, g, c12, p_ssim);
   FNR_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_image_pixels, dim3((unsigned)n_pb), dim3(IM_THREADS), 0, st, (long long)H * W, rgb, image, semantics,
                      mask, p_pix);

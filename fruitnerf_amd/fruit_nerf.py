@@ -634,7 +634,7 @@ class FruitModel(nn.Module):
         """fruit_nerf.py:403-458 on the device: one entry point (fnr_image_metrics, csrc/image_metrics.hip) for everything
         the reference computes with torchmetrics, no per-metric torch launches and ONE host read of eight sums.
 
-        PSNR and SSIM (torchmetrics defaults: 11x11 gaussian, sigma 1.5, data_range 1) and the reference's IoU
+        PSNR and SSIM (torchmetrics defaults: 11x11 gaussian, sigma 1.5, data_range None: the images' own value range; PSNR: data_range 1) and the reference's IoU
         (fruit_nerf.py:449-453): `F.softmax(outputs["semantics"])` WITHOUT a dim on the [H,W,1] map — torch's legacy
         implicit dim for a 3-D tensor is 0, so the softmax runs over image ROWS, every value is ~1/H < 0.5, and
         BinaryJaccardIndex (threshold 0.5) sees an all-False prediction: "iou" is ~0 whatever the model learned.

@@ -30,6 +30,10 @@ def all_gather_rows(local: Tensor, world_size: int) -> Tensor:
         return local
     import torch.distributed as dist
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no all_gather for device tensors (the one-GPU test rig: two ranks on one device, RCCL refuses that):
+        # stage through the host.  On real peers the backend is RCCL and the payload never leaves the devices.
+        return all_gather_rows(local.cpu(), world_size).to(local.device)
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world_size)]
     dist.all_gather(sizes, n)

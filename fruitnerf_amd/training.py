@@ -19,7 +19,7 @@ from __future__ import annotations
 import functools
 import os
 
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -381,8 +381,11 @@ class FusedAdam:
         self.group_steps = {name: 0 for name in self.arena.group_ranges}   # optimiser steps a group actually took
         # sparse-touch skipping of the fused table steps (fnr_table_adam.touched): one bit per pair of table rows, "ever
         # received a gradient", per hash table; valid while it covers every pair with a non-zero moment (true from zero
-        # moments on; rebuild_touched() after loading moments from elsewhere)
-        self._touched: Dict[int, Tensor] = {}
+        # moments on).  Keyed by the table's arena offset -> (length, bitmap).  Any optimiser step over a table's span that
+        # does NOT go through the fused table kernels (step_span / step: the exchange path, fuse_table_optimizer=False,
+        # scaler_step) makes moments non-zero without setting bits, so those paths drop the span's bitmap and the next
+        # fused step rebuilds it from the moments; rebuild_touched() after loading or editing moments from outside.
+        self._touched: Dict[int, Tuple[int, Tensor]] = {}
 
     def current_lr(self, name: str) -> float:
         g = self.groups[name]
@@ -410,15 +413,22 @@ class FusedAdam:
         """The persistent pair bitmap of `table` (arena span [a, a + n)); None when skipping does not apply."""
         if not SPARSE_TOUCH_SKIPPING or self.weight_decay != 0.0 or n % 128 != 0:
             return None
-        bm = self._touched.get(id(table))
+        hit = self._touched.get(a)
+        bm = hit[1] if hit is not None and hit[0] == n else None
         if bm is None or bm.device != self.arena.params.device:
             # from the moments (all zero at construction): bit i of word i / 32 = "pair i has a non-zero moment"
             m, v = self.exp_avg[a:a + n].view(-1, 4), self.exp_avg_sq[a:a + n].view(-1, 4)
             ever = ((m != 0) | (v != 0)).any(dim=1).view(-1, 32)           # [n / 128 words, 32 pairs]
             words = (ever.to(torch.int64) << torch.arange(32, device=ever.device, dtype=torch.int64)).sum(dim=1)
             bm = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()   # same 32 bits
-            self._touched[id(table)] = bm
+            self._touched[a] = (n, bm)
         return bm
+
+    def _invalidate_touched(self, a: int, b: int) -> None:
+        """Arena elements [a, b) are about to take an optimiser step outside the fused table kernels."""
+        if self._touched:
+            for ta in [ta for ta, (tn, _) in self._touched.items() if ta < b and a < ta + tn]:
+                del self._touched[ta]
 
     def rebuild_touched(self) -> None:
         """Forget the bitmaps: they are rebuilt from the moments at the next fused table step (after exp_avg / exp_avg_sq
@@ -462,6 +472,7 @@ class FusedAdam:
         group: whose step counter feeds the bias corrections (default: the group that contains a); step: that counter's
         value when the update was planned (a deferred update runs after later bookkeeping)."""
         if b > a:
+            self._invalidate_touched(a, b)
             if group is None:
                 group = next(n for n, (ga, gb) in self.arena.group_ranges.items() if ga <= a < gb)
             fn = K.adam_step if self.algorithm == "adam" else K.radam_step
@@ -504,6 +515,8 @@ class FusedAdam:
             for a, b, lr, name in runs:
                 self.step_span(a, b, lr, grad_scale, group=name)
         else:   # one launch for all of them (the groups' MLP weights are a few thousand floats each)
+            for a, b, _, _ in runs:
+                self._invalidate_touched(a, b)
             K.adam_step_spans(self.arena.params, self.arena.grads, self.exp_avg, self.exp_avg_sq,
                               [(a, b - a, lr, self.group_steps[name]) for a, b, lr, name in runs], self.algorithm,
                               self.betas[0], self.betas[1], self.eps, grad_scale, True, weight_decay=self.weight_decay)

@@ -583,7 +583,8 @@ int fnr_cloud_voxel_down_sample(const double* xyz, const double* rgb, int64_t n,
 /* FruitModel.get_image_metrics_and_images (fruit_nerf/fruit_nerf.py:403-458) on the device: everything the reference
  * computes with torchmetrics on a rendered [H, W, 3] image, as raw sums (the host forms the four ratios):
  *   PSNR(data_range 1, :427): squared error of clamp(rgb, 0, 1) (:408) against the image;
- *   SSIM (:428; torchmetrics defaults: 11 x 11 gaussian, sigma 1.5, k1 0.01, k2 0.03): the mean over the
+ *   SSIM (:428; torchmetrics defaults: 11 x 11 gaussian, sigma 1.5, k1 0.01, k2 0.03, data_range None = the larger of
+ *        the value ranges of the image and of clamp(rgb, 0, 1), found on the device): the mean over the
  *        (H - 10) x (W - 10) x 3 interior values of the valid-window SSIM map (torchmetrics pads by 5 and crops the
  *        padded border away again); gauss11: HOST array of the 11 normalised float32 window weights;
  *   IoU  (:449-453): BinaryJaccardIndex(threshold 0.5) of `F.softmax(semantics)` — no dim given: on the [H, W, 1] map

@@ -3,13 +3,14 @@
 
 torchmetrics is a third-party dependency that is absent here (not vendored in /root/reference, not installable: parity
 "recalled" for its constants, like nerfstudio's); its published algorithm for the defaults the reference uses
-(`structural_similarity_index_measure(preds, target, gaussian_kernel=True, sigma=1.5, kernel_size=11, data_range=1.0,
-k1=0.01, k2=0.03)`, torchmetrics/functional/image/ssim.py):
+(`structural_similarity_index_measure(preds, target, gaussian_kernel=True, sigma=1.5, kernel_size=11, data_range=None,
+k1=0.01, k2=0.03)`, torchmetrics/functional/image/ssim.py; the reference passes no data_range — fruit_nerf.py:176,424 —
+so torchmetrics' `_ssim_update` takes `max(preds.max() - preds.min(), target.max() - target.min())`):
     window w = outer(g, g), g_i = exp(-(d_i / sigma)^2 / 2) / sum, d = arange((1 - 11) / 2, (1 + 11) / 2)  (float32 in
     torchmetrics: the window is rounded to float32 here too, everything after that is float64);
     reflect-pad preds and target by 5; mu_p, mu_t, E[pp], E[tt], E[pt] = valid 11 x 11 filtering of the padded images;
     sigma_p^2 = E[pp] - mu_p^2, sigma_t^2 = E[tt] - mu_t^2, sigma_pt = E[pt] - mu_p mu_t;
-    ssim = ((2 mu_p mu_t + c1)(2 sigma_pt + c2)) / ((mu_p^2 + mu_t^2 + c1)(sigma_p^2 + sigma_t^2 + c2)), c1 = 1e-4, c2 = 9e-4;
+    ssim = ((2 mu_p mu_t + c1)(2 sigma_pt + c2)) / ((mu_p^2 + mu_t^2 + c1)(sigma_p^2 + sigma_t^2 + c2)), c1 = (0.01 R)^2, c2 = (0.03 R)^2 with R the data range;
     the map is cropped by the pad on every side again and averaged — so only windows that never touch the padding count.
 PSNR(data_range = 1) = 10 log10(1 / mse); BinaryJaccardIndex(threshold = 0.5) = |pred & target| / |pred | target|
 (0 for an empty union).  The reference's `F.softmax(outputs["semantics"])` has no dim: torch's legacy implicit dim for a
@@ -25,10 +26,13 @@ def gaussian_window(kernel_size: int = 11, sigma: float = 1.5) -> np.ndarray:
 
 
 def ssim(pred: np.ndarray, target: np.ndarray, kernel_size: int = 11, sigma: float = 1.5, k1: float = 0.01,
-         k2: float = 0.03, data_range: float = 1.0) -> float:
-    """pred, target: [H, W, C] in [0, data_range] -> mean SSIM (float64)."""
+         k2: float = 0.03, data_range=None) -> float:
+    """pred, target: [H, W, C] -> mean SSIM (float64).  data_range None (torchmetrics' default, what the reference uses):
+    the larger of the two images' value ranges."""
     p = np.moveaxis(np.asarray(pred, np.float64), -1, 0)
     t = np.moveaxis(np.asarray(target, np.float64), -1, 0)
+    if data_range is None:
+        data_range = max(float(p.max() - p.min()), float(t.max() - t.min()))
     g = gaussian_window(kernel_size, sigma).astype(np.float64)
     pad = (kernel_size - 1) // 2
     p = np.pad(p, ((0, 0), (pad, pad), (pad, pad)), mode="reflect")

@@ -263,7 +263,7 @@ def test_sparse_touch_skipping_changes_nothing(dev):
     torch.cuda.synchronize()
     table = hm.field.mlp_base_grid.hash_table
     a, n = [(off, k) for _, p, off, k in hm.arena().entries if p is table][0]
-    bm = opt._touched[id(table)]
+    bm = opt._touched[a][1]                     # keyed by the table's arena offset: (length, bitmap)
     bits = ((bm.to(torch.int64)[:, None] >> torch.arange(32, device=dev)) & 1).bool().reshape(-1)
     m, v = opt.exp_avg[a:a + n].view(-1, 4), opt.exp_avg_sq[a:a + n].view(-1, 4)
     nonzero = ((m != 0) | (v != 0)).any(dim=1)

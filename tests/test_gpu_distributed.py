@@ -33,6 +33,7 @@ def test_bench_runs_over_a_one_rank_rccl_group(dev):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["value"] > 0
     assert d["config"]["table_optimizer"].startswith("separate")
+    assert d["config"]["rccl_ranks"] == {"world_size": 1, "backend": "nccl", "devices": 1}   # what the group itself reports
 
 
 def test_bench_gpus_2_starts_two_ranks(dev):
@@ -50,6 +51,7 @@ def test_bench_gpus_2_starts_two_ranks(dev):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["steps"] == 4 and d["value"] > 0
     assert d["config"]["table_optimizer"].startswith("separate")
+    assert d["config"]["rccl_ranks"] == {"world_size": 2, "backend": "gloo", "devices": 1}
     # WHICH entry point a 4-step window with two ranks interleaving on one device measures as the slowest is timing, not
     # function: only the shape of the roofline object is asserted here
     sys.path.insert(0, ROOT)

@@ -163,6 +163,59 @@ def test_scatter_with_overflowing_queues_still_conserves_the_gradient(dev):
     assert L.scatter_overflows(reset=True) == 0
 
 
+def test_sparse_touch_bitmap_survives_an_overflowing_scatter(dev):
+    """rows whose FIRST gradient arrives on a step that overflows a queue take their optimiser step in the
+    accumulate kernel's row-by-row sweep (the level's gradient partly sits in the table, put there by atomics); that sweep
+    has to set the sparse-touch bits too, or the next wide sweep skips those pairs and their moments stop decaying.
+    Two fused steps — an overflowing one (two points, 196 608 samples), then random rays — with the bitmap against the
+    same two steps with every row swept: parameters and both moments bit-identical."""
+    import fruitnerf_amd.training as T
+    from fruitnerf_amd import _kernels as K, _lib as L
+    N = 4096 * 48
+    R, S = 4096, 48
+    g = torch.Generator(device=dev).manual_seed(1)
+    d_feats = torch.randn(16, N, 2, device=dev, generator=g) * 1e-3
+    two = _rays(2, dev, seed=5)
+    alt = torch.arange(N, device=dev) % 2
+    rb = _rays(R, dev, seed=9)
+    saved = T.SPARSE_TOUCH_SKIPPING
+    states = []
+    try:
+        for sparse in (True, False):
+            T.SPARSE_TOUCH_SKIPPING = sparse
+            m = _full_model(dev)
+            m.train()
+            fld = m.field
+            opt = T.FusedAdam(m)
+            table = fld.mlp_base_grid.hash_table
+            gnet = fld.net_struct(grads=True)
+            rays = K.RaysArg(two.origins[alt].contiguous(), two.directions[alt].contiguous(),
+                             torch.full((N, 1), 0.4, device=dev), torch.full((N, 1), 0.4, device=dev),
+                             torch.zeros(N, 1, dtype=torch.long, device=dev))
+            _, eu = K.sample_spaced(rays, 1, 1, None)
+            L.scatter_overflows(reset=True)
+            args, (a, b) = opt.table_adam_args(table)
+            assert (args.touched is not None) == sparse
+            K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays, eu, 1, d_feats, args)
+            assert L.scatter_overflows(reset=True) > 1_000_000
+            opt.begin_step()
+            rays2 = K.RaysArg(rb.origins, rb.directions, torch.full((R, 1), 0.05, device=dev),
+                              torch.full((R, 1), 1000.0, device=dev), rb.camera_indices)
+            _, eu2 = K.sample_spaced(rays2, 1, S, None)
+            for _ in range(2):      # the first step's rows only decay here (random rays do not hit those 256 rows)
+                args, _ = opt.table_adam_args(table)
+                K.hash_encode_bwd_adam(gnet.grid, fld.warp_struct(), rays2, eu2, S, d_feats, args)
+                assert L.scatter_overflows(reset=True) == 0
+                opt.begin_step()
+            torch.cuda.synchronize()
+            states.append((m.arena().params[a:b].clone(), opt.exp_avg[a:b].clone(), opt.exp_avg_sq[a:b].clone()))
+    finally:
+        T.SPARSE_TOUCH_SKIPPING = saved
+    for x, y in zip(*states):
+        assert torch.equal(x, y), f"{int((x != y).sum())} entries differ between the sparse-touch and the dense sweeps"
+    assert int((states[0][1] != 0).sum()) > 100_000
+
+
 def test_adam_leaves_untouched_parameters_alone_and_is_idempotent_on_zero_grad(dev):
     """Zero gradients with zero moments leave parameters bit-identical (19.4 M-element arena), and a second step
     with zero gradients only decays the moments."""
@@ -303,12 +356,13 @@ def test_train_prologue_is_the_separate_launches(dev):
         assert torch.equal(out["spacing"], spacing) and torch.equal(out["euclid"], euclid)
 
 
-@pytest.mark.parametrize("shape", [(11, 11), (64, 75), (203, 131)])
-def test_image_metrics_kernel_matches_the_float64_oracle(dev, shape):
+@pytest.mark.parametrize("shape,span", [((11, 11), 1.0), ((64, 75), 1.0), ((64, 75), 0.55), ((203, 131), 1.0)])
+def test_image_metrics_kernel_matches_the_float64_oracle(dev, shape, span):
     """fnr_image_metrics (csrc/image_metrics.hip) on synthetic images with structure (smooth ramps + noise, a prediction
     with out-of-range values so that the clamp matters, saturated and near-zero logits): SSIM within 1e-5 and PSNR within
     1e-4 dB of the float64 restatement of torchmetrics' algorithm, both IoUs exact; (11, 11) is the smallest image with an
-    SSIM value (one window), the others have ragged 32 x 32 tiles."""
+    SSIM value (one window), the others have ragged 32 x 32 tiles.  span < 1: both images squeezed into [0.2, 0.2 + span] —
+    the reference passes no data_range, so torchmetrics derives c1 / c2 from the images' own value range."""
     import numpy as np
     from fruitnerf_amd import _kernels as K
     from oracle import image_metrics as oim
@@ -318,6 +372,8 @@ def test_image_metrics_kernel_matches_the_float64_oracle(dev, shape):
     image = torch.stack([0.5 + 0.4 * torch.sin(6 * xx + 2 * yy), yy * xx, 0.3 + 0.2 * torch.cos(9 * yy)], dim=-1)
     image = (image + 0.05 * torch.rand(H, W, 3, generator=g)).clamp(0, 1)
     rgb = image + 0.15 * torch.randn(H, W, 3, generator=g)          # leaves [0, 1]: the metrics see clamp(rgb)
+    if span != 1.0:
+        image, rgb = 0.2 + span * image, 0.2 + span * rgb.clamp(0, 1)
     sem = 8.0 * torch.randn(H, W, 1, generator=g)
     mask = (torch.rand(H, W, 1, generator=g) > 0.6).float()
     sums = K.image_metrics(rgb.to(dev), image.to(dev), sem.to(dev)[..., 0], mask.to(dev)[..., 0]).tolist()

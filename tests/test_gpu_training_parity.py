@@ -604,6 +604,109 @@ def test_fused_table_optimizer_matches_the_separate_step(dev, shape, algorithm, 
     assert int((p0 != runs[0][0][1][0][a:b]).sum()) > 0            # the table did move between step 1 and step 12
 
 
+def test_sparse_touch_bitmap_survives_unfused_table_steps(dev):
+    """the sparse-touch bitmap is only maintained by the fused table kernels; a step of the table that goes
+    through fnr_adam_step instead (fuse_table_optimizer=False here; the exchange path, scaler_step) makes moments non-zero
+    without setting bits.  FusedAdam drops the bitmap of any span stepped that way and rebuilds it from the moments at the
+    next fused step: fused / unfused steps interleaved, each step on OTHER rays (so that rows get their first gradient on
+    the unfused steps), with the skipping on against every row swept — bit-identical parameters and moments."""
+    import fruitnerf_amd.training as T
+    from fruitnerf_amd.rays import RayBundle
+    cfg = util.small_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, seed=3)
+    R = 96
+    hb = {k: v.to(dev) for k, v in _batch(R, 5).items()}
+    g = torch.Generator().manual_seed(0)
+    pattern = (True, False, True, True, False, True)
+    jits = [[torch.rand(R, 1, generator=g).to(dev) for _ in range(3)] for _ in pattern]
+    bundles = []
+    for i in range(len(pattern)):
+        o, d, pa, cam = util.random_rays(R, 7, seed=20 + i)
+        bundles.append(RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)))
+    saved = T.SPARSE_TOUCH_SKIPPING
+    states = []
+    try:
+        for sparse in (True, False):
+            T.SPARSE_TOUCH_SKIPPING = sparse
+            hm = util.make_hip_like(om, dev)
+            hm.train()
+            opt = T.FusedAdam(hm)
+            for step, fuse in enumerate(pattern):
+                T.fused_train_iteration(hm, opt, bundles[step], hb, step, jitter=jits[step], fuse_table_optimizer=fuse)
+                if sparse:
+                    assert bool(opt._touched) == fuse      # dropped by the unfused step, rebuilt by the next fused one
+            torch.cuda.synchronize()
+            states.append((hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
+    finally:
+        T.SPARSE_TOUCH_SKIPPING = saved
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), *states):
+        assert torch.equal(x, y), f"{name}: {int((x != y).sum())} entries differ between sparse-touch and dense sweeps"
+
+
+def test_fused_radam_step_of_fruit_nerf_big_tracks_torch_optim_radam(dev):
+    """`fruit_nerf_big` trains with RAdam (fruit_nerf_config.py:97-106).  Nine fused steps of that shape — the table's step
+    inside the scatter's accumulate kernel, the MLP weights' inside k_reduce_dw / k_embedding_grad, the proposal networks'
+    inside their backward (fnr_*_adam entry points, algorithm = radam), across the rectification threshold (rho_t > 5 from
+    step 6 on) — against the SAME HIP gradient kernels stepped by torch.optim.RAdam itself (a second model whose optimiser
+    hands the arena's gradient to torch.optim.RAdam(lr = the scheduler's, eps 1e-15) and copies the result back).  Equal
+    gradients in, so what differs is fp32 rounding inside the update: parameters agree to a 1e-3 fraction of the distance
+    they moved."""
+    import fruitnerf_amd.training as T
+    from fruitnerf_amd.rays import RayBundle
+    cfg = util.big_config(log2=15, prop_log2=13)
+    om = util.make_oracle(cfg, seed=3)
+    R = 128
+    hb = {k: v.to(dev) for k, v in _batch(R, 5).items()}
+    g = torch.Generator().manual_seed(0)
+    n_steps = 9                                     # < 10: the proposal networks are updated on every one of them
+    jits = [[torch.rand(R, 1, generator=g).to(dev) for _ in range(3)] for _ in range(n_steps)]
+    bundles = []
+    for i in range(n_steps):
+        o, d, pa, cam = util.random_rays(R, 7, seed=40 + i)
+        bundles.append(RayBundle(o.to(dev), d.to(dev), pa.to(dev), cam.to(dev)))
+
+    class TorchRAdam(T.FusedAdam):
+        """FusedAdam's bookkeeping (schedulers, counters), torch.optim.RAdam's arithmetic."""
+
+        def __init__(self, model):
+            super().__init__(model, algorithm="radam")
+            self.ref = self.arena.params.detach().clone().requires_grad_(True)
+            self.torch_opt = torch.optim.RAdam([self.ref], lr=1e-2, eps=self.eps, betas=self.betas)
+
+        def step(self, grad_scale=1.0, skip=(), done=()):
+            assert not skip and not done
+            lrs = self.begin_step(skip)
+            assert len(set(lrs.values())) == 1
+            self.torch_opt.param_groups[0]["lr"] = next(iter(lrs.values()))
+            self.ref.grad = self.arena.grads.detach().clone() * grad_scale
+            self.torch_opt.step()
+            self.arena.params.copy_(self.ref.detach())
+            self.arena.grads.zero_()
+
+    hm_f, hm_t = util.make_hip_like(om, dev), util.make_hip_like(om, dev)
+    hm_f.train()
+    hm_t.train()
+    p0 = hm_f.arena().params.clone()
+    opt_f, opt_t = T.FusedAdam(hm_f, algorithm="radam"), TorchRAdam(hm_t)
+    for step in range(n_steps):
+        T.fused_train_iteration(hm_f, opt_f, bundles[step], hb, step, jitter=jits[step])
+        T.fused_train_iteration(hm_t, opt_t, bundles[step], hb, step, jitter=jits[step], fuse_table_optimizer=False)
+        torch.cuda.synchronize()
+        a, b = hm_f.arena().params, hm_t.arena().params
+        diff, moved = (a - b).abs(), (b - p0).abs()
+        print(f"[fused RAdam vs torch.optim.RAdam] step {step + 1}: max diff {float(diff.max()):.3e}  mean diff "
+              f"{float(diff.mean()):.3e}  mean |moved| {float(moved.mean()):.3e}  max |moved| {float(moved.max()):.3e}")
+        assert float(diff.max()) <= 1e-3 * float(moved.max()) + 1e-7, step
+        assert float(diff.mean()) <= 1e-3 * float(moved.mean()) + 1e-9, step
+    assert float(moved.max()) > 1e-3                 # the rectified steps did move the parameters
+    # moments too: torch keeps them in its state, the fused path in FusedAdam's arenas
+    st = opt_t.torch_opt.state[opt_t.ref]
+    for name, x, y in (("exp_avg", opt_f.exp_avg, st["exp_avg"]), ("exp_avg_sq", opt_f.exp_avg_sq, st["exp_avg_sq"])):
+        d = float((x - y).abs().max())
+        print(f"[fused RAdam vs torch.optim.RAdam] {name}: max diff {d:.3e} of max {float(y.abs().max()):.3e}")
+        assert d <= 1e-3 * float(y.abs().max()), name
+
+
 def test_ray_gradient_paths_agree(dev):
     """The saved-Jacobian path (forward encode stores d feats / d x) and the gather path (backward re-reads the table)
     of the hash grid's input gradient give the same ray gradients."""

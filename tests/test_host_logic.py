@@ -675,3 +675,29 @@ def test_a_failed_scatter_call_drops_the_cached_workspaces():
     finally:
         K._SCATTER_WS.clear()
         K._SCATTER_WS.entries.update(saved)
+
+
+def test_clustering_template_fails_loudly_and_falls_back_only_for_lfs_pointers(tmp_path):
+    """a mistyped or corrupt template path must not silently become the 0.1-radius sphere (the template's
+    volume drives the split / prune thresholds); None and a Git-LFS pointer file (what the reference's *_template.ply are
+    in its repository snapshot) do fall back, and say so."""
+    import numpy as np
+    import pytest
+    from fruitnerf_amd.clustering.clustering_base import Clustering
+    assert Clustering(template_path=None).template_fallback is True
+    lfs = tmp_path / "apple_template.ply"
+    lfs.write_text("version https://git-lfs.github.com/spec/v1\noid sha256:0\nsize 1\n")
+    assert Clustering(template_path=lfs).template_fallback is True
+    with pytest.raises(FileNotFoundError):
+        Clustering(template_path=tmp_path / "appel_template.ply")
+    bad = tmp_path / "corrupt.ply"
+    bad.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty double x\nend_header\n\x00")
+    with pytest.raises(Exception):
+        Clustering(template_path=bad)
+    # a readable PLY is used as is
+    from fruitnerf_amd.export import ply
+    good = tmp_path / "good.ply"
+    pts = np.random.default_rng(0).standard_normal((50, 3)) * 0.05
+    ply.write_point_cloud(str(good), pts, np.zeros((50, 3)))
+    c = Clustering(template_path=good)
+    assert c.template_fallback is False

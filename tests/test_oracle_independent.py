@@ -191,10 +191,18 @@ def test_image_metrics_oracle_against_an_independent_ssim():
     mu_a, mu_b = f(a), f(b)
     saa, sbb, sab = f(a * a) - mu_a ** 2, f(b * b) - mu_b ** 2, f(a * b) - mu_a * mu_b
     m = ((2 * mu_a * mu_b + 1e-4) * (2 * sab + 9e-4)) / ((mu_a ** 2 + mu_b ** 2 + 1e-4) * (saa + sbb + 9e-4))
-    assert m.shape == (3, 30, 27) and abs(om.ssim(a, b) - float(m.mean())) < 1e-12
+    assert m.shape == (3, 30, 27) and abs(om.ssim(a, b, data_range=1.0) - float(m.mean())) < 1e-12
+    # data_range None (what the reference's call leaves torchmetrics with): the larger of the two images' value ranges
+    R = max(a.max() - a.min(), b.max() - b.min())
+    c1, c2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+    m = ((2 * mu_a * mu_b + c1) * (2 * sab + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (saa + sbb + c2))
+    assert abs(om.ssim(a, b) - float(m.mean())) < 1e-12
+    a2, b2 = 0.2 + 0.5 * a, 0.2 + 0.5 * b                     # squeezed images: the constants follow the range
+    assert abs(om.ssim(a2, b2) - om.ssim(a2, b2, data_range=0.5 * R)) < 1e-12
+    assert abs(om.ssim(a2, b2) - om.ssim(a2, b2, data_range=1.0)) > 1e-4
     ca, cb = np.full((20, 20, 3), 0.3), np.full((20, 20, 3), 0.7)
     # (the float32 window sums to 1 within 1e-7, so the 'variances' of a constant image are ~1e-8 against c2 = 9e-4)
-    assert abs(om.ssim(ca, cb) - (2 * 0.3 * 0.7 + 1e-4) / (0.09 + 0.49 + 1e-4)) < 2e-5
+    assert abs(om.ssim(ca, cb, data_range=1.0) - (2 * 0.3 * 0.7 + 1e-4) / (0.09 + 0.49 + 1e-4)) < 2e-5
     assert abs(om.psnr(ca, cb) - 10 * np.log10(1 / 0.16)) < 1e-9
     sem = np.ones((12, 11, 1))
     sem[2, 1, 0] = 10.0                                   # dominates its COLUMN: the row softmax is > 0.5 only there
