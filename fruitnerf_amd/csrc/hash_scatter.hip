@@ -42,46 +42,6 @@ __device__ unsigned long long g_scatter_overflow_records;   // records that went
 // same-line atomics serialise at ~12 ns).  fnr_debug_scatter_records: bench.py prices the record queue's round trip with it.
 __device__ unsigned long long g_scatter_records[2][64][16];
 
-// Hunt build only (tools/build_variant.sh seen -DFNR_SCATTER_DEBUG_SEEN): what the kernels of the LAST call
-// of each kind saw — per accumulate workgroup the queue count and the level maximum it read (its scalar loads), per emit
-// level the records the emit workgroups placed (atomics).  slot 0: the field's call, 1 / 2: the first / second proposal
-// level of a paired call.  tests/diagnostics/digest_perstep.py checksums this block every step (fnr_debug_scatter_seen_copy):
-// at an event step it tells "the accumulate kernel read other counters than the emit kernel left" from "equal counters,
-// other records".
-#ifdef FNR_SCATTER_DEBUG_SEEN
-constexpr int SEEN_SLOTS = 3, SEEN_BINS = 4096;
-constexpr int SEEN_HBINS = 32, SEEN_HQ = SEEN_HBINS * 8;   // bins per level / (level, bin) pairs of a proposal call
-struct ScatterSeen {
-  unsigned acc_n[SEEN_SLOTS][SEEN_BINS];       // qcount as read by the accumulate workgroup of (level, bin)
-  unsigned acc_vmax[SEEN_SLOTS][SEEN_BINS];    // qmax (float bits) as read by it
-  unsigned long long emit_records[SEEN_SLOTS][FNR_MAX_LEVELS];   // records placed by the emit kernel, per level
-  unsigned long long emit_calls[SEEN_SLOTS];   // emit launches so far (the harness resets the block per step)
-  // proposal calls (slots 1, 2; <= SEEN_HBINS bins a level x <= 8 levels): an ORDER-INDEPENDENT checksum of the records of
-  // every bin — the sum over its records of seen_record_hash(row, value pair) — as the emit kernel WROTE them into the queue
-  // and as the accumulate kernel READ them back.  Equal sums: the queue came back as written.
-  unsigned long long emit_sum[2][SEEN_HQ];
-  unsigned long long acc_sum[2][SEEN_HQ];
-  // ... and a position-weighted checksum of the bin's fixed-point gradient sums as the sweep found them in LDS (equal
-  // records read back + another value here = the LDS accumulation itself lost or doubled an add)
-  unsigned long long acc_grad[2][SEEN_HQ];
-  // ... and of the parameters and moments the fused optimiser sweep READ for the bin's rows (the arena was equal at the end
-  // of the previous step + another value here = the sweep read something else than what was there)
-  unsigned long long acc_pmv[2][SEEN_HQ];
-  // acc_n / acc_vmax hold the LARGEST value any wave of the workgroup read, these the complement of the SMALLEST: they differ
-  // from ~acc_n / ~acc_vmax exactly when the waves of one workgroup did not all read the same counter
-  unsigned acc_n_minc[SEEN_SLOTS][SEEN_BINS];
-  unsigned acc_vmax_minc[SEEN_SLOTS][SEEN_BINS];
-};
-__device__ ScatterSeen g_scatter_seen;
-__device__ __forceinline__ unsigned long long seen_record_hash(unsigned row, float vx, float vy) {
-  unsigned long long h = ((unsigned long long)__float_as_uint(vx) << 32) | (unsigned long long)__float_as_uint(vy);
-  h ^= (unsigned long long)(row + 1u) * 0x9E3779B97F4A7C15ull;
-  h ^= h >> 29;
-  h *= 0xBF58476D1CE4E5B9ull;
-  h ^= h >> 32;
-  return h;
-}
-#endif
 
 struct ScatterPlan {
   int log2_rows;         // log2(E)
@@ -189,87 +149,9 @@ __device__ __forceinline__ float run_sum(float v, const RunMasks& m) {
   return v;
 }
 
-// MEASURED SLOWER, NOT THE DEFAULT (round 4, same-box A/B, profiles/r04_raw/ab_emit.log: main-field scatter 194.5 -> 202.4 us,
-// 1 M-sample proposal call 91.6 -> 97.5 us with this form; 440 instead of 609 VALU instructions per pair, tools/isa_mix.py).
-// The static count was the wrong model: a DPP-modified VALU instruction does not issue at the plain rate, and the
-// compiler's mov_dpp + fma form interleaves the sixteen independent streams better than this fixed order.  Kept behind
-// -DFNR_EMIT_SCAN_FMAC for the record.
-// All sixteen value streams of a (sample, level) through the four gated steps as 64 v_fmac_f32 with a DPP-shifted source
-// (dst += shifted(dst) * gate; lanes without a source read 0): the compiler's form of the same arithmetic is
-// mov_dpp + fma per step (GCNDPPCombine does not fold a DPP move into v_fmac here).  Inline assembly is outside the
-// hazard recogniser's view: a DPP read needs two wait states after the VALU write of its source, so every step runs over
-// all sixteen registers before the next one starts (distance 16) and the block opens with s_nop 1.
-__device__ __forceinline__ void run_sums16(float (&a)[8], float (&b)[8], const RunMasks& m) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f32_dpp %0, %0, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %1, %1, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %2, %2, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %3, %3, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %4, %4, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %5, %5, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %6, %6, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %7, %7, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %8, %8, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %9, %9, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %10, %10, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %11, %11, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %12, %12, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %13, %13, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %14, %14, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %15, %15, %16 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %0, %0, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %1, %1, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %2, %2, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %3, %3, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %4, %4, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %5, %5, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %6, %6, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %7, %7, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %8, %8, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %9, %9, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %10, %10, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %11, %11, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %12, %12, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %13, %13, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %14, %14, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %15, %15, %17 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %0, %0, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %1, %1, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %2, %2, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %3, %3, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %4, %4, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %5, %5, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %6, %6, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %7, %7, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %8, %8, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %9, %9, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %10, %10, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %11, %11, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %12, %12, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %13, %13, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %14, %14, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %15, %15, %18 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %0, %0, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %1, %1, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %2, %2, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %3, %3, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %4, %4, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %5, %5, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %6, %6, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %7, %7, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %8, %8, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %9, %9, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %10, %10, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %11, %11, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %12, %12, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %13, %13, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %14, %14, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_fmac_f32_dpp %15, %15, %19 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]),
-        "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
-      : "v"(m.g1), "v"(m.g2), "v"(m.g4), "v"(m.g8));
-}
+// (Round 4 A/B, profiles/r04_raw/ab_emit.log: all sixteen streams as 64 hand-placed v_fmac_f32_dpp — 440 instead of 609
+// VALU instructions per pair — was SLOWER, 194.5 -> 202.4 us for the main-field scatter: a DPP-modified VALU instruction
+// does not issue at the plain rate, and the compiler's mov_dpp + fma form interleaves the streams better.  Removed.)
 
 // Debug build only (make EXTRA=-DFNR_EMIT_TIMING): wave 0 of every emit workgroup adds the shader-clock length of
 // each phase to g_emit_phase_clk[] (tools/microbench/scatter_phases.py reads it through fnr_debug_emit_phases).
@@ -295,9 +177,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
                                                       const float2* __restrict__ d_feats, float2* __restrict__ queue_v,
                                                       unsigned short* __restrict__ queue_r, unsigned* __restrict__ qcount, unsigned* __restrict__ qmax,
                                                       long long cap, int log2_rows, int level0, int level_count, int lpb
-#ifdef FNR_SCATTER_DEBUG_SEEN
-                                                      , int seen_slot
-#endif
                                                       ) {
   // LDS-staged multisplit: records are grouped by bin in LDS, then copied out as contiguous runs.
   // A workgroup takes its 512 samples through `lpb` consecutive levels: the sample position and its warp are computed
@@ -310,9 +189,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   __shared__ unsigned s_base[SC_MAX_BINS];  // per-bin start inside the global queue
   __shared__ unsigned s_max;                // max |value| emitted by this workgroup (float bits; order-preserving for >= 0)
   __shared__ unsigned s_wsum[SC_EMIT_THREADS / 64];
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  __shared__ unsigned long long s_hsum[SEEN_HBINS];   // (256 B: three workgroups still fit a CU)
-#endif
 #ifdef FNR_EMIT_TIMING
   unsigned long long t_phase__ = __builtin_readcyclecounter();
   unsigned t_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -341,10 +217,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     s_cnt[i] = 0;
   }
   if (threadIdx.x == 0) s_max = 0;
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  const bool seen_hash = seen_slot >= 1 && bins <= SEEN_HBINS && level_count <= 8;
-  if (seen_hash && threadIdx.x < SEEN_HBINS) s_hsum[threadIdx.x] = 0ull;
-#endif
   __syncthreads();
   EMIT_T(0);
   const int scaling = grid.scalings[level];
@@ -382,9 +254,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       vxk[q][k] = valid ? wgt[k] * gf.x : 0.0f;
       vyk[q][k] = valid ? wgt[k] * gf.y : 0.0f;
     }
-#ifdef FNR_EMIT_SCAN_FMAC   // A/B builds (tools/build_variant.sh): 64 hand-placed v_fmac_f32_dpp, see run_sums16
-    if (rm.any_run) run_sums16(vxk[q], vyk[q], rm);
-#else
     if (rm.any_run) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -392,7 +261,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
         vyk[q][k] = run_sum(vyk[q][k], rm);
       }
     }
-#endif
 #ifdef FNR_EMIT_TIMING
     {
       asm volatile("" ::"v"(vxk[q][0]), "v"(vyk[q][7]));
@@ -452,9 +320,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
 #pragma unroll
   for (int w = 0; w < SC_EMIT_THREADS / 64; ++w) total += s_wsum[w];
   unsigned run = woff + incl - tsum;
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  if (threadIdx.x == 0 && total) atomicAdd(&g_scatter_seen.emit_records[seen_slot][lrel], (unsigned long long)total);
-#endif
 #pragma unroll
   for (int t = 0; t < SC_BINS_PER_THREAD; ++t) {
     const int i = threadIdx.x * SC_BINS_PER_THREAD + t;
@@ -514,15 +379,8 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       const size_t q = ((size_t)lrel * bins + bin) * cap + slot;
       queue_v[q] = v;
       queue_r[q] = (unsigned short)row_in_bin;
-#ifdef FNR_SCATTER_DEBUG_SEEN
-      if (seen_hash) atomicAdd(&s_hsum[bin], seen_record_hash(row_in_bin, v.x, v.y));
-#endif
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
-#if defined(FNR_SCATTER_ATOMIC_COUNTERS) || defined(FNR_SCATTER_RMW_COUNTERS)
-      atomicMax(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], 1u);
-#else
       qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;  // tells the accumulate kernel that the table holds part of the sum
-#endif
       ++overflowed_here;                             // fnr_debug_scatter_overflows: one atomic per thread, below
       const size_t row = ((size_t)bin << log2_rows) + row_in_bin;
       atomicAdd(table + 2 * row, v.x);
@@ -531,13 +389,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   if (overflowed_here) atomicAdd(&g_scatter_overflow_records, (unsigned long long)overflowed_here);
   EMIT_T(5);
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  if (seen_hash) {
-    __syncthreads();
-    if (threadIdx.x < bins && s_hsum[threadIdx.x] != 0ull)
-      atomicAdd(&g_scatter_seen.emit_sum[seen_slot - 1][lrel * SEEN_HBINS + threadIdx.x], s_hsum[threadIdx.x]);
-  }
-#endif
   __syncthreads();  // the next level re-uses the bin tables and the record staging
   }  // levels of this workgroup
 #ifdef FNR_EMIT_TIMING
@@ -572,9 +423,6 @@ struct AccArgs {
   int log2_rows, level0, nbins;   // nbins = level_count * bins per level = workgroups of this call
   int kind;                       // 0: the field's table, 1: a proposal network's (g_scatter_records)
   TableAdam adam;
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  int seen_slot;                  // g_scatter_seen slot of this call
-#endif
 };
 
 // s_acc: [rows][2] two's-complement fixed point in DYNAMIC LDS, 16 bytes per row of the bin (128 KiB for the main
@@ -596,72 +444,10 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   const int gbin = A.nbins - 1 - vblock;  // (level - level0) * bins + bin
   const int lrel = gbin / bins, bin = gbin - lrel * bins;
   const int level = level0 + lrel;
-#if defined(FNR_SCATTER_RMW_COUNTERS)
-  // A/B build (tools/build_variant.sh rmw_counters -DFNR_SCATTER_RMW_COUNTERS): every access to a counter
-  // word, in every kernel, is a device-scope atomic READ-MODIFY-WRITE — executed where the emit kernel's atomics were, past
-  // the scalar cache, the CU's L1 and the XCD's L2 (an atomic drops the line from the issuing L2: MI355X_MICROARCH.md,
-  // "stores of each flavour") — so that no cached copy of a counter line, stale or not, is ever read.  Thread 0 fetches and
-  // clears the bin's count with one exchange, reads the level's maximum / overflow flag with an or-with-0, and hands the
-  // three values to the workgroup through the first words of the (not yet zeroed) accumulator.
-  unsigned* s_bcast = reinterpret_cast<unsigned*>(s_acc);
-  if (threadIdx.x == 0) {
-    // (an `atomicMax(p, 0u)` is folded into an agent-scope atomic LOAD — global_load sc1, served by the XCD's L2 — by
-    //  the compiler: the zero is hidden behind an empty asm so that the read really is a read-modify-write)
-    unsigned zero = 0u;
-    asm volatile("" : "+v"(zero));
-    const unsigned n_rd = atomicExch(&qcount[(size_t)gbin * SC_CNT_STRIDE], 0u);
-    const unsigned vm_rd = atomicOr(&qmax[(size_t)lrel * SC_CNT_STRIDE], zero);
-    const unsigned ov_rd = atomicOr(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], zero);
-    s_bcast[0] = n_rd, s_bcast[1] = vm_rd, s_bcast[2] = ov_rd;
-  }
-  __syncthreads();
-  long long n = s_bcast[0];
-  const float vmax = __uint_as_float(s_bcast[1]);
-  const bool overflowed = s_bcast[2] != 0u;
-  __syncthreads();   // everyone has its copy: thread 0 may go on (and the accumulator may be zeroed below)
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  if ((threadIdx.x & 63) == 0 && gbin < SEEN_BINS) {
-    atomicMax(&g_scatter_seen.acc_n[A.seen_slot][gbin], (unsigned)n);
-    atomicMax(&g_scatter_seen.acc_n_minc[A.seen_slot][gbin], ~(unsigned)n);
-    atomicMax(&g_scatter_seen.acc_vmax[A.seen_slot][gbin], __float_as_uint(vmax));
-    atomicMax(&g_scatter_seen.acc_vmax_minc[A.seen_slot][gbin], ~__float_as_uint(vmax));
-  }
-#endif
-  if (threadIdx.x == 0) {
-    // the level's maximum is shared by its `bins` workgroups: the last of them to have read it clears it (its own read
-    // above has returned: the exchange below cannot overtake it)
-    if (atomicAdd(&qdone[(size_t)lrel * SC_CNT_STRIDE], 1u) == (unsigned)bins - 1u) {
-      atomicExch(&qmax[(size_t)lrel * SC_CNT_STRIDE], 0u);
-      atomicExch(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], 0u);
-      atomicExch(&qdone[(size_t)lrel * SC_CNT_STRIDE], 0u);
-    }
-  }
-#else
-#ifdef FNR_SCATTER_ATOMIC_COUNTERS
-  // A/B build (tools/build_variant.sh): the counters are written by agent-scope atomics in the emit
-  // kernel — read and reset them at the same scope instead of through plain accesses (which the memory model allows
-  // across a kernel boundary; these are the only small lines every step rewrites and every XCD's L2 keeps)
-  long long n = __hip_atomic_load(&qcount[(size_t)gbin * SC_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const float vmax = __uint_as_float(__hip_atomic_load(&qmax[(size_t)lrel * SC_CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  const bool overflowed = __hip_atomic_load(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-#elif defined(FNR_SCATTER_FORCE_VECTOR_LOADS)
-  // hunt builds: the counter loads FORCED onto the vector path (an opaque zero in a VGPR makes the address non-uniform for
-  // the compiler).  Which path the compiler picks for these uniform loads changes with the surrounding code — the shipped
-  // build had vector loads in the first call's copy of k_scatter_accumulate2<true> only, the instrumented builds get scalar
-  // loads everywhere — and the hazard only exists on the vector path.  `seen_nowait` (+ FNR_SCATTER_NO_COUNTER_WAIT)
-  // is the code as it shipped until the end of round 4, in its hazardous form, in BOTH copies: it must reproduce the
-  // events; `seen_vec` is the fix under the same loads: it must not.
-  unsigned vzero = 0u;
-  asm volatile("" : "+v"(vzero));
-  long long n = qcount[(size_t)gbin * SC_CNT_STRIDE + vzero];
-  const float vmax = __uint_as_float(qmax[(size_t)lrel * SC_CNT_STRIDE + vzero]);
-  const bool overflowed = qmax[(size_t)lrel * SC_CNT_STRIDE + 1 + vzero] != 0u;
-#else
   long long n = qcount[(size_t)gbin * SC_CNT_STRIDE];
   const float vmax = __uint_as_float(qmax[(size_t)lrel * SC_CNT_STRIDE]);  // largest |value| of the whole level
   // some emit workgroup overflowed a queue of this level and added records to the gradient table with atomics
   const bool overflowed = qmax[(size_t)lrel * SC_CNT_STRIDE + 1] != 0u;
-#endif
   // EVERY WAVE MUST HOLD ITS COPIES BEFORE ANYONE MAY RESET A COUNTER.  The loads above are uniform, and the compiler is free
   // to issue them as scalar loads or as vector loads; a workgroup barrier on gfx950 only waits for LDS / scalar traffic
   // (lgkmcnt), NOT for outstanding vector loads (the workgroup-scope fence of __syncthreads omits vmcnt(0)).  In
@@ -673,48 +459,31 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   // found by reading the ISA at the end of round 4: `s_barrier` ahead of `s_waitcnt vmcnt(1)` in that one code path, scalar
   // loads + `s_waitcnt lgkmcnt(0)` ahead of the barrier in the second call's copy and in k_scatter_accumulate).  The
   // counters are inputs of the wait: the compiler has to have them in registers before it, whatever loads it chose.
+  // CONFIRMED ON HARDWARE IN ROUND 5 (tools/microbench/barrier_load_race.hip, profiles/r05_raw/barrier_load_race.log): the
+  // same load / barrier / reset pattern with vector loads and no wait returned 1264 stale level maxima in 200 000 rounds of
+  // 160 workgroups once a second stream kept the memory system busy; with this wait, and with scalar loads, none.
 #ifdef FNR_ACC_ZERO_EARLY
   // A/B build (tools/build_variant.sh zero_early -DFNR_ACC_ZERO_EARLY): the accumulator is zeroed HERE, while the counter
   // loads are in flight — it does not depend on them — and the barrier below covers it, so the second barrier (and the
   // load latency the wait exposes) goes: one barrier and ~1 us less per accumulate workgroup
   for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0ull;
 #endif
-#ifndef FNR_SCATTER_NO_COUNTER_WAIT   // (hunt build `seen_nowait`: the code as it was, to reproduce the events)
   {
-    const unsigned seen_n = (unsigned)n, seen_max = __float_as_uint(vmax), seen_ovf = overflowed ? 1u : 0u;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(seen_n), "v"(seen_max), "v"(seen_ovf) : "memory");
+    const unsigned held_n = (unsigned)n, held_max = __float_as_uint(vmax), held_ovf = overflowed ? 1u : 0u;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(held_n), "v"(held_max), "v"(held_ovf) : "memory");
   }
-#endif
   // now every thread has its copy: put the counters back to zero, so the NEXT call on this workspace needs no memset
   // launch (the caller says so with workspace_clean = 1).  The level's max is shared by its `bins` workgroups: the
   // last of them to have read it (its own increment of `qdone` follows its waves' loads) clears it.
   __syncthreads();
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  if ((threadIdx.x & 63) == 0 && gbin < SEEN_BINS) {   // every wave's copy: largest and (complemented) smallest
-    atomicMax(&g_scatter_seen.acc_n[A.seen_slot][gbin], (unsigned)n);
-    atomicMax(&g_scatter_seen.acc_n_minc[A.seen_slot][gbin], ~(unsigned)n);
-    atomicMax(&g_scatter_seen.acc_vmax[A.seen_slot][gbin], __float_as_uint(vmax));
-    atomicMax(&g_scatter_seen.acc_vmax_minc[A.seen_slot][gbin], ~__float_as_uint(vmax));
-  }
-#endif
   if (threadIdx.x == 0) {
-#ifdef FNR_SCATTER_ATOMIC_COUNTERS
-    __hip_atomic_store(&qcount[(size_t)gbin * SC_CNT_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (atomicAdd(&qdone[(size_t)lrel * SC_CNT_STRIDE], 1u) == (unsigned)bins - 1u) {
-      __hip_atomic_store(&qmax[(size_t)lrel * SC_CNT_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&qmax[(size_t)lrel * SC_CNT_STRIDE + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&qdone[(size_t)lrel * SC_CNT_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#else
     qcount[(size_t)gbin * SC_CNT_STRIDE] = 0u;
     if (atomicAdd(&qdone[(size_t)lrel * SC_CNT_STRIDE], 1u) == (unsigned)bins - 1u) {
       qmax[(size_t)lrel * SC_CNT_STRIDE] = 0u;
       qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 0u;
       qdone[(size_t)lrel * SC_CNT_STRIDE] = 0u;
     }
-#endif
   }
-#endif  // FNR_SCATTER_RMW_COUNTERS
   const bool have = n != 0 && vmax > 0.0f;
   if (threadIdx.x == 0 && n > 0)
     atomicAdd(&g_scatter_records[A.kind & 1][vblock & 63][0], (unsigned long long)(n > cap ? cap : n));
@@ -728,7 +497,7 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   int S = 62 - nb - e;
   if (S > 1000) S = 1000;
   const double scale = ldexp(1.0, S), inv = ldexp(1.0, -S);
-#if !defined(FNR_ACC_ZERO_EARLY) || defined(FNR_SCATTER_RMW_COUNTERS)
+#ifndef FNR_ACC_ZERO_EARLY
   for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0ull;
   __syncthreads();
 #endif
@@ -741,12 +510,6 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   const float4* qv2 = reinterpret_cast<const float4*>(qv);
   const ushort2* qr2 = reinterpret_cast<const ushort2*>(qr);
   const long long np = n >> 1;  // full pairs
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  unsigned long long hsum = 0ull;
-#define FNR_SEEN_HASH(row, vx, vy) hsum += seen_record_hash((row), (vx), (vy))
-#else
-#define FNR_SEEN_HASH(row, vx, vy) do { } while (0)
-#endif
   long long i = threadIdx.x;
   for (; i + 3 * (long long)blockDim.x < np; i += 4 * (long long)blockDim.x) {  // 8 loads (8 records) in flight per thread
     float4 v[4];
@@ -760,8 +523,6 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     for (int u = 0; u < 4; ++u) {
       acc_record(s_acc, row[u].x, make_float2(v[u].x, v[u].y), scale);
       acc_record(s_acc, row[u].y, make_float2(v[u].z, v[u].w), scale);
-      FNR_SEEN_HASH(row[u].x, v[u].x, v[u].y);
-      FNR_SEEN_HASH(row[u].y, v[u].z, v[u].w);
     }
   }
   for (; i < np; i += blockDim.x) {
@@ -769,27 +530,12 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     const ushort2 row = qr2[i];
     acc_record(s_acc, row.x, make_float2(v.x, v.y), scale);
     acc_record(s_acc, row.y, make_float2(v.z, v.w), scale);
-    FNR_SEEN_HASH(row.x, v.x, v.y);
-    FNR_SEEN_HASH(row.y, v.z, v.w);
   }
   if ((n & 1) && threadIdx.x == 0) {
     acc_record(s_acc, qr[n - 1], qv[n - 1], scale);
-    FNR_SEEN_HASH(qr[n - 1], qv[n - 1].x, qv[n - 1].y);
   }
-#undef FNR_SEEN_HASH
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  if (A.seen_slot >= 1 && bins <= SEEN_HBINS && A.nbins <= 8 * bins && hsum != 0ull)
-    atomicAdd(&g_scatter_seen.acc_sum[A.seen_slot - 1][lrel * SEEN_HBINS + bin], hsum);
-#endif
   __syncthreads();
   float2* dst = grid.table + ((size_t)level << grid.log2_T) + (size_t)bin * rows;
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  if (A.seen_slot >= 1 && bins <= SEEN_HBINS && A.nbins <= 8 * bins) {
-    unsigned long long gsum = 0ull;
-    for (int e = threadIdx.x; e < 2 * rows; e += blockDim.x) gsum += s_acc[e] * (unsigned long long)(2 * e + 1);
-    if (gsum != 0ull) atomicAdd(&g_scatter_seen.acc_grad[A.seen_slot - 1][lrel * SEEN_HBINS + bin], gsum);
-  }
-#endif
   if constexpr (ADAM) {
     const size_t row0 = ((size_t)level << grid.log2_T) + (size_t)bin * rows;
     // Two rows per thread through 16-byte loads / stores: this phase moves two thirds of the kernel's bytes (24 B in +
@@ -806,9 +552,6 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
       unsigned* tw = (adam.touched && rows >= 64) ? adam.touched + (row0 >> 6) : nullptr;
       // (Two iterations' parameters / moments in flight per thread — 96 B instead of 48 — changes nothing: 194.3 vs 194.9 us
       //  for the whole entry point, same-box A/B, profiles/r04_raw/ab_sweep.log.  The sweep is not latency-bound.)
-#ifdef FNR_SCATTER_DEBUG_SEEN
-      unsigned long long pmv_sum = 0ull;
-#endif
       for (int e4 = threadIdx.x; e4 < (rows >> 1); e4 += blockDim.x) {
         const long long a0 = (long long)s_acc[4 * e4], a1 = (long long)s_acc[4 * e4 + 1],
                         a2 = (long long)s_acc[4 * e4 + 2], a3 = (long long)s_acc[4 * e4 + 3];
@@ -819,11 +562,6 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
           if (!ever) atomicOr(&tw[e4 >> 5], 1u << (e4 & 31));   // first gradient of this pair (once per pair, ever)
         }
         float4 P = P4[e4], M = M4[e4], V = V4[e4];
-#ifdef FNR_SCATTER_DEBUG_SEEN
-        pmv_sum += seen_record_hash((unsigned)(4 * e4), P.x, P.y) + seen_record_hash((unsigned)(4 * e4 + 1), P.z, P.w) +
-                   seen_record_hash((unsigned)(4 * e4 + 2), M.x, M.y) + seen_record_hash((unsigned)(4 * e4 + 3), M.z, M.w) +
-                   3ull * seen_record_hash((unsigned)(4 * e4), V.x, V.y) + 5ull * seen_record_hash((unsigned)(4 * e4 + 1), V.z, V.w);
-#endif
         const float g0 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a0 * inv) : 0.0f;
         const float g1 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a1 * inv) : 0.0f;
         const float g2 = (a2 != 0 || a3 != 0) ? 0.0f + (float)((double)a2 * inv) : 0.0f;
@@ -836,10 +574,6 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
         M4[e4] = M;
         V4[e4] = V;
       }
-#ifdef FNR_SCATTER_DEBUG_SEEN
-      if (A.seen_slot >= 1 && bins <= SEEN_HBINS && A.nbins <= 8 * bins && pmv_sum != 0ull)
-        atomicAdd(&g_scatter_seen.acc_pmv[A.seen_slot - 1][lrel * SEEN_HBINS + bin], pmv_sum);
-#endif
       return;
     }
     // (row-by-row sweep: unaligned spans, and levels some queue of which overflowed.  It visits every row, but it has to
@@ -898,12 +632,6 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate2(AccArgs a, AccArgs
   else accumulate_bin<ADAM>(b, (int)blockIdx.x - a.nbins, s_acc);
 }
 
-#ifdef FNR_SCATTER_DEBUG_SEEN
-#define FNR_SEEN_ARG(x) , x
-static int g_seen_slot_next = 0;   // host: the slot of the next scatter_emit (set by the entry points; 0 = the field's call)
-#else
-#define FNR_SEEN_ARG(x)
-#endif
 
 // emit of one scatter call -> the arguments its accumulate launch needs
 template <class Source>
@@ -944,15 +672,12 @@ static int scatter_emit(const fnr_grid* grid_grad, const Warp& warp, const Sourc
   } else if (pairs)
     hipLaunchKernelGGL((k_scatter_emit<Source, true>), dim3((unsigned)chunks, gy), dim3(SC_EMIT_THREADS),
                        0, st, gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap,
-                       p.log2_rows, level0, level_count, lpb FNR_SEEN_ARG(g_seen_slot_next));
+                       p.log2_rows, level0, level_count, lpb);
   else
     hipLaunchKernelGGL((k_scatter_emit<Source, false>), dim3((unsigned)chunks, gy), dim3(SC_EMIT_THREADS),
                        0, st, gd, warp, src, N, d_feats, queue_v, queue_r, qcount, qcount + nbins_all * SC_CNT_STRIDE, p.cap,
-                       p.log2_rows, level0, level_count, lpb FNR_SEEN_ARG(g_seen_slot_next));
+                       p.log2_rows, level0, level_count, lpb);
   FNR_LAUNCH_CHECK();
-#ifdef FNR_SCATTER_DEBUG_SEEN
-  acc.seen_slot = g_seen_slot_next;
-#endif
   acc.grid = gd;
   acc.queue_v = queue_v, acc.queue_r = queue_r, acc.qcount = qcount;
   acc.qmax = qcount + nbins_all * SC_CNT_STRIDE;
@@ -1261,19 +986,6 @@ extern "C" int fnr_debug_scatter_records(uint64_t* records_host, int reset) {
   return FNR_OK;
 }
 
-#ifdef FNR_SCATTER_DEBUG_SEEN
-// Hunt build only (not in include/fruitnerf_hip.h): device-to-device copy of g_scatter_seen into `dst` on `stream`, then
-// (reset != 0) the block is zeroed on the same stream.  -> bytes copied, or 0 if `dst_bytes` is too small.
-extern "C" size_t fnr_debug_scatter_seen_copy(void* dst, size_t dst_bytes, int reset, void* stream) {
-  if (!dst || dst_bytes < sizeof(ScatterSeen)) return 0;
-  void* src = nullptr;
-  if (hipGetSymbolAddress(&src, HIP_SYMBOL(g_scatter_seen)) != hipSuccess) return 0;
-  if (hipMemcpyAsync(dst, src, sizeof(ScatterSeen), hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess) return 0;
-  if (reset && hipMemsetAsync(src, 0, sizeof(ScatterSeen), as_stream(stream)) != hipSuccess) return 0;
-  return sizeof(ScatterSeen);
-}
-extern "C" size_t fnr_debug_scatter_seen_bytes() { return sizeof(ScatterSeen); }
-#endif
 
 extern "C" size_t fnr_hash_scatter_workspace_bytes(int64_t n_samples, int n_levels, int log2_hashmap_size) {
   const ScatterPlan p = scatter_plan(n_samples, n_levels, log2_hashmap_size);
@@ -1461,16 +1173,10 @@ extern "C" int fnr_prop_density_bwd_pair(const fnr_prop_net* const* nets, const 
   FNR_PROF(OP_PROP_BWD, rays->n_rays * ((long long)S[0] + (long long)S[1]));   // one scope: both levels + the joint accumulate
   AccArgs acc[2];
   for (int q = 0; q < 2; ++q) {
-#ifdef FNR_SCATTER_DEBUG_SEEN
-    g_seen_slot_next = 1 + q;
-#endif
     const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
                                           d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
                                           adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
                                           adam ? grad_arena : nullptr, &acc[q], 0, false);
-#ifdef FNR_SCATTER_DEBUG_SEEN
-    g_seen_slot_next = 0;
-#endif
     if (rc) return rc;
   }
   const bool first_longer = (long long)S[0] >= (long long)S[1];
@@ -1503,16 +1209,10 @@ extern "C" int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, 
   AccArgs acc[2];
   for (int phase = 1; phase <= 2; ++phase) {
     for (int q = 0; q < 2; ++q) {
-#ifdef FNR_SCATTER_DEBUG_SEEN
-      g_seen_slot_next = 1 + q;
-#endif
       const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
                                             d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
                                             adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
                                             adam ? grad_arena : nullptr, &acc[q], phase, false);
-#ifdef FNR_SCATTER_DEBUG_SEEN
-      g_seen_slot_next = 0;
-#endif
       if (rc) return rc;
     }
     if (phase == 1 && position_ready_event)

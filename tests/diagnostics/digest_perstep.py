@@ -37,7 +37,8 @@ WS_DIGEST = os.environ.get("FNR_DIGEST_WS") == "1"
 # Per-BIN checksums of both proposal tables every step (always on: two reductions per step): at an event step they name the
 # (level, accumulate bin) whose rows differ — one bin (a queue count), a whole level (the level's maximum, i.e. the
 # fixed-point scale), or scattered rows (records).
-# FNR_DIGEST_SEEN=1 (needs the `seen` library variant: tools/build_variant.sh seen -DFNR_SCATTER_DEBUG_SEEN, FNR_LIB_PATH):
+# FNR_DIGEST_SEEN=1 — ONLY with a `seen` build of the library (-DFNR_SCATTER_DEBUG_SEEN), which left the tree in round 5 once
+# the divergence was confirmed and fixed (the instrumented hash_scatter.hip is in the history at commit 6211740):
 # what the scatter kernels of the step saw — the queue count and level maximum every accumulate workgroup of the two
 # proposal levels READ, and the records the emit kernels PLACED per level — is copied out of the library every step.
 SEEN_DIGEST = os.environ.get("FNR_DIGEST_SEEN") == "1"

@@ -123,15 +123,13 @@ def test_exchange_path_step_is_the_single_process_step(dev):
         grouped = run(1)
         T.EXCHANGE_LEVEL_GROUPS = old_groups
         # the sharded optimiser step (reduce-scatter, own shard's step, all-gather of the parameters; opt-in): on one rank
-        # the shard is the whole span but for its unaligned tail.  Written at the end of round 4 without a GPU: runs only
-        # when asked for (FNR_RUN_UNVALIDATED=1) until it has passed once on a box.
-        sharded = None
-        if os.environ.get("FNR_RUN_UNVALIDATED") == "1":
-            T.SHARDED_FIELD_OPTIMIZER = True
-            try:
-                sharded = run(1)
-            finally:
-                T.SHARDED_FIELD_OPTIMIZER = False
+        # the shard is the whole span but for its unaligned tail.  (Passed on a box in round 5's first GPU call,
+        # profiles/r05_raw/tests_unvalidated.log: always on since.)
+        T.SHARDED_FIELD_OPTIMIZER = True
+        try:
+            sharded = run(1)
+        finally:
+            T.SHARDED_FIELD_OPTIMIZER = False
     finally:
         T.DEFER_FIELD_UPDATE = False
         T.EXCHANGE_MIN_WORLD = old
@@ -142,10 +140,9 @@ def test_exchange_path_step_is_the_single_process_step(dev):
     for snap_a, snap_b in zip(exch[0], grouped[0]):
         for x, y in zip(snap_a, snap_b):
             assert torch.equal(x, y)
-    if sharded is not None:
-        for snap_a, snap_b in zip(exch[0], sharded[0]):
-            for x, y in zip(snap_a, snap_b):
-                assert torch.equal(x, y), "sharded optimiser step differs from the all-reduce path on one rank"
+    for snap_a, snap_b in zip(exch[0], sharded[0]):
+        for x, y in zip(snap_a, snap_b):
+            assert torch.equal(x, y), "sharded optimiser step differs from the all-reduce path on one rank"
     (s1, s2), (a, b) = single
     (e1, e2), _ = exch
     for x, y in zip(s1[:3], e1[:3]):                     # after the first step
