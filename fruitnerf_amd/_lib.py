@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FNR_LIB_PATH") or os.path.join(_HERE, "lib", "libfrui
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 10     # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 11     # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -125,6 +125,8 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "fnr_field_mlp_bwd_adam": (_i, [P(fnr_field_net), P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, P(fnr_table_adam), _vp, _vp, C.c_size_t, _vp]),
+    "fnr_field_mlp_bwd_adam_phase": (_i, [P(fnr_field_net), P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _vp, P(fnr_table_adam), _vp, _vp, C.c_size_t, _i, _vp]),
     "fnr_hash_scatter_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "fnr_hash_encode_bwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _i, _vp]),
     "fnr_hash_encode_bwd_adam": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, C.c_size_t, _i,

@@ -54,7 +54,14 @@ struct ScatterPlan {
 static ScatterPlan scatter_plan(long long N, int n_levels, int log2_T) {
   ScatterPlan p;
   int log2_rows = log2_T - 5;  // at least 32 bins per level (measured best for the 2^17-row proposal tables) ...
-  if (log2_rows > 13) log2_rows = 13;  // ... but at most 8192 rows per bin
+  // ... but at most 8192 rows per bin (128 KiB of accumulator: one accumulate workgroup per CU); FNR_SCATTER_LOG2_ROWS
+  // = 12 (A/B knob, read per call): 4096-row bins, two accumulate workgroups per CU, twice the bins per level
+  int rows_cap = 13;
+  if (const char* e = getenv("FNR_SCATTER_LOG2_ROWS")) {
+    const int v = atoi(e);
+    if (v >= 10 && v <= 13) rows_cap = v;
+  }
+  if (log2_rows > rows_cap) log2_rows = rows_cap;
   if (log2_rows < 0) log2_rows = 0;
   p.log2_rows = log2_rows;
   p.bins_per_level = 1 << (log2_T - log2_rows);
@@ -625,8 +632,14 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(AccArgs a) {
 }
 // two scatter calls in one launch (the two proposal levels' tables: 160 workgroups each on 256 CUs — side by side they
 // cost the longer of the two instead of their sum); the longer queues (call a) are dispatched first
+#ifndef FNR_ACC2_WAVES
+// minimum waves per SIMD the register allocation has to allow: 8 = TWO 1024-thread workgroups per CU.  The proposal
+// tables' 4096-row bins take 64 KiB of LDS each, but without the bound the kernel got 79 registers = 6 waves per SIMD =
+// ONE workgroup per CU, and a paired call's 320 workgroups ran as 256 + 64 (round 5; 48 registers with it, no spills)
+#define FNR_ACC2_WAVES 8
+#endif
 template <bool ADAM>
-__global__ __launch_bounds__(1024) void k_scatter_accumulate2(AccArgs a, AccArgs b) {
+__global__ __launch_bounds__(1024, FNR_ACC2_WAVES) void k_scatter_accumulate2(AccArgs a, AccArgs b) {
   unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(acc_smem);
   if ((int)blockIdx.x < a.nbins) accumulate_bin<ADAM>(a, (int)blockIdx.x, s_acc);
   else accumulate_bin<ADAM>(b, (int)blockIdx.x - a.nbins, s_acc);

@@ -953,13 +953,24 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         fld = model.field
         net, gnet = fld.net_struct(), fld.net_struct(grads=True)
         d_pos = None
+        # The weight-gradient tails of the MLP backward (k_color_ray_grads, k_embedding_grad, k_reduce_dw with their
+        # optimiser steps: ~28 us of small latency-bound launches) feed nothing but the NEXT forward's weight preparation.
+        # On a step whose second-stream segment starts right behind the MLP backward (no proposal backward: tail()
+        # below) they open that segment and run underneath the table scatter instead of ahead of it
+        # (fnr_field_mlp_bwd_adam_phase; same kernels on the same values: bit-identical, tests/test_gpu_determinism.py).
+        mlp_tails = None
+        split_tails = bool(MLP_TAILS_ON_SIDE and weight_adam is not None and tail_on_side and exchange is None
+                           and not prop_bwd and not serialize_streams)
         if ray_grads is not None and rctx.field_jacobian is not None:
-            d_feats, d_pos = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector,
-                                             d_density, d_rgb_s, d_logit, jacobian=rctx.field_jacobian,
-                                             weight_adam=weight_adam)
+            res = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector,
+                                  d_density, d_rgb_s, d_logit, jacobian=rctx.field_jacobian,
+                                  weight_adam=weight_adam, defer_tails=split_tails)
+            d_feats, d_pos = res[0], res[1]
+            mlp_tails = res[2] if split_tails else None
         else:
-            d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
-                                      d_rgb_s, d_logit, weight_adam=weight_adam)
+            res = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
+                                  d_rgb_s, d_logit, weight_adam=weight_adam, defer_tails=split_tails)
+            d_feats, mlp_tails = (res[0], res[1]) if split_tails else (res, None)
         field_source = None
         if ray_grads is not None:
             if d_pos is not None:
@@ -1012,6 +1023,10 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 fj.fork(side_, None if serialize_streams else tail_ready)
                 crosses_to(side_, ray_sources, field_source, d_o, d_d, rays)
             with torch.cuda.stream(side_):
+                if first and mlp_tails is not None:
+                    crosses_to(side_, rctx, d_rgb_s, d_logit, d_density, d_feats, d_pos)
+                    mlp_tails()                    # phase 2 of the MLP backward, underneath the table scatter
+                    model.__dict__["_mlp_tails_split"] = model.__dict__.get("_mlp_tails_split", 0) + 1
                 if first and not sources_early:
                     if ray_grads is not None:
                         K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
@@ -1112,6 +1127,9 @@ SERIALIZE_STREAMS = os.environ.get("FNR_SERIALIZE_STREAMS") == "1"   # (profilin
 # kernels slow each other in the XCDs' L2s (each network's 5 MB tables fit one L2, two do not).  Kept for measurements.
 PROPOSAL_LEVEL_STREAMS = os.environ.get("FNR_PROPOSAL_LEVEL_STREAMS", "0") == "1"
 PAIR_PROPOSAL_LEVELS = os.environ.get("FNR_PAIR_PROPOSAL_LEVELS", "1") != "0"   # see _proposal_backward
+# The MLP backward's weight-gradient tails on the second stream (steps without a proposal backward; see
+# fused_forward_backward).  FNR_MLP_TAILS_ON_SIDE=0: the one-call form, everything on the launch stream (A/B).
+MLP_TAILS_ON_SIDE = os.environ.get("FNR_MLP_TAILS_ON_SIDE", "1") != "0"
 FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
 FUSE_WEIGHT_OPTIMIZER = True  # ... and the field's MLP weights + embedding step inside k_reduce_dw / k_embedding_grad
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter

@@ -68,6 +68,7 @@ def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None, tor
     finally:
         T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD, T.FUSE_WEIGHT_OPTIMIZER = saved
     torch.cuda.synchronize()
+    _run.last_model = hm
     return (hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), cam_opt.pose_adjustment.data.clone(),
             torch.stack(losses))
 
@@ -108,6 +109,27 @@ def test_paired_proposal_levels_are_the_separate_calls(dev):
         T.PAIR_PROPOSAL_LEVELS = saved
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("mlp_precision", ["bf16x3", "fp32"])
+def test_mlp_backward_tails_on_the_second_stream_change_nothing(dev, mlp_precision):
+    """training.MLP_TAILS_ON_SIDE (round 5): on steps without a proposal backward the MLP backward's weight-gradient tails
+    (k_color_ray_grads, k_embedding_grad, k_reduce_dw + their optimiser steps: fnr_field_mlp_bwd_adam_phase, phase 2) open
+    the second stream's segment and run underneath the table scatter.  60 steps (every step trains the proposal networks
+    until step 10, every other one after: both step shapes) with the split against the one-call form: identical
+    parameters, moments, poses, losses."""
+    import fruitnerf_amd.training as T
+    on = _run(dev, 60, mlp_precision)
+    assert _run.last_model.__dict__.get("_mlp_tails_split", 0) == 25     # steps 11, 13, ..., 59: no proposal backward
+    saved, T.MLP_TAILS_ON_SIDE = T.MLP_TAILS_ON_SIDE, False
+    try:
+        off = _run(dev, 60, mlp_precision)
+    finally:
+        T.MLP_TAILS_ON_SIDE = saved
+    assert _run.last_model.__dict__.get("_mlp_tails_split", 0) == 0
+    assert saved is True                     # the default under test
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), on, off):
+        assert torch.equal(x, y), f"{name} differ between the split and the one-call MLP backward"
 
 
 def test_sampling_ahead_is_sampling_at_the_start_of_the_step(dev):
