@@ -371,6 +371,23 @@ def composite_bwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: T
     return d_density, d_rgb, d_logit
 
 
+def composite_bwd_targets(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, weights: Tensor,
+                          out_rgb: Tensor, image: Tensor, out_sem: Tensor, mask: Tensor, sem_weight: float):
+    """composite_bwd with the per-ray loss gradients formed inside the kernel from the composited outputs and the batch
+    (fnr_composite_bwd_targets): no dependence on the losses launch, same bits."""
+    lib = L.load()
+    dev = rays.device
+    N = rays.n * S
+    d_density = torch.empty(N, device=dev)
+    d_rgb = torch.empty(N, 3, device=dev)
+    d_logit = torch.empty(N, device=dev)
+    L.check(lib.fnr_composite_bwd_targets(rays.ref, S, L.ptr(euclid), L.ptr(density), L.ptr(rgb), L.ptr(weights),
+                                          L.ptr(_f32c(out_rgb)), L.ptr(_f32c(image)), L.ptr(_f32c(out_sem.reshape(-1))),
+                                          L.ptr(_f32c(mask.reshape(-1))), float(sem_weight), L.ptr(d_density),
+                                          L.ptr(d_rgb), L.ptr(d_logit), L.stream_ptr(dev)), "composite_bwd_targets")
+    return d_density, d_rgb, d_logit
+
+
 def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weights: Tensor,
                 upstream: Optional[Tensor]) -> Tensor:
     lib = L.load()

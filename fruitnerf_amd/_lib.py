@@ -117,6 +117,8 @@ SIGNATURES = {
     "fnr_interlevel_fwd": (_i, [_i64, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "fnr_distortion": (_i, [_i64, _i, _vp, _vp, _vp, _vp]),
     "fnr_composite_bwd": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_composite_bwd_targets": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp,
+                                       _vp]),
     "fnr_weights_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fnr_field_mlp_bwd_workspace_bytes": (C.c_size_t, [_i64, _i]),
     "fnr_field_mlp_bwd": (_i, [P(fnr_field_net), P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

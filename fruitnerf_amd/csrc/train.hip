@@ -414,7 +414,19 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
 // backward of w_i = (1 - exp(-d_i s_i)) exp(-sum_{j<i} d_j s_j):
 //   dL/ds_k = d_k [ g_k T_{k+1} - sum_{i>k} g_i w_i ],  T_{k+1} = exp(-sum_{j<=k} d_j s_j)
 // ---------------------------------------------------------------------------------------------------
-template <bool COMPOSITE>
+// TARGETS (fnr_composite_bwd_targets): the per-ray loss gradients are not read from memory but formed here from the
+// composited outputs and the batch — g_rgb = 2 (rgb - image) / (3 R), g_sem = w_sem (sigmoid(sem) - mask) / R: the very
+// expressions of k_train_losses, so the same bits — which makes this launch independent of the losses launch: a training
+// step runs the MLP backward straight behind the forward while the loss VALUES (and the interlevel loss with the proposal
+// levels' weights backward) are summed on the second stream.
+struct LossTargets {
+  const float* out_rgb;    // [R,3] composited colour
+  const float* image;      // [R,3]
+  const float* out_sem;    // [R]   composited logit
+  const float* mask;       // [R]
+  float sem_weight;
+};
+template <bool COMPOSITE, bool TARGETS = false>
 __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const float* __restrict__ euclid,
                                                      const float* __restrict__ density,
                                                      const float* __restrict__ weights,
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const f
                                                      const float* __restrict__ g_rgb,     // COMPOSITE: [R,3]
                                                      const float* __restrict__ g_sem,     // COMPOSITE: [R]
                                                      float* __restrict__ d_density, float* __restrict__ d_rgb,
-                                                     float* __restrict__ d_logit) {
+                                                     float* __restrict__ d_logit, LossTargets tg = LossTargets{}) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r = (long long)blockIdx.x * 4 + wave;
   if (r >= R) return;
@@ -435,10 +447,22 @@ __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const f
   const float up = upstream ? upstream[0] : 1.0f;
   float gr = 0.0f, gg = 0.0f, gb = 0.0f, gs = 0.0f, l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, bgw = 0.0f;
   if (COMPOSITE) {
-    gr = g_rgb[3 * r];
-    gg = g_rgb[3 * r + 1];
-    gb = g_rgb[3 * r + 2];
-    gs = g_sem[r];
+    if constexpr (TARGETS) {
+      const float inv3r = 1.0f / (float)(3 * R), invr = 1.0f / (float)R;   // (k_train_losses, rgb / semantic role)
+      const float d0 = tg.out_rgb[3 * r] - tg.image[3 * r], d1 = tg.out_rgb[3 * r + 1] - tg.image[3 * r + 1],
+                  d2 = tg.out_rgb[3 * r + 2] - tg.image[3 * r + 2];
+      gr = 2.0f * d0 * inv3r;
+      gg = 2.0f * d1 * inv3r;
+      gb = 2.0f * d2 * inv3r;
+      const float x = tg.out_sem[r], y = tg.mask[r];
+      const float sg = 1.0f / (1.0f + expf(-x));
+      gs = tg.sem_weight * (sg - y) * invr;
+    } else {
+      gr = g_rgb[3 * r];
+      gg = g_rgb[3 * r + 1];
+      gb = g_rgb[3 * r + 2];
+      gs = g_sem[r];
+    }
     const float* cl = rgb + (r * S + (S - 1)) * 3;
     l0 = cl[0];
     l1 = cl[1];
@@ -669,6 +693,24 @@ extern "C" int fnr_composite_bwd(const fnr_rays* rays, int S, const float* eucli
   hipLaunchKernelGGL((k_weights_bwd<true>), dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      (long long)rays->n_rays, S, euclid_bins, density, weights, (const float*)nullptr,
                      (const float*)nullptr, rgb, g_rgb, g_semantics, d_density, d_rgb, d_logit);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+extern "C" int fnr_composite_bwd_targets(const fnr_rays* rays, int S, const float* euclid_bins, const float* density,
+                                         const float* rgb, const float* weights, const float* out_rgb, const float* image,
+                                         const float* out_semantics, const float* mask, float semantic_loss_weight,
+                                         float* d_density, float* d_rgb, float* d_logit, void* stream) {
+  FNR_CHECK_ARG(rays && euclid_bins && density && rgb && weights && out_rgb && image && out_semantics && mask && d_density &&
+                    d_rgb && d_logit,
+                "composite_bwd_targets: null argument");
+  FNR_CHECK_ARG(S > 0 && S <= 64 * WB_MAXE, "composite_bwd_targets: S %d out of range", S);
+  if (rays->n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_COMPOSITE_BWD, rays->n_rays * (long long)S);
+  const LossTargets tg{out_rgb, image, out_semantics, mask, semantic_loss_weight};
+  hipLaunchKernelGGL((k_weights_bwd<true, true>), dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     (long long)rays->n_rays, S, euclid_bins, density, weights, (const float*)nullptr,
+                     (const float*)nullptr, rgb, (const float*)nullptr, (const float*)nullptr, d_density, d_rgb, d_logit, tg);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -16,6 +16,7 @@ Gradients are written by the HIP backward kernels straight into the model's flat
 """
 from __future__ import annotations
 
+import contextlib
 import functools
 import os
 
@@ -834,6 +835,12 @@ class _ForkJoin:
 
     def __init__(self, main):
         self.main, self.open, self.segments, self.joins = main, None, 0, 0
+        self.extra = []        # further streams forked off the launch stream during this call (joined with the second one)
+
+    def fork_extra(self, stream, event):
+        """A third stream that runs work enqueued behind `event` (recorded on the launch stream during this call)."""
+        stream.wait_event(event)
+        self.extra.append(stream)
 
     def fork(self, side, event=None):
         if event is not None:
@@ -848,9 +855,12 @@ class _ForkJoin:
             self.main.wait_stream(self.open)
             self.open = None
             self.joins += 1
+        for st in self.extra:
+            self.main.wait_stream(st)
+        self.extra = []
 
     def check(self):
-        if self.open is not None:
+        if self.open is not None or self.extra:
             raise RuntimeError("fused_forward_backward: returning with unjoined work on the second stream")
 
 
@@ -899,10 +909,24 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         prop_bwd = bool(rctx.training and rctx.updated)
         prop_levels = [(lv["S"], lv["spacing"], lv["weights"]) + ((lv["euclid"], lv["density"]) if prop_bwd else ())
                        for lv in rctx.levels[:-1]]
-        losses, d_rgb, d_sem, d_wps = K.train_losses(outputs["rgb"], image, outputs["semantics"], mask,
-                                                     cfg.semantic_loss_weight, S, fin["spacing"], fin["weights"],
-                                                     prop_levels, cfg.interlevel_loss_mult, want_metrics,
-                                                     accum, fuse_weights_bwd=prop_bwd)
+        # The loss VALUES (five scalars for the log) and the interlevel loss with the proposal levels' weights backward feed
+        # the second stream's work only; what the field backward needs from the losses — the per-ray gradients of MSE and
+        # BCE — the composite backward forms itself (fnr_composite_bwd_targets: same expressions, same bits).  So with two
+        # streams the losses launch (~30 us, latency-bound) opens the SECOND stream's segment, next to the composite + MLP
+        # backward instead of ahead of them (round 5; LOSSES_ON_SIDE).
+        main = torch.cuda.current_stream(dev)
+        fj = _ForkJoin(main)
+        side = None
+        losses_on_side = bool(LOSSES_ON_SIDE and overlap_proposal_backward and not serialize_streams)
+        if losses_on_side:
+            side = _second_stream(model, dev)
+            fj.fork(side)                       # behind the forward pass
+            crosses_to(side, outputs, image, mask, rctx, accum)
+        with torch.cuda.stream(side) if losses_on_side else contextlib.nullcontext():
+            losses, d_rgb, d_sem, d_wps = K.train_losses(outputs["rgb"], image, outputs["semantics"], mask,
+                                                         cfg.semantic_loss_weight, S, fin["spacing"], fin["weights"],
+                                                         prop_levels, cfg.interlevel_loss_mult, want_metrics,
+                                                         accum, fuse_weights_bwd=prop_bwd)
         loss_dict = {"rgb_loss": losses[0], "semantics_loss": losses[1], "interlevel_loss": losses[3]}
         metrics_dict = {"psnr": losses[2], "distortion": losses[4]} if want_metrics else {}
 
@@ -919,9 +943,6 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         # launches fill the gaps and tails of the field kernels (measured: -3 % on the steps that have one); bench.py
         # serialises the two streams on the steps whose launches it brackets with HIP events (serialize_streams: a
         # duration measured while another stream's kernels share the CUs describes neither kernel).
-        main = torch.cuda.current_stream(dev)
-        fj = _ForkJoin(main)
-        side = None
         up = None   # d_wps is d(loss)/d(density) already (fuse_weights_bwd above)
         # The ray gradients' sources are complete once the MLP backward is (its d_pos) and the proposal chain's MLP
         # backwards have run; their reduction and the camera optimiser's ~30 us of small launches do not need the
@@ -934,8 +955,9 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         sources_early = False   # the proposal chain recorded `pos_ready` ahead of its scatter
         if prop_bwd:
             if overlap_proposal_backward:
-                side = _second_stream(model, dev)
-                fj.fork(side)
+                if not losses_on_side:          # (else: the segment is open already, the losses launch heads it)
+                    side = _second_stream(model, dev)
+                    fj.fork(side)
                 crosses_to(side, rctx, d_wps, d_o, d_d)
                 pos_ready = None
                 if tail_on_side and not serialize_streams and exchange is None:
@@ -948,8 +970,13 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 crosses_to(main, ray_sources)
                 if serialize_streams:
                     main.wait_stream(side)
-        d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
-                                                      rctx.weights, d_rgb, d_sem)
+        if losses_on_side:
+            d_density, d_rgb_s, d_logit = K.composite_bwd_targets(rays, S, fin["euclid"], rctx.sample_density,
+                                                                  rctx.sample_rgb, rctx.weights, outputs["rgb"], image,
+                                                                  outputs["semantics"], mask, cfg.semantic_loss_weight)
+        else:
+            d_density, d_rgb_s, d_logit = K.composite_bwd(rays, S, fin["euclid"], rctx.sample_density, rctx.sample_rgb,
+                                                          rctx.weights, d_rgb, d_sem)
         fld = model.field
         net, gnet = fld.net_struct(), fld.net_struct(grads=True)
         d_pos = None
@@ -961,6 +988,11 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         mlp_tails = None
         split_tails = bool(MLP_TAILS_ON_SIDE and weight_adam is not None and tail_on_side and exchange is None
                            and not prop_bwd and not serialize_streams)
+        # ... and on the steps WITH a proposal backward (the second stream is the longer chain there) on a third stream of
+        # their own (MLP_TAILS_THIRD_STREAM, A/B knob): forked behind the branch kernels, joined at the end of the call
+        tails_third = bool(MLP_TAILS_THIRD_STREAM and weight_adam is not None and overlap_proposal_backward and
+                           exchange is None and not serialize_streams and not split_tails)
+        split_tails = split_tails or tails_third
         if ray_grads is not None and rctx.field_jacobian is not None:
             res = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector,
                                   d_density, d_rgb_s, d_logit, jacobian=rctx.field_jacobian,
@@ -971,6 +1003,18 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             res = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
                                   d_rgb_s, d_logit, weight_adam=weight_adam, defer_tails=split_tails)
             d_feats, mlp_tails = (res[0], res[1]) if split_tails else (res, None)
+        if tails_third:
+            third = model.__dict__.get("_third_stream")
+            if third is None or third.device != dev:
+                third = model.__dict__["_third_stream"] = torch.cuda.Stream(device=dev)
+                model.__dict__["_third_event"] = torch.cuda.Event()
+            ev3 = model.__dict__["_third_event"]
+            ev3.record(main)                           # the branch kernels are enqueued
+            fj.fork_extra(third, ev3)
+            with torch.cuda.stream(third):
+                mlp_tails()
+            model.__dict__["_mlp_tails_third"] = model.__dict__.get("_mlp_tails_third", 0) + 1
+            mlp_tails = None
         field_source = None
         if ray_grads is not None:
             if d_pos is not None:
@@ -1060,7 +1104,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             fj.join()                              # every local of this call outlives the second stream's launches
             fj.check()
             return loss_dict, metrics_dict
-        if side is not None:
+        if side is not None or fj.extra:
             fj.join()                              # proposal gradients (and their ray-gradient sources) are final
             for src in ray_sources or ():
                 src[3].record_stream(main)
@@ -1127,9 +1171,13 @@ SERIALIZE_STREAMS = os.environ.get("FNR_SERIALIZE_STREAMS") == "1"   # (profilin
 # kernels slow each other in the XCDs' L2s (each network's 5 MB tables fit one L2, two do not).  Kept for measurements.
 PROPOSAL_LEVEL_STREAMS = os.environ.get("FNR_PROPOSAL_LEVEL_STREAMS", "0") == "1"
 PAIR_PROPOSAL_LEVELS = os.environ.get("FNR_PAIR_PROPOSAL_LEVELS", "1") != "0"   # see _proposal_backward
+# The losses launch on the second stream, the composite backward forming its own per-ray loss gradients (see
+# fused_forward_backward).  FNR_LOSSES_ON_SIDE=0: losses on the launch stream ahead of the backward, as before (A/B).
+LOSSES_ON_SIDE = os.environ.get("FNR_LOSSES_ON_SIDE", "1") != "0"
 # The MLP backward's weight-gradient tails on the second stream (steps without a proposal backward; see
 # fused_forward_backward).  FNR_MLP_TAILS_ON_SIDE=0: the one-call form, everything on the launch stream (A/B).
 MLP_TAILS_ON_SIDE = os.environ.get("FNR_MLP_TAILS_ON_SIDE", "1") != "0"
+MLP_TAILS_THIRD_STREAM = os.environ.get("FNR_MLP_TAILS_THIRD_STREAM", "0") == "1"
 FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
 FUSE_WEIGHT_OPTIMIZER = True  # ... and the field's MLP weights + embedding step inside k_reduce_dw / k_embedding_grad
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter

@@ -309,6 +309,17 @@ int fnr_composite_bwd(const fnr_rays* rays, int S, const float* euclid_bins, con
                       const float* weights, const float* g_rgb, const float* g_semantics, float* d_density,
                       float* d_rgb, float* d_logit, void* stream);
 
+/* fnr_composite_bwd with the per-ray loss gradients formed in the kernel (ABI 11): g_rgb = 2 (out_rgb - image) / (3 R),
+ * g_semantics = semantic_loss_weight (sigmoid(out_semantics) - mask) / R — MSELoss / BCEWithLogitsLoss(mean) backward
+ * with unit upstream (fruit_nerf.py:359-367), the expressions fnr_train_losses evaluates, so d_density / d_rgb / d_logit
+ * are bit-identical to fnr_train_losses + fnr_composite_bwd.  It makes the backward independent of the losses launch: a
+ * training step runs it straight behind the forward and sums the loss values on another stream.
+ * out_rgb [R,3], out_semantics [R]: what fnr_composite_fwd returned; image [R,3], mask [R]: the batch. */
+int fnr_composite_bwd_targets(const fnr_rays* rays, int S, const float* euclid_bins, const float* density,
+                              const float* rgb, const float* weights, const float* out_rgb, const float* image,
+                              const float* out_semantics, const float* mask, float semantic_loss_weight,
+                              float* d_density, float* d_rgb, float* d_logit, void* stream);
+
 /* Backward of RaySamples.get_weights for a proposal level: d_weights [R,S] (x *upstream if non-NULL, a
  * device scalar) -> d_density [R,S]. */
 int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, const float* density, const float* weights,

@@ -130,6 +130,17 @@ def test_mlp_backward_tails_on_the_second_stream_change_nothing(dev, mlp_precisi
     assert saved is True                     # the default under test
     for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), on, off):
         assert torch.equal(x, y), f"{name} differ between the split and the one-call MLP backward"
+    # training.LOSSES_ON_SIDE (round 5): the losses launch heads the second stream's segment and the composite backward
+    # forms the per-ray loss gradients itself (fnr_composite_bwd_targets) — against the losses launch ahead of the backward
+    # on the launch stream (fnr_train_losses -> fnr_composite_bwd): the same bits, logged losses included
+    saved, T.LOSSES_ON_SIDE = T.LOSSES_ON_SIDE, False
+    try:
+        inline = _run(dev, 60, mlp_precision)
+    finally:
+        T.LOSSES_ON_SIDE = saved
+    assert saved is True
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), on, inline):
+        assert torch.equal(x, y), f"{name} differ between the losses launch on the second stream and on the launch stream"
 
 
 def test_sampling_ahead_is_sampling_at_the_start_of_the_step(dev):

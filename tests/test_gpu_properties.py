@@ -211,8 +211,17 @@ def test_sparse_touch_bitmap_survives_an_overflowing_scatter(dev):
             states.append((m.arena().params[a:b].clone(), opt.exp_avg[a:b].clone(), opt.exp_avg_sq[a:b].clone()))
     finally:
         T.SPARSE_TOUCH_SKIPPING = saved
-    for x, y in zip(*states):
-        assert torch.equal(x, y), f"{int((x != y).sum())} entries differ between the sparse-touch and the dense sweeps"
+    # The overflow fallback adds floats with global atomics, so the 256 hot rows' sums (2 points x 8 corners x 16 levels)
+    # differ in their last bits from run to run (include/fruitnerf_hip.h, fnr_debug_scatter_overflows): those entries are
+    # compared to 1e-4 — a row whose moments had stopped decaying would be 19 % off after two steps (beta1^2 = 0.81) —
+    # and every other entry bit for bit.
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), *states):
+        n_diff = int((x != y).sum())
+        assert n_diff <= 512, f"{name}: {n_diff} entries differ between the sparse-touch and the dense sweeps"
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-12), \
+            f"{name}: max rel diff {float(((x - y).abs() / y.abs().clamp_min(1e-12)).max()):.3e} — rows frozen by a missing bit?"
+    m_hot = states[0][1].abs() > 1e-3           # the hot rows' first moments: 0.1 x 0.81 x a sum of ~1e5 gradients of 1e-3
+    assert 16 <= int(m_hot.sum()) <= 512, int(m_hot.sum())
     assert int((states[0][1] != 0).sum()) > 100_000
 
 
