@@ -15,10 +15,11 @@ trace() {  # label, env...
   python tools/kt_agg.py $f fnr | grep -E "k_prop_bwd|k_scatter|k_prop_reduce|k_train_losses|k_weights_bwd|k_field_mlp_bwd|k_color_ray|k_reduce_dw|k_embedding" | cut -c1-175
 }
 {
-  trace default A=1
-  trace old_prop_bwd_acc2 FNR_LIB_PATH=$V/acc2w4/libfruitnerf_hip.so
-  trace propbwd_w2 FNR_LIB_PATH=$V/propbwd_w2/libfruitnerf_hip.so
-  trace rows12 FNR_SCATTER_LOG2_ROWS=12
+  trace default A=1                                                       # k_prop_bwd: LDS weights, 3 waves per SIMD (14 spilled registers)
+  trace oldprop FNR_LIB_PATH=$V/oldprop/libfruitnerf_hip.so               # k_prop_bwd as it was (302 scalar registers spilled to lanes)
+  trace oldprop_acc2w4 FNR_LIB_PATH=$V/oldprop_acc2w4/libfruitnerf_hip.so # ... and the paired accumulate at one workgroup per CU
+  trace propbwd_w2 FNR_LIB_PATH=$V/propbwd_w2/libfruitnerf_hip.so         # k_prop_bwd: LDS weights, 188 registers, 2 waves per SIMD, no spills
+  trace rows12 FNR_SCATTER_LOG2_ROWS=12                                   # main table in 4096-row bins (two accumulate workgroups per CU)
 } 2>&1 | tee $O/kt_variants.log
 {
   timeout 200 python tools/ab_quick.py T.LOSSES_ON_SIDE=0,1
