@@ -401,17 +401,13 @@ def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weig
 
 def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, h_saved,
                   selector: Tensor, d_density: Tensor, d_rgb: Tensor, d_logit: Tensor, jacobian: Optional[Tensor] = None,
-                  weight_adam=None, defer_tails: bool = False):
+                  weight_adam=None):
     """h_saved: what field_mlp_fwd(want_h=True) returned — (h [N,16], ray_bias [R,64], packed weights); a bare h tensor
     is accepted too (the per-ray bias and the fragment image are then recomputed).
     jacobian (hash_encode_fwd(want_jacobian=True)): -> (d_feats, d_position [N,4]): the hash grid's input gradient per
     sample rides along (fnr_field_mlp_bwd_rays); position_grad_reduce(..., d_position.view(1, N, 4), ...) finishes it.
     weight_adam = (fnr_table_adam, gradient arena): the optimiser step of the MLP weights + embedding is taken by the
-    kernels that finish their gradients (fnr_field_mlp_bwd_adam, FusedAdam.weight_adam_args).
-    defer_tails (with weight_adam): only the branch kernels are enqueued now (fnr_field_mlp_bwd_adam_phase, phase 1) and
-    the result gains a last member `tails`: calling it enqueues phase 2 — the weight-gradient tails and their optimiser
-    steps — on whatever stream is current THEN (it keeps the workspace alive; the caller orders the streams and drops
-    `tails` only once the launch stream has waited for that stream)."""
+    kernels that finish their gradients (fnr_field_mlp_bwd_adam, FusedAdam.weight_adam_args)."""
     lib = L.load()
     fwd_mode = h_saved[3] if isinstance(h_saved, tuple) and len(h_saved) > 3 else None
     h_saved, ray_bias, packed = (tuple(h_saved) + (None, None))[:3] if isinstance(h_saved, tuple) else (h_saved, None, None)
@@ -425,16 +421,6 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
     if weight_adam is not None:
         adam, grad_arena = weight_adam
         d_pos = torch.empty(N, 4, device=dev) if jacobian is not None else None
-        if defer_tails:
-            def phase(k: int) -> None:
-                L.check(lib.fnr_field_mlp_bwd_adam_phase(
-                    C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved), L.ptr(ray_bias), L.ptr(packed),
-                    L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.ptr(d_feats), L.ptr(jacobian),
-                    L.ptr(d_pos), C.byref(adam), L.ptr(grad_arena), L.ptr(ws), nbytes, k, L.stream_ptr(dev)),
-                    "field_mlp_bwd_adam_phase")
-            phase(1)
-            tails = lambda: phase(2)     # noqa: E731  (closes over ws and every argument tensor)
-            return (d_feats, d_pos, tails) if jacobian is not None else (d_feats, tails)
         L.check(lib.fnr_field_mlp_bwd_adam(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
                                            L.ptr(ray_bias), L.ptr(packed), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb),
                                            L.ptr(d_logit), L.ptr(d_feats), L.ptr(jacobian), L.ptr(d_pos), C.byref(adam),

@@ -127,8 +127,6 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "fnr_field_mlp_bwd_adam": (_i, [P(fnr_field_net), P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, P(fnr_table_adam), _vp, _vp, C.c_size_t, _vp]),
-    "fnr_field_mlp_bwd_adam_phase": (_i, [P(fnr_field_net), P(fnr_field_net), P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                          _vp, _vp, _vp, _vp, _vp, P(fnr_table_adam), _vp, _vp, C.c_size_t, _i, _vp]),
     "fnr_hash_scatter_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "fnr_hash_encode_bwd": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _i, _i, _vp, C.c_size_t, _i, _vp]),
     "fnr_hash_encode_bwd_adam": (_i, [P(fnr_grid), P(fnr_warp), P(fnr_rays), _vp, _i, _vp, _vp, C.c_size_t, _i,

@@ -848,13 +848,7 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                          const float* ray_bias_saved, const float* packed_saved, const uint8_t* selector,
                          const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
                          const BwdWorkspace& ws, hipStream_t st, const float* jacobian = nullptr,
-                         float* d_position = nullptr, const WeightAdam* wadam = nullptr, int phases = 3) {
-  // phases (fnr_field_mlp_bwd_adam_phase): 3 = the whole backward on `st`; 1 = only the kernels d_feats / d_position
-  // depend on (colour, semantic, base branch: what the table scatter waits for); 2 = only the weight-gradient tails
-  // (k_color_ray_grads, k_embedding_grad, k_reduce_dw: ~28 us of small latency-bound launches that nothing but the NEXT
-  // forward's weight preparation depends on) — a caller runs phase 2 on another stream underneath the table scatter.
-  // The partial-image regions of the kernels are disjoint, so the order of the launches does not change a bit.
-  const bool ph_main = (phases & 1) != 0, ph_tails = (phases & 2) != 0;
+                         float* d_position = nullptr, const WeightAdam* wadam = nullptr) {
   const float2* jac = reinterpret_cast<const float2*>(jacobian);
   float4* d_pos = reinterpret_cast<float4*>(d_position);
   const long long n_tiles = (N + 15) / 16;
@@ -873,19 +867,17 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
   if (packed_saved) {
     packed = const_cast<float*>(packed_saved);  // the forward pass's fragment image of the same weights
     bf16_image = reinterpret_cast<char*>(packed) + field_fwd_ws_image_offset();  // ... and its bf16 pieces
-  } else if (ph_main) {
+  } else {
     launch_pack_field_weights<Cfg>(p, packed, st);
     FNR_LAUNCH_CHECK();
   }
   const float* ray_bias = ray_bias_saved;
   if (!ray_bias) {
-    if (ph_main) {
-      launch_color_ray_bias<Cfg>(packed, rd, net->embedding, nullptr, ws.ray_bias, st);
-      FNR_LAUNCH_CHECK();
-    }
+    launch_color_ray_bias<Cfg>(packed, rd, net->embedding, nullptr, ws.ray_bias, st);
+    FNR_LAUNCH_CHECK();
     ray_bias = ws.ray_bias;
   }
-  if (gsum_extra && ph_main) FNR_HIP(hipMemsetAsync(gsum_extra, 0, (size_t)rd.n_rays * 64 * sizeof(float), st));
+  if (gsum_extra) FNR_HIP(hipMemsetAsync(gsum_extra, 0, (size_t)rd.n_rays * 64 * sizeof(float), st));
   // every branch uses the same number of workgroups so that they share one partial-image buffer
   long long blocks = (n_tiles + 3) / 4;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -896,9 +888,7 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
   constexpr int cfg_id = Cfg::NSEM == 2 ? 0 : 1;
   const bool bf_all = mode != FNR_MLP_FP32;
   const bool bf_sem_big = mode != FNR_MLP_FP32 && Cfg::NSEM == 3;
-  if (!ph_main) {
-    // (phase 2 alone: the branch kernels ran in the phase-1 call)
-  } else if (bf_all) {
+  if (bf_all) {
     const int rc = field_mlp_bwd_bf16(cfg_id, mode, 0, p, bf16_pack, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector,
                                       d_density, d_rgb, d_logit, df2, ws.d_h, ws.gsum_tile, gsum_extra, partials, blocks, st);
     if (rc) return rc;
@@ -910,7 +900,7 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                        ws.d_h, ws.gsum_tile, gsum_extra, partials);
   }
   FNR_LAUNCH_CHECK();
-  auto color_tails = [&]() -> int {
+  {
     // per-ray finish of mlp_head layer 0: every workgroup owns one partial image row that exists
     long long rb = (rd.n_rays + RAYG_RB - 1) / RAYG_RB;
     if (rb > blocks) rb = blocks;
@@ -924,15 +914,8 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
       hipLaunchKernelGGL((k_embedding_grad<Cfg, false>), dim3((unsigned)net->n_images), dim3(1024), 0, st, rd, ws.g_ray,
                          packed, grads->embedding, WeightAdam{});
     FNR_LAUNCH_CHECK();
-    return FNR_OK;
-  };
-  if (phases == 3) {   // the one-call order (colour tails right behind the colour branch)
-    const int rc = color_tails();
-    if (rc) return rc;
   }
-  if (!ph_main) {
-    // phase 2 alone
-  } else if (bf_sem_big) {
+  if (bf_sem_big) {
     int rc = field_mlp_bwd_sem_big_bf16(mode, p, bf16_image, packed, N, h_saved, d_logit, partials, blocks, st);
     if (rc) return rc;
     rc = field_mlp_bwd_bf16(cfg_id, mode, 2, p, false, packed, bf16_image, ray_bias, rd, S, N, f2, h_saved, selector, d_density,
@@ -956,20 +939,10 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
                        partials);
     FNR_LAUNCH_CHECK();
   }
-  if (!bf_all && ph_main) {
+  if (!bf_all) {
     hipLaunchKernelGGL((k_field_mlp_bwd_base<Cfg, 8>), grid, dim3(512), 0, st, packed, N, f2, selector, d_density, ws.d_h,
                        df2, partials);
     FNR_LAUNCH_CHECK();
-  }
-  // fp32 chains: their base-branch kernel does not carry the contraction with the encode's Jacobian
-  if (jac && d_pos && !bf_all && ph_main) {
-    const int rc = position_contract(N, net->grid.n_levels, jac, df2, d_pos, st);
-    if (rc) return rc;
-  }
-  if (!ph_tails) return FNR_OK;
-  if (phases == 2) {
-    const int rc = color_tails();
-    if (rc) return rc;
   }
   constexpr int TOT = Cfg::W_TOTAL + Cfg::B_TOTAL;
   if (wadam)
@@ -979,6 +952,8 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     hipLaunchKernelGGL((k_reduce_dw<Cfg, false>), dim3((TOT + RD_IDX - 1) / RD_IDX), dim3(RD_IDX * RD_Y), 0, st, partials,
                        (int)blocks, gp, WeightAdam{});
   FNR_LAUNCH_CHECK();
+  // fp32 chains: their base-branch kernel does not carry the contraction with the encode's Jacobian
+  if (jac && d_pos && !bf_all) return position_contract(N, net->grid.n_levels, jac, df2, d_pos, st);
   return FNR_OK;
 }
 }  // namespace
@@ -993,7 +968,7 @@ static int field_mlp_bwd_entry(const fnr_field_net* net, const fnr_field_net* gr
                                  const float* packed_saved, const uint8_t* selector, const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
                                  void* workspace, size_t workspace_bytes, void* stream, const float* jacobian,
                                float* d_position, const fnr_table_adam* weight_adam = nullptr,
-                               const float* grad_arena = nullptr, int phases = 3) {
+                               const float* grad_arena = nullptr) {
   WeightAdam wa{};
   if (weight_adam) {
     FNR_CHECK_ARG(grad_arena, "field_mlp_bwd_adam: grad_arena missing");
@@ -1022,14 +997,14 @@ static int field_mlp_bwd_entry(const fnr_field_net* net, const fnr_field_net* gr
                 "field_mlp_bwd: workspace too small");
   const BwdWorkspace ws = bwd_workspace(workspace, rays->n_rays, S);
   const RaysDev rd = make_rays(rays);
-  FNR_PROF(phases == 2 ? -1 : OP_MLP_BWD, N);   // (phase 2 alone is never event-timed: bench.py's timed steps use the one-call form)
+  FNR_PROF(OP_MLP_BWD, N);
   if (cfg == 0)
     return field_mlp_bwd_launch<FieldCfgBase>(p, gp, net, grads, rd, S, N, feats, h_saved, ray_bias_saved, packed_saved,
                                               selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream), jacobian, d_position,
-                                              weight_adam ? &wa : nullptr, phases);
+                                              weight_adam ? &wa : nullptr);
   return field_mlp_bwd_launch<FieldCfgBig>(p, gp, net, grads, rd, S, N, feats, h_saved, ray_bias_saved, packed_saved,
                                            selector, d_density, d_rgb, d_logit, d_feats, ws, as_stream(stream), jacobian, d_position,
-                                              weight_adam ? &wa : nullptr, phases);
+                                              weight_adam ? &wa : nullptr);
 }
 
 extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
@@ -1052,21 +1027,6 @@ extern "C" int fnr_field_mlp_bwd_adam(const fnr_field_net* net, const fnr_field_
   return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
                              d_logit, d_feats, workspace, workspace_bytes, stream, jacobian, d_position, weight_adam,
                              grad_arena);
-}
-
-extern "C" int fnr_field_mlp_bwd_adam_phase(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays,
-                                            int S, const float* feats, const float* h_saved, const float* ray_bias_saved,
-                                            const float* packed_saved, const uint8_t* selector, const float* d_density,
-                                            const float* d_rgb, const float* d_logit, float* d_feats,
-                                            const float* jacobian, float* d_position, const fnr_table_adam* weight_adam,
-                                            const float* grad_arena, void* workspace, size_t workspace_bytes, int phase,
-                                            void* stream) {
-  FNR_CHECK_ARG(weight_adam && grad_arena, "field_mlp_bwd_adam_phase: weight_adam / grad_arena missing");
-  FNR_CHECK_ARG((jacobian == nullptr) == (d_position == nullptr), "field_mlp_bwd_adam_phase: jacobian and d_position go together");
-  FNR_CHECK_ARG(phase == 1 || phase == 2, "field_mlp_bwd_adam_phase: phase %d (1 = branch kernels, 2 = weight-gradient tails)", phase);
-  return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
-                             d_logit, d_feats, workspace, workspace_bytes, stream, jacobian, d_position, weight_adam,
-                             grad_arena, phase);
 }
 
 extern "C" int fnr_field_mlp_bwd_rays(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,

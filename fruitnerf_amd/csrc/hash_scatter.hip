@@ -54,14 +54,7 @@ struct ScatterPlan {
 static ScatterPlan scatter_plan(long long N, int n_levels, int log2_T) {
   ScatterPlan p;
   int log2_rows = log2_T - 5;  // at least 32 bins per level (measured best for the 2^17-row proposal tables) ...
-  // ... but at most 8192 rows per bin (128 KiB of accumulator: one accumulate workgroup per CU); FNR_SCATTER_LOG2_ROWS
-  // = 12 (A/B knob, read per call): 4096-row bins, two accumulate workgroups per CU, twice the bins per level
-  int rows_cap = 13;
-  if (const char* e = getenv("FNR_SCATTER_LOG2_ROWS")) {
-    const int v = atoi(e);
-    if (v >= 10 && v <= 13) rows_cap = v;
-  }
-  if (log2_rows > rows_cap) log2_rows = rows_cap;
+  if (log2_rows > 13) log2_rows = 13;  // ... but at most 8192 rows per bin
   if (log2_rows < 0) log2_rows = 0;
   p.log2_rows = log2_rows;
   p.bins_per_level = 1 << (log2_T - log2_rows);
@@ -217,14 +210,15 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     src.position(n, px, py, pz);
     warp_position(warp, px, py, pz, x);
   }
+  // Barriers per level (round 5: 6 -> 4 for bins <= 64): the bin counters and the level maximum are zeroed once here and
+  // again during each level's copy-out (nothing reads them there), so a level opens without a barrier of its own; and up
+  // to 64 bins are scanned + reserved by wave 0 alone, without the cross-wave step and its barrier.
+  for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) s_cnt[i] = 0;
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
   for (int li = 0; li < lpb && lrel0 + li < level_count; ++li) {
   const int lrel = lrel0 + li;           // level inside this call's range: indexes the counters and queues
   const int level = level0 + lrel;       // level of the grid: indexes scalings, d_feats and the gradient table
-  for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) {
-    s_cnt[i] = 0;
-  }
-  if (threadIdx.x == 0) s_max = 0;
-  __syncthreads();
   EMIT_T(0);
   const int scaling = grid.scalings[level];
   const float2 gf = gf_next;
@@ -304,6 +298,28 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   __syncthreads();
   EMIT_T(1);
   if (threadIdx.x == 0 && s_max != 0u) atomicMax(&qmax[(size_t)lrel * SC_CNT_STRIDE], s_max);
+  unsigned total = 0;
+  if (bins <= 64) {
+    // wave 0: exclusive scan of the per-bin counts by shuffles + one global reservation per non-empty bin
+    if (wave == 0) {
+      const unsigned c = (lane < bins) ? s_cnt[lane] : 0u;
+      unsigned incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned u = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += u;
+      }
+      if (lane < bins) {
+        s_off[lane] = incl - c;
+        s_base[lane] = c ? atomicAdd(&qcount[(size_t)(lrel * bins + lane) * SC_CNT_STRIDE], c) : 0u;
+        s_cnt[lane] = 0;
+      }
+      if (lane == 63) s_wsum[0] = incl;
+    }
+    __syncthreads();
+    EMIT_T(3);
+    total = s_wsum[0];
+  } else {
   // exclusive scan of the per-bin counts (bins <= 1024 = 4 per thread) + one global reservation per non-empty bin
   unsigned c4[SC_BINS_PER_THREAD], tsum = 0;
 #pragma unroll
@@ -323,7 +339,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   EMIT_T(2);
   unsigned woff = 0;
   for (int w = 0; w < wave; ++w) woff += s_wsum[w];
-  unsigned total = 0;
 #pragma unroll
   for (int w = 0; w < SC_EMIT_THREADS / 64; ++w) total += s_wsum[w];
   unsigned run = woff + incl - tsum;
@@ -339,6 +354,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   __syncthreads();
   EMIT_T(3);
+  }  // bins > 64
   // place the records bin by bin in LDS
 #pragma unroll
   for (int q = 0; q < SC_PER_THREAD; ++q) {
@@ -374,6 +390,10 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   __syncthreads();
   EMIT_T(4);
+  // (the cursors and the level maximum are dead from here on: zero them for the next level, whose count phase then starts
+  //  behind this level's closing barrier)
+  for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) s_cnt[i] = 0;
+  if (threadIdx.x == 0) s_max = 0;
   // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 8-byte + 2-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
   unsigned overflowed_here = 0;
@@ -632,14 +652,8 @@ __global__ __launch_bounds__(1024) void k_scatter_accumulate(AccArgs a) {
 }
 // two scatter calls in one launch (the two proposal levels' tables: 160 workgroups each on 256 CUs — side by side they
 // cost the longer of the two instead of their sum); the longer queues (call a) are dispatched first
-#ifndef FNR_ACC2_WAVES
-// minimum waves per SIMD the register allocation has to allow: 8 = TWO 1024-thread workgroups per CU.  The proposal
-// tables' 4096-row bins take 64 KiB of LDS each, but without the bound the kernel got 79 registers = 6 waves per SIMD =
-// ONE workgroup per CU, and a paired call's 320 workgroups ran as 256 + 64 (round 5; 48 registers with it, no spills)
-#define FNR_ACC2_WAVES 8
-#endif
 template <bool ADAM>
-__global__ __launch_bounds__(1024, FNR_ACC2_WAVES) void k_scatter_accumulate2(AccArgs a, AccArgs b) {
+__global__ __launch_bounds__(1024) void k_scatter_accumulate2(AccArgs a, AccArgs b) {
   unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(acc_smem);
   if ((int)blockIdx.x < a.nbins) accumulate_bin<ADAM>(a, (int)blockIdx.x, s_acc);
   else accumulate_bin<ADAM>(b, (int)blockIdx.x - a.nbins, s_acc);
@@ -758,11 +772,8 @@ static int binned_scatter(const fnr_grid* grid_grad, const Warp& warp, const Sou
 // ------------------------------------------------------------------------------------------------
 constexpr int PROP_PART = 320;   // floats per workgroup partial: dW0 tile 256 + dW1 16 + db0 16 + db1 (+ pad)
 
-#ifndef FNR_PROP_BWD_WAVES
-#define FNR_PROP_BWD_WAVES 3   // waves per SIMD the register allocation has to allow = workgroups per CU (LDS allows 3)
-#endif
 template <int L, int H, bool POSGRAD>
-__global__ __launch_bounds__(256, FNR_PROP_BWD_WAVES) void k_prop_bwd(GridDev grid, float4* __restrict__ d_xw, Warp warp, RaySource src,
+__global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restrict__ d_xw, Warp warp, RaySource src,
                                                   long long N, const float* __restrict__ w0,
                                                   const float* __restrict__ b0, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float2* __restrict__ feat_save,
@@ -773,31 +784,7 @@ __global__ __launch_bounds__(256, FNR_PROP_BWD_WAVES) void k_prop_bwd(GridDev gr
   __shared__ float s_ha[256][H + 1];   // relu(hidden) * d_out  (for dW1)
   __shared__ float s_f[256][K + 1];    // input features
   __shared__ float s_do[256];          // d_out
-  // The network's 16 x K + 33 weights, staged once.  As uniform (scalar) loads from global memory the compiler hoisted all
-  // of them out of the persistent loop: 193 live scalars against 102 scalar registers — 302 of them spilled into vector
-  // register LANES, and every use became a v_readlane (311 of the loop's 1499 vector instructions, plus the moves around
-  // them; round 5, tools/isa_mix.py).  From LDS they are broadcast ds_read_b128 whose values feed packed FMAs directly
-  // (v_pk_fma_f32: two hidden units per instruction in the forward recompute, two features per instruction in the
-  // backward), the barriers of the loop keep them from being hoisted, and the loop drops to ~900 vector instructions.
-  //   s_wf (forward):  pair p of hidden units, entry k: (w0[2p][k], w0[2p+1][k]); entry K: (b0, b0'); entry K+1: (w1, w1')
-  //   s_wb (backward): row o: w0[o][0 .. K-1], w1[o], padding to a multiple of 4 floats
-  typedef float f2v __attribute__((ext_vector_type(2)));
-  constexpr int RSF = K + 2, RSB = (K + 1 + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) f2v s_wf[(H / 2) * RSF];
-  __shared__ __attribute__((aligned(16))) float s_wb[H * RSB];
   static_assert(H == 16 && K <= 16, "phase 2 is a single 16x16 MFMA tile");
-  for (int i = threadIdx.x; i < (H / 2) * RSF; i += 256) {
-    const int pr = i / RSF, c = i - pr * RSF, o = 2 * pr;
-    f2v v;
-    v.x = c < K ? w0[o * K + c] : c == K ? b0[o] : w1[o];
-    v.y = c < K ? w0[(o + 1) * K + c] : c == K ? b0[o + 1] : w1[o + 1];
-    s_wf[i] = v;
-  }
-  for (int i = threadIdx.x; i < H * RSB; i += 256) {
-    const int o = i / RSB, c = i - o * RSB;
-    s_wb[i] = c < K ? w0[o * K + c] : c == K ? w1[o] : 0.0f;
-  }
-  __syncthreads();
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -826,44 +813,31 @@ __global__ __launch_bounds__(256, FNR_PROP_BWD_WAVES) void k_prop_bwd(GridDev gr
         f[2 * l + 1] = v.y;
       }
     }
-    // the pre-activations are not kept: relu(a) goes to LDS right away (phase 2 multiplies it by the sample's d_out,
-    // the same product as before, formed later) and the backward pass below only needs the sign bits — 16 registers less
-    unsigned active = 0u;
+    float a[H];
     float out = b1[0];
 #pragma unroll
-    for (int pr = 0; pr < H / 2; ++pr) {   // hidden units 2 pr, 2 pr + 1: each sums b0 + w0[.][0] f[0] + ... in that order
-      const f2v* row = &s_wf[pr * RSF];
-      f2v t = row[K];
+    for (int o = 0; o < H; ++o) {
+      float t = b0[o];
 #pragma unroll
-      for (int k = 0; k < K; ++k) t = __builtin_elementwise_fma(row[k], f2v{f[k], f[k]}, t);
-      const float r0 = fmaxf(t.x, 0.0f), r1 = fmaxf(t.y, 0.0f);
-      s_ha[tid][2 * pr] = r0;
-      s_ha[tid][2 * pr + 1] = r1;
-      active |= (t.x > 0.0f ? 1u : 0u) << (2 * pr) | (t.y > 0.0f ? 2u : 0u) << (2 * pr);
-      const f2v w1p = row[K + 1];
-      out = fmaf(w1p.x, r0, out);
-      out = fmaf(w1p.y, r1, out);
+      for (int k = 0; k < K; ++k) t = fmaf(w0[o * K + k], f[k], t);
+      a[o] = t;
+      out = fmaf(w1[o], fmaxf(t, 0.0f), out);
     }
     if (n < N && sel) dout = d_density[n] * expf(fminf(fmaxf(out, -15.0f), 15.0f));  // trunc_exp backward
-    f2v df2[K / 2];
-#pragma unroll
-    for (int k = 0; k < K / 2; ++k) df2[k] = f2v{0.0f, 0.0f};
-#pragma unroll
-    for (int o = 0; o < H; ++o) {
-      const float* row = &s_wb[o * RSB];
-      const float dh = ((active >> o) & 1u) ? dout * row[K] : 0.0f;
-      s_dh[tid][o] = dh;
-      const f2v* row2 = reinterpret_cast<const f2v*>(row);
-#pragma unroll
-      for (int k = 0; k < K / 2; ++k) df2[k] = __builtin_elementwise_fma(f2v{dh, dh}, row2[k], df2[k]);
-    }
     float df[K];
 #pragma unroll
-    for (int k = 0; k < K / 2; ++k) df[2 * k] = df2[k].x, df[2 * k + 1] = df2[k].y;
+    for (int k = 0; k < K; ++k) df[k] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < H; ++o) {
+      const float dh = (a[o] > 0.0f) ? dout * w1[o] : 0.0f;
+      s_dh[tid][o] = dh;
+      s_ha[tid][o] = fmaxf(a[o], 0.0f) * dout;
+#pragma unroll
+      for (int k = 0; k < K; ++k) df[k] = fmaf(dh, w0[o * K + k], df[k]);
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) s_f[tid][k] = f[k];
     db1 += dout;
-    s_do[tid] = dout;
     if (n < N) {
 #pragma unroll
       for (int l = 0; l < L; ++l) d_feats[(size_t)l * N + n] = make_float2(df[2 * l], df[2 * l + 1]);
@@ -904,7 +878,7 @@ __global__ __launch_bounds__(256, FNR_PROP_BWD_WAVES) void k_prop_bwd(GridDev gr
 #pragma unroll 4
     for (int st = 0; st < 16; ++st) {
       const int row = row0 + 4 * st;
-      const float a1 = s_dh[row][j], a2 = s_ha[row][j] * s_do[row];   // relu(hidden) * d_out
+      const float a1 = s_dh[row][j], a2 = s_ha[row][j];
       const float bf = (j < K) ? s_f[row][j < K ? j : 0] : 0.0f;
       d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, d1, 0, 0, 0);
       d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, ones_col0, d2, 0, 0, 0);

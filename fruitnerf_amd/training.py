@@ -835,12 +835,6 @@ class _ForkJoin:
 
     def __init__(self, main):
         self.main, self.open, self.segments, self.joins = main, None, 0, 0
-        self.extra = []        # further streams forked off the launch stream during this call (joined with the second one)
-
-    def fork_extra(self, stream, event):
-        """A third stream that runs work enqueued behind `event` (recorded on the launch stream during this call)."""
-        stream.wait_event(event)
-        self.extra.append(stream)
 
     def fork(self, side, event=None):
         if event is not None:
@@ -855,12 +849,9 @@ class _ForkJoin:
             self.main.wait_stream(self.open)
             self.open = None
             self.joins += 1
-        for st in self.extra:
-            self.main.wait_stream(st)
-        self.extra = []
 
     def check(self):
-        if self.open is not None or self.extra:
+        if self.open is not None:
             raise RuntimeError("fused_forward_backward: returning with unjoined work on the second stream")
 
 
@@ -980,41 +971,13 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         fld = model.field
         net, gnet = fld.net_struct(), fld.net_struct(grads=True)
         d_pos = None
-        # The weight-gradient tails of the MLP backward (k_color_ray_grads, k_embedding_grad, k_reduce_dw with their
-        # optimiser steps: ~28 us of small latency-bound launches) feed nothing but the NEXT forward's weight preparation.
-        # On a step whose second-stream segment starts right behind the MLP backward (no proposal backward: tail()
-        # below) they open that segment and run underneath the table scatter instead of ahead of it
-        # (fnr_field_mlp_bwd_adam_phase; same kernels on the same values: bit-identical, tests/test_gpu_determinism.py).
-        mlp_tails = None
-        split_tails = bool(MLP_TAILS_ON_SIDE and weight_adam is not None and tail_on_side and exchange is None
-                           and not prop_bwd and not serialize_streams)
-        # ... and on the steps WITH a proposal backward (the second stream is the longer chain there) on a third stream of
-        # their own (MLP_TAILS_THIRD_STREAM, A/B knob): forked behind the branch kernels, joined at the end of the call
-        tails_third = bool(MLP_TAILS_THIRD_STREAM and weight_adam is not None and overlap_proposal_backward and
-                           exchange is None and not serialize_streams and not split_tails)
-        split_tails = split_tails or tails_third
         if ray_grads is not None and rctx.field_jacobian is not None:
-            res = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector,
-                                  d_density, d_rgb_s, d_logit, jacobian=rctx.field_jacobian,
-                                  weight_adam=weight_adam, defer_tails=split_tails)
-            d_feats, d_pos = res[0], res[1]
-            mlp_tails = res[2] if split_tails else None
+            d_feats, d_pos = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector,
+                                             d_density, d_rgb_s, d_logit, jacobian=rctx.field_jacobian,
+                                             weight_adam=weight_adam)
         else:
-            res = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
-                                  d_rgb_s, d_logit, weight_adam=weight_adam, defer_tails=split_tails)
-            d_feats, mlp_tails = (res[0], res[1]) if split_tails else (res, None)
-        if tails_third:
-            third = model.__dict__.get("_third_stream")
-            if third is None or third.device != dev:
-                third = model.__dict__["_third_stream"] = torch.cuda.Stream(device=dev)
-                model.__dict__["_third_event"] = torch.cuda.Event()
-            ev3 = model.__dict__["_third_event"]
-            ev3.record(main)                           # the branch kernels are enqueued
-            fj.fork_extra(third, ev3)
-            with torch.cuda.stream(third):
-                mlp_tails()
-            model.__dict__["_mlp_tails_third"] = model.__dict__.get("_mlp_tails_third", 0) + 1
-            mlp_tails = None
+            d_feats = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
+                                      d_rgb_s, d_logit, weight_adam=weight_adam)
         field_source = None
         if ray_grads is not None:
             if d_pos is not None:
@@ -1067,10 +1030,6 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 fj.fork(side_, None if serialize_streams else tail_ready)
                 crosses_to(side_, ray_sources, field_source, d_o, d_d, rays)
             with torch.cuda.stream(side_):
-                if first and mlp_tails is not None:
-                    crosses_to(side_, rctx, d_rgb_s, d_logit, d_density, d_feats, d_pos)
-                    mlp_tails()                    # phase 2 of the MLP backward, underneath the table scatter
-                    model.__dict__["_mlp_tails_split"] = model.__dict__.get("_mlp_tails_split", 0) + 1
                 if first and not sources_early:
                     if ray_grads is not None:
                         K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
@@ -1104,7 +1063,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             fj.join()                              # every local of this call outlives the second stream's launches
             fj.check()
             return loss_dict, metrics_dict
-        if side is not None or fj.extra:
+        if side is not None:
             fj.join()                              # proposal gradients (and their ray-gradient sources) are final
             for src in ray_sources or ():
                 src[3].record_stream(main)
@@ -1174,10 +1133,6 @@ PAIR_PROPOSAL_LEVELS = os.environ.get("FNR_PAIR_PROPOSAL_LEVELS", "1") != "0"   
 # The losses launch on the second stream, the composite backward forming its own per-ray loss gradients (see
 # fused_forward_backward).  FNR_LOSSES_ON_SIDE=0: losses on the launch stream ahead of the backward, as before (A/B).
 LOSSES_ON_SIDE = os.environ.get("FNR_LOSSES_ON_SIDE", "1") != "0"
-# The MLP backward's weight-gradient tails on the second stream (steps without a proposal backward; see
-# fused_forward_backward).  FNR_MLP_TAILS_ON_SIDE=0: the one-call form, everything on the launch stream (A/B).
-MLP_TAILS_ON_SIDE = os.environ.get("FNR_MLP_TAILS_ON_SIDE", "1") != "0"
-MLP_TAILS_THIRD_STREAM = os.environ.get("FNR_MLP_TAILS_THIRD_STREAM", "0") == "1"
 FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
 FUSE_WEIGHT_OPTIMIZER = True  # ... and the field's MLP weights + embedding step inside k_reduce_dw / k_embedding_grad
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter

@@ -365,22 +365,6 @@ int fnr_field_mlp_bwd_adam(const fnr_field_net* net, const fnr_field_net* grads,
                            float* d_position /* optional */, const struct fnr_table_adam* weight_adam,
                            const float* grad_arena, void* workspace, size_t workspace_bytes, void* stream);
 
-/* fnr_field_mlp_bwd_adam in two calls, so that a caller with two streams can take the weight-gradient tails off the
- * step's critical chain (ABI 11).  phase 1: the branch kernels (colour, semantic, base) — everything d_feats / d_position
- * depend on, i.e. what the table scatter waits for; phase 2: k_color_ray_grads, k_embedding_grad and k_reduce_dw (the
- * per-ray finish of mlp_head's first layer, the appearance-embedding gradient, the fixed-order sum of the per-workgroup
- * partial images, each with its optimiser step) — ~28 us of small latency-bound launches whose only consumer is the NEXT
- * forward's weight preparation.  Same arguments and the SAME workspace in both calls; phase 2 may be enqueued on another
- * stream once that stream waits for phase 1 (the caller orders the streams and keeps the workspace alive until phase 2
- * has run).  The kernels write disjoint regions of the partial images, so the results are bit-identical to the one-call
- * form (tests/test_gpu_determinism.py).  No counterpart in the reference (autograd orders its own launches). */
-int fnr_field_mlp_bwd_adam_phase(const fnr_field_net* net, const fnr_field_net* grads, const fnr_rays* rays, int S,
-                                 const float* feats, const float* h_saved, const float* ray_bias_saved /* optional */,
-                                 const float* packed_saved /* optional */, const uint8_t* selector,
-                                 const float* d_density, const float* d_rgb, const float* d_logit, float* d_feats,
-                                 const float* jacobian, float* d_position, const fnr_table_adam* weight_adam,
-                                 const float* grad_arena, void* workspace, size_t workspace_bytes, int phase,
-                                 void* stream);
 
 /* Backward of fnr_hash_encode_fwd: adds (+=) the trilinear scatter of d_feats [L][N][2] into
  * grid_grad->table for the levels [level_begin, level_begin + level_count) (all levels: 0, n_levels; data-parallel

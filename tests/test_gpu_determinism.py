@@ -68,7 +68,6 @@ def _run(dev, steps, mlp_precision, overlap=None, prologue=True, ahead=None, tor
     finally:
         T.OVERLAP_PROPOSAL_BACKWARD, T.SAMPLE_AHEAD, T.FUSE_WEIGHT_OPTIMIZER = saved
     torch.cuda.synchronize()
-    _run.last_model = hm
     return (hm.arena().params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), cam_opt.pose_adjustment.data.clone(),
             torch.stack(losses))
 
@@ -112,33 +111,19 @@ def test_paired_proposal_levels_are_the_separate_calls(dev):
 
 
 @pytest.mark.parametrize("mlp_precision", ["bf16x3", "fp32"])
-def test_mlp_backward_tails_on_the_second_stream_change_nothing(dev, mlp_precision):
-    """training.MLP_TAILS_ON_SIDE (round 5): on steps without a proposal backward the MLP backward's weight-gradient tails
-    (k_color_ray_grads, k_embedding_grad, k_reduce_dw + their optimiser steps: fnr_field_mlp_bwd_adam_phase, phase 2) open
-    the second stream's segment and run underneath the table scatter.  60 steps (every step trains the proposal networks
-    until step 10, every other one after: both step shapes) with the split against the one-call form: identical
-    parameters, moments, poses, losses."""
+def test_losses_on_the_second_stream_change_nothing(dev, mlp_precision):
+    """training.LOSSES_ON_SIDE (round 5): the losses launch heads the second stream's segment and the composite backward
+    forms the per-ray loss gradients itself (fnr_composite_bwd_targets) — against the losses launch ahead of the backward
+    on the launch stream (fnr_train_losses -> fnr_composite_bwd).  60 steps (every step trains the proposal networks until
+    step 10, every other one after: both step shapes): identical parameters, moments, poses and logged losses."""
     import fruitnerf_amd.training as T
     on = _run(dev, 60, mlp_precision)
-    assert _run.last_model.__dict__.get("_mlp_tails_split", 0) == 25     # steps 11, 13, ..., 59: no proposal backward
-    saved, T.MLP_TAILS_ON_SIDE = T.MLP_TAILS_ON_SIDE, False
-    try:
-        off = _run(dev, 60, mlp_precision)
-    finally:
-        T.MLP_TAILS_ON_SIDE = saved
-    assert _run.last_model.__dict__.get("_mlp_tails_split", 0) == 0
-    assert saved is True                     # the default under test
-    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), on, off):
-        assert torch.equal(x, y), f"{name} differ between the split and the one-call MLP backward"
-    # training.LOSSES_ON_SIDE (round 5): the losses launch heads the second stream's segment and the composite backward
-    # forms the per-ray loss gradients itself (fnr_composite_bwd_targets) — against the losses launch ahead of the backward
-    # on the launch stream (fnr_train_losses -> fnr_composite_bwd): the same bits, logged losses included
     saved, T.LOSSES_ON_SIDE = T.LOSSES_ON_SIDE, False
     try:
         inline = _run(dev, 60, mlp_precision)
     finally:
         T.LOSSES_ON_SIDE = saved
-    assert saved is True
+    assert saved is True                     # the default under test
     for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), on, inline):
         assert torch.equal(x, y), f"{name} differ between the losses launch on the second stream and on the launch stream"
 

@@ -212,13 +212,14 @@ def test_sparse_touch_bitmap_survives_an_overflowing_scatter(dev):
     finally:
         T.SPARSE_TOUCH_SKIPPING = saved
     # The overflow fallback adds floats with global atomics, so the 256 hot rows' sums (2 points x 8 corners x 16 levels)
-    # differ in their last bits from run to run (include/fruitnerf_hip.h, fnr_debug_scatter_overflows): those entries are
-    # compared to 1e-4 — a row whose moments had stopped decaying would be 19 % off after two steps (beta1^2 = 0.81) —
+    # differ in their last digits from run to run (include/fruitnerf_hip.h, fnr_debug_scatter_overflows; measured: up to
+    # 1.5e-4 relative on a parameter after three steps): those entries are compared to 2e-3 — a row whose moments had
+    # stopped decaying would be 19 % off after two steps (beta1^2 = 0.81), its parameter a whole step (2.5 %) —
     # and every other entry bit for bit.
     for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), *states):
         n_diff = int((x != y).sum())
         assert n_diff <= 512, f"{name}: {n_diff} entries differ between the sparse-touch and the dense sweeps"
-        assert torch.allclose(x, y, rtol=1e-4, atol=1e-12), \
+        assert torch.allclose(x, y, rtol=2e-3, atol=1e-6), \
             f"{name}: max rel diff {float(((x - y).abs() / y.abs().clamp_min(1e-12)).max()):.3e} — rows frozen by a missing bit?"
     m_hot = states[0][1].abs() > 1e-3           # the hot rows' first moments: 0.1 x 0.81 x a sum of ~1e5 gradients of 1e-3
     assert 16 <= int(m_hot.sum()) <= 512, int(m_hot.sum())

@@ -66,14 +66,3 @@ def test_scatter_kernels_use_no_scratch_and_keep_three_emit_workgroups_per_cu(sc
         if "k_scatter_emit" in name:
             assert 3 * ((lds + 511) // 512 * 512) <= 160 * 1024, (name, lds)
 
-
-def test_paired_accumulate_kernel_fits_two_workgroups_per_cu(scatter_asm):
-    """Round 5: k_scatter_accumulate2 (both proposal tables' accumulate in one launch, 320 workgroups of 1024 threads with
-    64 KiB of LDS each) had 79 registers — 6 waves per SIMD, ONE workgroup per CU, 256 + 64 — until its launch bounds asked
-    for 8 waves per SIMD.  Two workgroups per CU need <= 64 registers per lane (MI355X_MICROARCH: 512 / 64 = 8 waves)."""
-    text = "\n".join(scatter_asm)
-    meta = re.findall(r"\.name:\s*(\S+)\s*\n(?:.*\n)*?\s*\.vgpr_count:\s*(\d+)", text)
-    regs = {name: int(v) for name, v in meta if "k_scatter_accumulate2" in name}
-    assert len(regs) == 2, regs
-    for name, v in regs.items():
-        assert v <= 64, (name, v)
