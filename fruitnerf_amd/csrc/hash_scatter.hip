@@ -210,15 +210,14 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     src.position(n, px, py, pz);
     warp_position(warp, px, py, pz, x);
   }
-  // Barriers per level (round 5: 6 -> 4 for bins <= 64): the bin counters and the level maximum are zeroed once here and
-  // again during each level's copy-out (nothing reads them there), so a level opens without a barrier of its own; and up
-  // to 64 bins are scanned + reserved by wave 0 alone, without the cross-wave step and its barrier.
-  for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) s_cnt[i] = 0;
-  if (threadIdx.x == 0) s_max = 0;
-  __syncthreads();
   for (int li = 0; li < lpb && lrel0 + li < level_count; ++li) {
   const int lrel = lrel0 + li;           // level inside this call's range: indexes the counters and queues
   const int level = level0 + lrel;       // level of the grid: indexes scalings, d_feats and the gradient table
+  for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) {
+    s_cnt[i] = 0;
+  }
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
   EMIT_T(0);
   const int scaling = grid.scalings[level];
   const float2 gf = gf_next;
@@ -298,28 +297,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   __syncthreads();
   EMIT_T(1);
   if (threadIdx.x == 0 && s_max != 0u) atomicMax(&qmax[(size_t)lrel * SC_CNT_STRIDE], s_max);
-  unsigned total = 0;
-  if (bins <= 64) {
-    // wave 0: exclusive scan of the per-bin counts by shuffles + one global reservation per non-empty bin
-    if (wave == 0) {
-      const unsigned c = (lane < bins) ? s_cnt[lane] : 0u;
-      unsigned incl = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned u = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += u;
-      }
-      if (lane < bins) {
-        s_off[lane] = incl - c;
-        s_base[lane] = c ? atomicAdd(&qcount[(size_t)(lrel * bins + lane) * SC_CNT_STRIDE], c) : 0u;
-        s_cnt[lane] = 0;
-      }
-      if (lane == 63) s_wsum[0] = incl;
-    }
-    __syncthreads();
-    EMIT_T(3);
-    total = s_wsum[0];
-  } else {
   // exclusive scan of the per-bin counts (bins <= 1024 = 4 per thread) + one global reservation per non-empty bin
   unsigned c4[SC_BINS_PER_THREAD], tsum = 0;
 #pragma unroll
@@ -339,6 +316,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   EMIT_T(2);
   unsigned woff = 0;
   for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+  unsigned total = 0;
 #pragma unroll
   for (int w = 0; w < SC_EMIT_THREADS / 64; ++w) total += s_wsum[w];
   unsigned run = woff + incl - tsum;
@@ -354,7 +332,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   __syncthreads();
   EMIT_T(3);
-  }  // bins > 64
   // place the records bin by bin in LDS
 #pragma unroll
   for (int q = 0; q < SC_PER_THREAD; ++q) {
@@ -390,10 +367,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   __syncthreads();
   EMIT_T(4);
-  // (the cursors and the level maximum are dead from here on: zero them for the next level, whose count phase then starts
-  //  behind this level's closing barrier)
-  for (int i = threadIdx.x; i < bins; i += SC_EMIT_THREADS) s_cnt[i] = 0;
-  if (threadIdx.x == 0) s_max = 0;
   // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 8-byte + 2-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
   unsigned overflowed_here = 0;
