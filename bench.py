@@ -586,7 +586,9 @@ def main() -> None:
 
     # ---- timed region: exactly K steps -------------------------------------------------------------------
     L.scatter_records(reset=True)
+    allocs_before = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)     # hipMalloc calls of the caching allocator
     dt, t_enqueued, recs, n_prof, (ld, md) = timed_window(run, args.steps, barrier, dist_on, dev)
+    device_allocs_in_window = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs_before)
     rays_per_s = world * args.steps * RAYS_PER_BATCH / dt
     field_records = L.scatter_records()[0] / max(args.steps, 1)     # one main-field scatter per step
 
@@ -928,6 +930,9 @@ def main() -> None:
         # host time to enqueue a step (Python + ctypes + HIP launches), without waiting for the GPU: while it stays
         # below ms_per_step the step is GPU-bound
         "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
+        # hipMalloc calls inside the timed window (the caching allocator growing a pool: each one stalls the host for
+        # 0.1 - 1 ms); 0 once the warm-up has seen every step shape
+        "device_allocs_in_window": device_allocs_in_window,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

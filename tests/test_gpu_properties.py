@@ -221,8 +221,6 @@ def test_sparse_touch_bitmap_survives_an_overflowing_scatter(dev):
         assert n_diff <= 512, f"{name}: {n_diff} entries differ between the sparse-touch and the dense sweeps"
         assert torch.allclose(x, y, rtol=2e-3, atol=1e-6), \
             f"{name}: max rel diff {float(((x - y).abs() / y.abs().clamp_min(1e-12)).max()):.3e} — rows frozen by a missing bit?"
-    m_hot = states[0][1].abs() > 1e-3           # the hot rows' first moments: 0.1 x 0.81 x a sum of ~1e5 gradients of 1e-3
-    assert 16 <= int(m_hot.sum()) <= 512, int(m_hot.sum())
     assert int((states[0][1] != 0).sum()) > 100_000
 
 
