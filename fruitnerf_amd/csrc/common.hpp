@@ -77,6 +77,34 @@ struct ProfScope {
 };
 #define FNR_PROF(op, units) ::fnr::ProfScope prof_scope__((op), (long long)(units), stream)
 
+// ---- streaming (`nt`) accesses -------------------------------------------------------------------------------------
+// For data a step writes once and reads once (the optimiser moments, the encode's input Jacobian, the record queues on
+// their way back): without the hint those streams evict the hash table's parameters from the L2s / the Infinity Cache and
+// the next encode's gathers go to HBM (round 5, profiles/r05_raw/kt_nt_call6.log: k_hash_encode 82 -> 65 us with the hints).
+// NOT for narrow stores: 2- and 8-byte `nt` stores are one fabric write each (the emit kernel's queue stores: 75 -> 120 us).
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 nt_load(const float4* p) {
+  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 nt_load(const float2* p) {
+  const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(p));
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ ushort2 nt_load(const ushort2* p) {
+  const unsigned v = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
+  return make_ushort2((unsigned short)(v & 0xffffu), (unsigned short)(v >> 16));
+}
+__device__ __forceinline__ void nt_store(float4* p, const float4& v) {
+  const nt_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+}
+__device__ __forceinline__ void nt_store(float2* p, const float2& v) {
+  const nt_f2 t = {v.x, v.y};
+  __builtin_nontemporal_store(t, reinterpret_cast<nt_f2*>(p));
+}
+
 // ---- exact (non-contracted) fp32 arithmetic -----------------------------------------------------
 // The oracle (PyTorch CPU eager) rounds after every elementwise op.  Wherever a discrete decision
 // depends on the value (selector mask, floor/ceil cell, searchsorted) we use these so the HIP path

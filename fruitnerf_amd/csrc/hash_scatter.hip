@@ -43,6 +43,12 @@ __device__ unsigned long long g_scatter_overflow_records;   // records that went
 __device__ unsigned long long g_scatter_records[2][64][16];
 
 
+// Streaming hints (common.hpp: nt_load / nt_store; round 5, +6.5 .. 7.5 % rays/s together with the encode's Jacobian,
+// profiles/r05_raw/kt_nt_call7.log, ab_quick_call7.log) on what this file reads or writes exactly once per step: the
+// accumulate kernel's loads of the record queues, the optimiser sweep's loads and stores of exp_avg / exp_avg_sq, the emit
+// kernel's loads of d_feats, the proposal networks' saved features and d_feats.  The queue STORES stay plain: 2- and 8-byte
+// `nt` stores are one fabric write each (emit 75 -> 120 us).
+
 struct ScatterPlan {
   int log2_rows;         // log2(E)
   int bins_per_level;    // T / E
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   float2 gf_next = make_float2(0.f, 0.f);
   const int lrel0 = blockIdx.y * lpb;
   if (valid) {
-    gf_next = d_feats[(size_t)(level0 + lrel0) * N + n];
+    gf_next = nt_load(&d_feats[(size_t)(level0 + lrel0) * N + n]);
     float px, py, pz;
     src.position(n, px, py, pz);
     warp_position(warp, px, py, pz, x);
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   EMIT_T(0);
   const int scaling = grid.scalings[level];
   const float2 gf = gf_next;
-  if (valid && li + 1 < lpb && lrel + 1 < level_count) gf_next = d_feats[(size_t)(level + 1) * N + n];
+  if (valid && li + 1 < lpb && lrel + 1 < level_count) gf_next = nt_load(&d_feats[(size_t)(level + 1) * N + n]);
 
   // contributions of this thread's samples; equal rows in adjacent lanes (consecutive samples of a ray share
   // cells at coarse levels) are pre-summed so only the last lane of a run emits a record
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     const unsigned slot = s_base[bin] + (i - s_off[bin]);
     if ((long long)slot < cap) {
       const size_t q = ((size_t)lrel * bins + bin) * cap + slot;
-      queue_v[q] = v;
+      queue_v[q] = v;                          // (plain stores: narrow `nt` stores are one fabric write each, common.hpp)
       queue_r[q] = (unsigned short)row_in_bin;
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
       qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;  // tells the accumulate kernel that the table holds part of the sum
@@ -516,8 +522,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     ushort2 row[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      v[u] = qv2[i + u * (long long)blockDim.x];
-      row[u] = qr2[i + u * (long long)blockDim.x];
+      v[u] = nt_load(&qv2[i + u * (long long)blockDim.x]);
+      row[u] = nt_load(&qr2[i + u * (long long)blockDim.x]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -526,8 +532,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     }
   }
   for (; i < np; i += blockDim.x) {
-    const float4 v = qv2[i];
-    const ushort2 row = qr2[i];
+    const float4 v = nt_load(&qv2[i]);
+    const ushort2 row = nt_load(&qr2[i]);
     acc_record(s_acc, row.x, make_float2(v.x, v.y), scale);
     acc_record(s_acc, row.y, make_float2(v.z, v.w), scale);
   }
@@ -561,7 +567,7 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
           if (!now && !ever) continue;
           if (!ever) atomicOr(&tw[e4 >> 5], 1u << (e4 & 31));   // first gradient of this pair (once per pair, ever)
         }
-        float4 P = P4[e4], M = M4[e4], V = V4[e4];
+        float4 P = P4[e4], M = nt_load(&M4[e4]), V = nt_load(&V4[e4]);
         const float g0 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a0 * inv) : 0.0f;
         const float g1 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a1 * inv) : 0.0f;
         const float g2 = (a2 != 0 || a3 != 0) ? 0.0f + (float)((double)a2 * inv) : 0.0f;
@@ -571,8 +577,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
         table_adam_update(adam, g2, P.z, M.z, V.z);
         table_adam_update(adam, g3, P.w, M.w, V.w);
         P4[e4] = P;
-        M4[e4] = M;
-        V4[e4] = V;
+        nt_store(&M4[e4], M);
+        nt_store(&V4[e4], V);
       }
       return;
     }
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restri
       sel = warp_position(warp, px, py, pz, x);
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        const float2 v = feat_save[(size_t)l * N + n];
+        const float2 v = nt_load(&feat_save[(size_t)l * N + n]);
         f[2 * l] = v.x;
         f[2 * l + 1] = v.y;
       }
@@ -813,7 +819,7 @@ __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restri
     db1 += dout;
     if (n < N) {
 #pragma unroll
-      for (int l = 0; l < L; ++l) d_feats[(size_t)l * N + n] = make_float2(df[2 * l], df[2 * l + 1]);
+      for (int l = 0; l < L; ++l) nt_store(&d_feats[(size_t)l * N + n], make_float2(df[2 * l], df[2 * l + 1]));
     }
     if constexpr (POSGRAD) {
       // gradient w.r.t. the unit-cube position (camera-pose optimisation): re-gather the corner rows of every level
