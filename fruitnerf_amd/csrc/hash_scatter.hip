@@ -331,7 +331,13 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     const int i = threadIdx.x * SC_BINS_PER_THREAD + t;
     if (i < bins) {
       s_off[i] = run;
+#ifdef FNR_EMIT_PAIR_STORES
+      // an EVEN number of slots per (workgroup, level, bin): every reservation then starts at an even slot, and the copy-out
+      // below writes two records per store (16 + 4 bytes); an odd run is closed by a zero-valued pad record
+      s_base[i] = c4[t] ? atomicAdd(&qcount[(size_t)(lrel * bins + i) * SC_CNT_STRIDE], (c4[t] + 1u) & ~1u) : 0u;
+#else
       s_base[i] = c4[t] ? atomicAdd(&qcount[(size_t)(lrel * bins + i) * SC_CNT_STRIDE], c4[t]) : 0u;
+#endif
       s_cnt[i] = 0;
       run += c4[t];
     }
@@ -376,6 +382,40 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 8-byte + 2-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
   unsigned overflowed_here = 0;
+#ifdef FNR_EMIT_PAIR_STORES
+  for (unsigned i = threadIdx.x; i < total; i += SC_EMIT_THREADS) {
+    const unsigned key = s_key[i];
+    const unsigned bin = key >> 16, r0 = key & 0xffffu;
+    const unsigned j = i - s_off[bin];               // position inside the bin's run of this workgroup
+    if (j & 1u) continue;                            // the even record of a pair stores both
+    const float2 v0 = s_val[i];
+    const bool has1 = j + 1u < s_cnt[bin];           // (the placement cursor ended at the run's length)
+    const float2 v1 = has1 ? s_val[i + 1] : make_float2(0.0f, 0.0f);
+    const unsigned r1 = has1 ? (s_key[i + 1] & 0xffffu) : r0;   // pad: adds zero to a row of this bin
+    const unsigned slot = s_base[bin] + j;           // even
+    if ((long long)slot < cap) {                     // (cap is even: the pair fits or overflows together)
+      const size_t q = ((size_t)lrel * bins + bin) * cap + slot;
+#ifdef FNR_EMIT_NT_VALUES
+      nt_store(reinterpret_cast<float4*>(&queue_v[q]), make_float4(v0.x, v0.y, v1.x, v1.y));
+#else
+      *reinterpret_cast<float4*>(&queue_v[q]) = make_float4(v0.x, v0.y, v1.x, v1.y);
+#endif
+      *reinterpret_cast<ushort2*>(&queue_r[q]) = make_ushort2((unsigned short)r0, (unsigned short)r1);
+    } else {
+      qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;
+      const size_t row_a = ((size_t)bin << log2_rows) + r0;
+      ++overflowed_here;
+      atomicAdd(table + 2 * row_a, v0.x);
+      atomicAdd(table + 2 * row_a + 1, v0.y);
+      if (has1) {
+        const size_t row_b = ((size_t)bin << log2_rows) + r1;
+        ++overflowed_here;
+        atomicAdd(table + 2 * row_b, v1.x);
+        atomicAdd(table + 2 * row_b + 1, v1.y);
+      }
+    }
+  }
+#else
   for (unsigned i = threadIdx.x; i < total; i += SC_EMIT_THREADS) {
     const float2 v = s_val[i];
     const unsigned key = s_key[i];
@@ -393,6 +433,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       atomicAdd(table + 2 * row + 1, v.y);
     }
   }
+#endif
   if (overflowed_here) atomicAdd(&g_scatter_overflow_records, (unsigned long long)overflowed_here);
   EMIT_T(5);
   __syncthreads();  // the next level re-uses the bin tables and the record staging
