@@ -104,6 +104,28 @@ __device__ __forceinline__ void nt_store(float2* p, const float2& v) {
   const nt_f2 t = {v.x, v.y};
   __builtin_nontemporal_store(t, reinterpret_cast<nt_f2*>(p));
 }
+// Class c is streaming iff bit c of FNR_NT_MASK is set.  NT_JAC_LD IS OFF: with the Jacobian's loads in
+// k_field_mlp_bwd_base_coop streaming, training stopped being bit-reproducible — tests/test_gpu_determinism.py failed in 4
+// of 4 repetitions with that class alone and in none of 4 with each of the other seven, alone or together
+// (profiles/r05_raw/nt_bisect_call10.log).  Those are the only streaming loads of the library that are in flight TOGETHER
+// WITH PLAIN LOADS and consumed behind PARTIAL `s_waitcnt vmcnt(n)` waits (issued ahead of a dW round, used after it); every
+// other streaming load is waited for together with everything else outstanding, or among its own kind.  Whether `nt` loads
+// (which bypass the CU's L1) may return out of order with plain ones on gfx950 is not something this round could establish;
+// the rule kept here: no streaming load where the compiler may count loads of both kinds.
+#ifndef FNR_NT_MASK
+#define FNR_NT_MASK 0xef
+#endif
+enum NtClass { NT_QUEUE_LD = 0, NT_MOMENT_LD = 1, NT_MOMENT_ST = 2, NT_JAC_ST = 3, NT_JAC_LD = 4, NT_DFEATS_LD = 5, NT_PROP_FEATS = 6, NT_PROP_DFEATS_ST = 7 };
+template <int CLASS, class T>
+__device__ __forceinline__ T ntc_load(const T* p) {
+  if constexpr ((FNR_NT_MASK >> CLASS) & 1) return nt_load(p);
+  else return *p;
+}
+template <int CLASS, class T>
+__device__ __forceinline__ void ntc_store(T* p, const T& v) {
+  if constexpr ((FNR_NT_MASK >> CLASS) & 1) nt_store(p, v);
+  else *p = v;
+}
 
 // ---- exact (non-contracted) fp32 arithmetic -----------------------------------------------------
 // The oracle (PyTorch CPU eager) rounds after every elementwise op.  Wherever a discrete decision

@@ -914,7 +914,7 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) jv[3 * m + a] = nt_load(&jac[((size_t)(4 * m + g) * 3 + a) * N + nn]);   // its only use
+        for (int a = 0; a < 3; ++a) jv[3 * m + a] = ntc_load<NT_JAC_LD>(&jac[((size_t)(4 * m + g) * 3 + a) * N + nn]);   // its only use
     }
     cs_dw<NS, 1, CB_ROWS>(sG, sX, wave >> 1, 0, wave & 1, accA, lane);
     if (wave >= 4) cs_bias<NS, CB_ROWS>(sG, wave - 4, bA, lane);

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   float2 gf_next = make_float2(0.f, 0.f);
   const int lrel0 = blockIdx.y * lpb;
   if (valid) {
-    gf_next = nt_load(&d_feats[(size_t)(level0 + lrel0) * N + n]);
+    gf_next = ntc_load<NT_DFEATS_LD>(&d_feats[(size_t)(level0 + lrel0) * N + n]);
     float px, py, pz;
     src.position(n, px, py, pz);
     warp_position(warp, px, py, pz, x);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   EMIT_T(0);
   const int scaling = grid.scalings[level];
   const float2 gf = gf_next;
-  if (valid && li + 1 < lpb && lrel + 1 < level_count) gf_next = nt_load(&d_feats[(size_t)(level + 1) * N + n]);
+  if (valid && li + 1 < lpb && lrel + 1 < level_count) gf_next = ntc_load<NT_DFEATS_LD>(&d_feats[(size_t)(level + 1) * N + n]);
 
   // contributions of this thread's samples; equal rows in adjacent lanes (consecutive samples of a ray share
   // cells at coarse levels) are pre-summed so only the last lane of a run emits a record
@@ -331,13 +331,7 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     const int i = threadIdx.x * SC_BINS_PER_THREAD + t;
     if (i < bins) {
       s_off[i] = run;
-#ifdef FNR_EMIT_PAIR_STORES
-      // an EVEN number of slots per (workgroup, level, bin): every reservation then starts at an even slot, and the copy-out
-      // below writes two records per store (16 + 4 bytes); an odd run is closed by a zero-valued pad record
-      s_base[i] = c4[t] ? atomicAdd(&qcount[(size_t)(lrel * bins + i) * SC_CNT_STRIDE], (c4[t] + 1u) & ~1u) : 0u;
-#else
       s_base[i] = c4[t] ? atomicAdd(&qcount[(size_t)(lrel * bins + i) * SC_CNT_STRIDE], c4[t]) : 0u;
-#endif
       s_cnt[i] = 0;
       run += c4[t];
     }
@@ -382,40 +376,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 8-byte + 2-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
   unsigned overflowed_here = 0;
-#ifdef FNR_EMIT_PAIR_STORES
-  for (unsigned i = threadIdx.x; i < total; i += SC_EMIT_THREADS) {
-    const unsigned key = s_key[i];
-    const unsigned bin = key >> 16, r0 = key & 0xffffu;
-    const unsigned j = i - s_off[bin];               // position inside the bin's run of this workgroup
-    if (j & 1u) continue;                            // the even record of a pair stores both
-    const float2 v0 = s_val[i];
-    const bool has1 = j + 1u < s_cnt[bin];           // (the placement cursor ended at the run's length)
-    const float2 v1 = has1 ? s_val[i + 1] : make_float2(0.0f, 0.0f);
-    const unsigned r1 = has1 ? (s_key[i + 1] & 0xffffu) : r0;   // pad: adds zero to a row of this bin
-    const unsigned slot = s_base[bin] + j;           // even
-    if ((long long)slot < cap) {                     // (cap is even: the pair fits or overflows together)
-      const size_t q = ((size_t)lrel * bins + bin) * cap + slot;
-#ifdef FNR_EMIT_NT_VALUES
-      nt_store(reinterpret_cast<float4*>(&queue_v[q]), make_float4(v0.x, v0.y, v1.x, v1.y));
-#else
-      *reinterpret_cast<float4*>(&queue_v[q]) = make_float4(v0.x, v0.y, v1.x, v1.y);
-#endif
-      *reinterpret_cast<ushort2*>(&queue_r[q]) = make_ushort2((unsigned short)r0, (unsigned short)r1);
-    } else {
-      qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;
-      const size_t row_a = ((size_t)bin << log2_rows) + r0;
-      ++overflowed_here;
-      atomicAdd(table + 2 * row_a, v0.x);
-      atomicAdd(table + 2 * row_a + 1, v0.y);
-      if (has1) {
-        const size_t row_b = ((size_t)bin << log2_rows) + r1;
-        ++overflowed_here;
-        atomicAdd(table + 2 * row_b, v1.x);
-        atomicAdd(table + 2 * row_b + 1, v1.y);
-      }
-    }
-  }
-#else
   for (unsigned i = threadIdx.x; i < total; i += SC_EMIT_THREADS) {
     const float2 v = s_val[i];
     const unsigned key = s_key[i];
@@ -423,7 +383,9 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     const unsigned slot = s_base[bin] + (i - s_off[bin]);
     if ((long long)slot < cap) {
       const size_t q = ((size_t)lrel * bins + bin) * cap + slot;
-      queue_v[q] = v;                          // (plain stores: narrow `nt` stores are one fabric write each, common.hpp)
+      // (plain, one record per store: narrow `nt` stores are one fabric write each — emit 75 -> 120 us — and two records per
+      //  store with even-sized reservations + zero pads measured 71 -> 79 us, profiles/r05_raw/kt_pair_call8.log)
+      queue_v[q] = v;
       queue_r[q] = (unsigned short)row_in_bin;
     } else {  // hot bin: fall back to global atomics (rare; keeps the result independent of `cap`)
       qmax[(size_t)lrel * SC_CNT_STRIDE + 1] = 1u;  // tells the accumulate kernel that the table holds part of the sum
@@ -433,7 +395,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
       atomicAdd(table + 2 * row + 1, v.y);
     }
   }
-#endif
   if (overflowed_here) atomicAdd(&g_scatter_overflow_records, (unsigned long long)overflowed_here);
   EMIT_T(5);
   __syncthreads();  // the next level re-uses the bin tables and the record staging
@@ -563,8 +524,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     ushort2 row[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      v[u] = nt_load(&qv2[i + u * (long long)blockDim.x]);
-      row[u] = nt_load(&qr2[i + u * (long long)blockDim.x]);
+      v[u] = ntc_load<NT_QUEUE_LD>(&qv2[i + u * (long long)blockDim.x]);
+      row[u] = ntc_load<NT_QUEUE_LD>(&qr2[i + u * (long long)blockDim.x]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -573,8 +534,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
     }
   }
   for (; i < np; i += blockDim.x) {
-    const float4 v = nt_load(&qv2[i]);
-    const ushort2 row = nt_load(&qr2[i]);
+    const float4 v = ntc_load<NT_QUEUE_LD>(&qv2[i]);
+    const ushort2 row = ntc_load<NT_QUEUE_LD>(&qr2[i]);
     acc_record(s_acc, row.x, make_float2(v.x, v.y), scale);
     acc_record(s_acc, row.y, make_float2(v.z, v.w), scale);
   }
@@ -608,7 +569,7 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
           if (!now && !ever) continue;
           if (!ever) atomicOr(&tw[e4 >> 5], 1u << (e4 & 31));   // first gradient of this pair (once per pair, ever)
         }
-        float4 P = P4[e4], M = nt_load(&M4[e4]), V = nt_load(&V4[e4]);
+        float4 P = P4[e4], M = ntc_load<NT_MOMENT_LD>(&M4[e4]), V = ntc_load<NT_MOMENT_LD>(&V4[e4]);
         const float g0 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a0 * inv) : 0.0f;
         const float g1 = (a0 != 0 || a1 != 0) ? 0.0f + (float)((double)a1 * inv) : 0.0f;
         const float g2 = (a2 != 0 || a3 != 0) ? 0.0f + (float)((double)a2 * inv) : 0.0f;
@@ -618,8 +579,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
         table_adam_update(adam, g2, P.z, M.z, V.z);
         table_adam_update(adam, g3, P.w, M.w, V.w);
         P4[e4] = P;
-        nt_store(&M4[e4], M);
-        nt_store(&V4[e4], V);
+        ntc_store<NT_MOMENT_ST>(&M4[e4], M);
+        ntc_store<NT_MOMENT_ST>(&V4[e4], V);
       }
       return;
     }
@@ -828,7 +789,7 @@ __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restri
       sel = warp_position(warp, px, py, pz, x);
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        const float2 v = nt_load(&feat_save[(size_t)l * N + n]);
+        const float2 v = ntc_load<NT_PROP_FEATS>(&feat_save[(size_t)l * N + n]);
         f[2 * l] = v.x;
         f[2 * l + 1] = v.y;
       }
@@ -860,7 +821,7 @@ __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restri
     db1 += dout;
     if (n < N) {
 #pragma unroll
-      for (int l = 0; l < L; ++l) nt_store(&d_feats[(size_t)l * N + n], make_float2(df[2 * l], df[2 * l + 1]));
+      for (int l = 0; l < L; ++l) ntc_store<NT_PROP_DFEATS_ST>(&d_feats[(size_t)l * N + n], make_float2(df[2 * l], df[2 * l + 1]));
     }
     if constexpr (POSGRAD) {
       // gradient w.r.t. the unit-cube position (camera-pose optimisation): re-gather the corner rows of every level

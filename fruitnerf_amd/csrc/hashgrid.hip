@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_hash_encode(GridDev grid, Warp warp, So
       // (streaming stores: the 75 MB Jacobian is read once, by the MLP backward's base branch — as plain stores it pushed
       //  the table's own rows out of the caches: k_hash_encode 82 -> 72 us with the hint here and on the other
       //  write-once / read-once streams of the step, common.hpp)
-      for (int a = 0; a < 3; ++a) nt_store(&jac[((size_t)level * 3 + a) * N + n[u]], make_float2(s * gx[a], s * gy[a]));
+      for (int a = 0; a < 3; ++a) ntc_store<NT_JAC_ST>(&jac[((size_t)level * 3 + a) * N + n[u]], make_float2(s * gx[a], s * gy[a]));
     }
   }
 }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_prop_density(GridDev grid, Warp warp, R
     float2 v = grid_lookup(grid.table + ((size_t)l << grid.log2_T), x, grid.scalings[l], mask);
     f[2 * l] = v.x;
     f[2 * l + 1] = v.y;
-    if (feat_save) nt_store(&feat_save[(size_t)l * N + n], v);   // read once, by k_prop_bwd on the steps that train the network
+    if (feat_save) ntc_store<NT_PROP_FEATS>(&feat_save[(size_t)l * N + n], v);   // read once, by k_prop_bwd on the steps that train the network
   }
   float out = b1[0];
 #pragma unroll

@@ -218,7 +218,7 @@ __device__ __forceinline__ void contract_jacobian(const float2* __restrict__ jac
     for (int u = 0; u < 8; ++u) {
       gf[u] = d_feats[(size_t)(l + u) * N + n];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) j[u][a] = nt_load(&jac[((size_t)(l + u) * 3 + a) * N + n]);   // the Jacobian's only use
+      for (int a = 0; a < 3; ++a) j[u][a] = ntc_load<NT_JAC_LD>(&jac[((size_t)(l + u) * 3 + a) * N + n]);   // the Jacobian's only use
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -229,7 +229,7 @@ __device__ __forceinline__ void contract_jacobian(const float2* __restrict__ jac
     const float2 gf = d_feats[(size_t)l * N + n];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float2 j = nt_load(&jac[((size_t)l * 3 + a) * N + n]);
+      const float2 j = ntc_load<NT_JAC_LD>(&jac[((size_t)l * 3 + a) * N + n]);
       g[a] += gf.x * j.x + gf.y * j.y;
     }
   }
