@@ -908,7 +908,9 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         main = torch.cuda.current_stream(dev)
         fj = _ForkJoin(main)
         side = None
-        losses_on_side = bool(LOSSES_ON_SIDE and overlap_proposal_backward and not serialize_streams)
+        # (single process only: on the exchange path — one-rank RCCL A/B, profiles/r05_raw/exchange_losses_ab.log — it is
+        #  neutral to slightly negative, 0.860 - 0.870 against 0.857 ms/step: the second stream has the collectives' tail there)
+        losses_on_side = bool(LOSSES_ON_SIDE and overlap_proposal_backward and not serialize_streams and exchange is None)
         if losses_on_side:
             side = _second_stream(model, dev)
             fj.fork(side)                       # behind the forward pass
