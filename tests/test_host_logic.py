@@ -701,3 +701,40 @@ def test_clustering_template_fails_loudly_and_falls_back_only_for_lfs_pointers(t
     ply.write_point_cloud(str(good), pts, np.zeros((50, 3)))
     c = Clustering(template_path=good)
     assert c.template_fallback is False
+
+
+def test_touched_bitmaps_are_keyed_by_arena_offset_and_dropped_by_unfused_steps(monkeypatch):
+    """FusedAdam's sparse-touch bitmaps: keyed by the table's arena offset (not by id(), which can be reused),
+    rebuilt from the moments, and dropped by any optimiser step over the table's span that does not go through the fused
+    table kernels — on CPU tensors, with the Adam launch itself replaced (the bookkeeping is host logic)."""
+    import types
+    import torch
+    import fruitnerf_amd.training as T
+    table_a, table_b = torch.zeros(256 * 2), torch.zeros(128 * 2)
+    params = torch.zeros(64 + table_a.numel() + table_b.numel())
+    arena = types.SimpleNamespace(params=params, grads=torch.zeros_like(params),
+                                  entries=[("w", None, 0, 64), ("a", table_a, 64, table_a.numel()),
+                                           ("b", table_b, 64 + table_a.numel(), table_b.numel())],
+                                  group_ranges={"fields": (0, params.numel())})
+    model = types.SimpleNamespace(arena=lambda: arena)
+    opt = T.FusedAdam(model)
+    launches = []
+    monkeypatch.setattr(T.K, "adam_step", lambda *a, **k: launches.append(a[0].numel()))
+    monkeypatch.setattr(T, "SPARSE_TOUCH_SKIPPING", True)
+    opt.exp_avg[64 + 8] = 1.0                                     # pair 2 of table a has a moment
+    bm_a = opt.touched_bitmap(table_a, 64, table_a.numel())
+    bm_b = opt.touched_bitmap(table_b, 64 + table_a.numel(), table_b.numel())
+    assert bm_a.numel() == table_a.numel() // 128 and int(bm_a[0]) == 1 << 2 and int(bm_b.abs().sum()) == 0
+    assert opt.touched_bitmap(table_a, 64, table_a.numel()) is bm_a             # cached under the offset
+    assert set(opt._touched) == {64, 64 + table_a.numel()}
+    opt.begin_step()
+    opt.step_span(0, 64, 1e-2, group="fields")                    # the MLP weights only: no table span touched
+    assert set(opt._touched) == {64, 64 + table_a.numel()} and launches == [64]
+    opt.step_span(32, 64 + 16, 1e-2, group="fields")              # overlaps table a's head
+    assert set(opt._touched) == {64 + table_a.numel()}
+    assert opt.touched_bitmap(table_a, 64, table_a.numel()) is not bm_a         # rebuilt from the moments
+    opt.rebuild_touched()
+    assert not opt._touched
+    # skipping does not apply with weight decay or to a span that is not a whole number of 128-float words
+    assert T.FusedAdam(model, weight_decay=1e-3).touched_bitmap(table_a, 64, table_a.numel()) is None
+    assert opt.touched_bitmap(table_a, 64, 100) is None
