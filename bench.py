@@ -371,6 +371,7 @@ def timed_window(run, steps, barrier, dist_on, dev):
     t0 = time.perf_counter()
     last = None
     n_prof = 0
+    host_plain = host_prof = 0.0
     try:
         for i in range(steps):
             on = i % PROFILE_EVERY == 0
@@ -380,9 +381,19 @@ def timed_window(run, steps, barrier, dist_on, dev):
             # not next to them (training.SERIALIZE_STREAMS; same results either way)
             T.SERIALIZE_STREAMS = bool(on) or serialize
             n_prof += on
+            th = time.perf_counter()
             last = run.one_step()
+            th = time.perf_counter() - th
+            if on:
+                host_prof += th
+            else:
+                host_plain += th
     finally:
         T.SERIALIZE_STREAMS = serialize
+    # host time of the steps that are NOT event-timed (replayed by the native sequencer once their shape is recorded) and of
+    # the event-timed ones (always interpreted: their launches carry HIP events and their streams are serialised)
+    run.host_ms = {"plain_steps": round(host_plain / max(steps - n_prof, 1) * 1e3, 4),
+                   "event_timed_steps": round(host_prof / max(n_prof, 1) * 1e3, 4), "event_timed": int(n_prof)}
     run.model.field.flush_deferred_update()   # N > 1: the last step's field collective + optimiser step (training.DEFER_FIELD_UPDATE)
     t_enqueued = time.perf_counter() - t0     # host side done (launches queued); the GPU is still working
     torch.cuda.synchronize()
@@ -588,6 +599,8 @@ def main() -> None:
     L.scatter_records(reset=True)
     allocs_before = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)     # hipMalloc calls of the caching allocator
     dt, t_enqueued, recs, n_prof, (ld, md) = timed_window(run, args.steps, barrier, dist_on, dev)
+    headline_host_ms = dict(run.host_ms)
+    headline_sequencer = dict(run.steps.stats, enabled=bool(_training.NATIVE_SEQUENCER and not dist_on))
     device_allocs_in_window = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs_before)
     rays_per_s = world * args.steps * RAYS_PER_BATCH / dt
     field_records = L.scatter_records()[0] / max(args.steps, 1)     # one main-field scatter per step
@@ -774,6 +787,66 @@ def main() -> None:
                                  "'second_stream': proposal-network backward, ray-gradient reduction, camera step and the next "
                                  "step's sampling on the second HIP stream (the default); 'one_stream': everything in-stream",
                          "one_stream": headline_window(False), "second_stream": headline_window(True)}
+        # The path an UNMODIFIED Nerfstudio Trainer drives (fruit_pipeline.py:120-146 + Trainer.train_iteration): callbacks
+        # by location, model(ray_bundle) -> get_metrics_dict -> get_loss_dict -> reduce(add) -> backward() through the
+        # autograd Functions -> optimizer.step() -> schedulers — the plugin API only, no TrainingSteps, no look-ahead, no
+        # fused optimiser steps inside the backward kernels.  Once with the library's optimiser (FusedAdam.step: one launch
+        # over the arena) and once with torch.optim.Adam on get_param_groups() + nerfstudio's per-group schedulers, i.e.
+        # with nothing of this repository outside the model.  Rays come from the batcher's pixel-sampling launch with the
+        # cameras as given (nerfstudio's camera optimiser is autograd over torch ops and lives in the datamanager).
+        def plugin_api_window(kind: str, n_warm: int = 10, n_steps: int = 100):
+            import functools
+            from fruitnerf_amd.engine.callbacks import TrainingCallbackAttributes, TrainingCallbackLocation as Loc
+            from fruitnerf_amd.training import FusedAdam, exponential_decay_lr, skipped_groups
+            r3 = MethodRun(args.method, args.mlp_precision, "off", dev, rank, world, data, train_ids, len(i_train))
+            m3 = r3.model
+            cbs = m3.get_training_callbacks(TrainingCallbackAttributes(optimizers=None, grad_scaler=None, pipeline=None))
+            groups = m3.get_param_groups()
+            if kind == "fused_adam":
+                opt3 = r3.opt
+            else:
+                m3.arena()                     # parameters re-homed into the arena before torch.optim captures them
+                Opt = torch.optim.Adam if M["algorithm"] == "adam" else torch.optim.RAdam
+                opt3 = {g: Opt(groups[g], lr=M["groups"][g]["lr"], eps=1e-15) for g in groups}
+            t1 = 0.0
+            for step in range(n_warm + n_steps):
+                if step == n_warm:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                for cb in cbs:
+                    cb.run_callback_at_location(step, location=Loc.BEFORE_TRAIN_ITERATION)
+                o, d, cam, batch = r3.batcher.sample(r3.rays)
+                if kind != "fused_adam":
+                    for op_ in opt3.values():
+                        op_.zero_grad(set_to_none=False)       # gradients are views of the arena: zeroed in place
+                outputs = m3(RayBundle(o, d, None, cam))
+                metrics_dict = m3.get_metrics_dict(outputs, batch)
+                loss_dict = m3.get_loss_dict(outputs, batch, metrics_dict)
+                functools.reduce(torch.add, loss_dict.values()).backward()
+                skip = skipped_groups(m3)
+                if kind == "fused_adam":
+                    opt3.step(skip=skip)
+                else:
+                    for g, op_ in opt3.items():
+                        if g not in skip:                      # (torch.optim skips parameters whose .grad is None)
+                            op_.step()
+                        gl = M["groups"][g]
+                        for pg in op_.param_groups:            # ExponentialDecayScheduler, stepped every iteration
+                            pg["lr"] = exponential_decay_lr(step + 1, gl["lr"], gl["lr_final"], gl["max_steps"]) \
+                                if gl.get("lr_final") is not None else gl["lr"]
+                for cb in cbs:
+                    cb.run_callback_at_location(step, location=Loc.AFTER_TRAIN_ITERATION)
+            torch.cuda.synchronize()
+            v = round(n_steps * RAYS_PER_BATCH / (time.perf_counter() - t1), 1)
+            del r3, m3, opt3
+            torch.cuda.empty_cache()
+            return v
+        plugin_api = {"note": "train rays/s of the loop an unmodified Nerfstudio Trainer runs over the plugin surface "
+                              "(callbacks, model(ray_bundle), get_metrics_dict, get_loss_dict, backward() through the autograd "
+                              "Functions, optimizer.step()); fresh model, steps 10..110, camera optimiser off; the headline "
+                              "loop (training.TrainingSteps) fuses the optimiser steps into the backward kernels and samples ahead",
+                      "fused_adam": plugin_api_window("fused_adam"),
+                      "torch_optim_adam": plugin_api_window("torch_optim")}
         # the other arithmetic modes of the field MLPs on the SAME loop (headline mode restored afterwards): bf16x3 is
         # parity grade (tests/test_gpu_bf16.py), bf16 is BASELINE config 2's throughput mode
         mlp_modes = None
@@ -807,6 +880,7 @@ def main() -> None:
         full_count = count_fruits_end_to_end(emodel, pipe, sample_volume, scene, dev, n_side=512)
         counting = counting_stage_bench(dev, cpu=not args.no_cpu_baseline)
         secondary = {"train_rays_per_s_by_proposal_backward_stream": overlap_modes,
+                     "train_rays_per_s_plugin_api": plugin_api,
                      "train_rays_per_s_by_mlp_precision": mlp_modes,
                      "train_rays_per_s_camera_optimizer_off": cam_off,
                      "train_rays_per_s_camera_optimizer_off_note": f"100 steps measured after step {run.step_idx - 100} "
@@ -930,6 +1004,10 @@ def main() -> None:
         # host time to enqueue a step (Python + ctypes + HIP launches), without waiting for the GPU: while it stays
         # below ms_per_step the step is GPU-bound
         "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
+        # ... split: the steps a recorded step program replays (training.NATIVE_SEQUENCER: one fnr_program_replay call per
+        # step) and the event-timed steps of the roofline leg, which are interpreted; and what the sequencer did over the run
+        "host_enqueue_ms_by_step_kind": headline_host_ms,
+        "native_sequencer": headline_sequencer,
         # hipMalloc calls inside the timed window (the caching allocator growing a pool: each one stalls the host for
         # 0.1 - 1 ms); 0 once the warm-up has seen every step shape
         "device_allocs_in_window": device_allocs_in_window,

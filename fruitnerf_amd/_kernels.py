@@ -22,6 +22,66 @@ def _f32c(t: Tensor) -> Tensor:
     return t.contiguous()
 
 
+class StepArena:
+    """A caller-owned slab for the per-step buffers of a training loop (training.TrainingSteps): bump allocation, reset
+    every other step.  While one is active (`use_arena`) the wrappers below take their output / scratch buffers from it
+    instead of torch's caching allocator, so a step's buffers sit at the SAME addresses whenever the same sequence of
+    calls runs from the same reset point — what a recorded step program (fnr_program_*) replays against.  Requests
+    that do not fit fall back to torch.empty and are counted (`overflow_bytes`): the owner grows the slab between steps."""
+
+    ALIGN = 256
+
+    def __init__(self, device, capacity: int):
+        self.device = torch.device(device)
+        self.capacity = int(capacity)
+        self.buf = torch.empty(self.capacity, dtype=torch.uint8, device=self.device)
+        self._typed = {torch.uint8: self.buf}
+        self.offset = 0
+        self.overflow_bytes = 0
+        self.high_water = 0
+
+    def reset(self) -> None:
+        self.offset = 0
+
+    def alloc(self, shape, dtype) -> Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * _ITEMSIZE[dtype]
+        start = self.offset
+        end = start + nbytes
+        if end > self.capacity:
+            self.overflow_bytes += nbytes
+            return torch.empty(*shape, dtype=dtype, device=self.device)
+        self.offset = (end + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        if self.offset > self.high_water:
+            self.high_water = self.offset
+        typed = self._typed.get(dtype)
+        if typed is None:
+            typed = self._typed[dtype] = self.buf.view(dtype)
+        isz = _ITEMSIZE[dtype]
+        t = typed[start // isz:end // isz]           # (start is a multiple of ALIGN, hence of the item size)
+        return t.view(*shape) if len(shape) != 1 else t
+
+
+_ITEMSIZE = {torch.float32: 4, torch.uint8: 1, torch.int32: 4, torch.int64: 8, torch.float64: 8}
+_ARENA: Optional[StepArena] = None
+
+
+def use_arena(arena: Optional[StepArena]) -> Optional[StepArena]:
+    """Make `arena` (or none) the source of the wrappers' per-call buffers -> the previous one."""
+    global _ARENA
+    prev, _ARENA = _ARENA, arena
+    return prev
+
+
+def _empty(*shape, dtype=torch.float32, device=None) -> Tensor:
+    a = _ARENA
+    if a is not None and a.device == device:
+        return a.alloc(shape, dtype)
+    return torch.empty(*shape, dtype=dtype, device=device)
+
+
 class RaysArg:
     """fnr_rays view of RayBundle tensors (keeps the converted tensors alive)."""
 
@@ -101,6 +161,43 @@ def host_linspace(start: float, end: float, steps: int, device) -> Tensor:
     return t
 
 
+# ---- stream dependencies (recordable by step programs: fnr_program_*) ---------------------------------
+
+
+def _raw(stream) -> Optional[int]:
+    """hipStream_t of a torch.cuda.Stream (or a raw handle / None = the default stream)."""
+    return stream.cuda_stream if hasattr(stream, "cuda_stream") else stream
+
+
+class Event:
+    """A hipEvent_t (timing disabled) owned by the caller: what crosses between the launch stream and the second stream
+    of a training step.  Unlike torch.cuda.Event its record / wait go through the C ABI, so a step program records them."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        L.check(L.load().fnr_event_create(C.byref(h)), "event_create")
+        self.handle = h.value
+
+    def record(self, stream) -> None:
+        L.check(L.load().fnr_event_record(self.handle, _raw(stream)), "event_record")
+
+    def __del__(self):
+        try:
+            if self.handle and L._lib is not None:
+                L.load().fnr_event_destroy(self.handle)
+        except Exception:   # interpreter shutdown
+            pass
+
+
+def stream_wait_event(stream, event: Event) -> None:
+    L.check(L.load().fnr_stream_wait_event(_raw(stream), event.handle), "stream_wait_event")
+
+
+def stream_wait_stream(waiting, signalling) -> None:
+    """Work enqueued on `waiting` from now on runs after everything `signalling` holds now (the host does not block)."""
+    L.check(L.load().fnr_stream_wait_stream(_raw(waiting), _raw(signalling)), "stream_wait_stream")
+
+
 # ---- samplers ---------------------------------------------------------------------------------------
 
 
@@ -109,8 +206,8 @@ def sample_spaced(rays: RaysArg, spacing_kind: int, S: int, t_rand: Optional[Ten
     lib = L.load()
     dev = rays.device
     base = host_linspace(0.0, 1.0, S + 1, dev)
-    spacing = torch.empty(rays.n, S + 1, device=dev)
-    euclid = torch.empty(rays.n, S + 1, device=dev)
+    spacing = _empty(rays.n, S + 1, device=dev)
+    euclid = _empty(rays.n, S + 1, device=dev)
     tr = None if t_rand is None else _f32c(t_rand.reshape(-1))
     per_bin = 0
     if tr is not None and tr.numel() != rays.n:
@@ -126,14 +223,14 @@ def weights_pdf(rays: RaysArg, spacing_kind: int, S_prev: int, S_new: int, densi
                 euclid_prev: Tensor, anneal: float, rand: Optional[Tensor], want_depth: bool = True):
     lib = L.load()
     dev = rays.device
-    weights = torch.empty(rays.n, S_prev, device=dev)
-    depth = torch.empty(rays.n, device=dev) if want_depth else None
+    weights = _empty(rays.n, S_prev, device=dev)
+    depth = _empty(rays.n, device=dev) if want_depth else None
     spacing_new = euclid_new = u_base = None
     if S_new > 0:
         nb = S_new + 1
         u_base = host_linspace(0.0, 1.0 - (1.0 / nb), nb, dev)
-        spacing_new = torch.empty(rays.n, nb, device=dev)
-        euclid_new = torch.empty(rays.n, nb, device=dev)
+        spacing_new = _empty(rays.n, nb, device=dev)
+        euclid_new = _empty(rays.n, nb, device=dev)
     rd = None if rand is None else _f32c(rand.reshape(-1))
     L.check(lib.fnr_weights_pdf(rays.ref, spacing_kind, S_prev, S_new, L.ptr(density), L.ptr(spacing_prev),
                                 L.ptr(euclid_prev), float(anneal), L.ptr(u_base), L.ptr(rd), L.ptr(weights),
@@ -149,8 +246,8 @@ def prop_density_fwd(net: L.fnr_prop_net, warp: L.fnr_warp, rays: RaysArg, eucli
                      save_feats: bool = False):
     lib = L.load()
     dev = rays.device
-    density = torch.empty(rays.n, S, device=dev)
-    feats = torch.empty(net.grid.n_levels, rays.n * S, 2, device=dev) if save_feats else None
+    density = _empty(rays.n, S, device=dev)
+    feats = _empty(net.grid.n_levels, rays.n * S, 2, device=dev) if save_feats else None
     L.check(lib.fnr_prop_density_fwd(C.byref(net), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(density),
                                      L.ptr(feats), L.stream_ptr(dev)), "prop_density_fwd")
     return density, feats
@@ -162,9 +259,9 @@ def hash_encode_fwd(grid: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, euclid: T
     lib = L.load()
     dev = rays.device
     N = rays.n * S
-    feats = torch.empty(grid.n_levels, N, 2, device=dev)
-    selector = torch.empty(N, dtype=torch.uint8, device=dev)
-    jac = torch.empty(grid.n_levels, 3, N, 2, device=dev) if want_jacobian else None
+    feats = _empty(grid.n_levels, N, 2, device=dev)
+    selector = _empty(N, dtype=torch.uint8, device=dev)
+    jac = _empty(grid.n_levels, 3, N, 2, device=dev) if want_jacobian else None
     L.check(lib.fnr_hash_encode_fwd(C.byref(grid), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(feats),
                                     L.ptr(selector), L.ptr(jac), L.stream_ptr(dev)), "hash_encode_fwd")
     return (feats, selector, jac) if want_jacobian else (feats, selector)
@@ -186,8 +283,8 @@ def hash_encode_lattice(grid: L.fnr_grid, warp: L.fnr_warp, lat: LatticeArg, ray
     lib = L.load()
     dev = lat.device
     N = n_rays * lat.c.n_z
-    feats = torch.empty(grid.n_levels, N, 2, device=dev)
-    selector = torch.empty(N, dtype=torch.uint8, device=dev)
+    feats = _empty(grid.n_levels, N, 2, device=dev)
+    selector = _empty(N, dtype=torch.uint8, device=dev)
     L.check(lib.fnr_hash_encode_lattice(C.byref(grid), C.byref(warp), lat.ref, ray_begin, n_rays, L.ptr(feats),
                                         L.ptr(selector), L.stream_ptr(dev)), "hash_encode_lattice")
     return feats, selector
@@ -213,19 +310,19 @@ def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, se
     lib = L.load()
     dev = rays.device
     N = rays.n * S
-    density = torch.empty(N, device=dev)
-    rgb = torch.empty(N, 3, device=dev)
-    logit = torch.empty(N, device=dev)
-    geo = torch.empty(N, net.geo_feat_dim, device=dev) if want_geo else None
+    density = _empty(N, device=dev)
+    rgb = _empty(N, 3, device=dev)
+    logit = _empty(N, device=dev)
+    geo = _empty(N, net.geo_feat_dim, device=dev) if want_geo else None
     # base-MLP output [N, 16 | 32]: saved for field_mlp_bwd; the fruit_nerf_big shape always needs it (its two
     # launches hand h over through it); + the per-ray part of mlp_head's first layer [R,64]
     h_dim = lib.fnr_field_h_dim(C.byref(net))
     if h_dim < 0:
         raise RuntimeError("fruitnerf_hip field_mlp_fwd: " + L.last_error())
-    h = torch.empty(N, h_dim, device=dev) if (want_h or h_dim > 16) else None
-    ray_bias = torch.empty(rays.n, 64, device=dev) if want_h else None
+    h = _empty(N, h_dim, device=dev) if (want_h or h_dim > 16) else None
+    ray_bias = _empty(rays.n, 64, device=dev) if want_h else None
     # training: a private workspace, so that its packed fragment image can be handed to field_mlp_bwd
-    ws = (torch.empty(lib.fnr_field_mlp_fwd_workspace_bytes(0), dtype=torch.uint8, device=dev) if want_h
+    ws = (_empty(lib.fnr_field_mlp_fwd_workspace_bytes(0), dtype=torch.uint8, device=dev) if want_h
           else _mlp_fwd_workspace(dev, rays.n))
     L.check(lib.fnr_field_mlp_fwd(C.byref(net), rays.ref, S, L.ptr(feats), L.ptr(selector), L.ptr(mean_embedding),
                                   L.ptr(density), L.ptr(rgb), L.ptr(logit), L.ptr(geo), L.ptr(h), L.ptr(ray_bias),
@@ -239,7 +336,7 @@ def field_mlp_fwd(net: L.fnr_field_net, rays: RaysArg, S: int, feats: Tensor, se
 
 def embedding_mean(embedding: Tensor) -> Tensor:
     lib = L.load()
-    out = torch.empty(embedding.shape[1], device=embedding.device)
+    out = _empty(embedding.shape[1], device=embedding.device)
     L.check(lib.fnr_embedding_mean(L.ptr(embedding), embedding.shape[0], embedding.shape[1], L.ptr(out),
                                    L.stream_ptr(embedding.device)), "embedding_mean")
     return out
@@ -248,12 +345,12 @@ def embedding_mean(embedding: Tensor) -> Tensor:
 def composite_fwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, logit: Tensor, training: bool):
     lib = L.load()
     dev = rays.device
-    weights = torch.empty(rays.n, S, device=dev)
-    out_rgb = torch.empty(rays.n, 3, device=dev)
-    acc = torch.empty(rays.n, device=dev)
-    depth = torch.empty(rays.n, device=dev)
-    sem = torch.empty(rays.n, device=dev)
-    label = torch.empty(rays.n, dtype=torch.int64, device=dev)
+    weights = _empty(rays.n, S, device=dev)
+    out_rgb = _empty(rays.n, 3, device=dev)
+    acc = _empty(rays.n, device=dev)
+    depth = _empty(rays.n, device=dev)
+    sem = _empty(rays.n, device=dev)
+    label = _empty(rays.n, dtype=torch.int64, device=dev)
     L.check(lib.fnr_composite_fwd(rays.ref, S, L.ptr(euclid), L.ptr(density), L.ptr(rgb), L.ptr(logit),
                                   1 if training else 0, L.ptr(weights), L.ptr(out_rgb), L.ptr(acc), L.ptr(depth),
                                   L.ptr(sem), L.ptr(label), L.stream_ptr(dev)), "composite_fwd")
@@ -271,7 +368,7 @@ def export_compact(lat: Optional[LatticeArg], ray_begin: int, n_rays: int, posit
     lib = L.load()
     dev = density.device
     N = density.numel()
-    ws = torch.empty(lib.fnr_export_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    ws = _empty(lib.fnr_export_workspace_bytes(N), dtype=torch.uint8, device=dev)
     cap = points[0].shape[0]
     assert all(p.shape[0] == cap for p in points) and all(c.shape[0] == cap for c in colors)
     parr = (C.c_void_p * 3)(*[L.ptr(p) for p in points])
@@ -289,9 +386,9 @@ def losses_fwd(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tensor
     lib = L.load()
     dev = rgb.device
     R = rgb.shape[0]
-    losses = torch.empty(3, device=dev)  # rgb_loss, semantics_loss, psnr
-    d_rgb = torch.empty(R, 3, device=dev)
-    d_sem = torch.empty(R, device=dev)
+    losses = _empty(3, device=dev)  # rgb_loss, semantics_loss, psnr
+    d_rgb = _empty(R, 3, device=dev)
+    d_sem = _empty(R, device=dev)
     L.check(lib.fnr_losses_fwd(R, L.ptr(_f32c(rgb)), L.ptr(_f32c(image.reshape(R, 3))),
                                L.ptr(_f32c(semantics.reshape(R))), L.ptr(_f32c(fruit_mask.reshape(R))),
                                float(semantic_loss_weight), L.ptr(losses), L.ptr(d_rgb), L.ptr(d_sem),
@@ -304,7 +401,7 @@ def interlevel_fwd(S_f: int, spacing_f: Tensor, weights_f: Tensor, S_p: int, spa
     lib = L.load()
     dev = spacing_f.device
     R = spacing_f.shape[0]
-    d_wp = torch.empty(R, S_p, device=dev)
+    d_wp = _empty(R, S_p, device=dev)
     L.check(lib.fnr_interlevel_fwd(R, S_f, L.ptr(spacing_f), L.ptr(weights_f), S_p, L.ptr(spacing_p), L.ptr(weights_p),
                                    float(mult), L.ptr(loss_acc), L.ptr(d_wp), L.stream_ptr(dev)), "interlevel_fwd")
     return d_wp
@@ -335,11 +432,13 @@ def train_losses(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tens
     R = rgb.shape[0]
     rgb, image = _f32c(rgb), _f32c(image.reshape(R, 3))
     semantics, fruit_mask = _f32c(semantics.reshape(R)), _f32c(fruit_mask.reshape(R))
+    # (never from the step arena: callers keep a step's loss scalars beyond the step after next — a replayed step
+    #  program writes them to the buffer fnr_step_scalars.losses names)
     losses = torch.empty(5, device=dev)
-    d_rgb = torch.empty(R, 3, device=dev)
-    d_sem = torch.empty(R, device=dev)
+    d_rgb = _empty(R, 3, device=dev)
+    d_sem = _empty(R, device=dev)
     n = len(levels)
-    outs = [torch.empty(R, lv[0], device=dev) for lv in levels]
+    outs = [_empty(R, lv[0], device=dev) for lv in levels]
     sp = (C.c_int * max(n, 1))(*[int(lv[0]) for lv in levels])
     vps = lambda ts: (C.c_void_p * max(n, 1))(*[L.ptr(t) for t in ts])   # noqa: E731
     if fuse_weights_bwd:
@@ -362,9 +461,9 @@ def composite_bwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: T
     lib = L.load()
     dev = rays.device
     N = rays.n * S
-    d_density = torch.empty(N, device=dev)
-    d_rgb = torch.empty(N, 3, device=dev)
-    d_logit = torch.empty(N, device=dev)
+    d_density = _empty(N, device=dev)
+    d_rgb = _empty(N, 3, device=dev)
+    d_logit = _empty(N, device=dev)
     L.check(lib.fnr_composite_bwd(rays.ref, S, L.ptr(euclid), L.ptr(density), L.ptr(rgb), L.ptr(weights),
                                   L.ptr(_f32c(g_rgb)), L.ptr(_f32c(g_sem.reshape(-1))), L.ptr(d_density),
                                   L.ptr(d_rgb), L.ptr(d_logit), L.stream_ptr(dev)), "composite_bwd")
@@ -378,9 +477,9 @@ def composite_bwd_targets(rays: RaysArg, S: int, euclid: Tensor, density: Tensor
     lib = L.load()
     dev = rays.device
     N = rays.n * S
-    d_density = torch.empty(N, device=dev)
-    d_rgb = torch.empty(N, 3, device=dev)
-    d_logit = torch.empty(N, device=dev)
+    d_density = _empty(N, device=dev)
+    d_rgb = _empty(N, 3, device=dev)
+    d_logit = _empty(N, device=dev)
     L.check(lib.fnr_composite_bwd_targets(rays.ref, S, L.ptr(euclid), L.ptr(density), L.ptr(rgb), L.ptr(weights),
                                           L.ptr(_f32c(out_rgb)), L.ptr(_f32c(image)), L.ptr(_f32c(out_sem.reshape(-1))),
                                           L.ptr(_f32c(mask.reshape(-1))), float(sem_weight), L.ptr(d_density),
@@ -393,7 +492,7 @@ def weights_bwd(S: int, euclid: Tensor, density: Tensor, weights: Tensor, d_weig
     lib = L.load()
     dev = euclid.device
     R = euclid.shape[0]
-    d_density = torch.empty(R, S, device=dev)
+    d_density = _empty(R, S, device=dev)
     L.check(lib.fnr_weights_bwd(R, S, L.ptr(euclid), L.ptr(density), L.ptr(weights), L.ptr(d_weights),
                                 L.ptr(upstream), L.ptr(d_density), L.stream_ptr(dev)), "weights_bwd")
     return d_density
@@ -415,19 +514,19 @@ def field_mlp_bwd(net: L.fnr_field_net, grads: L.fnr_field_net, rays: RaysArg, S
         packed = None   # the forward ran in another arithmetic: its workspace lacks this mode's fragment images — repack
     dev = rays.device
     N = rays.n * S
-    d_feats = torch.empty_like(feats)
+    d_feats = _empty(*feats.shape, device=dev)
     nbytes = lib.fnr_field_mlp_bwd_workspace_bytes(rays.n, S)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _empty(nbytes, dtype=torch.uint8, device=dev)
     if weight_adam is not None:
         adam, grad_arena = weight_adam
-        d_pos = torch.empty(N, 4, device=dev) if jacobian is not None else None
+        d_pos = _empty(N, 4, device=dev) if jacobian is not None else None
         L.check(lib.fnr_field_mlp_bwd_adam(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
                                            L.ptr(ray_bias), L.ptr(packed), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb),
                                            L.ptr(d_logit), L.ptr(d_feats), L.ptr(jacobian), L.ptr(d_pos), C.byref(adam),
                                            L.ptr(grad_arena), L.ptr(ws), nbytes, L.stream_ptr(dev)), "field_mlp_bwd_adam")
         return (d_feats, d_pos) if jacobian is not None else d_feats
     if jacobian is not None:
-        d_pos = torch.empty(N, 4, device=dev)
+        d_pos = _empty(N, 4, device=dev)
         L.check(lib.fnr_field_mlp_bwd_rays(C.byref(net), C.byref(grads), rays.ref, S, L.ptr(feats), L.ptr(h_saved),
                                            L.ptr(ray_bias), L.ptr(packed), L.ptr(selector), L.ptr(d_density), L.ptr(d_rgb),
                                            L.ptr(d_logit), L.ptr(d_feats), L.ptr(jacobian), L.ptr(d_pos), L.ptr(ws), nbytes,
@@ -449,6 +548,7 @@ class _WorkspaceCache:
     def __init__(self, per_tag: int = 2):
         self.per_tag = per_tag
         self.entries = {}          # key -> buffer; dict order = recency (oldest first)
+        self.fresh = 0             # buffers made so far (a call that got a fresh one was told workspace_clean = 0)
 
     def get(self, key, make):
         """-> (buffer, clean): clean = 1 when the buffer has been used by these kernels before (counters left zeroed)."""
@@ -460,6 +560,7 @@ class _WorkspaceCache:
         for k in same[:max(0, len(same) - self.per_tag + 1)]:
             del self.entries[k]
         buf = self.entries[key] = make()
+        self.fresh += 1
         return buf, 0
 
     # dict-like views for diagnostics
@@ -488,6 +589,12 @@ def _scatter_workspace(dev, nbytes: int, tag: str):
     key = (dev.type, dev.index, L.stream_ptr(dev), nbytes, tag)
     buf, clean = _SCATTER_WS.get(key, lambda: torch.empty(nbytes, dtype=torch.uint8, device=dev))
     return buf, (0 if SCATTER_MEMSET_EVERY_CALL else clean)
+
+
+def fresh_workspaces() -> int:
+    """How many scatter workspaces have been created so far: a step during which this moved ran a scatter with
+    workspace_clean = 0 (its memset launch is not part of the steady-state sequence a step program should hold)."""
+    return _SCATTER_WS.fresh
 
 
 def _forget_scatter_workspaces(dev) -> None:
@@ -539,7 +646,7 @@ def prop_density_bwd(net: L.fnr_prop_net, grads: L.fnr_prop_net, warp: L.fnr_war
     lib = L.load()
     nbytes = lib.fnr_prop_density_bwd_workspace_bytes(rays.n * S, net.grid.n_levels, net.grid.log2_hashmap_size)
     ws, clean = _scatter_workspace(rays.device, nbytes, "prop")
-    d_pos = torch.empty(rays.n * S, 4, device=rays.device) if want_position_grad else None
+    d_pos = _empty(rays.n * S, 4, device=rays.device) if want_position_grad else None
     if adam is not None:
         t_adam, w_adam, grad_arena = adam
         _scatter_check(lib.fnr_prop_density_bwd_adam(C.byref(net), C.byref(grads), C.byref(warp), rays.ref, L.ptr(euclid), S,
@@ -558,7 +665,7 @@ def prop_density_bwd_pair(nets, grads, warps, rays: RaysArg, euclids, S, feats, 
                           adam=None, position_ready=None):
     """fnr_prop_density_bwd_pair: both proposal levels of a step (lists of two), their accumulate launches as one.
     adam = ([table fnr_table_adam x 2], weight fnr_table_adam, gradient arena) or None.  -> [d_position | None] x 2.
-    position_ready (torch.cuda.Event): fnr_prop_density_bwd_pair_split — both MLP backwards first, the event recorded on
+    position_ready (Event): fnr_prop_density_bwd_pair_split — both MLP backwards first, the event recorded on
     the current stream once the d_position tensors are final, then the scatter."""
     lib = L.load()
     dev = rays.device
@@ -567,7 +674,7 @@ def prop_density_bwd_pair(nets, grads, warps, rays: RaysArg, euclids, S, feats, 
         nb = lib.fnr_prop_density_bwd_workspace_bytes(rays.n * S[q], nets[q].grid.n_levels, nets[q].grid.log2_hashmap_size)
         w, c = _scatter_workspace(dev, nb, f"prop{q}")
         ws.append(w), nbytes.append(nb), clean.append(c)
-        d_pos.append(torch.empty(rays.n * S[q], 4, device=dev) if want_position_grad else None)
+        d_pos.append(_empty(rays.n * S[q], 4, device=dev) if want_position_grad else None)
     PN, PW, PT = C.POINTER(L.fnr_prop_net), C.POINTER(L.fnr_warp), C.POINTER(L.fnr_table_adam)
     vp = lambda ts: (C.c_void_p * 2)(*[L.ptr(t) for t in ts])   # noqa: E731
     t_adams = w_adam = grad_arena = None
@@ -580,9 +687,7 @@ def prop_density_bwd_pair(nets, grads, warps, rays: RaysArg, euclids, S, feats, 
             vp(d_density), vp(d_pos), t_adams, w_adam, L.ptr(grad_arena), vp(ws), (C.c_size_t * 2)(*nbytes),
             (C.c_int * 2)(*clean), L.stream_ptr(dev))
     if position_ready is not None:
-        if not position_ready.cuda_event:     # torch creates the HIP event lazily: on its first record
-            position_ready.record(torch.cuda.current_stream(dev))
-        _scatter_check(lib.fnr_prop_density_bwd_pair_split(*args, C.c_void_p(position_ready.cuda_event)),
+        _scatter_check(lib.fnr_prop_density_bwd_pair_split(*args, C.c_void_p(position_ready.handle)),
                        "prop_density_bwd_pair_split", dev)
     else:
         _scatter_check(lib.fnr_prop_density_bwd_pair(*args), "prop_density_bwd_pair", dev)
@@ -593,7 +698,7 @@ def hash_encode_input_grad(grid: L.fnr_grid, warp: L.fnr_warp, rays: RaysArg, eu
                            d_feats: Tensor) -> Tensor:
     """Per-level gradient w.r.t. the unit-cube sample positions: [L][N][4]."""
     lib = L.load()
-    partial = torch.empty(grid.n_levels, rays.n * S, 4, device=rays.device)
+    partial = _empty(grid.n_levels, rays.n * S, 4, device=rays.device)
     L.check(lib.fnr_hash_encode_input_grad(C.byref(grid), C.byref(warp), rays.ref, L.ptr(euclid), S, L.ptr(d_feats),
                                            L.ptr(partial), L.stream_ptr(rays.device)), "hash_encode_input_grad")
     return partial
@@ -831,12 +936,12 @@ def train_prologue(image_set: ImageSetArg, train_ids: Tensor, n_rays: int, seed:
     ids = train_ids.to(torch.int64).contiguous()
     n_train = ids.numel()
     out = {
-        "u": torch.empty(R, 3, device=dev), "jitter": torch.empty(n_jitter, R, device=dev),
-        "origins": torch.empty(R, 3, device=dev), "directions": torch.empty(R, 3, device=dev),
-        "cam": torch.empty(R, dtype=torch.int32, device=dev), "image": torch.empty(R, 3, device=dev),
-        "mask": torch.empty(R, device=dev), "spacing": torch.empty(R, S0 + 1, device=dev),
-        "euclid": torch.empty(R, S0 + 1, device=dev),
-        "c2w_adjusted": torch.empty(n_train, 3, 4, device=dev) if pose_adjustment is not None else None,
+        "u": _empty(R, 3, device=dev), "jitter": _empty(n_jitter, R, device=dev),
+        "origins": _empty(R, 3, device=dev), "directions": _empty(R, 3, device=dev),
+        "cam": _empty(R, dtype=torch.int32, device=dev), "image": _empty(R, 3, device=dev),
+        "mask": _empty(R, device=dev), "spacing": _empty(R, S0 + 1, device=dev),
+        "euclid": _empty(R, S0 + 1, device=dev),
+        "c2w_adjusted": _empty(n_train, 3, 4, device=dev) if pose_adjustment is not None else None,
         "S0": S0, "near": float(near), "far": float(far), "spacing_kind": spacing_kind,
     }
     base = host_linspace(0.0, 1.0, S0 + 1, dev)
@@ -855,11 +960,11 @@ def sample_pixels(image_set: ImageSetArg, train_ids: Tensor, u: Tensor, c2w_adju
     dev = u.device
     R = u.shape[0]
     ids = train_ids.to(torch.int64).contiguous()
-    origins = torch.empty(R, 3, device=dev)
-    directions = torch.empty(R, 3, device=dev)
-    cam = torch.empty(R, dtype=torch.int32, device=dev)
-    image = torch.empty(R, 3, device=dev)
-    mask = torch.empty(R, device=dev)
+    origins = _empty(R, 3, device=dev)
+    directions = _empty(R, 3, device=dev)
+    cam = _empty(R, dtype=torch.int32, device=dev)
+    image = _empty(R, 3, device=dev)
+    mask = _empty(R, device=dev)
     L.check(lib.fnr_sample_pixels(C.byref(image_set.c), L.ptr(ids), ids.numel(), R, L.ptr(_f32c(u)),
                                   L.ptr(c2w_adjusted), L.ptr(origins), L.ptr(directions), L.ptr(cam), L.ptr(image), L.ptr(mask), L.stream_ptr(dev)),
             "sample_pixels")

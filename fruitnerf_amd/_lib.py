@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FNR_LIB_PATH") or os.path.join(_HERE, "lib", "libfrui
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 11     # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 12     # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -54,9 +54,30 @@ class fnr_field_net(C.Structure):
 
 
 class fnr_table_adam(C.Structure):
+    # slot: which fnr_step_scalars.adam entry supplies lr / step when a recorded step program replays the call (0: none)
     _fields_ = [("algorithm", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("eps", C.c_float), ("step", C.c_int64), ("grad_scale", C.c_float), ("weight_decay", C.c_float),
-                ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("touched", C.c_void_p)]
+                ("eps", C.c_float), ("slot", C.c_int32), ("step", C.c_int64), ("grad_scale", C.c_float),
+                ("weight_decay", C.c_float), ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("touched", C.c_void_p)]
+
+
+def table_adam(algorithm: int, lr: float, beta1: float, beta2: float, eps: float, step: int, grad_scale: float,
+               weight_decay: float, params, exp_avg, exp_avg_sq, touched, slot: int = 0) -> "fnr_table_adam":
+    return fnr_table_adam(algorithm, lr, beta1, beta2, eps, slot, step, grad_scale, weight_decay, params, exp_avg,
+                          exp_avg_sq, touched)
+
+
+FNR_PROGRAM_ADAM_SLOTS = 4
+ADAM_SLOTS = {"fields": 1, "proposal_networks": 2, "camera_opt": 3}     # optimiser group -> fnr_table_adam.slot
+
+
+class fnr_adam_scalars(C.Structure):
+    _fields_ = [("lr", C.c_float), ("reserved", C.c_int32), ("step", C.c_int64)]
+
+
+class fnr_step_scalars(C.Structure):
+    _fields_ = [("prologue_offset", C.c_uint64), ("anneal", C.c_float), ("reserved", C.c_int32),
+                ("adam", fnr_adam_scalars * FNR_PROGRAM_ADAM_SLOTS), ("losses", C.c_void_p)]
 
 
 class fnr_adam_span(C.Structure):
@@ -166,6 +187,19 @@ SIGNATURES = {
                                        _vp]),
     "fnr_image_metrics_workspace_bytes": (C.c_size_t, [_i, _i]),
     "fnr_image_metrics": (_i, [_i, _i, _vp, _vp, _vp, _vp, P(C.c_float), _vp, _vp, C.c_size_t, _vp]),
+    "fnr_program_create": (_i, [P(_vp)]),
+    "fnr_program_destroy": (_i, [_vp]),
+    "fnr_program_begin": (_i, [_vp]),
+    "fnr_program_end": (_i, [_vp]),
+    "fnr_program_abort": (_i, [_vp]),
+    "fnr_program_size": (_i64, [_vp]),
+    "fnr_program_op_name": (C.c_char_p, [_vp, _i64]),
+    "fnr_program_replay": (_i, [_vp, P(fnr_step_scalars)]),
+    "fnr_event_create": (_i, [P(_vp)]),
+    "fnr_event_destroy": (_i, [_vp]),
+    "fnr_event_record": (_i, [_vp, _vp]),
+    "fnr_stream_wait_event": (_i, [_vp, _vp]),
+    "fnr_stream_wait_stream": (_i, [_vp, _vp]),
     "fnr_export_workspace_bytes": (C.c_size_t, [_i64]),
     "fnr_export_compact": (_i, [P(fnr_lattice), _i64, _i64, _vp, _i64, _vp, _vp, _vp, P(_vp), P(_vp), _i64, _vp, _vp,
                                 _vp]),
@@ -203,11 +237,16 @@ def check(rc: int, what: str = "") -> None:
         raise RuntimeError(f"fruitnerf_hip {what} failed (rc={rc}): {last_error()}")
 
 
+_ptr_keep: Optional[list] = None     # while a step program is being recorded: every tensor whose pointer is handed out
+
+
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     """Device pointer of a contiguous tensor (None -> NULL)."""
     if t is None:
         return None
     assert t.is_contiguous(), "fruitnerf_hip needs contiguous tensors"
+    if _ptr_keep is not None:
+        _ptr_keep.append(t)          # a recorded program replays this pointer: its tensor must outlive the program
     return t.data_ptr()
 
 
@@ -242,13 +281,61 @@ PROFILE_OPS = ["sample_spaced", "weights_pdf", "prop_density_fwd", "hash_encode_
                "position_grad", "cloud"]
 
 
+_profile_state = {"on": False, "paused": False}
+
+
 def profile_enable(on: bool, ops=None) -> None:
     mask = (1 << 64) - 1 if ops is None else sum(1 << PROFILE_OPS.index(o) for o in ops)
     check(load().fnr_profile_enable(1 if on else 0, mask), "profile_enable")
+    _profile_state["on"], _profile_state["paused"] = bool(on), False
 
 
 def profile_pause(paused: bool) -> None:
     check(load().fnr_profile_pause(1 if paused else 0), "profile_pause")
+    _profile_state["paused"] = bool(paused)
+
+
+def profile_recording() -> bool:
+    """True while entry points bracket their launches with HIP events (a step program recorded or replayed then would
+    carry / drop those events: training.TrainingSteps takes the interpreted path on such steps)."""
+    return _profile_state["on"] and not _profile_state["paused"]
+
+
+class _CallLog:
+    """Stands in for the loaded library while a step program is being recorded: every entry point called from Python is
+    noted by name, so that the recording can be checked against what Python asked for (a call the C side did not record
+    would silently be missing from every replay)."""
+
+    def __init__(self, lib):
+        self._lib, self.names = lib, []
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        names = self.names
+
+        def logged(*a):
+            names.append(name)
+            return fn(*a)
+        return logged
+
+
+def begin_call_log(keep: Optional[list] = None) -> "_CallLog":
+    """keep: receives every tensor whose device pointer ptr() hands out while the log is active."""
+    global _lib, _ptr_keep
+    lib = load()
+    if isinstance(lib, _CallLog):
+        raise RuntimeError("a call log is already active")
+    _lib = _CallLog(lib)
+    _ptr_keep = keep
+    return _lib
+
+
+def end_call_log(log: "_CallLog") -> list:
+    global _lib, _ptr_keep
+    if _lib is log:
+        _lib = log._lib
+    _ptr_keep = None
+    return log.names
 
 
 def scatter_overflows(reset: bool = False) -> int:

@@ -100,13 +100,21 @@ class CameraAdam:
         (fnr_camera_pose_grad_adam) — same learning rate / step as step() would use."""
         from ..training import exponential_decay_lr
         from .. import _lib as L
+        lr, step = self.advance()
+        c = self.cfg
+        p = self.opt.pose_adjustment
+        return L.table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], c.eps,
+                            step, grad_scale, c.weight_decay, L.ptr(p.data), L.ptr(self.exp_avg),
+                            L.ptr(self.exp_avg_sq), None, slot=L.ADAM_SLOTS["camera_opt"])
+
+    def advance(self):
+        """Count one optimiser step -> (its learning rate, its 1-based step number): the host bookkeeping of
+        fused_step_args() (a replayed step program patches these two into the recorded call)."""
+        from ..training import exponential_decay_lr
         self.step_count += 1
         c = self.cfg
         lr = c.lr if c.lr_final is None else exponential_decay_lr(self.step_count - 1, c.lr, c.lr_final, c.max_steps)
-        p = self.opt.pose_adjustment
-        return L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], c.eps,
-                                self.step_count, grad_scale, c.weight_decay, L.ptr(p.data), L.ptr(self.exp_avg),
-                                L.ptr(self.exp_avg_sq), None)
+        return lr, self.step_count
 
     def step(self, grad_scale: float = 1.0) -> None:
         from ..training import exponential_decay_lr

@@ -10,6 +10,7 @@
 // [n_train, 6] tangent vectors: one workgroup per camera gathers its rays (ballot), so there are no atomics on the
 // shared rows.
 #include "camera_math.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -202,6 +203,7 @@ using namespace fnr;
 
 extern "C" int fnr_camera_adjust(const float* c2w, const int64_t* train_ids, int n_train, const float* pose_adjustment,
                                  float* c2w_adjusted, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_camera_adjust");
   FNR_CHECK_ARG(c2w && train_ids && pose_adjustment && c2w_adjusted && n_train > 0, "camera_adjust: null argument");
   hipLaunchKernelGGL(k_camera_adjust, dim3((unsigned)((n_train + 63) / 64)), dim3(64), 0, as_stream(stream), c2w,
                      reinterpret_cast<const long long*>(train_ids), n_train, pose_adjustment, c2w_adjusted);
@@ -213,6 +215,7 @@ extern "C" int fnr_camera_pose_grad(const fnr_image_set* set, const int64_t* tra
                                     const float* u, const int32_t* camera_indices, const float* pose_adjustment,
                                     const float* c2w_adjusted, const float* d_origins, const float* d_directions,
                                     float* pose_grad, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_camera_pose_grad");
   FNR_CHECK_ARG(set && set->c2w && train_ids && u && camera_indices && pose_adjustment && c2w_adjusted && d_origins &&
                     d_directions && pose_grad && n_train > 0,
                 "camera_pose_grad: null argument");
@@ -229,6 +232,15 @@ extern "C" int fnr_camera_pose_grad_adam(const fnr_image_set* set, const int64_t
                                          const float* u, const int32_t* camera_indices, const float* c2w_adjusted,
                                          const float* d_origins, const float* d_directions, float* pose_grad,
                                          const fnr_table_adam* adam, void* stream) {
+  if (seq::recording() && set && adam) {
+    const fnr_image_set set_ = *set;
+    const fnr_table_adam adam_ = *adam;
+    seq::push("fnr_camera_pose_grad_adam", [=](const fnr_step_scalars* sc) {
+      const fnr_table_adam a = seq::patched(adam_, sc);
+      return fnr_camera_pose_grad_adam(&set_, train_ids, n_train, n_rays, u, camera_indices, c2w_adjusted, d_origins,
+                                       d_directions, pose_grad, &a, stream);
+    });
+  }
   FNR_CHECK_ARG(set && set->c2w && train_ids && u && camera_indices && c2w_adjusted && d_origins && d_directions &&
                     pose_grad && adam && n_train > 0,
                 "camera_pose_grad_adam: null argument");

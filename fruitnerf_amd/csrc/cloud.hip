@@ -18,6 +18,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "sequencer.hpp"
 
 #include <rocprim/rocprim.hpp>
 
@@ -563,6 +564,7 @@ extern "C" size_t fnr_cloud_workspace_bytes(int64_t n_points) {
 
 extern "C" int fnr_cloud_bounds(const double* xyz, int64_t n, double* lo_hi, void* workspace, size_t workspace_bytes,
                                 void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_cloud_bounds");
   FNR_CHECK_ARG(n >= 1 && n < 2147483647LL, "cloud_bounds: n out of range (an empty cloud has no bounds)");
   FNR_CHECK_ARG(xyz && lo_hi && workspace && workspace_bytes >= 64, "cloud_bounds: null argument / workspace < 64 B");
   hipStream_t st = as_stream(stream);
@@ -582,6 +584,7 @@ extern "C" int fnr_cloud_bounds(const double* xyz, int64_t n, double* lo_hi, voi
 extern "C" int fnr_cloud_radius_count(const double* xyz, int64_t n, const double* lo, const double* hi, double radius,
                                       int inclusive, int32_t* counts, void* workspace, size_t workspace_bytes,
                                       void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_cloud_radius_count");
   FNR_CHECK_ARG(n >= 0 && n < 2147483647LL, "cloud_radius_count: n out of range");
   if (n == 0) return FNR_OK;
   FNR_CHECK_ARG(xyz && counts, "cloud_radius_count: null argument");
@@ -609,6 +612,7 @@ extern "C" int fnr_cloud_radius_count(const double* xyz, int64_t n, const double
 extern "C" int fnr_cloud_dbscan(const double* xyz, int64_t n, const double* lo, const double* hi, double eps,
                                 int32_t min_samples, int32_t* labels, int32_t* n_clusters, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_cloud_dbscan");
   FNR_CHECK_ARG(n >= 0 && n < 2147483647LL, "cloud_dbscan: n out of range");
   hipStream_t st = as_stream(stream);
   if (n == 0) {
@@ -653,6 +657,7 @@ extern "C" int fnr_cloud_voxel_down_sample(const double* xyz, const double* rgb,
                                            const double* max_bound, double voxel_size, double* xyz_out,
                                            double* rgb_out, int32_t* n_out, void* workspace, size_t workspace_bytes,
                                            void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_cloud_voxel_down_sample");
   FNR_CHECK_ARG(n >= 0 && n < 2147483647LL, "cloud_voxel_down_sample: n out of range");
   FNR_CHECK_ARG(n_out, "cloud_voxel_down_sample: null n_out");
   hipStream_t st = as_stream(stream);

@@ -3,6 +3,7 @@
 // makes the exported point lists identical (not just equal in count) to the reference's per-batch
 // boolean-mask indexing.  HBM-bound: 20 B read per sample (density, rgb, logit), twice.
 #include "common.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -181,6 +182,7 @@ extern "C" int fnr_export_compact(const fnr_lattice* lat, int64_t ray_begin, int
                                   const float* rgb, const float* logit, float* const points[3],
                                   float* const colors[3], int64_t capacity, uint64_t* counts, void* workspace,
                                   void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_export_compact");
   FNR_CHECK_ARG(density && rgb && logit && points && colors && counts && workspace, "export_compact: null argument");
   FNR_CHECK_ARG((lat != nullptr) != (positions != nullptr), "export_compact: give either a lattice or positions");
   long long N;

@@ -7,6 +7,7 @@
 // Roofline: MFMA fp32 (157.3 TF peak): 33 024 useful FLOP/sample, 36 864 issued (padding).
 #include "field_layers.hpp"
 #include "field_bf16.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -255,6 +256,14 @@ extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays,
                                  const uint8_t* selector, const float* mean_embedding, float* density, float* rgb,
                                  float* logit, float* geo_out, float* h_save, float* ray_bias_save,
                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (seq::recording() && net && rays) {
+    const fnr_field_net net_ = *net;
+    const fnr_rays rays_ = *rays;
+    seq::push("fnr_field_mlp_fwd", [=](const fnr_step_scalars*) {
+      return fnr_field_mlp_fwd(&net_, &rays_, S, feats, selector, mean_embedding, density, rgb, logit, geo_out, h_save,
+                               ray_bias_save, workspace, workspace_bytes, stream);
+    });
+  }
   FNR_CHECK_ARG(net && rays && feats && density && rgb && logit && S > 0, "field_mlp_fwd: null argument");
   FNR_CHECK_ARG(rays->directions, "field_mlp_fwd: rays.directions is null");
   FNR_CHECK_ARG(mean_embedding || (rays->camera_indices && net->embedding),
@@ -285,6 +294,7 @@ extern "C" int fnr_field_mlp_fwd(const fnr_field_net* net, const fnr_rays* rays,
 }
 
 extern "C" int fnr_embedding_mean(const float* embedding, int n_images, int dim, float* out, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_embedding_mean");
   FNR_CHECK_ARG(embedding && out && n_images > 0 && dim > 0, "embedding_mean: bad argument");
   hipLaunchKernelGGL(k_embedding_mean, dim3(dim), dim3(64), 0, as_stream(stream), embedding, n_images, dim, out);
   FNR_LAUNCH_CHECK();

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "field_layers.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -1012,6 +1013,7 @@ extern "C" int fnr_field_mlp_bwd(const fnr_field_net* net, const fnr_field_net* 
                                  const float* packed_saved, const uint8_t* selector, const float* d_density,
                                  const float* d_rgb, const float* d_logit, float* d_feats, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_field_mlp_bwd");
   return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
                              d_logit, d_feats, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
@@ -1022,6 +1024,17 @@ extern "C" int fnr_field_mlp_bwd_adam(const fnr_field_net* net, const fnr_field_
                                       const float* d_rgb, const float* d_logit, float* d_feats, const float* jacobian,
                                       float* d_position, const fnr_table_adam* weight_adam, const float* grad_arena,
                                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (seq::recording() && net && grads && rays && weight_adam) {
+    const fnr_field_net net_ = *net, grads_ = *grads;
+    const fnr_rays rays_ = *rays;
+    const fnr_table_adam adam_ = *weight_adam;
+    seq::push("fnr_field_mlp_bwd_adam", [=](const fnr_step_scalars* sc) {
+      const fnr_table_adam a = seq::patched(adam_, sc);
+      return fnr_field_mlp_bwd_adam(&net_, &grads_, &rays_, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density,
+                                    d_rgb, d_logit, d_feats, jacobian, d_position, &a, grad_arena, workspace, workspace_bytes,
+                                    stream);
+    });
+  }
   FNR_CHECK_ARG(weight_adam && grad_arena, "field_mlp_bwd_adam: weight_adam / grad_arena missing");
   FNR_CHECK_ARG((jacobian == nullptr) == (d_position == nullptr), "field_mlp_bwd_adam: jacobian and d_position go together");
   return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
@@ -1034,6 +1047,7 @@ extern "C" int fnr_field_mlp_bwd_rays(const fnr_field_net* net, const fnr_field_
                                       const float* packed_saved, const uint8_t* selector, const float* d_density,
                                       const float* d_rgb, const float* d_logit, float* d_feats, const float* jacobian,
                                       float* d_position, void* workspace, size_t workspace_bytes, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_field_mlp_bwd_rays");
   FNR_CHECK_ARG(jacobian && d_position, "field_mlp_bwd_rays: jacobian / d_position missing");
   return field_mlp_bwd_entry(net, grads, rays, S, feats, h_saved, ray_bias_saved, packed_saved, selector, d_density, d_rgb,
                              d_logit, d_feats, workspace, workspace_bytes, stream, jacobian, d_position);

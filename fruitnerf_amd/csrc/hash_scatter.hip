@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "hash_sources.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -1004,6 +1005,7 @@ extern "C" int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* wa
                                    const float* euclid_bins, int S, const float* d_feats, int level_begin,
                                    int level_count, void* workspace, size_t workspace_bytes, int workspace_clean,
                                    void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_hash_encode_bwd");
   FNR_CHECK_ARG(grid_grad && warp && rays && euclid_bins && d_feats && S > 0, "hash_encode_bwd: null argument");
   FNR_CHECK_ARG(grid_grad->n_levels >= 1 && grid_grad->n_levels <= FNR_MAX_LEVELS, "hash_encode_bwd: n_levels");
   const long long N = rays->n_rays * (long long)S;
@@ -1018,6 +1020,17 @@ extern "C" int fnr_hash_encode_bwd_adam(const fnr_grid* grid_grad, const fnr_war
                                         const float* euclid_bins, int S, const float* d_feats, void* workspace,
                                         size_t workspace_bytes, int workspace_clean, const fnr_table_adam* adam,
                                         void* stream) {
+  if (seq::recording() && grid_grad && warp && rays && adam) {
+    const fnr_grid grid_ = *grid_grad;
+    const fnr_warp warp_ = *warp;
+    const fnr_rays rays_ = *rays;
+    const fnr_table_adam adam_ = *adam;
+    seq::push("fnr_hash_encode_bwd_adam", [=](const fnr_step_scalars* sc) {
+      const fnr_table_adam a = seq::patched(adam_, sc);
+      return fnr_hash_encode_bwd_adam(&grid_, &warp_, &rays_, euclid_bins, S, d_feats, workspace, workspace_bytes,
+                                      workspace_clean, &a, stream);
+    });
+  }
   FNR_CHECK_ARG(grid_grad && warp && rays && euclid_bins && d_feats && S > 0, "hash_encode_bwd_adam: null argument");
   FNR_CHECK_ARG(grid_grad->n_levels >= 1 && grid_grad->n_levels <= FNR_MAX_LEVELS, "hash_encode_bwd_adam: n_levels");
   TableAdam t;
@@ -1145,6 +1158,7 @@ extern "C" int fnr_prop_density_bwd(const fnr_prop_net* net, const fnr_prop_net*
                                     const fnr_rays* rays, const float* euclid_bins, int S, const float* feat_save,
                                     const float* d_density, float* d_position, void* workspace,
                                     size_t workspace_bytes, int workspace_clean, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_prop_density_bwd");
   return prop_density_bwd_entry(net, grads, warp, rays, euclid_bins, S, feat_save, d_density, d_position, workspace,
                                 workspace_bytes, workspace_clean, stream, nullptr, nullptr, nullptr);
 }
@@ -1154,6 +1168,7 @@ extern "C" int fnr_prop_density_bwd_adam(const fnr_prop_net* net, const fnr_prop
                                          const float* d_density, float* d_position, const fnr_table_adam* table_adam,
                                          const fnr_table_adam* weight_adam, const float* grad_arena, void* workspace,
                                          size_t workspace_bytes, int workspace_clean, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_prop_density_bwd_adam");
   FNR_CHECK_ARG(table_adam && weight_adam && grad_arena, "prop_density_bwd_adam: optimiser descriptors missing");
   return prop_density_bwd_entry(net, grads, warp, rays, euclid_bins, S, feat_save, d_density, d_position, workspace,
                                 workspace_bytes, workspace_clean, stream, table_adam, weight_adam, grad_arena);
@@ -1170,6 +1185,41 @@ extern "C" int fnr_prop_density_bwd_pair(const fnr_prop_net* const* nets, const 
                                          const fnr_table_adam* const* table_adam, const fnr_table_adam* weight_adam,
                                          const float* grad_arena, void* const* workspace, const size_t* workspace_bytes,
                                          const int* workspace_clean, void* stream) {
+  if (seq::recording() && nets && grads && warps && rays && euclid_bins && S && feat_save && d_density && d_position &&
+      workspace && workspace_bytes && workspace_clean && nets[0] && nets[1] && grads[0] && grads[1] && warps[0] && warps[1]) {
+    struct Pair {
+      fnr_prop_net net[2], grad[2];
+      fnr_warp warp[2];
+      fnr_rays rays;
+      const float* euclid[2];
+      int S[2];
+      const float* feat[2];
+      const float* dd[2];
+      float* dpos[2];
+      fnr_table_adam tadam[2], wadam;
+      bool has_adam;
+      void* ws[2];
+      size_t ws_bytes[2];
+      int ws_clean[2];
+    } p;
+    for (int q = 0; q < 2; ++q) {
+      p.net[q] = *nets[q], p.grad[q] = *grads[q], p.warp[q] = *warps[q], p.euclid[q] = euclid_bins[q], p.S[q] = S[q];
+      p.feat[q] = feat_save[q], p.dd[q] = d_density[q], p.dpos[q] = d_position[q], p.ws[q] = workspace[q];
+      p.ws_bytes[q] = workspace_bytes[q], p.ws_clean[q] = workspace_clean[q];
+    }
+    p.rays = *rays;
+    p.has_adam = table_adam && table_adam[0] && table_adam[1] && weight_adam;
+    if (p.has_adam) p.tadam[0] = *table_adam[0], p.tadam[1] = *table_adam[1], p.wadam = *weight_adam;
+    seq::push("fnr_prop_density_bwd_pair", [=](const fnr_step_scalars* sc) {
+      const fnr_prop_net* n_[2] = {&p.net[0], &p.net[1]};
+      const fnr_prop_net* g_[2] = {&p.grad[0], &p.grad[1]};
+      const fnr_warp* w_[2] = {&p.warp[0], &p.warp[1]};
+      const fnr_table_adam t0 = seq::patched(p.tadam[0], sc), t1 = seq::patched(p.tadam[1], sc), wa = seq::patched(p.wadam, sc);
+      const fnr_table_adam* t_[2] = {&t0, &t1};
+      return fnr_prop_density_bwd_pair(n_, g_, w_, &p.rays, p.euclid, p.S, p.feat, p.dd, p.dpos, p.has_adam ? t_ : nullptr,
+                      p.has_adam ? &wa : nullptr, grad_arena, p.ws, p.ws_bytes, p.ws_clean, stream);
+    });
+  }
   FNR_CHECK_ARG(nets && grads && warps && rays && euclid_bins && S && feat_save && d_density && d_position && workspace &&
                     workspace_bytes && workspace_clean,
                 "prop_density_bwd_pair: null argument");
@@ -1202,6 +1252,41 @@ extern "C" int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, 
                                                const fnr_table_adam* const* table_adam, const fnr_table_adam* weight_adam,
                                                const float* grad_arena, void* const* workspace, const size_t* workspace_bytes,
                                                const int* workspace_clean, void* stream, void* position_ready_event) {
+  if (seq::recording() && nets && grads && warps && rays && euclid_bins && S && feat_save && d_density && d_position &&
+      workspace && workspace_bytes && workspace_clean && nets[0] && nets[1] && grads[0] && grads[1] && warps[0] && warps[1]) {
+    struct Pair {
+      fnr_prop_net net[2], grad[2];
+      fnr_warp warp[2];
+      fnr_rays rays;
+      const float* euclid[2];
+      int S[2];
+      const float* feat[2];
+      const float* dd[2];
+      float* dpos[2];
+      fnr_table_adam tadam[2], wadam;
+      bool has_adam;
+      void* ws[2];
+      size_t ws_bytes[2];
+      int ws_clean[2];
+    } p;
+    for (int q = 0; q < 2; ++q) {
+      p.net[q] = *nets[q], p.grad[q] = *grads[q], p.warp[q] = *warps[q], p.euclid[q] = euclid_bins[q], p.S[q] = S[q];
+      p.feat[q] = feat_save[q], p.dd[q] = d_density[q], p.dpos[q] = d_position[q], p.ws[q] = workspace[q];
+      p.ws_bytes[q] = workspace_bytes[q], p.ws_clean[q] = workspace_clean[q];
+    }
+    p.rays = *rays;
+    p.has_adam = table_adam && table_adam[0] && table_adam[1] && weight_adam;
+    if (p.has_adam) p.tadam[0] = *table_adam[0], p.tadam[1] = *table_adam[1], p.wadam = *weight_adam;
+    seq::push("fnr_prop_density_bwd_pair_split", [=](const fnr_step_scalars* sc) {
+      const fnr_prop_net* n_[2] = {&p.net[0], &p.net[1]};
+      const fnr_prop_net* g_[2] = {&p.grad[0], &p.grad[1]};
+      const fnr_warp* w_[2] = {&p.warp[0], &p.warp[1]};
+      const fnr_table_adam t0 = seq::patched(p.tadam[0], sc), t1 = seq::patched(p.tadam[1], sc), wa = seq::patched(p.wadam, sc);
+      const fnr_table_adam* t_[2] = {&t0, &t1};
+      return fnr_prop_density_bwd_pair_split(n_, g_, w_, &p.rays, p.euclid, p.S, p.feat, p.dd, p.dpos, p.has_adam ? t_ : nullptr,
+                      p.has_adam ? &wa : nullptr, grad_arena, p.ws, p.ws_bytes, p.ws_clean, stream, position_ready_event);
+    });
+  }
   FNR_CHECK_ARG(nets && grads && warps && rays && euclid_bins && S && feat_save && d_density && d_position && workspace &&
                     workspace_bytes && workspace_clean,
                 "prop_density_bwd_pair_split: null argument");

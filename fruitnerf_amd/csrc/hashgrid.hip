@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "hash_sources.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -147,6 +148,14 @@ using namespace fnr;
 extern "C" int fnr_hash_encode_fwd(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays,
                                    const float* euclid_bins, int S, float* feats, uint8_t* selector, float* jacobian,
                                    void* stream) {
+  if (seq::recording() && grid && warp && rays) {
+    const fnr_grid grid_ = *grid;
+    const fnr_warp warp_ = *warp;
+    const fnr_rays rays_ = *rays;
+    seq::push("fnr_hash_encode_fwd", [=](const fnr_step_scalars*) {
+      return fnr_hash_encode_fwd(&grid_, &warp_, &rays_, euclid_bins, S, feats, selector, jacobian, stream);
+    });
+  }
   FNR_CHECK_ARG(rays && euclid_bins && S > 0, "hash_encode_fwd: null rays/bins or S<=0");
   RaySource src{make_rays(rays), euclid_bins, S};
   return launch_encode(grid, warp, src, rays->n_rays * (long long)S, feats, selector, jacobian, stream);
@@ -155,6 +164,7 @@ extern "C" int fnr_hash_encode_fwd(const fnr_grid* grid, const fnr_warp* warp, c
 extern "C" int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* warp, const fnr_lattice* lat,
                                        int64_t ray_begin, int64_t n_rays, float* feats, uint8_t* selector,
                                        void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_hash_encode_lattice");
   FNR_CHECK_ARG(lat && lat->xs && lat->ys && lat->zs, "hash_encode_lattice: null lattice");
   FNR_CHECK_ARG(ray_begin >= 0 && n_rays >= 0 && ray_begin + n_rays <= (int64_t)lat->n_x * lat->n_y,
                 "hash_encode_lattice: ray range [%lld,+%lld) outside %d x %d lattice", (long long)ray_begin,
@@ -165,6 +175,14 @@ extern "C" int fnr_hash_encode_lattice(const fnr_grid* grid, const fnr_warp* war
 
 extern "C" int fnr_prop_density_fwd(const fnr_prop_net* net, const fnr_warp* warp, const fnr_rays* rays,
                                     const float* euclid_bins, int S, float* density, float* feat_save, void* stream) {
+  if (seq::recording() && net && warp && rays) {
+    const fnr_prop_net net_ = *net;
+    const fnr_warp warp_ = *warp;
+    const fnr_rays rays_ = *rays;
+    seq::push("fnr_prop_density_fwd", [=](const fnr_step_scalars*) {
+      return fnr_prop_density_fwd(&net_, &warp_, &rays_, euclid_bins, S, density, feat_save, stream);
+    });
+  }
   FNR_CHECK_ARG(net && warp && rays && euclid_bins && density && S > 0, "prop_density_fwd: null argument");
   FNR_UNSUPPORTED(net->hidden_dim == 16, "prop_density_fwd: hidden_dim %d not built (16 only)", net->hidden_dim);
   const long long N = rays->n_rays * (long long)S;

@@ -13,6 +13,7 @@
 // All sums leave the device as doubles (per-workgroup partials, summed in a fixed order by one workgroup): deterministic.
 // HBM-bound and tiny (an 800 x 800 image: ~15 MB read): latency is the launches, so four kernels in one entry point.
 #include "common.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -233,6 +234,7 @@ extern "C" size_t fnr_image_metrics_workspace_bytes(int H, int W) {
 extern "C" int fnr_image_metrics(int H, int W, const float* rgb, const float* image, const float* semantics,
                                  const float* mask, const float* gauss11, double* out, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_image_metrics");
   FNR_CHECK_ARG(rgb && image && gauss11 && out && workspace, "image_metrics: null argument");
   FNR_CHECK_ARG((semantics == nullptr) == (mask == nullptr), "image_metrics: semantics and mask come together");
   FNR_CHECK_ARG(H > 2 * IM_PAD && W > 2 * IM_PAD, "image_metrics: image %d x %d smaller than the 11 x 11 SSIM window", H, W);

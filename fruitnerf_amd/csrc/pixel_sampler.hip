@@ -5,6 +5,7 @@
 // One thread per ray; replaces ~15 small elementwise/index launches per step.  HBM-bound, 40 B written per ray.
 #include "camera_math.hpp"
 #include "sampler_math.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -172,6 +173,7 @@ using namespace fnr;
 extern "C" int fnr_sample_pixels(const fnr_image_set* set, const int64_t* train_ids, int n_train, int64_t n_rays,
                                  const float* u, const float* c2w_adjusted, float* origins, float* directions,
                                  int32_t* camera_indices, float* image, float* fruit_mask, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_sample_pixels");
   FNR_CHECK_ARG(set && train_ids && u && origins && directions && camera_indices && image && fruit_mask,
                 "sample_pixels: null argument");
   FNR_CHECK_ARG(set->images && set->masks && set->c2w && set->n_images > 0 && set->H > 0 && set->W > 0 && n_train > 0,
@@ -191,6 +193,14 @@ extern "C" int fnr_train_prologue(const fnr_image_set* set, const int64_t* train
                                   int32_t* camera_indices, float* image, float* fruit_mask, float near_plane,
                                   float far_plane, int spacing_kind, int S0, const float* base_bins, float* spacing0,
                                   float* euclid0, void* stream) {
+  if (seq::recording() && set) {
+    const fnr_image_set set_ = *set;
+    seq::push("fnr_train_prologue", [=](const fnr_step_scalars* sc) {
+      return fnr_train_prologue(&set_, train_ids, n_train, n_rays, seed, sc ? sc->prologue_offset : offset, pose_adjustment,
+                                c2w_adjusted, u, jitter, n_jitter, origins, directions, camera_indices, image, fruit_mask,
+                                near_plane, far_plane, spacing_kind, S0, base_bins, spacing0, euclid0, stream);
+    });
+  }
   FNR_CHECK_ARG(set && train_ids && u && jitter && origins && directions && camera_indices && image && fruit_mask &&
                     base_bins && spacing0 && euclid0,
                 "train_prologue: null argument");

@@ -13,6 +13,7 @@
 //   proposal nets: k_prop_bwd re-gathers (5 levels, tables L2-resident) and k_position_reduce finishes;
 //   k_hash_input_grad + k_position_reduce remain as the gather-based path for callers without a saved Jacobian.
 #include "hash_sources.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -302,6 +303,7 @@ using namespace fnr;
 extern "C" int fnr_position_grad_from_jacobian(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,
                                                int n_levels, const float* jacobian, const float* d_feats,
                                                float* d_origins, float* d_directions, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_position_grad_from_jacobian");
   FNR_CHECK_ARG(warp && rays && euclid_bins && jacobian && d_feats && d_origins && d_directions && S > 0 && n_levels >= 1,
                 "position_grad_from_jacobian: null argument");
   if (rays->n_rays == 0) return FNR_OK;
@@ -317,6 +319,7 @@ extern "C" int fnr_position_grad_from_jacobian(const fnr_warp* warp, const fnr_r
 extern "C" int fnr_hash_encode_input_grad(const fnr_grid* grid, const fnr_warp* warp, const fnr_rays* rays,
                                           const float* euclid_bins, int S, const float* d_feats, float* partial,
                                           void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_hash_encode_input_grad");
   FNR_CHECK_ARG(grid && warp && rays && euclid_bins && d_feats && partial && S > 0, "hash_encode_input_grad: null argument");
   FNR_CHECK_ARG(grid->n_levels >= 1 && grid->n_levels <= FNR_MAX_LEVELS, "hash_encode_input_grad: n_levels");
   const long long N = rays->n_rays * (long long)S;
@@ -336,6 +339,24 @@ extern "C" int fnr_position_grad_reduce_multi(int n_sources, const fnr_warp* con
                                               const float* const* euclid_bins, const int* S, const int* n_levels,
                                               const float* const* partials, int accumulate, float* d_origins,
                                               float* d_directions, void* stream) {
+  if (seq::recording() && n_sources >= 1 && n_sources <= FNR_MAX_POSITION_SOURCES && warps && rays && euclid_bins && S &&
+      n_levels && partials) {
+    constexpr int M = FNR_MAX_POSITION_SOURCES;
+    std::array<fnr_warp, M> warps_{};
+    for (int q = 0; q < n_sources; ++q)
+      if (warps[q]) warps_[q] = *warps[q];
+    const fnr_rays rays_ = *rays;
+    const auto eu_ = seq::copy_n<const float*, M>(euclid_bins, n_sources);
+    const auto S_ = seq::copy_n<int, M>(S, n_sources);
+    const auto lv_ = seq::copy_n<int, M>(n_levels, n_sources);
+    const auto pa_ = seq::copy_n<const float*, M>(partials, n_sources);
+    seq::push("fnr_position_grad_reduce_multi", [=](const fnr_step_scalars*) {
+      const fnr_warp* w_[M];
+      for (int q = 0; q < M; ++q) w_[q] = &warps_[q];
+      return fnr_position_grad_reduce_multi(n_sources, w_, &rays_, eu_.data(), S_.data(), lv_.data(), pa_.data(), accumulate,
+                                            d_origins, d_directions, stream);
+    });
+  }
   FNR_CHECK_ARG(n_sources >= 1 && n_sources <= FNR_MAX_POSITION_SOURCES && warps && rays && euclid_bins && S && n_levels &&
                     partials && d_origins && d_directions,
                 "position_grad_reduce_multi: bad argument (1..%d sources)", FNR_MAX_POSITION_SOURCES);
@@ -363,6 +384,7 @@ extern "C" int fnr_position_grad_reduce_multi(int n_sources, const fnr_warp* con
 extern "C" int fnr_position_grad_reduce(const fnr_warp* warp, const fnr_rays* rays, const float* euclid_bins, int S,
                                         int n_levels, const float* partial, float* d_origins, float* d_directions,
                                         void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_position_grad_reduce");
   FNR_CHECK_ARG(warp && rays && euclid_bins && partial && d_origins && d_directions && S > 0 && n_levels >= 1,
                 "position_grad_reduce: null argument");
   if (rays->n_rays == 0) return FNR_OK;

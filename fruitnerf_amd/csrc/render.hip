@@ -1,6 +1,7 @@
 // render.hip — alpha compositing for gfx950: RaySamples.get_weights + RGBRenderer("last_sample") +
 // AccumulationRenderer + DepthRenderer("median") + SemanticRenderer (fruit_nerf.py:325-348), one wave per ray.
 #include "common.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -110,6 +111,13 @@ extern "C" int fnr_composite_fwd(const fnr_rays* rays, int S, const float* eucli
                                  const float* rgb, const float* logit, int training, float* weights, float* out_rgb,
                                  float* out_accumulation, float* out_depth, float* out_semantics,
                                  int64_t* out_label, void* stream) {
+  if (seq::recording() && rays) {
+    const fnr_rays rays_ = *rays;
+    seq::push("fnr_composite_fwd", [=](const fnr_step_scalars*) {
+      return fnr_composite_fwd(&rays_, S, euclid_bins, density, rgb, logit, training, weights, out_rgb, out_accumulation,
+                               out_depth, out_semantics, out_label, stream);
+    });
+  }
   FNR_CHECK_ARG(rays && euclid_bins && density && rgb && logit && weights && out_rgb && out_accumulation &&
                     out_depth && out_semantics,
                 "composite_fwd: null argument");

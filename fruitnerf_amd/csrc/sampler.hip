@@ -5,6 +5,7 @@
 // of S floats per ray); they exist so the whole sampling chain stays on the device without launches of
 // dozens of small elementwise ops.
 #include "sampler_math.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -159,6 +160,7 @@ using namespace fnr;
 extern "C" int fnr_sample_spaced(const fnr_rays* rays, int spacing_kind, int S, const float* base_bins,
                                  const float* t_rand, int t_rand_per_bin, float* spacing_bins, float* euclid_bins,
                                  void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_sample_spaced");
   FNR_CHECK_ARG(rays && base_bins && spacing_bins && euclid_bins && S > 0, "sample_spaced: null argument");
   FNR_CHECK_ARG(rays->nears && rays->fars, "sample_spaced: rays.nears/fars must be set (collider, fruit_nerf.py:382)");
   FNR_CHECK_ARG(spacing_kind == 0 || spacing_kind == 1, "sample_spaced: spacing_kind %d", spacing_kind);
@@ -175,6 +177,13 @@ extern "C" int fnr_weights_pdf(const fnr_rays* rays, int spacing_kind, int S_pre
                                const float* spacing_prev, const float* euclid_prev, float anneal, const float* u_base,
                                const float* rand, float* weights, float* median_depth, float* spacing_new,
                                float* euclid_new, void* stream) {
+  if (seq::recording() && rays) {
+    const fnr_rays rays_ = *rays;
+    seq::push("fnr_weights_pdf", [=](const fnr_step_scalars* sc) {
+      return fnr_weights_pdf(&rays_, spacing_kind, S_prev, S_new, density, spacing_prev, euclid_prev, sc ? sc->anneal : anneal,
+                             u_base, rand, weights, median_depth, spacing_new, euclid_new, stream);
+    });
+  }
   FNR_CHECK_ARG(rays && density && euclid_prev && weights, "weights_pdf: null argument");
   FNR_CHECK_ARG(S_prev > 0 && S_prev <= PDF_MAX_PREV, "weights_pdf: S_prev %d out of range (1..%d)", S_prev,
                 PDF_MAX_PREV);

@@ -5,6 +5,7 @@
 //   optimiser: torch.optim.Adam semantics (fruit_nerf_config.py:47-56)
 // One wave per ray for the per-ray scans; everything here is bandwidth-trivial next to the field kernels.
 #include "common.hpp"
+#include "sequencer.hpp"
 
 namespace fnr {
 
@@ -648,6 +649,7 @@ using namespace fnr;
 extern "C" int fnr_losses_fwd(int64_t n_rays, const float* rgb, const float* image, const float* semantics,
                               const float* fruit_mask, float semantic_loss_weight, float* losses, float* d_rgb,
                               float* d_semantics, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_losses_fwd");
   FNR_CHECK_ARG(rgb && image && semantics && fruit_mask && losses && d_rgb && d_semantics && n_rays > 0,
                 "losses_fwd: null argument");
   FNR_PROF(OP_LOSSES, n_rays);
@@ -660,6 +662,7 @@ extern "C" int fnr_losses_fwd(int64_t n_rays, const float* rgb, const float* ima
 extern "C" int fnr_interlevel_fwd(int64_t n_rays, int S_f, const float* spacing_f, const float* weights_f, int S_p,
                                   const float* spacing_p, const float* weights_p, float mult, float* loss,
                                   float* d_weights_p, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_interlevel_fwd");
   FNR_CHECK_ARG(spacing_f && weights_f && spacing_p && weights_p && loss && d_weights_p, "interlevel_fwd: null argument");
   FNR_CHECK_ARG(S_f > 0 && S_p > 0 && S_p <= IL_MAX_P, "interlevel_fwd: S_p %d out of range", S_p);
   if (n_rays == 0) return FNR_OK;
@@ -672,6 +675,7 @@ extern "C" int fnr_interlevel_fwd(int64_t n_rays, int S_f, const float* spacing_
 
 extern "C" int fnr_distortion(int64_t n_rays, int S, const float* spacing, const float* weights, float* out,
                               void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_distortion");
   FNR_CHECK_ARG(spacing && weights && out && S > 0 && S <= 512, "distortion: bad argument");
   if (n_rays == 0) return FNR_OK;
   FNR_PROF(OP_DISTORTION, n_rays * (long long)S);
@@ -684,6 +688,7 @@ extern "C" int fnr_distortion(int64_t n_rays, int S, const float* spacing, const
 extern "C" int fnr_composite_bwd(const fnr_rays* rays, int S, const float* euclid_bins, const float* density,
                                  const float* rgb, const float* weights, const float* g_rgb, const float* g_semantics,
                                  float* d_density, float* d_rgb, float* d_logit, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_composite_bwd");
   FNR_CHECK_ARG(rays && euclid_bins && density && rgb && weights && g_rgb && g_semantics && d_density && d_rgb &&
                     d_logit,
                 "composite_bwd: null argument");
@@ -701,6 +706,13 @@ extern "C" int fnr_composite_bwd_targets(const fnr_rays* rays, int S, const floa
                                          const float* rgb, const float* weights, const float* out_rgb, const float* image,
                                          const float* out_semantics, const float* mask, float semantic_loss_weight,
                                          float* d_density, float* d_rgb, float* d_logit, void* stream) {
+  if (seq::recording() && rays) {
+    const fnr_rays rays_ = *rays;
+    seq::push("fnr_composite_bwd_targets", [=](const fnr_step_scalars*) {
+      return fnr_composite_bwd_targets(&rays_, S, euclid_bins, density, rgb, weights, out_rgb, image, out_semantics, mask,
+                                       semantic_loss_weight, d_density, d_rgb, d_logit, stream);
+    });
+  }
   FNR_CHECK_ARG(rays && euclid_bins && density && rgb && weights && out_rgb && image && out_semantics && mask && d_density &&
                     d_rgb && d_logit,
                 "composite_bwd_targets: null argument");
@@ -718,6 +730,7 @@ extern "C" int fnr_composite_bwd_targets(const fnr_rays* rays, int S, const floa
 extern "C" int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, const float* density,
                                const float* weights, const float* d_weights, const float* upstream,
                                float* d_density, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_weights_bwd");
   FNR_CHECK_ARG(euclid_bins && density && weights && d_weights && d_density, "weights_bwd: null argument");
   FNR_CHECK_ARG(S > 0 && S <= 64 * WB_MAXE, "weights_bwd: S %d out of range", S);
   if (n_rays == 0) return FNR_OK;
@@ -732,6 +745,7 @@ extern "C" int fnr_weights_bwd(int64_t n_rays, int S, const float* euclid_bins, 
 extern "C" int fnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                              float beta1, float beta2, float eps, int64_t step, float grad_scale, float weight_decay,
                              int zero_grad, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_adam_step");
   FNR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "adam_step: null argument");
   FNR_CHECK_ARG(n % 4 == 0 && step >= 1, "adam_step: n must be a multiple of 4 (arena is padded) and step >= 1");
   if (n == 0) return FNR_OK;
@@ -752,6 +766,7 @@ extern "C" int fnr_adam_step(float* params, float* grads, float* exp_avg, float*
 extern "C" int fnr_radam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, int64_t step, float grad_scale, float weight_decay,
                               int zero_grad, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_radam_step");
   FNR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "radam_step: null argument");
   FNR_CHECK_ARG(n % 4 == 0 && step >= 1, "radam_step: n must be a multiple of 4 (arena is padded) and step >= 1");
   if (n == 0) return FNR_OK;
@@ -778,6 +793,7 @@ extern "C" int fnr_radam_step(float* params, float* grads, float* exp_avg, float
 extern "C" int fnr_adam_step_spans(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_spans,
                                    const fnr_adam_span* spans, int algorithm, float beta1, float beta2, float eps,
                                    float grad_scale, float weight_decay, int zero_grad, void* stream) {
+  FNR_SEQ_UNRECORDABLE("fnr_adam_step_spans");
   FNR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && spans, "adam_step_spans: null argument");
   FNR_CHECK_ARG(n_spans >= 1 && n_spans <= FNR_MAX_ADAM_SPANS, "adam_step_spans: %d spans (1..%d)", n_spans,
                 FNR_MAX_ADAM_SPANS);
@@ -836,6 +852,25 @@ extern "C" int fnr_train_losses(int64_t n_rays, const float* rgb, const float* i
                                 const float* const* euclid_p, const float* const* density_p,
                                 float* const* d_density_p, float interlevel_mult, int want_distortion, float* accum,
                                 float* losses, void* stream) {
+  if (seq::recording() && n_levels >= 0 && n_levels <= FNR_MAX_PROPOSAL_LEVELS) {
+    constexpr int M = FNR_MAX_PROPOSAL_LEVELS;
+    const auto S_ = seq::copy_n<int, M>(S_p, n_levels);
+    const auto sp_ = seq::copy_n<const float*, M>(spacing_p, n_levels);
+    const auto wp_ = seq::copy_n<const float*, M>(weights_p, n_levels);
+    const auto dw_ = seq::copy_n<float*, M>(d_weights_p, n_levels);
+    const auto eu_ = seq::copy_n<const float*, M>(euclid_p, n_levels);
+    const auto dn_ = seq::copy_n<const float*, M>(density_p, n_levels);
+    const auto dd_ = seq::copy_n<float*, M>(d_density_p, n_levels);
+    const bool has_sp = spacing_p, has_wp = weights_p, has_dw = d_weights_p, has_eu = euclid_p, has_dn = density_p,
+               has_dd = d_density_p;
+    seq::push("fnr_train_losses", [=](const fnr_step_scalars* sc) {
+      return fnr_train_losses(n_rays, rgb, image, semantics, fruit_mask, semantic_loss_weight, d_rgb, d_semantics, S_f,
+                              spacing_f, weights_f, n_levels, S_.data(), has_sp ? sp_.data() : nullptr,
+                              has_wp ? wp_.data() : nullptr, has_dw ? dw_.data() : nullptr, has_eu ? eu_.data() : nullptr,
+                              has_dn ? dn_.data() : nullptr, has_dd ? dd_.data() : nullptr, interlevel_mult, want_distortion,
+                              accum, (sc && sc->losses) ? sc->losses : losses, stream);
+    });
+  }
   FNR_CHECK_ARG(rgb && image && semantics && fruit_mask && d_rgb && d_semantics && spacing_f && weights_f && accum &&
                     losses && n_rays > 0,
                 "train_losses: null argument");

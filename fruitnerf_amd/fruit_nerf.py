@@ -209,6 +209,11 @@ class FruitModel(nn.Module):
         self.colormap = torch.as_tensor(self.semantics.colors).clone().detach()   # fruit_nerf.py:76
         self._arena: Optional[ParamArena] = None
         self.populate_modules()
+        # nerfstudio Model.__init__ registers this zero-length parameter after populate_modules() (base_model.py; every
+        # checkpoint a Nerfstudio Trainer wrote carries the key `_model.device_indicator_param`, and
+        # FruitPipeline.load_pipeline loads with strict=True, fruit_pipeline.py:239-240).  It belongs to no parameter group
+        # (get_param_groups) and stays outside the arena.
+        self.device_indicator_param = nn.Parameter(torch.empty(0))
         if self._device.type == "cuda":
             self.to(self._device)
 
@@ -297,6 +302,13 @@ class FruitModel(nn.Module):
         if deterministic:
             self.proposal_sampler.eval()
         self.field.spatial_distortion = None
+
+    def update_to_step(self, step: int) -> None:
+        """nerfstudio Model.update_to_step: called by FruitPipeline.load_pipeline right before load_state_dict
+        (fruit_pipeline.py:239).  Nerfacto-family models keep no step-dependent module state (the anneal and the proposal
+        update schedule are driven by the training callbacks), so, like the base class, this changes no parameter; it only
+        invalidates whatever was sampled ahead with the weights that are about to be replaced (lookahead_version)."""
+        self.__dict__["_lookahead_epoch"] = self.__dict__.get("_lookahead_epoch", 0) + 1
 
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:  # fruit_nerf.py:185-189
         return {"proposal_networks": list(self.proposal_networks.parameters()),
@@ -492,7 +504,8 @@ class FruitModel(nn.Module):
         cached = self.__dict__.get("_lookahead_params")
         if cached is None or cached[0] is not arena:     # (module traversal per call cost ~45 us of host time per step)
             cached = self.__dict__["_lookahead_params"] = (arena, list(self.proposal_networks.parameters()))
-        return (id(arena), None if arena is None else arena.params.data_ptr()) + tuple(p._version for p in cached[1])
+        return (id(arena), None if arena is None else arena.params.data_ptr(), self.__dict__.get("_lookahead_epoch", 0)) \
+            + tuple(p._version for p in cached[1])
 
     def _empty_render(self, ray_bundle: RayBundle) -> Tuple[Dict, RenderContext]:
         dev = ray_bundle.origins.device

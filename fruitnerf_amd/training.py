@@ -27,6 +27,7 @@ import torch
 from torch import Tensor
 
 from . import _kernels as K
+from . import _lib as L
 
 
 def _anchor(model) -> Tensor:
@@ -448,10 +449,11 @@ class FusedAdam:
         g = self.groups[group]
         lr = (exponential_decay_lr(self.step_count, g["lr"], g["lr_final"], g["max_steps"])
               if g.get("lr_final") is not None else g["lr"])
-        args = L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], self.eps,
-                                self.group_steps[group] + 1, grad_scale, self.weight_decay,
-                                L.ptr(self.arena.params[a:a + n]), L.ptr(self.exp_avg[a:a + n]),
-                                L.ptr(self.exp_avg_sq[a:a + n]), L.ptr(self.touched_bitmap(table, a, n)))
+        args = L.table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], self.eps,
+                            self.group_steps[group] + 1, grad_scale, self.weight_decay,
+                            L.ptr(self.arena.params[a:a + n]), L.ptr(self.exp_avg[a:a + n]),
+                            L.ptr(self.exp_avg_sq[a:a + n]), L.ptr(self.touched_bitmap(table, a, n)),
+                            slot=L.ADAM_SLOTS.get(group, 0))
         return args, (a, a + n)
 
     def weight_adam_args(self, group: str = "fields", grad_scale: float = 1.0):
@@ -462,9 +464,10 @@ class FusedAdam:
         g = self.groups[group]
         lr = (exponential_decay_lr(self.step_count, g["lr"], g["lr_final"], g["max_steps"])
               if g.get("lr_final") is not None else g["lr"])
-        args = L.fnr_table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], self.eps,
-                                self.group_steps[group] + 1, grad_scale, self.weight_decay,
-                                L.ptr(self.arena.params), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), None)
+        args = L.table_adam(0 if self.algorithm == "adam" else 1, lr, self.betas[0], self.betas[1], self.eps,
+                            self.group_steps[group] + 1, grad_scale, self.weight_decay,
+                            L.ptr(self.arena.params), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), None,
+                            slot=L.ADAM_SLOTS.get(group, 0))
         return (args, self.arena.grads), tuple(self.arena.group_ranges[group])
 
     def step_span(self, a: int, b: int, lr: float, grad_scale: float = 1.0, group: Optional[str] = None,
@@ -837,16 +840,17 @@ class _ForkJoin:
         self.main, self.open, self.segments, self.joins = main, None, 0, 0
 
     def fork(self, side, event=None):
+        # (through the C ABI, not torch.cuda.Stream.wait_*: a step program records these — fnr_stream_wait_*)
         if event is not None:
-            side.wait_event(event)
+            K.stream_wait_event(side, event)
         else:
-            side.wait_stream(self.main)
+            K.stream_wait_stream(side, self.main)
         self.open = side
         self.segments += 1
 
     def join(self):
         if self.open is not None:
-            self.main.wait_stream(self.open)
+            K.stream_wait_stream(self.main, self.open)
             self.open = None
             self.joins += 1
 
@@ -929,7 +933,7 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         d_o = d_d = None
         ray_sources = [] if ray_grads is not None else None     # (warp, euclid, S, partial) of every chain, in order
         if ray_grads is not None:
-            both = torch.empty(2, rays.n, 3, device=dev)
+            both = K._empty(2, rays.n, 3, device=dev)
             d_o, d_d = ray_grads["origins"], ray_grads["directions"] = both[0], both[1]
         # The proposal-network backward (interlevel loss) and the field backward (rgb + semantic losses) share no
         # buffers.  overlap_proposal_backward=True runs the former on a second HIP stream so that its ~14 small/medium
@@ -956,13 +960,13 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 if tail_on_side and not serialize_streams and exchange is None:
                     pos_ready = model.__dict__.get("_pos_ready_event")
                     if pos_ready is None:
-                        pos_ready = model.__dict__["_pos_ready_event"] = torch.cuda.Event()
+                        pos_ready = model.__dict__["_pos_ready_event"] = K.Event()
                 with torch.cuda.stream(side):
                     sources_early = bool(_proposal_backward(model, rctx, d_wps, up, d_o, d_d, collect=ray_sources,
                                                             optimizer=proposal_optimizer, position_ready=pos_ready))
                 crosses_to(main, ray_sources)
                 if serialize_streams:
-                    main.wait_stream(side)
+                    K.stream_wait_stream(main, side)
         if losses_on_side:
             d_density, d_rgb_s, d_logit = K.composite_bwd_targets(rays, S, fin["euclid"], rctx.sample_density,
                                                                   rctx.sample_rgb, rctx.weights, outputs["rgb"], image,
@@ -993,18 +997,18 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             # a step that trains the proposal networks: the second stream is the longer chain (their backward, then the
             # look-ahead that needs their step AND the cameras'), so the reduction + camera step go to THIS stream, between
             # the MLP backward and the table scatter, and the look-ahead only waits for them and for the proposal scatter
-            main.wait_event(pos_ready)
+            K.stream_wait_event(main, pos_ready)
             K.position_grad_reduce_multi(ray_sources + [field_source], rays, d_o, d_d, accumulate=False)
             if after_ray_grads is not None:
                 after_ray_grads()
             tail_ready = model.__dict__.get("_tail_ready_event")
             if tail_ready is None:
-                tail_ready = model.__dict__["_tail_ready_event"] = torch.cuda.Event()
+                tail_ready = model.__dict__["_tail_ready_event"] = K.Event()
             tail_ready.record(main)                # the cameras have taken their step
         elif tail_on_side:
             tail_ready = model.__dict__.get("_tail_ready_event")
             if tail_ready is None:
-                tail_ready = model.__dict__["_tail_ready_event"] = torch.cuda.Event()
+                tail_ready = model.__dict__["_tail_ready_event"] = K.Event()
             tail_ready.record(main)                # the MLP backward (its d_pos) is enqueued
         def scatter():
             if exchange is None and table_adam is not None:
@@ -1265,6 +1269,40 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
 SAMPLE_AHEAD = os.environ.get("FNR_SAMPLE_AHEAD", "1") != "0"
 
 
+# Native step sequencer (round 6): a step whose launch sequence has been seen before is REPLAYED by one call of the C ABI
+# (fnr_program_replay) instead of being re-interpreted — ~30 entry-point calls, 48 buffer allocations, 150 pointer
+# conversions and the stream bookkeeping of this file collapse into a dictionary lookup, a 64-byte struct of per-step
+# scalars and one ctypes call (host enqueue 0.53 -> ~0.2 ms/step; what is left is the HIP runtime's launch cost).  Same
+# entry points, same arguments, same streams, same order: bit-identical training (tests/test_gpu_sequencer.py).
+# FNR_NATIVE_SEQUENCER=0: every step is interpreted (A/B, debugging).
+NATIVE_SEQUENCER = os.environ.get("FNR_NATIVE_SEQUENCER", "1") != "0"
+# a step shape is recorded on its n-th interpreted occurrence (the first ones create lazily-built state — second stream,
+# events, touched bitmaps, persistent workspaces — through launches a recording must not contain)
+RECORD_ON_OCCURRENCE = 2
+
+
+class _StepProgram:
+    """One recorded step (fnr_program_*) + what the host has to restore around a replay."""
+
+    def __init__(self):
+        import ctypes as C
+        h = C.c_void_p()
+        L.check(L.load().fnr_program_create(C.byref(h)), "program_create")
+        self.handle = h.value
+        self.keep = []              # every tensor / struct the recorded calls point at
+        self.next = None            # (RayBundle, batch) the recorded look-ahead produced (fixed addresses)
+        self.last_draw = self.last_presample = None
+        self.next_offset = 0        # bump offset of the other arena behind the look-ahead's buffers
+        self.n_ops = 0
+
+    def __del__(self):
+        try:
+            if self.handle and L._lib is not None:
+                L.load().fnr_program_destroy(self.handle)
+        except Exception:   # interpreter shutdown
+            pass
+
+
 class TrainingSteps:
     """The training loop's body for one model: batcher.sample -> fused_train_iteration, with the start of iteration
     i + 1 — fnr_train_prologue (pixels, corrected cameras, rays, level-0 bins, jitters) and the proposal sampler's levels
@@ -1273,6 +1311,13 @@ class TrainingSteps:
     scatter + optimiser step, which they do not depend on.  Same launches on the same values as sampling at the start
     of iteration i + 1 (counter-based random numbers, schedule flags checked by the model), so the parameters after any
     number of steps are bit-identical with SAMPLE_AHEAD off.
+
+    Single process on a HIP device: the per-step buffers come from two step arenas (K.StepArena; iteration i uses arena
+    i & 1, whose first bytes hold what iteration i - 1 sampled ahead for it), so a step shape — (parity, does this step
+    train the proposal networks, does the next one, metrics, camera optimiser, arithmetic) — always runs on the same
+    addresses; its second interpreted occurrence is recorded (fnr_program_begin / _end) and every later one replayed by
+    fnr_program_replay with the step's scalars (NATIVE_SEQUENCER).  The loss tensors a step returns are fresh
+    allocations; everything else a step produced lives in its arena until the step after next.
 
     camera: (CameraOptimizer, CameraAdam) or None; the batcher is the third member fused_train_iteration wants."""
 
@@ -1283,7 +1328,17 @@ class TrainingSteps:
         self.step_idx = 0
         self._next = None
         self._next_version = ()
+        # step arenas + programs (single process, HIP device)
+        self._arenas = None
+        self._arena_version = 0
+        self._next_layout = None        # (arena version, parity, offset behind the look-ahead, clean) of what _next points into
+        self._programs = {}             # key -> _StepProgram
+        self._unrecordable = {}         # key -> reason
+        self._seen = {}                 # key -> interpreted occurrences
+        self._scalars = L.fnr_step_scalars()
+        self.stats = {"replayed": 0, "interpreted": 0, "recorded": 0, "record_failed": 0, "arena_grown": 0}
 
+    # ---- look-ahead ----------------------------------------------------------------------------------------------
     def _draw(self, finishing_step: Optional[int]):
         from .rays import RayBundle
         level0 = self.model.level0_spec()
@@ -1300,6 +1355,14 @@ class TrainingSteps:
         """Forget what was sampled ahead (the proposal networks or the cameras were changed from outside, or the
         batcher was used in between): the next step() samples at its start.  The draw itself is consumed."""
         self._next = None
+        self._next_layout = None
+
+    def drop_programs(self) -> None:
+        """Forget every recorded step program (anything a program captured BY VALUE was changed from outside: loss
+        weights, near / far planes, the batcher's image set ...; pointers and the scheduled scalars are tracked)."""
+        self._programs.clear()
+        self._unrecordable.clear()
+        self._seen.clear()
 
     def _outside_version(self) -> tuple:
         """Version counters of what the prologue of a look-ahead read besides the proposal networks: the camera poses."""
@@ -1308,38 +1371,243 @@ class TrainingSteps:
         pose = getattr(self.camera[0], "pose_adjustment", None)
         return () if pose is None else (pose.data_ptr(), pose._version)
 
+    # ---- step arenas ---------------------------------------------------------------------------------------------
+    def _arena_mode(self) -> bool:
+        dev = getattr(self.model, "device", None)
+        return bool(NATIVE_SEQUENCER and self.world_size < EXCHANGE_MIN_WORLD and dev is not None and dev.type == "cuda"
+                    and hasattr(self.model, "proposal_sampler"))
+
+    def _ensure_arenas(self) -> None:
+        need = 0
+        if self._arenas is not None:
+            for a in self._arenas:
+                if a.overflow_bytes:
+                    need = max(need, int((a.high_water + a.overflow_bytes) * 1.25) + (32 << 20))
+            if not need:
+                return
+            self.stats["arena_grown"] += 1
+        else:
+            cfg = self.model.config
+            s_prop = sum(cfg.num_proposal_samples_per_ray)
+            need = int(self.n_rays * (cfg.num_nerf_samples_per_ray * 900 + s_prop * 80) * 1.3) + (32 << 20)
+        dev = self.model.device
+        self._arenas = [K.StepArena(dev, need), K.StepArena(dev, need)]
+        self._arena_version += 1
+        self._programs.clear()          # they point into the old slabs (which live on while a program or _next holds them)
+        self._seen.clear()
+        self._next_layout = None
+
+    def _program_key(self, parity: int, start_offset: int, updated: bool, updated_next: bool, want_metrics: bool) -> tuple:
+        model = self.model
+        fld = model.field
+        cfg = model.config
+        dev = model.device
+        side = model.__dict__.get("_side_stream")
+        return (self._arena_version, parity, start_offset, updated, updated_next, bool(want_metrics), self.camera is not None,
+                getattr(fld, "mlp_precision", None), model.arena().params.data_ptr(), id(self.optimizer),
+                L.stream_ptr(dev), None if side is None else side.cuda_stream,
+                OVERLAP_PROPOSAL_BACKWARD, SERIALIZE_STREAMS, LOSSES_ON_SIDE, PAIR_PROPOSAL_LEVELS, FUSE_CAMERA_OPTIMIZER,
+                FUSE_WEIGHT_OPTIMIZER, FUSE_TABLE_OPTIMIZER, SPARSE_TOUCH_SKIPPING, STREAM_SAFE,
+                cfg.semantic_loss_weight, cfg.interlevel_loss_mult, cfg.near_plane, cfg.far_plane)
+
+    # ---- one step ------------------------------------------------------------------------------------------------
     def step(self, want_metrics: bool = True):
         if self._next is not None and self._next[0] == self.step_idx and self._next_version != self._outside_version():
             # the cameras were edited between two steps: the rays drawn ahead used the old poses.  Draw again with the
             # SAME counter (counter-based random numbers: the same pixels through the new poses — what sampling at the
             # start of this step would have drawn)
             self._next = None
+            self._next_layout = None
             if getattr(self.batcher, "_offset", 0) > 0:
                 self.batcher._offset -= 1
+        if not self._arena_mode():
+            return self._step_interpreted(want_metrics, None)
+        model = self.model
+        sampler = model.proposal_sampler
+        step = self.step_idx
+        parity = step & 1
+        self._ensure_arenas()
+        arena = self._arenas[parity]
+        have_next = self._next is not None and self._next[0] == step
+        in_layout = have_next and self._next_layout is not None and self._next_layout[:2] == (self._arena_version, parity)
+        if in_layout:
+            arena.offset = self._next_layout[2]      # continue behind what the previous step sampled ahead into this arena
+        else:
+            arena.reset()
+        key = None
+        if in_layout and self._next_layout[3] and model.training and SAMPLE_AHEAD and not L.profile_recording():
+            ahead = self._next[1].presampled.get("ahead") if self._next[1].presampled else None
+            updated = sampler.updated_now()
+            if ahead is not None and ahead["updated"] == updated and ahead["anneal"] == model.anneal_at(step) \
+                    and ahead.get("param_version") == model.lookahead_version():
+                # what the look-ahead of THIS step will see: sample_ahead() runs behind _render, which restarts the count
+                # of steps since the last update on a step that updates (ProposalNetworkSampler.updated_after)
+                since = 0 if updated else sampler._steps_since_update
+                updated_next = bool(since + 1 > sampler.update_sched(step) or step < 10)
+                key = self._program_key(parity, arena.offset, updated, updated_next, want_metrics)
+        if key is not None:
+            prog = self._programs.get(key)
+            if prog is not None:
+                return self._replay(prog, step, want_metrics, updated)
+            n = self._seen[key] = self._seen.get(key, 0) + 1
+            if n >= RECORD_ON_OCCURRENCE and key not in self._unrecordable:
+                return self._step_interpreted(want_metrics, arena, record_key=key)
+        return self._step_interpreted(want_metrics, arena)
+
+    def _step_interpreted(self, want_metrics: bool, arena, record_key=None):
         if self._next is not None and self._next[0] == self.step_idx:
             _, rb, batch = self._next
         else:
-            rb, batch = self._draw(None)
+            prev = K.use_arena(arena)
+            try:
+                rb, batch = self._draw(None)
+            finally:
+                K.use_arena(prev)
         self._next = None
+        self._next_layout = None
         step = self.step_idx
-
+        other = self._arenas[1 - (step & 1)] if arena is not None else None
         launch_stream = torch.cuda.current_stream(self.model.device) if STREAM_SAFE else None
 
         def ahead():
-            # On the second stream these tensors come from ITS allocator pool and are consumed on the launch stream by
-            # the next iteration.  No Tensor.record_stream (one event per tensor and free: ~40 barrier packets a step,
-            # measured +6 % step time): a block of either pool is only ever reused by work that its stream enqueues
-            # after waiting for the other one — the second stream starts each iteration's work with a wait on the launch
-            # stream (fork of the proposal backward / the MLP-backward event), the launch stream ends each iteration
-            # with a wait on the second — i.e. after every consumer of the block's previous contents (_ForkJoin asserts
-            # that structure; FNR_STREAM_SAFE=1 registers the tensors with the allocator as well).
-            self._next = (step + 1,) + self._draw(step)
+            # On the second stream these tensors are consumed on the launch stream by the next iteration.  No
+            # Tensor.record_stream (one event per tensor and free: ~40 barrier packets a step, measured +6 % step time):
+            # the buffers of iteration i + 1 are only written by work the second stream enqueues after waiting for the
+            # launch stream, and the launch stream ends each iteration with a wait on the second — i.e. after every
+            # consumer of their previous contents (_ForkJoin asserts that structure; FNR_STREAM_SAFE=1 registers the
+            # tensors with the allocator as well).  With step arenas they go to the OTHER arena, from its start: its
+            # previous contents belong to iteration i - 1, which the launch stream has joined.
+            if other is not None:
+                other.reset()
+                K.use_arena(other)
+            try:
+                self._next = (step + 1,) + self._draw(step)
+            finally:
+                if other is not None:
+                    K.use_arena(arena)
             self._next_version = self._outside_version()
+            if other is not None:
+                # (arena version, parity, where the next step's own buffers start, nothing overflowed into the allocator)
+                self._next_layout = (self._arena_version, 1 - (step & 1), other.offset, not other.overflow_bytes)
             crosses_to(launch_stream, self._next, getattr(self.batcher, "last_draw", None),
                        getattr(self.batcher, "last_presample", None))
 
-        out = fused_train_iteration(self.model, self.optimizer, rb, batch, step, world_size=self.world_size,
-                                    want_metrics=want_metrics, camera=self.camera,
-                                    ahead=ahead if (SAMPLE_AHEAD and self.model.training) else None)
+        prog = log = None
+        fresh_ws = K.fresh_workspaces()
+        if record_key is not None:
+            prog = _StepProgram()
+            log = L.begin_call_log(keep=prog.keep)
+            rc = L.load().fnr_program_begin(prog.handle)
+            if rc != 0:
+                L.end_call_log(log)
+                L.check(rc, "program_begin")
+        prev = K.use_arena(arena)
+        try:
+            out = fused_train_iteration(self.model, self.optimizer, rb, batch, step, world_size=self.world_size,
+                                        want_metrics=want_metrics, camera=self.camera,
+                                        ahead=ahead if (SAMPLE_AHEAD and self.model.training) else None)
+        except BaseException:
+            if prog is not None:
+                L.end_call_log(log)
+                L.load().fnr_program_abort(prog.handle)
+            raise
+        finally:
+            K.use_arena(prev)
+        if prog is not None:
+            self._finish_recording(prog, log, record_key, rb, batch, arena, other, fresh_ws)
+        self.stats["interpreted"] += 1
         self.step_idx += 1
         return out
+
+    def _finish_recording(self, prog, log, key, rb, batch, arena, other, fresh_ws_before) -> None:
+        names = L.end_call_log(log)
+        lib = L.load()
+        rc = lib.fnr_program_end(prog.handle)
+        reason = None
+        if rc != 0:
+            reason = "unrecordable entry point: " + L.last_error()
+        else:
+            asked = [n for n in names if n not in _PROGRAM_QUERIES]
+            got = [lib.fnr_program_op_name(prog.handle, i).decode() for i in range(lib.fnr_program_size(prog.handle))]
+            if asked != got:
+                reason = f"python asked for {len(asked)} calls, the library recorded {len(got)}: " + \
+                         repr([(a, g) for a, g in zip(asked, got) if a != g][:3])
+        transient = arena.overflow_bytes or other.overflow_bytes or K.fresh_workspaces() != fresh_ws_before \
+            or self._next is None or self._next_layout is None or not self._next_layout[3]
+        if reason is not None:
+            self._unrecordable[key] = reason
+            self.stats["record_failed"] += 1
+            lib.fnr_program_abort(prog.handle)
+            return
+        if transient:               # grown arenas / a first-use workspace: the same shape records on a later occurrence
+            lib.fnr_program_abort(prog.handle)
+            return
+        prog.n_ops = int(lib.fnr_program_size(prog.handle))
+        prog.next = (self._next[1], self._next[2])
+        prog.next_offset = self._next_layout[2]
+        prog.last_draw = getattr(self.batcher, "last_draw", None)
+        prog.last_presample = getattr(self.batcher, "last_presample", None)
+        prog.keep += [rb, batch, self._arenas]
+        self._programs[key] = prog
+        self.stats["recorded"] += 1
+
+    def _replay(self, prog, step: int, want_metrics: bool, updated: bool):
+        """The host side of one replayed step: exactly the bookkeeping the interpreted step does on Python objects (schedule
+        counters, optimiser step counts, the batcher's random-number counter, the look-ahead's hand-over) around ONE call."""
+        model, opt, sampler, batcher = self.model, self.optimizer, self.model.proposal_sampler, self.batcher
+        sc = self._scalars
+        sampler._anneal = model.anneal_at(step)                          # set_anneal(step)
+        # optimiser scalars of THIS update (FusedAdam.table_adam_args / weight_adam_args: lr at the current scheduler step,
+        # step count + 1), then what optimizer.step(skip, done) does to the counters once everything is fused
+        groups, count = opt.groups, opt.step_count
+        for name, slot in (("fields", 0), ("proposal_networks", 1)):
+            g = groups[name]
+            sc.adam[slot].lr = (exponential_decay_lr(count, g["lr"], g["lr_final"], g["max_steps"])
+                                if g.get("lr_final") is not None else g["lr"])
+            sc.adam[slot].step = opt.group_steps[name] + 1
+        skip = () if (updated or not opt.skip_groups_without_grad) else ("proposal_networks",)
+        opt.step_count = count + 1
+        for name in opt.group_steps:
+            if name not in skip:
+                opt.group_steps[name] += 1
+        if self.camera is not None:
+            sc.adam[2].lr, sc.adam[2].step = self.camera[1].advance()
+        # _render's bookkeeping
+        model.__dict__["_ahead_used"] = model.__dict__.get("_ahead_used", 0) + 1
+        if updated:
+            sampler._steps_since_update = 0
+        model._last_render_updated = bool(updated)
+        # the look-ahead of iteration step + 1 (TrainingSteps._draw / FruitModel.sample_ahead)
+        batcher._offset = getattr(batcher, "_offset", 0) + 1
+        sc.prologue_offset = batcher._offset & 0xFFFFFFFFFFFFFFFF
+        anneal_next = model.anneal_at(step + 1)
+        sc.anneal = anneal_next
+        losses = torch.empty(5, device=model.device)
+        sc.losses = losses.data_ptr()
+        rc = L._lib.fnr_program_replay(prog.handle, sc)
+        if rc != 0:
+            K._forget_scatter_workspaces(model.device)
+            self.drop_programs()
+            L.check(rc, "program_replay")
+        rb, batch = prog.next
+        ahead = rb.presampled["ahead"]
+        ahead["anneal"] = anneal_next
+        ahead["param_version"] = model.lookahead_version()
+        batcher.last_draw, batcher.last_presample = prog.last_draw, prog.last_presample
+        self._next = (step + 1, rb, batch)
+        self._next_version = self._outside_version()
+        self._next_layout = (self._arena_version, 1 - (step & 1), prog.next_offset, True)
+        sampler.step_cb(step)                                              # AFTER_TRAIN_ITERATION callback
+        self.stats["replayed"] += 1
+        self.step_idx = step + 1
+        l0, l1, l2, l3, l4 = losses.unbind(0)
+        return ({"rgb_loss": l0, "semantics_loss": l1, "interlevel_loss": l3},
+                {"psnr": l2, "distortion": l4} if want_metrics else {})
+
+
+# entry points a recording does not contain: pure host queries, and the program API itself
+_PROGRAM_QUERIES = frozenset(["fnr_field_mlp_fwd_workspace_bytes", "fnr_field_h_dim", "fnr_field_mlp_bwd_workspace_bytes",
+                              "fnr_hash_scatter_workspace_bytes", "fnr_prop_density_bwd_workspace_bytes", "fnr_last_error",
+                              "fnr_program_begin", "fnr_program_end", "fnr_program_abort", "fnr_program_size",
+                              "fnr_program_op_name", "fnr_program_create", "fnr_program_destroy", "fnr_event_create",
+                              "fnr_event_destroy", "fnr_abi_version"])

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 11
+#define FNR_ABI_VERSION 12
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -397,6 +397,8 @@ int fnr_hash_encode_bwd(const fnr_grid* grid_grad, const fnr_warp* warp, const f
 typedef struct fnr_table_adam {
   int32_t algorithm;
   float lr, beta1, beta2, eps;
+  int32_t slot; /* step programs (below): 1..FNR_PROGRAM_ADAM_SLOTS = on replay `lr` and `step` come from
+                   fnr_step_scalars.adam[slot - 1]; 0 = the recorded values.  Ignored outside a replay. */
   int64_t step;
   float grad_scale, weight_decay;
   float* params;
@@ -547,6 +549,53 @@ typedef struct fnr_adam_span {
 int fnr_adam_step_spans(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int n_spans,
                         const fnr_adam_span* spans, int algorithm, float beta1, float beta2, float eps,
                         float grad_scale, float weight_decay, int zero_grad, void* stream);
+
+/* ---- step programs: a training step's launch sequence, recorded once and replayed natively (ABI 12) ------------- */
+/* The reference's loop is nerfstudio's Python Trainer (fruit_pipeline.py:120-146 under Trainer.train_iteration); ours
+ * (fruitnerf_amd/training.py::TrainingSteps) is ~30 calls of this ABI per step on two HIP streams.  Every pointer of a
+ * step is stable (parameter arenas, persistent workspaces, the caller's double-buffered step arena), so the sequence is
+ * recorded ONCE per step shape and replayed by one call: between fnr_program_begin and fnr_program_end the recordable
+ * entry points called on this thread — fnr_train_prologue, fnr_prop_density_fwd, fnr_weights_pdf, fnr_hash_encode_fwd,
+ * fnr_field_mlp_fwd, fnr_composite_fwd, fnr_train_losses, fnr_composite_bwd_targets, fnr_field_mlp_bwd_adam,
+ * fnr_hash_encode_bwd_adam, fnr_prop_density_bwd_pair(_split), fnr_position_grad_reduce_multi,
+ * fnr_camera_pose_grad_adam and the stream operations below — run as usual AND append themselves (arguments by value,
+ * host structs / host arrays copied) to the program; any other entry point that enqueues device work poisons the
+ * recording (fnr_program_end then fails and the program stays empty).  fnr_program_replay calls them again in order, on
+ * the streams they were recorded on, with the per-step scalars patched in.  The caller keeps every recorded buffer
+ * alive and unchanged in place for as long as it replays the program. */
+#define FNR_PROGRAM_ADAM_SLOTS 4
+typedef struct fnr_step_scalars {
+  uint64_t prologue_offset; /* fnr_train_prologue: `offset` (the step's random-number counter) */
+  float anneal;             /* fnr_weights_pdf: `anneal` */
+  int32_t reserved;
+  struct {
+    float lr;
+    int32_t reserved;
+    int64_t step;           /* 0 = keep the recorded lr / step of this slot */
+  } adam[FNR_PROGRAM_ADAM_SLOTS]; /* by fnr_table_adam.slot - 1 */
+  float* losses;            /* fnr_train_losses: `losses` (5 floats, device); NULL = the recorded buffer */
+} fnr_step_scalars;
+typedef struct fnr_program fnr_program;
+int fnr_program_create(fnr_program** out);
+int fnr_program_destroy(fnr_program* program);
+/* begin: the program is emptied and this thread records into it; end: stops recording, fails (and empties the program)
+ * if an unrecordable entry point ran in between; abort: stops recording and empties the program. */
+int fnr_program_begin(fnr_program* program);
+int fnr_program_end(fnr_program* program);
+int fnr_program_abort(fnr_program* program);
+int64_t fnr_program_size(const fnr_program* program);
+/* name of the entry point behind operation i (a static string), NULL when out of range */
+const char* fnr_program_op_name(const fnr_program* program, int64_t i);
+/* scalars NULL: every operation with its recorded arguments.  Stops at the first failing operation and returns its code. */
+int fnr_program_replay(const fnr_program* program, const fnr_step_scalars* scalars);
+/* Stream dependencies (recordable): events are hipEvent_t created with timing disabled, owned by the caller.
+ * fnr_stream_wait_stream: work enqueued on `waiting` after the call runs after everything enqueued on `signalling`
+ * before it (one event of an internal pool is recorded and waited for; the host does not block). */
+int fnr_event_create(void** event_out);
+int fnr_event_destroy(void* event);
+int fnr_event_record(void* event, void* stream);
+int fnr_stream_wait_event(void* stream, void* event);
+int fnr_stream_wait_stream(void* waiting, void* signalling);
 
 /* ---- export --------------------------------------------------------------------------------- */
 /* sample_volume's masks + gathers (export/exporter_utils.py:111-153) as an order-preserving stream

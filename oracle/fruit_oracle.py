@@ -283,6 +283,13 @@ class FruitModel(nn.Module):
         self.collider = ns.NearFarCollider(near_plane=config.near_plane, far_plane=config.far_plane)
         self.rgb_loss = nn.MSELoss()
         self.binary_cross_entropy_loss = nn.BCEWithLogitsLoss(reduction="mean")
+        # nerfstudio Model.__init__ (the base class of the reference's FruitModel, fruit_nerf.py:62) registers this
+        # zero-length parameter after populate_modules(); it is part of every checkpoint (tests/golden/reference_pipeline.npz
+        # holds the reference model's own key list)
+        self.device_indicator_param = nn.Parameter(torch.empty(0))
+
+    def update_to_step(self, step: int) -> None:
+        """nerfstudio Model.update_to_step: a no-op for this model (called by FruitPipeline.load_pipeline, fruit_pipeline.py:239)."""
 
     # fruit_nerf.py:179-183
     def setup_inference(self, render_rgb, num_inference_samples, sampler_mode_as_in_reference: bool = False):

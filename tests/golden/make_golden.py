@@ -60,6 +60,8 @@ def main(cfg=None, file_name="fruit_nerf_small.npz", with_camera=True):
     for k, v in ld.items():
         out["loss::" + k] = np.float32(v.item())
     for name, p in om.named_parameters():
+        if p.grad is None:          # nerfstudio's zero-length device_indicator_param: part of the state dict, no gradient
+            continue
         if "hash_table" in name:
             out["gradsum::" + name] = np.float64(p.grad.double().abs().sum().item())
         else:

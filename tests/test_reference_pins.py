@@ -212,6 +212,8 @@ def test_oracle_model_trains_like_the_reference_model():
             for i in range(3):
                 assert np.array_equal(res["weights_list"][i].detach().numpy(), g[f"train::{step}::weights{i}"])
             for n, p in m.named_parameters():
+                if n == "device_indicator_param":       # zero-length, never part of the graph (nerfstudio Model base)
+                    continue
                 got = p.grad.double().abs().sum().item() if p.grad is not None else 0.0
                 want = float(g[f"train::{step}::gradsum::{n}"])
                 # (index_add on the CPU accumulates in thread order: the sums agree to rounding, not to the bit)
@@ -339,3 +341,87 @@ def test_second_counting_stage_matches_the_reference_split_large_cluster():
     text = str(g["stdout"])
     assert f"Second stage clustering count: {count}" in text
     assert f"First clustering stage count after fused (tiny) clusters: {fc.counter - fc.fuse_counter}" in text
+
+
+# ---- the checkpoint contract: the reference FruitModel's state dict and its FruitPipeline.load_pipeline ---------------
+# (tests/golden/reference_pipeline.npz, written by make_reference_pipeline_golden.py from the reference's own classes)
+
+PIPELINE_PINS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_pipeline.npz")
+
+
+def _product_model_small():
+    from tests.golden.make_reference_pipeline_golden import product_model
+    return product_model()
+
+
+def test_product_state_dict_keys_are_the_reference_models():
+    """Key set, order-independent, BOTH ways, with shapes and dtypes: what the reference FruitModel (over nerfstudio's
+    Model base, incl. its zero-length `device_indicator_param`) puts into a checkpoint is exactly what the product model
+    emits and accepts."""
+    g = np.load(PIPELINE_PINS)
+    want = {k: (s, d) for k, s, d in zip(g["state_keys"].tolist(), g["state_shapes"].tolist(), g["state_dtypes"].tolist())}
+    sd = _product_model_small().state_dict()
+    got = {k: (",".join(str(int(s)) for s in v.shape), str(v.dtype)) for k, v in sd.items()}
+    assert sorted(set(want) - set(got)) == [], "keys of a reference checkpoint the product model does not have"
+    assert sorted(set(got) - set(want)) == [], "keys the product model emits that the reference model does not"
+    assert got == want
+    assert "device_indicator_param" in got and got["device_indicator_param"][0] == "0"
+
+
+@pytest.mark.parametrize("prefix", ["", "module."])
+def test_reference_shaped_checkpoint_loads_the_way_load_pipeline_loads_it(prefix):
+    """FruitPipeline.load_pipeline's three steps (fruit_pipeline.py:235-240) on a checkpoint with the reference's keys:
+    strip `module.`, `model.update_to_step(step)`, `load_state_dict(state, strict=True)`."""
+    g = np.load(PIPELINE_PINS)
+    assert bool(g["loaded::plain"]) and bool(g["loaded::ddp"])       # the reference's own method ran at generation time
+    gen = torch.Generator().manual_seed(3)
+    ckpt = {}
+    for k, s, d in zip(g["state_keys"].tolist(), g["state_shapes"].tolist(), g["state_dtypes"].tolist()):
+        shape = tuple(int(x) for x in s.split(",")) if s else ()
+        dtype = getattr(torch, d.replace("torch.", ""))
+        ckpt[prefix + k] = (torch.rand(shape, generator=gen) if dtype.is_floating_point
+                            else torch.randint(1, 30, shape, generator=gen)).to(dtype)
+    model = _product_model_small()
+    # (parameters under two names in every checkpoint — `mlp_base = Sequential(mlp_base_grid, mlp_base_mlp)`,
+    #  fruit_field.py:141 — hold one value)
+    first = {}
+    for k, v in model.state_dict().items():
+        if v.numel():
+            ckpt[prefix + k] = ckpt[prefix + first.setdefault(v.data_ptr(), k)]
+    state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt.items()}
+    model.update_to_step(1234)
+    missing, unexpected = model.load_state_dict(state, strict=True)
+    assert not missing and not unexpected
+    after = model.state_dict()
+    for k, v in state.items():
+        assert torch.equal(after[k], v), k
+    # the zero-length parameter belongs to no optimiser group and never reaches the arena
+    assert all(p.numel() > 0 for ps in model.get_param_groups().values() for p in ps)
+
+
+def test_update_to_step_invalidates_what_was_sampled_ahead():
+    model = _product_model_small()
+    before = model.lookahead_version()
+    model.update_to_step(10)
+    assert model.lookahead_version() != before
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/fruit_nerf"), reason="needs the reference sources (build box only)")
+@pytest.mark.parametrize("prefix", ["", "module."])
+def test_reference_load_pipeline_runs_on_the_product_model(prefix):
+    """The reference's OWN FruitPipeline.load_pipeline, executed live on a pipeline whose `_model` is the product model
+    (in a subprocess: the stub import machinery it needs must not leak into this test session)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from tests.golden import make_reference_pipeline_golden as m\n"
+            "ref = m.reference_model().state_dict()\n"
+            "pipe, loaded = m.run_reference_load_pipeline(%r, ref)\n"
+            "got = pipe._model.state_dict()\n"
+            "assert set(got) == set(ref), (set(got) ^ set(ref))\n"
+            "assert all(torch.equal(got[k], v) for k, v in ref.items())\n"
+            "print('loaded', len(ref))\n" % (root, prefix))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "loaded 42" in res.stdout
