@@ -125,7 +125,7 @@ FAMILIES = {
 def load_pmc_traffic():
     """HBM bytes per entry-point launch from the COMMITTED rocprofv3 PMC passes of this bench command
     (profiles/pmc_traffic.json, written by tools/make_profile_summary.py from the FETCH_SIZE / WRITE_SIZE passes of
-    tools/prof_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  PMC counters cannot be read inside this
+    tools/gpu_call.sh (legs kt, pmc); FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").  PMC counters cannot be read inside this
     process; the file names the build and command it was collected from."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

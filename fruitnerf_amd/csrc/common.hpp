@@ -81,7 +81,9 @@ struct ProfScope {
 // For data a step writes once and reads once (the optimiser moments, the encode's input Jacobian, the record queues on
 // their way back): without the hint those streams evict the hash table's parameters from the L2s / the Infinity Cache and
 // the next encode's gathers go to HBM (round 5, profiles/r05_raw/kt_nt_call6.log: k_hash_encode 82 -> 65 us with the hints).
-// NOT for narrow stores: 2- and 8-byte `nt` stores are one fabric write each (the emit kernel's queue stores: 75 -> 120 us).
+// NOT for SCATTERED narrow stores: the emit kernel's queue stores (an 8-byte value pair + a 2-byte row per record, a few
+// records per bin and wave) as `nt` are one fabric write each: 75 -> 120 us.  Coalesced 8-byte `nt` stores — a wave writes one
+// contiguous 512-byte run: NT_JAC_ST, NT_PROP_* — combine into full lines and are fine.
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 typedef float nt_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 nt_load(const float4* p) {

@@ -160,20 +160,8 @@ __device__ __forceinline__ float run_sum(float v, const RunMasks& m) {
 // VALU instructions per pair — was SLOWER, 194.5 -> 202.4 us for the main-field scatter: a DPP-modified VALU instruction
 // does not issue at the plain rate, and the compiler's mov_dpp + fma form interleaves the streams better.  Removed.)
 
-// Debug build only (make EXTRA=-DFNR_EMIT_TIMING): wave 0 of every emit workgroup adds the shader-clock length of
-// each phase to g_emit_phase_clk[] (tools/microbench/scatter_phases.py reads it through fnr_debug_emit_phases).
-#ifdef FNR_EMIT_TIMING
-constexpr int EMIT_T_SLOTS = 1 << 16;
-__device__ unsigned g_emit_phase_clk[EMIT_T_SLOTS][8];   // per workgroup (plain stores: atomics would serialise)
-#define EMIT_T(k)                                                                              \
-  do {                                                                                         \
-    const unsigned long long now__ = __builtin_readcyclecounter();                             \
-    t_acc__[k] += (unsigned)(now__ - t_phase__);                                               \
-    t_phase__ = now__;                                                                         \
-  } while (0)
-#else
-#define EMIT_T(k) do { } while (0)
-#endif
+// (The phase timers of rounds 2 - 5 — -DFNR_EMIT_TIMING, fnr_debug_emit_phases, tools/microbench/scatter_phases.py — and the
+// accumulate kernel's zero_early A/B variant left the tree in round 6; they are in the history at commit 48e9f7b.)
 
 // PAIRS: the two x-neighbours of a cell edge — corners (0,3), (1,2), (4,7), (5,6) of the oracle's order — always fall
 // into the same bin when every level's resolution is below the bin size (x only touches row bits below log2(res + 1),
@@ -196,10 +184,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   __shared__ unsigned s_base[SC_MAX_BINS];  // per-bin start inside the global queue
   __shared__ unsigned s_max;                // max |value| emitted by this workgroup (float bits; order-preserving for >= 0)
   __shared__ unsigned s_wsum[SC_EMIT_THREADS / 64];
-#ifdef FNR_EMIT_TIMING
-  unsigned long long t_phase__ = __builtin_readcyclecounter();
-  unsigned t_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   const int bins = 1 << (grid.log2_T - log2_rows);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t mask = (1u << grid.log2_T) - 1u;
@@ -225,7 +209,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   if (threadIdx.x == 0) s_max = 0;
   __syncthreads();
-  EMIT_T(0);
   const int scaling = grid.scalings[level];
   const float2 gf = gf_next;
   if (valid && li + 1 < lpb && lrel + 1 < level_count) gf_next = ntc_load<NT_DFEATS_LD>(&d_feats[(size_t)(level + 1) * N + n]);
@@ -238,13 +221,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   unsigned emit_mask[SC_PER_THREAD];
 #pragma unroll
   for (int q = 0; q < SC_PER_THREAD; ++q) {
-#ifdef FNR_EMIT_TIMING
-    {  // x and gf are in registers once this dependent dummy has been consumed
-      asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(gf.x), "v"(gf.y));
-      const unsigned long long now__ = __builtin_readcyclecounter();
-      t_acc__[6] += (unsigned)(now__ - t_phase__);
-    }
-#endif
     float wgt[8];
     const GridLevel g = corner_weights(x, scaling, mask, hk[q], wgt);
     // exact cell identity: floor coordinates + whether ceil differs (coordinates < 2^16, checked on the host)
@@ -268,13 +244,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
         vyk[q][k] = run_sum(vyk[q][k], rm);
       }
     }
-#ifdef FNR_EMIT_TIMING
-    {
-      asm volatile("" ::"v"(vxk[q][0]), "v"(vyk[q][7]));
-      const unsigned long long now__ = __builtin_readcyclecounter();
-      t_acc__[7] += (unsigned)(now__ - t_phase__);
-    }
-#endif
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (rm.tail && (vxk[q][k] != 0.0f || vyk[q][k] != 0.0f)) {
@@ -302,7 +271,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   for (int dsh = 32; dsh >= 1; dsh >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, dsh, 64));
   if (lane == 0 && tmax > 0.0f) atomicMax(&s_max, __float_as_uint(tmax));
   __syncthreads();
-  EMIT_T(1);
   if (threadIdx.x == 0 && s_max != 0u) atomicMax(&qmax[(size_t)lrel * SC_CNT_STRIDE], s_max);
   // exclusive scan of the per-bin counts (bins <= 1024 = 4 per thread) + one global reservation per non-empty bin
   unsigned c4[SC_BINS_PER_THREAD], tsum = 0;
@@ -320,7 +288,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
   }
   if (lane == 63) s_wsum[wave] = incl;
   __syncthreads();
-  EMIT_T(2);
   unsigned woff = 0;
   for (int w = 0; w < wave; ++w) woff += s_wsum[w];
   unsigned total = 0;
@@ -338,7 +305,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     }
   }
   __syncthreads();
-  EMIT_T(3);
   // place the records bin by bin in LDS
 #pragma unroll
   for (int q = 0; q < SC_PER_THREAD; ++q) {
@@ -373,7 +339,6 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     }
   }
   __syncthreads();
-  EMIT_T(4);
   // copy out: consecutive records of a bin go to consecutive queue slots (coalesced 8-byte + 2-byte stores)
   float* table = reinterpret_cast<float*>(grid.table + ((size_t)level << grid.log2_T));
   unsigned overflowed_here = 0;
@@ -397,15 +362,8 @@ __global__ __launch_bounds__(SC_EMIT_THREADS) void k_scatter_emit(GridDev grid, 
     }
   }
   if (overflowed_here) atomicAdd(&g_scatter_overflow_records, (unsigned long long)overflowed_here);
-  EMIT_T(5);
   __syncthreads();  // the next level re-uses the bin tables and the record staging
   }  // levels of this workgroup
-#ifdef FNR_EMIT_TIMING
-  {
-    const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) & (EMIT_T_SLOTS - 1);
-    if (threadIdx.x < 8) g_emit_phase_clk[slot][threadIdx.x] += t_acc__[threadIdx.x];
-  }
-#endif
 }
 
 // LDS fp32 atomics (ds_add_f32) retire ~1 lane every 3 clocks per CU on gfx950 (measured: 200 G/s chip-wide,
@@ -471,12 +429,6 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   // CONFIRMED ON HARDWARE IN ROUND 5 (tools/microbench/barrier_load_race.hip, profiles/r05_raw/barrier_load_race.log): the
   // same load / barrier / reset pattern with vector loads and no wait returned 1264 stale level maxima in 200 000 rounds of
   // 160 workgroups once a second stream kept the memory system busy; with this wait, and with scalar loads, none.
-#ifdef FNR_ACC_ZERO_EARLY
-  // A/B build (tools/build_variant.sh zero_early -DFNR_ACC_ZERO_EARLY): the accumulator is zeroed HERE, while the counter
-  // loads are in flight — it does not depend on them — and the barrier below covers it, so the second barrier (and the
-  // load latency the wait exposes) goes: one barrier and ~1 us less per accumulate workgroup
-  for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0ull;
-#endif
   {
     const unsigned held_n = (unsigned)n, held_max = __float_as_uint(vmax), held_ovf = overflowed ? 1u : 0u;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(held_n), "v"(held_max), "v"(held_ovf) : "memory");
@@ -506,10 +458,8 @@ __device__ __forceinline__ void accumulate_bin(const AccArgs& A, int vblock, uns
   int S = 62 - nb - e;
   if (S > 1000) S = 1000;
   const double scale = ldexp(1.0, S), inv = ldexp(1.0, -S);
-#ifndef FNR_ACC_ZERO_EARLY
   for (int i = threadIdx.x; i < 2 * rows; i += blockDim.x) s_acc[i] = 0ull;
   __syncthreads();
-#endif
   if (!have) n = 0;
   const float2* qv = queue_v + (size_t)gbin * cap;
   const unsigned short* qr = queue_r + (size_t)gbin * cap;
@@ -949,21 +899,6 @@ __global__ __launch_bounds__(PRD_E * PRD_Y) void k_prop_reduce(const float* __re
 
 using namespace fnr;
 
-#ifdef FNR_EMIT_TIMING
-extern "C" int fnr_debug_emit_phases(unsigned long long* out_host, int reset) {
-  static unsigned* host = nullptr;
-  if (!host) host = (unsigned*)malloc(sizeof(unsigned) * EMIT_T_SLOTS * 8);
-  FNR_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_emit_phase_clk), sizeof(unsigned) * EMIT_T_SLOTS * 8));
-  for (int k = 0; k < 8; ++k) out_host[k] = 0;
-  for (int i = 0; i < EMIT_T_SLOTS; ++i)
-    for (int k = 0; k < 8; ++k) out_host[k] += host[i * 8 + k];
-  if (reset) {
-    memset(host, 0, sizeof(unsigned) * EMIT_T_SLOTS * 8);
-    FNR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_emit_phase_clk), host, sizeof(unsigned) * EMIT_T_SLOTS * 8));
-  }
-  return FNR_OK;
-}
-#endif
 
 extern "C" int fnr_debug_scatter_overflows(uint64_t* count_host, int reset) {
   FNR_CHECK_ARG(count_host, "debug_scatter_overflows: null argument");

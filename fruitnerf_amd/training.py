@@ -1129,7 +1129,7 @@ OVERLAP_PROPOSAL_BACKWARD = os.environ.get("FNR_OVERLAP_PROPOSAL_BACKWARD", "1")
 # serialize_streams): a step like this gives per-kernel durations that describe one kernel, without switching allocator
 # pools between steps (one-stream and two-stream steps alternating made the caching allocator grow both pools: hipMalloc
 # calls inside bench.py's timed window)
-SERIALIZE_STREAMS = os.environ.get("FNR_SERIALIZE_STREAMS") == "1"   # (profiling runs: tools/prof_round.sh)
+SERIALIZE_STREAMS = os.environ.get("FNR_SERIALIZE_STREAMS") == "1"   # (profiling runs: tools/gpu_call.sh, legs kt / pmc)
 # The proposal levels' backward chains next to each other (level 0 on the launch stream, level 1 on a side stream; they
 # share no buffers).  OFF: measured on MI355X (round 3, A/B on one box) the step gets 4 % SLOWER (0.908 -> 0.943 ms) — a
 # cross-stream fork + join costs ~12 us of GPU time per handshake on this stack and the two chains of latency-bound
@@ -1374,8 +1374,9 @@ class TrainingSteps:
     # ---- step arenas ---------------------------------------------------------------------------------------------
     def _arena_mode(self) -> bool:
         dev = getattr(self.model, "device", None)
-        return bool(NATIVE_SEQUENCER and self.world_size < EXCHANGE_MIN_WORLD and dev is not None and dev.type == "cuda"
-                    and hasattr(self.model, "proposal_sampler"))
+        # (FNR_STREAM_SAFE is about the caching allocator's view of the cross-stream tensors: that mode keeps the allocator)
+        return bool(NATIVE_SEQUENCER and not STREAM_SAFE and self.world_size < EXCHANGE_MIN_WORLD and dev is not None
+                    and dev.type == "cuda" and hasattr(self.model, "proposal_sampler"))
 
     def _ensure_arenas(self) -> None:
         need = 0

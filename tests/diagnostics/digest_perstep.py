@@ -153,6 +153,9 @@ def one_run():
     if SEEN_DIGEST:
         import ctypes as C
         lib = L.load()
+        if not hasattr(lib, "fnr_debug_scatter_seen_bytes"):
+            raise SystemExit("FNR_DIGEST_SEEN=1 needs the instrumented library (-DFNR_SCATTER_DEBUG_SEEN: hash_scatter.hip of "
+                             "commit 6211740); the shipped library does not export fnr_debug_scatter_seen_*")
         lib.fnr_debug_scatter_seen_bytes.restype = C.c_size_t
         lib.fnr_debug_scatter_seen_copy.restype = C.c_size_t
         lib.fnr_debug_scatter_seen_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]

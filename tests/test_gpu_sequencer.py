@@ -146,9 +146,9 @@ def test_outside_changes_send_the_step_back_to_the_interpreter(dev):
 
 
 def test_unrecordable_configurations_stay_interpreted(dev):
-    """A step that calls an entry point without a recording hook (here: the proposal networks' optimiser step NOT fused into
-    their backward, so FusedAdam.step launches fnr_adam_step_spans) poisons its recording: the shape is marked, every such
-    step is interpreted, nothing is ever replayed wrongly."""
+    """A step that calls an entry point without a recording hook (here: the MLP weights' optimiser steps NOT fused into the
+    backward kernels, so the step runs fnr_field_mlp_bwd_rays and FusedAdam.step launches fnr_adam_step_spans) poisons its
+    recording: the shape is marked with the entry point's name, every such step is interpreted, nothing is replayed."""
     import fruitnerf_amd.training as T
 
     def run():
@@ -165,7 +165,8 @@ def test_unrecordable_configurations_stay_interpreted(dev):
     p_i, _, _ = _interpreted(run)
     assert torch.equal(p_n, p_i)
     assert stats["replayed"] == 0 and stats["record_failed"] >= 1
-    assert any("fnr_adam_step" in r for r in why.values()), why
+    assert why and all("ran while recording and cannot be replayed" in r for r in why.values()), why
+    assert any("fnr_field_mlp_bwd_rays" in r or "fnr_adam_step" in r for r in why.values()), why
 
 
 def test_replayed_step_enqueues_faster_than_the_interpreter(dev):

@@ -47,21 +47,25 @@ for leg in "$@"; do
       [ $name = kt ] && export FNR_SERIALIZE_STREAMS=1
       (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$name -o p -- python /root/repo/bench.py $arg > $O/${name}_bench.json 2>/tmp/pf_$name.err)
       unset FNR_SERIALIZE_STREAMS
-      python tools/kt_agg.py /tmp/pf_$name/p_kernel_trace.csv fnr > $O/${name}_kernels.txt 2>&1
-      python tools/kt_step.py /tmp/pf_$name/p_kernel_trace.csv > $O/${name}_timeline.txt 2>&1
-      head -60 /tmp/pf_$name/p_kernel_stats.csv > $O/${name}_stats_head.csv 2>/dev/null
-      echo "[$name] $(wc -l < $O/${name}_kernels.txt) kernel rows";;
+      # (file names as tools/make_profile_summary.py reads them from profiles/<tag>_raw/)
+      sfx=""; [ $name = kt2 ] && sfx="_two_streams"
+      cp $O/${name}_bench.json $O/prof_bench$sfx.json
+      python tools/kt_agg.py /tmp/pf_$name/p_kernel_trace.csv fnr > $O/prof_kernel_trace$sfx.txt 2>&1
+      python tools/kt_agg.py /tmp/pf_$name/p_kernel_trace.csv > $O/prof_kernel_trace_top40$sfx.txt 2>&1
+      python tools/kt_step.py /tmp/pf_$name/p_kernel_trace.csv > $O/prof_step_timeline$sfx.txt 2>&1
+      head -60 /tmp/pf_$name/p_kernel_stats.csv > $O/prof_kernel_stats_head$sfx.csv 2>/dev/null
+      echo "[$name] $(wc -l < $O/prof_kernel_trace$sfx.txt) kernel rows";;
     pmc)
       [ -z "$arg" ] && arg="--steps 60 --warmup 10 $QUICK"
       export FNR_SERIALIZE_STREAMS=1
       (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf_f -o p -- python /root/repo/bench.py $arg > /dev/null 2>&1)
-      python tools/pmc_agg.py /tmp/pf_f/p_counter_collection.csv fnr > $O/pmc_fetch.txt 2>&1
+      python tools/pmc_agg.py /tmp/pf_f/p_counter_collection.csv fnr > $O/prof_fetch.txt 2>&1
       (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pf_w -o p -- python /root/repo/bench.py $arg > /dev/null 2>&1)
-      python tools/pmc_agg.py /tmp/pf_w/p_counter_collection.csv fnr > $O/pmc_write.txt 2>&1
+      python tools/pmc_agg.py /tmp/pf_w/p_counter_collection.csv fnr > $O/prof_write.txt 2>&1
       (cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/pf_s -o p -- python /root/repo/bench.py $arg > /dev/null 2>&1)
-      python tools/pmc_agg.py /tmp/pf_s/p_counter_collection.csv fnr > $O/pmc_sq.txt 2>&1
+      python tools/pmc_agg.py /tmp/pf_s/p_counter_collection.csv fnr > $O/prof_sq.txt 2>&1
       unset FNR_SERIALIZE_STREAMS
-      echo "[pmc] fetch $(wc -l < $O/pmc_fetch.txt) write $(wc -l < $O/pmc_write.txt) sq $(wc -l < $O/pmc_sq.txt) rows";;
+      echo "[pmc] fetch $(wc -l < $O/prof_fetch.txt) write $(wc -l < $O/prof_write.txt) sq $(wc -l < $O/prof_sq.txt) rows";;
     py)
       n=$(basename ${arg%% *} .py)
       python $arg > $O/$n.log 2>&1; echo "[py $arg] rc $?: $(tail -2 $O/$n.log | tr '\n' ' ' | cut -c1-300)";;

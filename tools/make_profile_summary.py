@@ -1,4 +1,4 @@
-"""profiles/<tag>_kernel_trace_pmc.md and profiles/pmc_traffic.json from the aggregates tools/prof_round.sh left under
+"""profiles/<tag>_kernel_trace_pmc.md and profiles/pmc_traffic.json from the aggregates tools/gpu_call.sh (legs kt, pmc, kt2) left under
 profiles/<tag>_raw/.   usage: python tools/make_profile_summary.py [tag, default r03] [git revision the run was made from]"""
 import json
 import re
@@ -71,7 +71,7 @@ f, w, sq = pmc(base + 'prof_fetch.txt'), pmc(base + 'prof_write.txt'), pmc(base 
 steps = max(n for name, g, n, *_ in rows if 'k_train_losses' in name)   # one per training step
 round_no = tag[1:].lstrip("0")
 out = [f'# Round {round_no} - rocprofv3 of `FNR_SERIALIZE_STREAMS=1 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality` (default arithmetic: bf16x3), build {rev}\n',
-       f'Collected by `tools/prof_round.sh` on 1xMI355X (gfx950, ROCm 7.2): one `--kernel-trace --stats` pass and three separate '
+       f'Collected by `tools/gpu_call.sh (legs kt, pmc, kt2)` on 1xMI355X (gfx950, ROCm 7.2): one `--kernel-trace --stats` pass and three separate '
        f'`--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ counters, each with `--kernel-trace` only), {steps} training steps each (10 '
        'warm-up + 60 timed + 12 of the per-entry-point breakdown).  FNR_SERIALIZE_STREAMS=1: the second HIP stream\'s launches '
        '(proposal-network backward, ray-gradient reduction, camera step, the next step\'s sampling) run before / after the launch '
@@ -161,7 +161,7 @@ for ep, parts in ENTRY.items():
                                                    '%.2f' % (total_b / alg) if alg else ''))
 json.dump({'source': f'profiles/{tag}_kernel_trace_pmc.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only) of '
                      '`FNR_SERIALIZE_STREAMS=1 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-quality`, FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM" '
-                     '(tools/prof_round.sh, tools/make_profile_summary.py)',
+                     '(tools/gpu_call.sh (legs kt, pmc, kt2), tools/make_profile_summary.py)',
            'build': rev, 'entry_points': {'fruit_nerf': traffic}}, open('/root/repo/profiles/pmc_traffic.json', 'w'), indent=1)
 
 out.append('\n## Bench lines of the same build (un-profiled)\n')
