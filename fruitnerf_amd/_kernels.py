@@ -419,14 +419,16 @@ def distortion(S: int, spacing: Tensor, weights: Tensor, out: Optional[Tensor] =
 
 def train_losses(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tensor, semantic_loss_weight: float,
                  S_f: int, spacing_f: Tensor, weights_f: Tensor, levels, interlevel_mult: float, want_distortion: bool,
-                 accum: Tensor, fuse_weights_bwd: bool = False):
+                 accum: Tensor, fuse_weights_bwd: bool = False, want_ray_grads: bool = True):
     """losses_fwd + interlevel_fwd per proposal level + distortion + the slot sums in one launch.
     levels: [(S_p, spacing_p, weights_p), ...]; accum: float buffer of FNR_TRAIN_LOSSES_ACCUM_FLOATS, zeroed before its
     first use (every completed call leaves it zeroed; it is re-zeroed here when the call fails).
     -> losses [5] (rgb_loss, semantics_loss, psnr, interlevel_loss, distortion), d_rgb [R,3], d_semantics [R],
        [d_weights_p per level].
     fuse_weights_bwd: levels are (S_p, spacing_p, weights_p, euclid_p, density_p) and the last list holds each level's
-    d(loss)/d(density) [R,S_p] (= weights_bwd of the level, unit upstream) instead of d_weights_p."""
+    d(loss)/d(density) [R,S_p] (= weights_bwd of the level, unit upstream) instead of d_weights_p.
+    want_ray_grads False: d_rgb / d_semantics are neither allocated nor written (-> None, None): the caller's composite
+    backward forms them itself (composite_bwd_targets)."""
     lib = L.load()
     dev = rgb.device
     R = rgb.shape[0]
@@ -435,8 +437,8 @@ def train_losses(rgb: Tensor, image: Tensor, semantics: Tensor, fruit_mask: Tens
     # (never from the step arena: callers keep a step's loss scalars beyond the step after next — a replayed step
     #  program writes them to the buffer fnr_step_scalars.losses names)
     losses = torch.empty(5, device=dev)
-    d_rgb = _empty(R, 3, device=dev)
-    d_sem = _empty(R, device=dev)
+    d_rgb = _empty(R, 3, device=dev) if want_ray_grads else None
+    d_sem = _empty(R, device=dev) if want_ray_grads else None
     n = len(levels)
     outs = [_empty(R, lv[0], device=dev) for lv in levels]
     sp = (C.c_int * max(n, 1))(*[int(lv[0]) for lv in levels])

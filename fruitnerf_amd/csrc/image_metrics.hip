@@ -106,11 +106,17 @@ __global__ __launch_bounds__(IM_THREADS) void k_image_ssim(int H, int W, const f
 __global__ __launch_bounds__(IM_THREADS) void k_image_range(long long n_val, const float* __restrict__ rgb,
                                                             const float* __restrict__ image, float* __restrict__ partial) {
   __shared__ float s_mm[IM_THREADS / 64][4];
+  __shared__ int s_nan[IM_THREADS / 64];
   float lo_a = __builtin_inff(), hi_a = -__builtin_inff(), lo_b = __builtin_inff(), hi_b = -__builtin_inff();
+  // torch's max() / min() and clamp() PROPAGATE NaN (preds.max() - preds.min() of a render with a NaN is NaN, and so is the
+  // SSIM); fminf / fmaxf drop it — a NaN anywhere is carried as a flag and written as NaN bounds
+  int bad = 0;
   for (long long i = (long long)blockIdx.x * IM_THREADS + threadIdx.x; i < n_val; i += (long long)gridDim.x * IM_THREADS) {
-    const float a = image[i], b = fminf(fmaxf(rgb[i], 0.0f), 1.0f);
+    const float a = image[i], raw = rgb[i], b = fminf(fmaxf(raw, 0.0f), 1.0f);
+    bad |= (a != a) | (raw != raw);
     lo_a = fminf(lo_a, a), hi_a = fmaxf(hi_a, a), lo_b = fminf(lo_b, b), hi_b = fmaxf(hi_b, b);
   }
+  bad = __any(bad);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     lo_a = fminf(lo_a, __shfl_xor(lo_a, d, 64)), hi_a = fmaxf(hi_a, __shfl_xor(hi_a, d, 64));
@@ -119,29 +125,37 @@ __global__ __launch_bounds__(IM_THREADS) void k_image_range(long long n_val, con
   if ((threadIdx.x & 63) == 0) {
     float* m = s_mm[threadIdx.x >> 6];
     m[0] = lo_a, m[1] = hi_a, m[2] = lo_b, m[3] = hi_b;
+    s_nan[threadIdx.x >> 6] = bad;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < IM_THREADS / 64; ++w)
+    for (int w = 1; w < IM_THREADS / 64; ++w) {
       lo_a = fminf(lo_a, s_mm[w][0]), hi_a = fmaxf(hi_a, s_mm[w][1]), lo_b = fminf(lo_b, s_mm[w][2]), hi_b = fmaxf(hi_b, s_mm[w][3]);
+      bad |= s_nan[w];
+    }
     float* o = partial + 4 * blockIdx.x;
-    o[0] = lo_a, o[1] = hi_a, o[2] = lo_b, o[3] = hi_b;
+    const float nan = __builtin_nanf("");
+    o[0] = bad ? nan : lo_a, o[1] = bad ? nan : hi_a, o[2] = bad ? nan : lo_b, o[3] = bad ? nan : hi_b;
   }
 }
 
 // one wave: the partial ranges -> c12 = {(0.01 * range)^2, (0.03 * range)^2}, c12[2] = range
 __global__ __launch_bounds__(64) void k_image_range_finish(const float* __restrict__ partial, int n, float* __restrict__ c12) {
   float lo_a = __builtin_inff(), hi_a = -__builtin_inff(), lo_b = __builtin_inff(), hi_b = -__builtin_inff();
-  for (int i = threadIdx.x; i < n; i += 64)
+  int bad = 0;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    bad |= partial[4 * i] != partial[4 * i];       // (a block that saw a NaN wrote NaN bounds)
     lo_a = fminf(lo_a, partial[4 * i]), hi_a = fmaxf(hi_a, partial[4 * i + 1]), lo_b = fminf(lo_b, partial[4 * i + 2]),
     hi_b = fmaxf(hi_b, partial[4 * i + 3]);
+  }
+  bad = __any(bad);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     lo_a = fminf(lo_a, __shfl_xor(lo_a, d, 64)), hi_a = fmaxf(hi_a, __shfl_xor(hi_a, d, 64));
     lo_b = fminf(lo_b, __shfl_xor(lo_b, d, 64)), hi_b = fmaxf(hi_b, __shfl_xor(hi_b, d, 64));
   }
   if (threadIdx.x == 0) {
-    const float range = fmaxf(hi_a - lo_a, hi_b - lo_b);
+    const float range = bad ? __builtin_nanf("") : fmaxf(hi_a - lo_a, hi_b - lo_b);
     const float k1r = 0.01f * range, k2r = 0.03f * range;
     c12[0] = k1r * k1r, c12[1] = k2r * k2r, c12[2] = range;
   }

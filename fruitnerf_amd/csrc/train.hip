@@ -11,6 +11,16 @@ namespace fnr {
 
 // ---------------------------------------------------------------------------------------------------
 // rgb MSE + semantic BCE-with-logits: values and unit gradients
+// The per-ray gradients of the two image losses, unit upstream: d MSELoss(mean over 3 R values) / d rgb_c and
+// d (w * BCEWithLogitsLoss(mean over R)) / d logit.  ONE definition for every kernel that forms them — losses_block,
+// k_train_losses and the composite backward that takes the targets itself (k_weights_bwd<.., TARGETS>): the bit-identity of
+// those paths (tests/test_gpu_training_parity.py::test_composite_bwd_targets_is_losses_then_composite_bwd) rests on it.
+__device__ __forceinline__ float mse_grad(float diff, float inv3r) { return 2.0f * diff * inv3r; }
+__device__ __forceinline__ float bce_logit_grad(float x, float y, float sem_weight, float invr) {
+  const float sg = 1.0f / (1.0f + expf(-x));
+  return sem_weight * (sg - y) * invr;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // One workgroup: a training batch is a few thousand rays, and finishing inside the kernel (block reduction, PSNR)
 // saves the memset, the atomics and three follow-up elementwise launches per step.
@@ -28,13 +38,12 @@ __device__ __forceinline__ void losses_block(long long R, const float* __restric
     for (int c = 0; c < 3; ++c) {
       const float d = rgb[3 * r + c] - image[3 * r + c];
       l_rgb += d * d;
-      d_rgb[3 * r + c] = 2.0f * d * inv3r;
+      d_rgb[3 * r + c] = mse_grad(d, inv3r);
     }
     const float x = sem[r], y = mask[r];
     // BCEWithLogits: max(x,0) - x*y + log1p(exp(-|x|))
     l_sem += fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
-    const float s = 1.0f / (1.0f + expf(-x));
-    d_sem[r] = sem_weight * (s - y) * invr;
+    d_sem[r] = bce_logit_grad(x, y, sem_weight, invr);
   }
   l_rgb = wave_sum(l_rgb);
   l_sem = wave_sum(l_sem);
@@ -335,12 +344,11 @@ __global__ __launch_bounds__(256) void k_train_losses(long long R, const float* 
       for (int c = 0; c < 3; ++c) {
         const float d = rgb[3 * r + c] - image[3 * r + c];
         l_rgb += d * d;
-        d_rgb[3 * r + c] = 2.0f * d * inv3r;
+        if (d_rgb) d_rgb[3 * r + c] = mse_grad(d, inv3r);     // (NULL: the composite backward forms them itself)
       }
       const float x = sem[r], y = mask[r];
       l_sem = fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
-      const float sg = 1.0f / (1.0f + expf(-x));
-      d_sem[r] = sem_weight * (sg - y) * invr;
+      if (d_sem) d_sem[r] = bce_logit_grad(x, y, sem_weight, invr);
     }
     l_rgb = wave_sum(l_rgb);
     l_sem = wave_sum(l_sem);
@@ -452,12 +460,10 @@ __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const f
       const float inv3r = 1.0f / (float)(3 * R), invr = 1.0f / (float)R;   // (k_train_losses, rgb / semantic role)
       const float d0 = tg.out_rgb[3 * r] - tg.image[3 * r], d1 = tg.out_rgb[3 * r + 1] - tg.image[3 * r + 1],
                   d2 = tg.out_rgb[3 * r + 2] - tg.image[3 * r + 2];
-      gr = 2.0f * d0 * inv3r;
-      gg = 2.0f * d1 * inv3r;
-      gb = 2.0f * d2 * inv3r;
-      const float x = tg.out_sem[r], y = tg.mask[r];
-      const float sg = 1.0f / (1.0f + expf(-x));
-      gs = tg.sem_weight * (sg - y) * invr;
+      gr = mse_grad(d0, inv3r);
+      gg = mse_grad(d1, inv3r);
+      gb = mse_grad(d2, inv3r);
+      gs = bce_logit_grad(tg.out_sem[r], tg.mask[r], tg.sem_weight, invr);
     } else {
       gr = g_rgb[3 * r];
       gg = g_rgb[3 * r + 1];
@@ -871,9 +877,9 @@ extern "C" int fnr_train_losses(int64_t n_rays, const float* rgb, const float* i
                               accum, (sc && sc->losses) ? sc->losses : losses, stream);
     });
   }
-  FNR_CHECK_ARG(rgb && image && semantics && fruit_mask && d_rgb && d_semantics && spacing_f && weights_f && accum &&
-                    losses && n_rays > 0,
+  FNR_CHECK_ARG(rgb && image && semantics && fruit_mask && spacing_f && weights_f && accum && losses && n_rays > 0,
                 "train_losses: null argument");
+  FNR_CHECK_ARG((d_rgb == nullptr) == (d_semantics == nullptr), "train_losses: d_rgb and d_semantics go together");
   FNR_CHECK_ARG(n_levels >= 0 && n_levels <= FNR_MAX_PROPOSAL_LEVELS, "train_losses: %d proposal levels (0..%d)",
                 n_levels, FNR_MAX_PROPOSAL_LEVELS);
   FNR_CHECK_ARG(S_f > 0 && (!want_distortion || S_f <= 512), "train_losses: S_f %d out of range", S_f);

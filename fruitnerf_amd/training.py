@@ -923,7 +923,8 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
             losses, d_rgb, d_sem, d_wps = K.train_losses(outputs["rgb"], image, outputs["semantics"], mask,
                                                          cfg.semantic_loss_weight, S, fin["spacing"], fin["weights"],
                                                          prop_levels, cfg.interlevel_loss_mult, want_metrics,
-                                                         accum, fuse_weights_bwd=prop_bwd)
+                                                         accum, fuse_weights_bwd=prop_bwd,
+                                                         want_ray_grads=not losses_on_side)
         loss_dict = {"rgb_loss": losses[0], "semantics_loss": losses[1], "interlevel_loss": losses[3]}
         metrics_dict = {"psnr": losses[2], "distortion": losses[4]} if want_metrics else {}
 

@@ -471,8 +471,8 @@ int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, const fnr_p
  * fnr_losses_fwd + fnr_interlevel_fwd for
  * each of the n_levels (<= FNR_MAX_PROPOSAL_LEVELS) proposal levels against the final level + (want_distortion)
  * fnr_distortion, and the sum of the accumulator slots.  losses [5] = rgb_loss, semantics_loss, psnr,
- * interlevel_loss, distortion (0 when not wanted); d_rgb [R,3], d_semantics [R], d_weights_p[l] [R,S_p[l]] as the
- * single calls give them.  accum: FNR_TRAIN_LOSSES_ACCUM_FLOATS floats (loss slots + completion counters), zeroed by
+ * interlevel_loss, distortion (0 when not wanted); d_rgb [R,3], d_semantics [R] (both NULL: not written — a caller whose
+ * composite backward forms them itself, fnr_composite_bwd_targets), d_weights_p[l] [R,S_p[l]] as the single calls give them.  accum: FNR_TRAIN_LOSSES_ACCUM_FLOATS floats (loss slots + completion counters), zeroed by
  * the caller before its FIRST use; every completed call leaves it zeroed again (the last workgroup cleans up), so a caller
  * that keeps the buffer launches no fill per step — after a FAILED call the caller must zero it again.  The slots hold
  * 64-bit fixed point (2^-34 resolution): a contribution that is not finite or beyond its row's bound (4096 for the per-ray

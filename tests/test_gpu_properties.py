@@ -396,3 +396,34 @@ def test_image_metrics_kernel_matches_the_float64_oracle(dev, shape, span):
     # without semantics: only the image sums
     sums2 = K.image_metrics(rgb.to(dev), image.to(dev)).tolist()
     assert sums2[0] == sums[0] and sums2[1] == sums[1] and sums2[2:6] == [0.0, 0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("case", ["nan_in_render", "nan_in_image"])
+def test_image_metrics_value_range_follows_torch_on_nan(dev, case):
+    """torchmetrics' SSIM with data_range=None takes max() - min() of the (clamped) images: torch's reductions and clamp
+    propagate NaN, so one NaN in the render (or the image) makes the range, c1 / c2 and the SSIM NaN — fminf / fmaxf would
+    drop it and report a finite SSIM.  Compared with the float64 restatement (NumPy propagates NaN the same
+    way).  (A constant image pair — range 0, c1 = c2 = 0 — makes every SSIM value 0 / 0 up to the rounding of the window
+    sums: garbage in torchmetrics, in the oracle and here alike; nothing to pin.)"""
+    import numpy as np
+    from fruitnerf_amd import _kernels as K
+    from oracle import image_metrics as oim
+    H, W = 40, 33
+    g = torch.Generator().manual_seed(11)
+    image = torch.rand(H, W, 3, generator=g)
+    rgb = (image + 0.1 * torch.randn(H, W, 3, generator=g))
+    if case == "nan_in_render":
+        rgb[17, 5, 1] = float("nan")
+    elif case == "nan_in_image":
+        image[3, 30, 2] = float("nan")
+    sem = torch.randn(H, W, 1, generator=g)
+    mask = (torch.rand(H, W, 1, generator=g) > 0.5).float()
+    sums = K.image_metrics(rgb.to(dev), image.to(dev), sem.to(dev)[..., 0], mask.to(dev)[..., 0]).tolist()
+    with np.errstate(all="ignore"):
+        want = oim.image_metrics(rgb.numpy(), image.numpy(), sem.numpy(), mask.numpy())
+    ssim = sums[1] / sums[6]
+    print(f"[image metrics {case}] ssim {ssim} oracle {want['ssim']}")
+    assert np.isnan(want["ssim"]), "the oracle (NumPy max / min / clip) propagates NaN"
+    assert np.isnan(ssim)
+    # the IoUs do not depend on the images
+    assert sums[2] / max(sums[3], 1.0) == pytest.approx(want["iou_sigmoid"], abs=1e-12)

@@ -217,7 +217,7 @@ def test_fruit_nerf_big_step_at_a_trained_state_matches_the_oracle(dev):
         print(f"[trained big] {k}: hip {a:.8e} oracle {r:.8e}")
         assert abs(a - r) <= LOSS_REL * max(abs(r), 1e-3), k
     named_h = dict(hm.named_parameters())
-    for name, p in om.named_parameters():
+    for name, p in util.named_trainable(om):
         ref = p.grad if p.grad is not None else torch.zeros_like(p)
         got = named_h[name].grad.detach().cpu()
         denom = ref.abs().double().sum().item()
@@ -322,8 +322,8 @@ def test_gradients_on_identical_samples_at_a_trained_state(dev, shape):
         assert abs(a - r) <= 1e-4 * max(abs(r), 1e-3), k
     named_h = dict(hm.named_parameters())
     worst = ("", 0.0)
-    ref_grads = {name: (p.grad if p.grad is not None else torch.zeros_like(p)) for name, p in om.named_parameters()}
-    for name, p in om.named_parameters():
+    ref_grads = {name: (p.grad if p.grad is not None else torch.zeros_like(p)) for name, p in util.named_trainable(om)}
+    for name, p in util.named_trainable(om):
         ref = ref_grads[name]
         got = named_h[name].grad.detach().cpu()
         scale = ref.abs().max().item()

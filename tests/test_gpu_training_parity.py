@@ -32,7 +32,7 @@ def _grad_report(om, hm, tag="", with_aggregate=False):
     sum|hip - ref| / sum|ref| per parameter)."""
     worst, worst_agg = 0.0, 0.0
     named_h = dict(hm.named_parameters())
-    for name, p in om.named_parameters():
+    for name, p in util.named_trainable(om):
         g_ref = p.grad if p.grad is not None else torch.zeros_like(p)
         g_hip = named_h[name].grad.detach().cpu()
         scale = g_ref.abs().max().item()
@@ -194,7 +194,7 @@ def test_three_training_steps_track_the_oracle(dev):
     opts = [torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15),
             torch.optim.Adam(groups["fields"], lr=1e-2, eps=1e-15)]
     hopt = FusedAdam(hm)
-    p0 = {n: p.detach().clone() for n, p in om.named_parameters()}
+    p0 = {n: p.detach().clone() for n, p in util.named_trainable(om)}
     R = 128
     for step in range(3):
         o, d, pa, cam = util.random_rays(R, 7, seed=100 + step)
@@ -218,7 +218,7 @@ def test_three_training_steps_track_the_oracle(dev):
             assert abs(a - b) <= tol * max(abs(b), 1e-3), (step, k)
     torch.cuda.synchronize()
     named_h = dict(hm.named_parameters())
-    for name, p in om.named_parameters():
+    for name, p in util.named_trainable(om):
         diff = (named_h[name].detach().cpu() - p.detach()).abs().max().item()
         print(f"[params after 3 steps] {name}: max_abs_diff {diff:.3e}")
         # Adam's first steps move every touched entry by ~lr regardless of gradient magnitude, so entries
@@ -1006,7 +1006,7 @@ def test_step_at_a_trained_state_matches_the_oracle(dev):
     # 1.9e-3 over both trained-state replays, profiles/r03_raw): L1-rel <= 1e-2 AND max-norm rel <= 1e-2 — a kernel
     # regression of 10x fails.  (The same-samples leg in tests/test_gpu_trained_state.py holds 5e-4 of max |g|.)
     named_h = dict(hm.named_parameters())
-    for name, p in om.named_parameters():
+    for name, p in util.named_trainable(om):
         ref = p.grad if p.grad is not None else torch.zeros_like(p)
         got = named_h[name].grad.detach().cpu()
         denom = ref.abs().double().sum().item()

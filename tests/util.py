@@ -137,6 +137,12 @@ def make_hip_like(oracle_model: fo.FruitModel, device, test_mode=None):
     return m
 
 
+def named_trainable(model):
+    """named_parameters() without nerfstudio's zero-length `device_indicator_param` (part of the checkpoint contract, never
+    of the graph: it has no gradient on either side)."""
+    return [(n, p) for n, p in model.named_parameters() if p.numel() > 0]
+
+
 def random_rays(R, num_images, seed=0, device="cpu"):
     """Origins on the unit sphere looking at the scene centre (SURVEY §8d micro-benchmark rays)."""
     g = torch.Generator().manual_seed(seed)
