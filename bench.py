@@ -1016,7 +1016,8 @@ def main() -> None:
         OptCls = torch.optim.Adam if M["algorithm"] == "adam" else torch.optim.RAdam
         oopts = [OptCls(groups["proposal_networks"], lr=1e-2, eps=1e-15), OptCls(groups["fields"], lr=1e-2, eps=1e-15)]
         cdata = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()}
-        cb = sa.PixelBatcher(cdata, train_ids.cpu(), seed=99)
+        from oracle import pixel_sampler as ops          # the CPU restatement of PixelSampler + RayGenerator
+        train_ids_cpu = train_ids.cpu()
         ocam = None
         if args.camera_optimizer != "off":  # same work as the GPU step: pose corrections + their Adam(weight_decay)
             from oracle import camera_opt as oc
@@ -1028,7 +1029,7 @@ def main() -> None:
         for i in range(n_cpu_warm + n_cpu):
             u = torch.rand(CPU_RAYS, 3, generator=gen_u)
             t1 = time.perf_counter()
-            o, d, cam, batch = cb.sample_torch(u)
+            o, d, cam, batch = ops.sample_pixels(cdata, train_ids_cpu, u)
             if ocam is not None:
                 kk = cam[:, 0]
                 yy = (u[:, 1] * HW).long().clamp_max(HW - 1)

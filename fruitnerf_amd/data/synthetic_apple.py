@@ -140,8 +140,7 @@ class PixelBatcher:
         self._set = None
 
     def sample(self, n_rays: int, camera_optimizer=None, level0: Optional[dict] = None):
-        """On a HIP device: one fused kernel (fnr_sample_pixels).  On the CPU (oracle baseline, host tests):
-        the equivalent torch ops below — this is data preparation for the oracle, not a fallback of the hot path.
+        """One fused kernel on the HIP device (fnr_sample_pixels / fnr_train_prologue); a batch on the CPU raises.
         camera_optimizer (cameras.camera_optimizers.CameraOptimizer, mode SO3xR3): rays come from the pose-corrected
         cameras; `last_draw` keeps what training.camera_backward_and_step needs to back-propagate into the poses.
         level0 (FruitModel.level0_spec(): S, near, far, n_jitter): the whole start of the step in ONE launch
@@ -172,16 +171,5 @@ class PixelBatcher:
             self.last_draw = {"u": u, "cam": cam, "c2w_adjusted": c2w_adj}
             self.last_presample = None
             return o, dirs, cam[:, None], {"image": image, "fruit_mask": mask[:, None]}
-        return self.sample_torch(u)
-
-    def sample_torch(self, u: Tensor):
-        d = self.data
-        n_rays = u.shape[0]
-        k = (u[:, 0] * self.image_ids.numel()).long().clamp_max(self.image_ids.numel() - 1)
-        y = (u[:, 1] * d["H"]).long().clamp_max(d["H"] - 1)
-        x = (u[:, 2] * d["W"]).long().clamp_max(d["W"] - 1)
-        img = self.image_ids[k]
-        o, dirs = pixel_rays(d["c2w"], img, y, x, d["fx"], d["fy"], d["cx"], d["cy"])
-        image = d["images"][img, y, x].float() / 255.0
-        mask = d["masks"][img, y, x].float()[:, None]
-        return o, dirs, k[:, None], {"image": image, "fruit_mask": mask}
+        raise RuntimeError(f"PixelBatcher.sample: the image batch is on {dev}; pixel sampling + ray generation run in "
+                           "libfruitnerf_hip.so on a HIP device (no CPU path; the CPU restatement is oracle/pixel_sampler.py)")

@@ -194,7 +194,8 @@ def main():
                     g_["lr"] = lr
                 scheds.append(sc)
         data_cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()}
-        cb = sa.PixelBatcher(data_cpu, train_ids.cpu(), seed=0)
+        from oracle import pixel_sampler as ops
+        cb = sa.PixelBatcher(data_cpu, train_ids.cpu(), seed=0)     # (holds data / image_ids for the oracle's sampler)
         tids = train_ids.cpu()
         traj, losses = [], []
 
@@ -208,7 +209,7 @@ def main():
         evo(start)
         t1 = time.time()
         for k, (u, jit) in enumerate(stream()):
-            o, d, cam, batch = cb.sample_torch(u)
+            o, d, cam, batch = ops.sample_pixels(cb.data, cb.image_ids, u)
             kk = cam[:, 0]
             yy = (u[:, 1] * HW).long().clamp_max(HW - 1)
             xx = (u[:, 2] * HW).long().clamp_max(HW - 1)

@@ -111,7 +111,8 @@ def main():
         def decay(h):   # nerfstudio ExponentialDecay without warm-up (fruit_nerf_config.py:47-56)
             return lambda s: float(np.exp(np.log(h["lr_final"] / h["lr"]) * min(s / h["max_steps"], 1.0)))
         scheds = [torch.optim.lr_scheduler.LambdaLR(o_, decay(h)) for o_, h in zip(opts, hyper) if h.get("lr_final")]
-        cb = sa.PixelBatcher(data, train_ids, seed=0)
+        from oracle import pixel_sampler as ops
+        cb = sa.PixelBatcher(data, train_ids, seed=0)               # (holds data / image_ids for the oracle's sampler)
 
     def evaluate(step):
         psnrs, inter, union = [], 0.0, 0.0
@@ -233,7 +234,7 @@ def main():
                                           {"image": image, "fruit_mask": mask[:, None]}, step,
                                           jitter=[j.to(dev) for j in jit], camera=(cam_opt, cadam, batcher))
         else:
-            o, d, cam, batch = cb.sample_torch(u)
+            o, d, cam, batch = ops.sample_pixels(cb.data, cb.image_ids, u)
             kk = cam[:, 0]
             yy = (u[:, 1] * HW).long().clamp_max(HW - 1)
             xx = (u[:, 2] * HW).long().clamp_max(HW - 1)

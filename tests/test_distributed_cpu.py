@@ -60,8 +60,9 @@ def _worker(rank, world, port, q):
     scene = sa.make_scene(seed=0)
     c2w = sa.make_cameras(4, seed=0)
     data = sa.render_dataset(scene, c2w, H=16, W=16, fx=22.0, fy=22.0)
-    b = sa.PixelBatcher(data, torch.arange(4), seed=1234 + rank)
-    o, d, cam, batch = b.sample(32)
+    from oracle import pixel_sampler as ops          # (CPU ranks: the oracle's sampler; the product samples on the device)
+    u = torch.rand(32, 3, generator=torch.Generator().manual_seed(1234 + rank))
+    o, d, cam, batch = ops.sample_pixels(data, torch.arange(4), u)
     gathered = [torch.zeros_like(d) for _ in range(world)]
     dist.all_gather(gathered, d)
     different_rays = not torch.equal(gathered[0], gathered[1])

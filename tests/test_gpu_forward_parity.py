@@ -213,20 +213,22 @@ def test_model_forward_end_to_end_fruit_nerf_big(dev, training):
     assert torch.equal(got["semantics_colormap"].cpu().float().view(-1), ref["semantics_colormap"].float().view(-1))
 
 
-def test_pixel_sampler_matches_torch_mirror(dev):
-    """fnr_sample_pixels (PixelSampler + RayGenerator) vs the torch ops the CPU baseline uses."""
+def test_pixel_sampler_matches_the_oracle(dev):
+    """fnr_sample_pixels (PixelSampler + RayGenerator) vs oracle/pixel_sampler.py (pinned on closed-form pinhole geometry,
+    tests/test_oracle_closed_form.py; what bench.py's CPU baseline draws its rays with)."""
     from fruitnerf_amd.data import synthetic_apple as sa
+    from oracle import pixel_sampler as ops
     scene = sa.make_scene(seed=0)
     c2w = sa.make_cameras(6, seed=0)
     data = sa.render_dataset(scene, c2w, H=48, W=40, fx=61.0, fy=59.0)
     ids = torch.tensor([0, 2, 3, 5])
-    cpu = sa.PixelBatcher(data, ids, seed=1)
     gdata = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
-    gpu = sa.PixelBatcher(gdata, ids.to(dev), seed=1)
     u = torch.rand(5000, 3)
     u[0] = torch.tensor([0.999999, 0.999999, 0.999999])
     u[1] = 0.0
-    o, d, cam, batch = cpu.sample_torch(u)
+    o, d, cam, batch = ops.sample_pixels(data, ids, u)
+    with pytest.raises(RuntimeError, match="no CPU path"):       # the product has no CPU sampler
+        sa.PixelBatcher(data, ids, seed=1).sample(16)
     from fruitnerf_amd import _kernels as K
     st = K.ImageSetArg(gdata["images"], gdata["masks"], gdata["c2w"], data["fx"], data["fy"], data["cx"], data["cy"])
     go, gd, gcam, gimg, gmask = K.sample_pixels(st, ids.to(dev), u.to(dev))

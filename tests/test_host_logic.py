@@ -228,8 +228,10 @@ def test_synthetic_scene_is_seeded_and_sane():
     assert data["images"].shape == (8, 40, 40, 3) and data["masks"].max() == 1
     frac = data["masks"].float().mean().item()
     assert 0.001 < frac < 0.3
-    b = sa.PixelBatcher(data, torch.arange(8), seed=3)
-    o, d, cam, batch = b.sample(64)
+    with pytest.raises(RuntimeError, match="no CPU path"):      # the product samples pixels on the HIP device only
+        sa.PixelBatcher(data, torch.arange(8), seed=3).sample(64)
+    from oracle import pixel_sampler as ops
+    o, d, cam, batch = ops.sample_pixels(data, torch.arange(8), torch.rand(64, 3, generator=torch.Generator().manual_seed(3)))
     assert o.shape == (64, 3) and torch.allclose(d.norm(dim=-1), torch.ones(64), atol=1e-5)
     assert batch["image"].shape == (64, 3) and batch["fruit_mask"].shape == (64, 1) and cam.max() < 8
 

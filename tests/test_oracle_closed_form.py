@@ -251,3 +251,54 @@ def test_camera_ray_generation_conventions():
     tv[0, :3] = torch.tensor([0.01, 0.02, -0.03])
     o2, d2 = oc.generate_rays(c2w, oc.exp_map_SO3xR3(tv), y, x, 10.0, 10.0, 8.0, 8.0)
     assert torch.allclose(o2[0] - o[0], tv[0, :3], atol=1e-7) and torch.allclose(d2, d, atol=1e-6)
+
+
+def test_pixel_rays_pinhole_geometry():
+    """oracle/pixel_sampler.py on closed forms: with an identity pose the ray through the principal point (pixel centre
+    exactly on (cx, cy)) is (0, 0, -1); fx pixels to the right it leaves at 45 degrees towards +x; fy pixels DOWN the image
+    towards -y; all rays are unit length and start at the camera centre; a rotated / translated camera rotates and moves
+    them rigidly.  The integer pixel (x, y) is sampled at (x + 0.5, y + 0.5)."""
+    from oracle import pixel_sampler as ops
+    fx, fy, cx, cy = 50.0, 40.0, 32.5, 24.5            # pixel (32, 24) has its centre on the principal point
+    eye = torch.eye(3, 4)[None]
+    cam = torch.zeros(4, dtype=torch.long)
+    x = torch.tensor([32, 82, 32, 0])
+    y = torch.tensor([24, 24, 64, 0])
+    o, d = ops.pixel_rays(eye, cam, y, x, fx, fy, cx, cy)
+    s = 0.5 ** 0.5
+    assert torch.equal(o, torch.zeros(4, 3))
+    assert torch.allclose(d[0], torch.tensor([0.0, 0.0, -1.0]), atol=1e-7)
+    assert torch.allclose(d[1], torch.tensor([s, 0.0, -s]), atol=1e-7)          # +fx pixels -> +x at 45 degrees
+    assert torch.allclose(d[2], torch.tensor([0.0, -s, -s]), atol=1e-7)         # +fy pixels (down) -> -y at 45 degrees
+    want3 = torch.tensor([(0.5 - cx) / fx, -(0.5 - cy) / fy, -1.0])
+    assert torch.allclose(d[3], want3 / want3.norm(), atol=1e-7)
+    assert torch.allclose(d.norm(dim=-1), torch.ones(4), atol=1e-6)
+    # rigid motion: 90 degrees about +y (camera now looks along -x), centre at (1, 2, 3)
+    R = torch.tensor([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]])
+    c2w = torch.cat([R, torch.tensor([[1.0], [2.0], [3.0]])], dim=1)[None]
+    o2, d2 = ops.pixel_rays(c2w, cam, y, x, fx, fy, cx, cy)
+    assert torch.equal(o2, torch.tensor([1.0, 2.0, 3.0]).expand(4, 3))
+    assert torch.allclose(d2, d @ R.T, atol=1e-7)
+    assert torch.allclose(d2[0], torch.tensor([-1.0, 0.0, 0.0]), atol=1e-7)
+
+
+def test_pixel_sampler_picks_floor_of_u_times_extent():
+    """sample_pixels: (slot, row, column) = floor(u * (n_train, H, W)) clamped to the last index; the slot (not the dataset
+    image) is the camera index; colours are uint8 / 255, the mask is 0 / 1."""
+    from oracle import pixel_sampler as ops
+    M, H, W = 5, 6, 7
+    g = torch.Generator().manual_seed(0)
+    data = {"images": torch.randint(0, 256, (M, H, W, 3), dtype=torch.uint8, generator=g),
+            "masks": torch.randint(0, 2, (M, H, W), dtype=torch.uint8, generator=g),
+            "c2w": torch.eye(3, 4).expand(M, 3, 4).clone(), "H": H, "W": W, "fx": 9.0, "fy": 9.0, "cx": W / 2, "cy": H / 2}
+    data["c2w"][:, :, 3] = torch.arange(M, dtype=torch.float32)[:, None]          # camera i sits at (i, i, i)
+    ids = torch.tensor([4, 1, 3])
+    u = torch.tensor([[0.0, 0.0, 0.0], [0.34, 0.5, 0.99], [0.999999, 0.999999, 0.999999], [0.67, 0.17, 0.43]])
+    o, d, cam, batch = ops.sample_pixels(data, ids, u)
+    assert cam[:, 0].tolist() == [0, 1, 2, 2]
+    assert o[:, 0].tolist() == [4.0, 1.0, 3.0, 3.0]                                # slots -> dataset images 4, 1, 3, 3
+    rows, cols = [0, 3, 5, 1], [0, 6, 6, 3]
+    for i, (k, r, c) in enumerate(zip([4, 1, 3, 3], rows, cols)):
+        assert torch.equal(batch["image"][i], data["images"][k, r, c].float() / 255.0)
+        assert batch["fruit_mask"][i, 0] == float(data["masks"][k, r, c])
+    assert batch["image"].dtype == torch.float32 and batch["fruit_mask"].shape == (4, 1)
