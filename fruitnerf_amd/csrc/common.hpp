@@ -106,14 +106,15 @@ __device__ __forceinline__ void nt_store(float2* p, const float2& v) {
   const nt_f2 t = {v.x, v.y};
   __builtin_nontemporal_store(t, reinterpret_cast<nt_f2*>(p));
 }
-// Class c is streaming iff bit c of FNR_NT_MASK is set.  NT_JAC_LD IS OFF: with the Jacobian's loads in
-// k_field_mlp_bwd_base_coop streaming, training stopped being bit-reproducible — tests/test_gpu_determinism.py failed in 4
-// of 4 repetitions with that class alone and in none of 4 with each of the other seven, alone or together
-// (profiles/r05_raw/nt_bisect_call10.log).  Those are the only streaming loads of the library that are in flight TOGETHER
-// WITH PLAIN LOADS and consumed behind PARTIAL `s_waitcnt vmcnt(n)` waits (issued ahead of a dW round, used after it); every
-// other streaming load is waited for together with everything else outstanding, or among its own kind.  Whether `nt` loads
-// (which bypass the CU's L1) may return out of order with plain ones on gfx950 is not something this round could establish;
-// the rule kept here: no streaming load where the compiler may count loads of both kinds.
+// Class c is streaming iff bit c of FNR_NT_MASK is set.  NT_JAC_LD is off because it buys nothing (same-box A/B, round 6:
+// 5.72 vs 5.74 M rays/s).  Round 5 switched it off for another reason — with the Jacobian's loads in
+// k_field_mlp_bwd_base_coop streaming, training stopped being bit-reproducible — and suspected the loads ("may `nt` loads
+// complete out of order with plain ones at a partial s_waitcnt vmcnt(n)?").  Round 6 measured: they may not
+// (tools/microbench/nt_load_order.hip, nt_visibility.hip: 0 events in 1e11 partial waits / 300 buffer rewrites per mode, across
+// policies, stores, address-register reuse, a streaming second stream); the defect sat in that kernel's position-gradient
+// reduction, in an instruction selection hipcc only makes in the schedule the `nt` loads give it, and is fenced there
+// (field_mlp_bf16.hip "EVERY PARTIAL SUM IS PINNED"; profiles/r06_raw/nt_hunt.md).  Partial waits with accesses of both
+// policies in flight are everywhere in this library (tools/isa_nt_scan.py: 71 places) and are fine.
 #ifndef FNR_NT_MASK
 #define FNR_NT_MASK 0xef
 #endif

@@ -915,6 +915,9 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int a = 0; a < 3; ++a) jv[3 * m + a] = ntc_load<NT_JAC_LD>(&jac[((size_t)(4 * m + g) * 3 + a) * N + nn]);   // its only use
+#ifdef FNR_JAC_WAIT0   // (round 6 hunt, tests/diagnostics/base_coop_repeat.py: every load of this wave complete right here)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
     cs_dw<NS, 1, CB_ROWS>(sG, sX, wave >> 1, 0, wave & 1, accA, lane);
     if (wave >= 4) cs_bias<NS, CB_ROWS>(sG, wave - 4, bA, lane);
@@ -926,17 +929,33 @@ __global__ __launch_bounds__(512, 2) void k_field_mlp_bwd_base_coop(
         d_feats[(size_t)(4 * m + g) * N + n] = make_float2(Gx[m >> 1][2 * (m & 1)], Gx[m >> 1][2 * (m & 1) + 1]);
     }
     if constexpr (POSGRAD) {
+      // EVERY PARTIAL SUM IS PINNED IN ITS OWN REGISTER (the empty asm statements).  Left to itself hipcc pairs the x / y sums
+      // into packed-FP32 instructions with cross-half operand selects and threads the six ds_bpermute shuffles through them
+      // (v_pk_add_f32 .. op_sel:[0,1] op_sel_hi:[1,0] ; ds_bpermute_b32 ; v_pk_add_f32 ..); in the schedule it picks when
+      // the Jacobian's loads are `nt`, ~10 of 12 288 waves per launch then end with a WRONG y component — 5 % off, only waves
+      // 0..3 (those that reach the sequence while the others still use the LDS pipe), never d_feats — which is what broke
+      // run-to-run reproducibility in round 5 (NT_JAC_LD).  Not the loads: `nt` and plain accesses complete in issue order and
+      // see earlier kernels' stores (tools/microbench/nt_load_order.hip, nt_visibility.hip: 0 events in 1e11); the same
+      // instructions in isolation do not fail either (pk_forward_hazard.hip) — the defect needs this kernel's context and is not
+      // understood beyond that (profiles/r06_raw/nt_hunt.md has the ISA and the probes).  Pinned, the sums compile to scalar
+      // v_fma / v_add in every build (tests/test_isa_invariants.py keeps packed instructions out of this reduction) and
+      // tests/diagnostics/base_coop_repeat.py gives identical, correct d_position on repeated calls with either load policy.
       float gp[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const float gx = Gx[m >> 1][2 * (m & 1)], gy = Gx[m >> 1][2 * (m & 1) + 1];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) gp[a] += gx * jv[3 * m + a].x + gy * jv[3 * m + a].y;
+        for (int a = 0; a < 3; ++a) {
+          gp[a] += gx * jv[3 * m + a].x + gy * jv[3 * m + a].y;
+          asm volatile("" : "+v"(gp[a]));
+        }
       }
 #pragma unroll
       for (int a = 0; a < 3; ++a) {  // the four level groups of a sample sit 16 lanes apart
         gp[a] += __shfl_xor(gp[a], 16, 64);
+        asm volatile("" : "+v"(gp[a]));
         gp[a] += __shfl_xor(gp[a], 32, 64);
+        asm volatile("" : "+v"(gp[a]));
       }
       if (valid && g == 0) d_pos[n] = make_float4(gp[0], gp[1], gp[2], 0.0f);
     }

@@ -539,7 +539,9 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
                                               int zero_grad) {
   const float step_size = lr / bc1;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    float4 P = p[i], G = g[i], M = m[i], V = v[i];
+    // moments and gradient: read once, written once per step — streaming, so that the sweep (the exchange path's 88 us over the
+    // main table) leaves the table's parameters in the caches for the next encode (round 5's hints, now on the unfused sweep too)
+    float4 P = p[i], G = ntc_load<NT_MOMENT_LD>(&g[i]), M = ntc_load<NT_MOMENT_LD>(&m[i]), V = ntc_load<NT_MOMENT_LD>(&v[i]);
     float* pp = reinterpret_cast<float*>(&P);
     float* gp = reinterpret_cast<float*>(&G);
     float* mp = reinterpret_cast<float*>(&M);
@@ -554,9 +556,9 @@ __global__ __launch_bounds__(256) void k_adam(float4* __restrict__ p, float4* __
       pp[c] = pp[c] - step_size * (mp[c] / denom);          // param.addcdiv_(exp_avg, denom, value=-step_size)
     }
     p[i] = P;
-    m[i] = M;
-    v[i] = V;
-    if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ntc_store<NT_MOMENT_ST>(&m[i], M);
+    ntc_store<NT_MOMENT_ST>(&v[i], V);
+    if (zero_grad) ntc_store<NT_MOMENT_ST>(&g[i], make_float4(0.f, 0.f, 0.f, 0.f));
   }
 }
 
@@ -568,7 +570,9 @@ __global__ __launch_bounds__(256) void k_radam(float4* __restrict__ p, float4* _
                                                float eps, float bc1, float bc2_sqrt, float rect, float grad_scale,
                                                float weight_decay, int zero_grad) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    float4 P = p[i], G = g[i], M = m[i], V = v[i];
+    // moments and gradient: read once, written once per step — streaming, so that the sweep (the exchange path's 88 us over the
+    // main table) leaves the table's parameters in the caches for the next encode (round 5's hints, now on the unfused sweep too)
+    float4 P = p[i], G = ntc_load<NT_MOMENT_LD>(&g[i]), M = ntc_load<NT_MOMENT_LD>(&m[i]), V = ntc_load<NT_MOMENT_LD>(&v[i]);
     float* pp = reinterpret_cast<float*>(&P);
     float* gp = reinterpret_cast<float*>(&G);
     float* mp = reinterpret_cast<float*>(&M);
@@ -588,9 +592,9 @@ __global__ __launch_bounds__(256) void k_radam(float4* __restrict__ p, float4* _
       }
     }
     p[i] = P;
-    m[i] = M;
-    v[i] = V;
-    if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ntc_store<NT_MOMENT_ST>(&m[i], M);
+    ntc_store<NT_MOMENT_ST>(&v[i], V);
+    if (zero_grad) ntc_store<NT_MOMENT_ST>(&g[i], make_float4(0.f, 0.f, 0.f, 0.f));
   }
 }
 
@@ -617,7 +621,9 @@ __global__ __launch_bounds__(256) void k_adam_spans(float4* __restrict__ p, floa
     const long long i = sp.off4[k] + (c - sp.cum4[k]);
     const float lr = sp.lr[k], bc1 = sp.bc1[k], bc2_sqrt = sp.bc2_sqrt[k], rect = sp.rect[k];
     const float step_size = lr / bc1;
-    float4 P = p[i], G = g[i], M = m[i], V = v[i];
+    // moments and gradient: read once, written once per step — streaming, so that the sweep (the exchange path's 88 us over the
+    // main table) leaves the table's parameters in the caches for the next encode (round 5's hints, now on the unfused sweep too)
+    float4 P = p[i], G = ntc_load<NT_MOMENT_LD>(&g[i]), M = ntc_load<NT_MOMENT_LD>(&m[i]), V = ntc_load<NT_MOMENT_LD>(&v[i]);
     float* pp = reinterpret_cast<float*>(&P);
     float* gp = reinterpret_cast<float*>(&G);
     float* mp = reinterpret_cast<float*>(&M);
@@ -642,9 +648,9 @@ __global__ __launch_bounds__(256) void k_adam_spans(float4* __restrict__ p, floa
       }
     }
     p[i] = P;
-    m[i] = M;
-    v[i] = V;
-    if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ntc_store<NT_MOMENT_ST>(&m[i], M);
+    ntc_store<NT_MOMENT_ST>(&v[i], V);
+    if (zero_grad) ntc_store<NT_MOMENT_ST>(&g[i], make_float4(0.f, 0.f, 0.f, 0.f));
   }
 }
 

@@ -612,9 +612,11 @@ def sync_gradients(arena, world_size: int) -> float:
 # only ones that stay current: optimiser state / N as well), the rest of its local gradient is zeroed, and the updated
 # parameters are ALL-GATHERED in place (the second half of the all-reduce): the same bytes on the links, (N - 1) / N of
 # the sweep saved per rank, and the ranks' parameters are identical by construction instead of by determinism.  Same
-# arithmetic per element as the all-reduce path.  Opt-in (FNR_SHARDED_FIELD_OPTIMIZER=1) until it has run on real peers:
-# CPU-tested on gloo (tests/test_distributed_cpu.py), which implements both collectives in place.
-SHARDED_FIELD_OPTIMIZER = os.environ.get("FNR_SHARDED_FIELD_OPTIMIZER") == "1"
+# arithmetic per element as the all-reduce path.  The DEFAULT since round 6 (FNR_SHARDED_FIELD_OPTIMIZER=0: every rank runs
+# the whole sweep behind an all-reduce): bit-identical to the all-reduce path on a one-rank RCCL group
+# (tests/test_gpu_distributed.py) and on two gloo ranks (tests/test_distributed_cpu.py: gloo implements both collectives in
+# place); with N ranks only 1 / N of the 88 us sweep stays on a rank's critical path.
+SHARDED_FIELD_OPTIMIZER = os.environ.get("FNR_SHARDED_FIELD_OPTIMIZER", "1") != "0"
 SHARD_ALIGN = 1024    # elements: every rank's shard starts on a 4 KiB boundary of the span
 
 

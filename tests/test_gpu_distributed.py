@@ -59,6 +59,24 @@ def test_bench_gpus_2_starts_two_ranks(dev):
     assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["kernel"] in bench.ROOFLINE_OPS
 
 
+def test_two_ranks_hold_identical_parameters_after_fused_steps(dev):
+    """DDP's contract on the exchange path with REAL kernels and rank-specific rays: two gloo ranks sharing device 0 (RCCL
+    refuses two ranks on one device) take 12 fused training steps — field / proposal / pose gradients averaged by the
+    bucketed exchange, the sharded optimiser step (default) — and must end with bit-identical parameters and poses
+    (tools/microbench/ddp_consistency.py is the worker; it asserts on rank 0)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(FNR_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "microbench", "ddp_consistency.py")],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "ranks hold identical parameters: True | finite: True" in out.stdout, out.stdout[-2000:]
+
+
 def test_exchange_path_step_is_the_single_process_step(dev):
     """Training steps (camera optimiser included) from identical states: the exchange path — scatter in level
     groups with an all-reduce per group, separate optimiser launches per bucket, pose gradient all-reduced — against
@@ -112,6 +130,8 @@ def test_exchange_path_step_is_the_single_process_step(dev):
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29641", rank=0, world_size=1, device_id=dev)
     old = T.EXCHANGE_MIN_WORLD
     T.EXCHANGE_MIN_WORLD = 1
+    saved_sharded, T.SHARDED_FIELD_OPTIMIZER = T.SHARDED_FIELD_OPTIMIZER, False     # (the all-reduce path first)
+    assert saved_sharded, "the sharded optimiser step is the default (round 6)"
     try:
         exch = run(1)
         # the same steps with the field's wait + optimiser step deferred to the next step's encode (and flushed by the
@@ -122,15 +142,12 @@ def test_exchange_path_step_is_the_single_process_step(dev):
         old_groups, T.EXCHANGE_LEVEL_GROUPS = T.EXCHANGE_LEVEL_GROUPS, 4
         grouped = run(1)
         T.EXCHANGE_LEVEL_GROUPS = old_groups
-        # the sharded optimiser step (reduce-scatter, own shard's step, all-gather of the parameters; opt-in): on one rank
-        # the shard is the whole span but for its unaligned tail.  (Passed on a box in round 5's first GPU call,
-        # profiles/r05_raw/tests_unvalidated.log: always on since.)
+        # the sharded optimiser step (reduce-scatter, own shard's step, all-gather of the parameters; the default since
+        # round 6): on one rank the shard is the whole span but for its unaligned tail
         T.SHARDED_FIELD_OPTIMIZER = True
-        try:
-            sharded = run(1)
-        finally:
-            T.SHARDED_FIELD_OPTIMIZER = False
+        sharded = run(1)
     finally:
+        T.SHARDED_FIELD_OPTIMIZER = saved_sharded
         T.DEFER_FIELD_UPDATE = False
         T.EXCHANGE_MIN_WORLD = old
         if created:

@@ -66,3 +66,53 @@ def test_scatter_kernels_use_no_scratch_and_keep_three_emit_workgroups_per_cu(sc
         if "k_scatter_emit" in name:
             assert 3 * ((lds + 511) // 512 * 512) <= 160 * 1024, (name, lds)
 
+
+
+# ---- round 6: the position-gradient reduction of k_field_mlp_bwd_base_coop (profiles/r06_raw/nt_hunt.md) ----------------
+# With `nt` loads of the Jacobian hipcc chose packed FP32 with cross-half operand selects threaded through the six
+# ds_bpermute shuffles of that reduction, and ~10 of 12 288 waves per launch computed a wrong y component.  The partial sums are
+# pinned in registers since; this keeps every build's reduction free of packed math, for both load policies.
+
+def _compile(src, out, extra=()):
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffp-contract=off",
+           "-S", "--cuda-device-only", *extra, "-o", str(out), os.path.join(CSRC, src)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    return out.read_text().split("\n")
+
+
+@pytest.mark.parametrize("mask", ["0xef", "0xff"])
+def test_position_gradient_reduction_is_free_of_packed_math(tmp_path, mask):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    lines = _compile("field_mlp_bf16.hip", tmp_path / "field_mlp_bf16.s", extra=[f"-DFNR_NT_MASK={mask}"])
+    kernels = [m.group(1) for m in (re.match(r"^(_ZN3fnr25k_field_mlp_bwd_base_coop\w+):", l) for l in lines) if m]
+    posgrad = [k for k in kernels if "Lb1EEE" in k]
+    assert len(posgrad) >= 4, kernels                     # (FieldCfgBase | FieldCfgBig) x (bf16 | bf16x3)
+    for name in posgrad:
+        body = [l for l in _kernel(lines, name) if l and not l.startswith((";", "."))]
+        shuffles = [i for i, l in enumerate(body) if l.startswith("ds_bpermute_b32")]
+        assert len(shuffles) == 6, (name, len(shuffles))   # x, y, z by 16 lanes, then by 32
+        window = body[shuffles[0] - 24:shuffles[-1] + 8]   # the sums that feed the first shuffle .. the adds behind the last
+        packed = [l for l in window if l.startswith("v_pk_")]
+        assert not packed, f"{name}: packed math in the position-gradient reduction (FNR_NT_MASK={mask}): {packed[:3]}"
+        if mask == "0xff":
+            assert any(l.startswith("global_load_dwordx2") and l.endswith(" nt") for l in body), "the variant under test streams the Jacobian"
+
+
+def test_streaming_accesses_share_partial_waits_only_in_known_kernels():
+    """tools/isa_nt_scan.py: partial `s_waitcnt vmcnt(n)` with `nt` and plain accesses both in flight are fine (measured:
+    tools/microbench/nt_load_order.hip) — this pins WHICH kernel families have them, so that a new one gets looked at."""
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_nt_scan
+    known = ("k_scatter_accumulate", "k_prop_bwd", "k_scatter_emit", "k_hash_encode", "k_prop_density", "k_adam", "k_radam")
+    seen = set()
+    for src in ("hash_scatter.hip", "hashgrid.hip", "field_mlp_bf16.hip", "position_grad.hip", "train.hip"):
+        for k, r in isa_nt_scan.scan_source(os.path.join(CSRC, src)).items():
+            if r["mixed"]:
+                fam = [f for f in known if f in k]
+                assert fam, f"{src}: {k[:80]} waits partially with nt and plain accesses in flight: a new place — read it, then list it"
+                seen.add(fam[0])
+    assert {"k_scatter_accumulate", "k_hash_encode"} <= seen     # the scan does find what is there

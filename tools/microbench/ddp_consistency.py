@@ -4,7 +4,7 @@ bit-identical parameters, and they must equal a single-process run that averages
       tools/microbench/ddp_consistency.py"""
 import os, sys, torch
 import torch.distributed as dist
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fruitnerf_amd.data import synthetic_apple as sa
 from fruitnerf_amd.fruit_nerf import FruitModel, FruitNerfModelConfig
 from fruitnerf_amd.data.semantics import apple_metadata
