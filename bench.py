@@ -370,6 +370,8 @@ def timed_window(run, steps, barrier, dist_on, dev):
     import fruitnerf_amd.training as T
     serialize = T.SERIALIZE_STREAMS
     L.profile_enable(True, ops=list(ROOFLINE_OPS))
+    if dist_on:      # every collective of the window bracketed by two events on the stream that issues / waits for it
+        T.COLLECTIVE_LOG = []
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -405,6 +407,20 @@ def timed_window(run, steps, barrier, dist_on, dev):
     dt = time.perf_counter() - t0
     recs = L.profile_collect()
     L.profile_enable(False)
+    run.collectives = None
+    if dist_on:
+        # per collective of the exchange: how often, how many bytes, milliseconds from issue to "the waiting stream may go on"
+        # (wire time + what the collective itself had to wait for + stream handshakes) — so that a first multi-GPU line says
+        # where its step time goes
+        log, T.COLLECTIVE_LOG = T.COLLECTIVE_LOG or [], None
+        by = {}
+        for label, nbytes, ms in T.collective_report(log):
+            by.setdefault(label, []).append((nbytes, ms))
+        run.collectives = {label: {"per_step": round(len(v) / steps, 3), "bytes": int(np.median([b for b, _ in v])),
+                                   "issue_to_done_ms_median": round(float(np.median([m for _, m in v])), 4),
+                                   "issue_to_done_ms_max": round(float(np.max([m for _, m in v])), 4),
+                                   "effective_GBps_median": round(float(np.median([b / max(m, 1e-6) / 1e6 for b, m in v])), 2)}
+                           for label, v in sorted(by.items())}
     if dist_on:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -604,6 +620,7 @@ def main() -> None:
     allocs_before = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)     # hipMalloc calls of the caching allocator
     dt, t_enqueued, recs, n_prof, (ld, md) = timed_window(run, args.steps, barrier, dist_on, dev)
     headline_host_ms = dict(run.host_ms)
+    headline_collectives = run.collectives
     headline_sequencer = dict(run.steps.stats, enabled=bool(_training.NATIVE_SEQUENCER and not dist_on))
     device_allocs_in_window = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs_before)
     rays_per_s = world * args.steps * RAYS_PER_BATCH / dt
@@ -1109,6 +1126,8 @@ def main() -> None:
                    # ranks of the group, its backend ("nccl" is RCCL on ROCm) and the distinct devices they run on
                    "rccl_ranks": group_report,
                    "exchange": None if not dist_on else f"{_training.EXCHANGE_LEVEL_GROUPS} field collective(s) per step + proposal networks on update steps + poses",
+                   # (rank 0's view) per collective: issued per step, bytes, milliseconds from issue to the consumer's go
+                   "exchange_collectives": headline_collectives,
                    "device": info["arch"], "setup_s": round(setup_s, 1)},
         "roofline": roofline,
         "roofline_other_bound": roofline_other,

@@ -578,7 +578,42 @@ DEFER_FIELD_UPDATE = os.environ.get("FNR_DEFER_FIELD_UPDATE") == "1"
 GRAD_BUCKET_ELEMS = 4 << 20   # 16 MiB fp32 buckets: large enough for xGMI ring bandwidth, small enough to pipeline
 
 
-def start_gradient_sync(arena, span, world_size: int, bucket_elems: int = GRAD_BUCKET_ELEMS):
+# bench.py --gpus N (and whoever wants a self-explaining first multi-GPU run): while COLLECTIVE_LOG is a list, every
+# collective of the gradient exchange is bracketed by two HIP events on the stream that issues / waits for it — recorded
+# right before the call is issued and right after the waiting stream has passed its wait — and noted as
+# (label, bytes, issue event, done event): elapsed_time(issue, done) is the time from issue to "the consumer may go on",
+# i.e. wire time + whatever the collective had to wait for + the handshakes.  None (default): no events, no cost.
+COLLECTIVE_LOG: Optional[list] = None
+_pending_collectives: Dict[int, tuple] = {}
+
+
+def _issued(work, label: str, nbytes: int):
+    if COLLECTIVE_LOG is not None and work is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _pending_collectives[id(work)] = (label, int(nbytes), ev)
+    return work
+
+
+def _wait(work) -> None:
+    work.wait()
+    tok = _pending_collectives.pop(id(work), None) if _pending_collectives else None
+    if tok is not None and COLLECTIVE_LOG is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        COLLECTIVE_LOG.append(tok + (ev,))
+
+
+def collective_report(log: list) -> list:
+    """[(label, bytes, milliseconds issue -> done)] of a COLLECTIVE_LOG (synchronises the events)."""
+    out = []
+    for label, nbytes, a, b in log:
+        b.synchronize()
+        out.append((label, nbytes, float(a.elapsed_time(b))))
+    return out
+
+
+def start_gradient_sync(arena, span, world_size: int, bucket_elems: int = GRAD_BUCKET_ELEMS, label: str = "all_reduce"):
     """Launch the all-reduce(SUM) of arena.grads[span] as asynchronous buckets on the process group's communication
     stream (RCCL over xGMI on GPUs, gloo in the CPU tests) and return [(a, b, work)].  The caller keeps launching
     compute that does not touch that span (the proposal-network backward runs while the field gradient is in
@@ -590,7 +625,7 @@ def start_gradient_sync(arena, span, world_size: int, bucket_elems: int = GRAD_B
     out = []
     for a in range(a0, b0, bucket_elems):
         b = min(a + bucket_elems, b0)
-        out.append((a, b, dist.all_reduce(arena.grads[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+        out.append((a, b, _issued(dist.all_reduce(arena.grads[a:b], op=dist.ReduceOp.SUM, async_op=True), label, 4 * (b - a))))
     return out
 
 
@@ -633,21 +668,21 @@ class _ShardedSpan:
         import torch.distributed as dist
         arena = optimizer.arena
         if self.work is not None:
-            self.work.wait()
+            _wait(self.work)
             optimizer.step_span(self.my_a, self.my_b, lr, scale, group=group, step=step)   # (zeroes the gradient it consumes)
             if self.my_a > self.a:
                 arena.grads[self.a:self.my_a].zero_()
             if self.main_b > self.my_b:
                 arena.grads[self.my_b:self.main_b].zero_()
-            gathered = dist.all_gather_into_tensor(arena.params[self.a:self.main_b], arena.params[self.my_a:self.my_b],
-                                                   async_op=True)
+            gathered = _issued(dist.all_gather_into_tensor(arena.params[self.a:self.main_b], arena.params[self.my_a:self.my_b],
+                                                           async_op=True), "all_gather(field parameters)", 4 * (self.main_b - self.a))
         else:
             gathered = None
         for ta, tb, twork in self.tail:
-            twork.wait()
+            _wait(twork)
             optimizer.step_span(ta, tb, lr, scale, group=group, step=step)
         if gathered is not None:
-            gathered.wait()
+            _wait(gathered)
 
 
 def start_sharded_gradient_sync(arena, span, world_size: int, rank: Optional[int] = None) -> list:
@@ -663,8 +698,9 @@ def start_sharded_gradient_sync(arena, span, world_size: int, rank: Optional[int
     my_a = my_b = a
     if shard > 0:
         my_a, my_b = a + rank * shard, a + (rank + 1) * shard
-        work = dist.reduce_scatter_tensor(arena.grads[my_a:my_b], arena.grads[a:main_b], op=dist.ReduceOp.SUM, async_op=True)
-    tail = start_gradient_sync(arena, (main_b, b), world_size) if b > main_b else []
+        work = _issued(dist.reduce_scatter_tensor(arena.grads[my_a:my_b], arena.grads[a:main_b], op=dist.ReduceOp.SUM,
+                                                  async_op=True), "reduce_scatter(field gradient)", 4 * (main_b - a))
+    tail = start_gradient_sync(arena, (main_b, b), world_size, label="all_reduce(field tail)") if b > main_b else []
     return [_ShardedSpan(a, b, main_b, my_a, my_b, work, tail)]
 
 
@@ -675,7 +711,7 @@ def finish_exchange_entry(optimizer: "FusedAdam", entry, lr: float, scale: float
         entry.finish(optimizer, lr, scale, group, step)
         return
     a, b, work = entry
-    work.wait()                                    # the stream this runs on waits for this bucket only
+    _wait(work)                                    # the stream this runs on waits for this bucket only
     optimizer.step_span(a, b, lr, scale, group=group, step=step)
 
 
@@ -744,7 +780,7 @@ class _FieldGradientExchange:
     def _start(self, span, bucket_elems: int) -> list:
         if SHARDED_FIELD_OPTIMIZER:
             return start_sharded_gradient_sync(self.arena, span, self.world)
-        return start_gradient_sync(self.arena, span, self.world, bucket_elems=bucket_elems)
+        return start_gradient_sync(self.arena, span, self.world, bucket_elems=bucket_elems, label="all_reduce(field gradient)")
 
     def issue(self) -> None:
         """Start the collectives of the spans noted while `hold` was set (in order)."""
@@ -1103,7 +1139,8 @@ def camera_backward(camera_optimizer, batcher, ray_grads: dict, world_size: int 
                        ray_grads["origins"], ray_grads["directions"], pose.grad)
     if world_size >= EXCHANGE_MIN_WORLD:
         import torch.distributed as dist
-        return dist.all_reduce(pose.grad, op=dist.ReduceOp.SUM, async_op=True), 1.0 / world_size
+        return _issued(dist.all_reduce(pose.grad, op=dist.ReduceOp.SUM, async_op=True), "all_reduce(poses)",
+                       4 * pose.grad.numel()), 1.0 / world_size
     return None, 1.0
 
 
@@ -1119,7 +1156,7 @@ def camera_backward_and_step(camera_optimizer, camera_adam, batcher, ray_grads: 
         return
     work, scale = camera_backward(camera_optimizer, batcher, ray_grads, world_size)
     if work is not None:
-        work.wait()
+        _wait(work)
     camera_adam.step(grad_scale=scale)
 
 
@@ -1214,14 +1251,15 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
 
         def camera_step():   # noqa: F811  (the exchange path's first half of the tail: issue the small collectives)
             with torch.no_grad():
-                small_groups["prop"] = start_gradient_sync(arena, spans["proposal_networks"], world_size) if prop_updated else []
+                small_groups["prop"] = start_gradient_sync(arena, spans["proposal_networks"], world_size,
+                                                           label="all_reduce(proposal networks)") if prop_updated else []
                 small_groups["cam"] = (camera_backward(camera[0], camera[2], ray_grads, world_size)
                                        if camera is not None else (None, 1.0))
 
         def exchange_finish():   # ... second half: their waits, 1 / world + optimiser steps
             with torch.no_grad():
                 for a, b, work in small_groups["prop"]:
-                    work.wait()                                # the stream this runs on waits for this bucket only
+                    _wait(work)                                # the stream this runs on waits for this bucket only
                     optimizer.step_span(a, b, lrs["proposal_networks"], scale, group="proposal_networks")
                 if prop_stepped and not prop_updated:   # torch < 2.0 semantics: zero gradients everywhere, still a step
                     pa, pb = spans["proposal_networks"]
@@ -1229,7 +1267,7 @@ def fused_train_iteration(model, optimizer: FusedAdam, ray_bundle, batch, step: 
                 if camera is not None:
                     cam_work, cam_scale = small_groups["cam"]
                     if cam_work is not None:
-                        cam_work.wait()
+                        _wait(cam_work)
                     camera[1].step(grad_scale=cam_scale)
     loss_dict, metrics_dict = fused_forward_backward(model, ray_bundle, batch, jitter, want_metrics, exchange,
                                                      ray_grads, overlap_proposal_backward=OVERLAP_PROPOSAL_BACKWARD,

@@ -496,7 +496,8 @@ def test_level_group_scatter_matches_single_scatter(dev, monkeypatch):
     all-reduced early): same gradients as the single scatter, and the exchanged spans tile the field's parameters."""
     from fruitnerf_amd.rays import RayBundle
     import fruitnerf_amd.training as T
-    monkeypatch.setattr(T, "start_gradient_sync", lambda arena, span, world, bucket_elems=0: [(span[0], span[1], None)])
+    monkeypatch.setattr(T, "start_gradient_sync", lambda arena, span, world, bucket_elems=0, **kw: [(span[0], span[1], None)])
+    monkeypatch.setattr(T, "SHARDED_FIELD_OPTIMIZER", False)     # (the level groups' spans as all-reduce buckets)
     cfg = util.small_config(log2=15, prop_log2=13)
     om = util.make_oracle(cfg, seed=9)
     R = 160
