@@ -213,8 +213,9 @@ def test_exchange_path_keeps_the_two_stream_schedule(dev):
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29643", rank=0, world_size=1, device_id=dev)
-    old, old_defer = T.EXCHANGE_MIN_WORLD, T.DEFER_FIELD_UPDATE
+    old, old_defer, old_sharded = T.EXCHANGE_MIN_WORLD, T.DEFER_FIELD_UPDATE, T.SHARDED_FIELD_OPTIMIZER
     T.EXCHANGE_MIN_WORLD, T.DEFER_FIELD_UPDATE = 1, True
+    T.SHARDED_FIELD_OPTIMIZER = False    # the ORDER of the all-reduces is what is logged here (sharded: a reduce-scatter in the field's place)
     log = []
     real = dist.all_reduce
 
