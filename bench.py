@@ -765,6 +765,12 @@ def main() -> None:
             gate_failures.append(f"scatter_queue_overflows = {quality['scatter_queue_overflows']} (must be 0)")
         if pinned is not None and int(pinned) != quality["parameter_checksum"]:
             gate_failures.append(f"parameter_checksum {quality['parameter_checksum']} != pinned {pinned} for {pin_key}")
+        second = quality.get("second_seed_stream")
+        if second is not None and os.path.exists(CHECKSUMS_PATH):
+            pinned2 = json.load(open(CHECKSUMS_PATH)).get(pin_key + ":batch_seed_4321")
+            second["parameter_checksum_pinned"] = pinned2
+            if pinned2 is not None and int(pinned2) != second["parameter_checksum"]:
+                gate_failures.append(f"second seed stream: parameter_checksum {second['parameter_checksum']} != pinned {pinned2}")
 
     # ---- secondary metrics: full-image eval rays/s and volume-export samples/s, trained weights ----
     secondary = None
@@ -1005,6 +1011,11 @@ def main() -> None:
                               "parameter_checksum": int(rb_.model.arena().params.view(torch.int32).sum(dtype=torch.int64))}
             if big["quality"]["scatter_queue_overflows"] > 0:
                 gate_failures.append(f"fruit_nerf_big: scatter_queue_overflows = {big['quality']['scatter_queue_overflows']}")
+            big_key = f"fruit_nerf_big:{args.mlp_precision}:{args.camera_optimizer}:{rb_.step_idx}:{HW}:{NUMERICS}"
+            pinned_b = json.load(open(CHECKSUMS_PATH)).get(big_key) if os.path.exists(CHECKSUMS_PATH) else None
+            big["quality"]["parameter_checksum_pinned"], big["quality"]["parameter_checksum_key"] = pinned_b, big_key
+            if pinned_b is not None and int(pinned_b) != big["quality"]["parameter_checksum"]:
+                gate_failures.append(f"fruit_nerf_big: parameter_checksum {big['quality']['parameter_checksum']} != pinned {pinned_b}")
         del rb_
         torch.cuda.empty_cache()
         if secondary is not None:
@@ -1140,7 +1151,9 @@ def main() -> None:
     if cpu:
         result["speedup_vs_cpu_baseline"] = round(rays_per_s / cpu["value"], 1)
     result["gates"] = {"failed": gate_failures,
-                       "checked": ["quality.scatter_queue_overflows == 0", "quality.parameter_checksum == pinned (when pinned)"]}
+                       "checked": ["scatter_queue_overflows == 0 (fruit_nerf, fruit_nerf_big)",
+                                   "parameter_checksum == the pinned one for the arithmetic generation (fruit_nerf both seed streams, "
+                                   "fruit_nerf_big; profiles/parameter_checksums.json)"]}
     print(json.dumps(result))
     if dist_on:
         import torch.distributed as dist

@@ -615,11 +615,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_field_mlp_bwd_sem_big(
 // their own, and a step that does not train the proposal networks ends without any optimiser launch.
 constexpr int RD_IDX = 128, RD_Y = 8;
 template <class Cfg, bool ADAM>
-__global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __restrict__ partials, int nblocks, FieldPtrs grads,
-                                                             WeightAdam wa) {
+__device__ __forceinline__ void reduce_dw_block(int block, const float* __restrict__ partials, int nblocks, const FieldPtrs& grads,
+                                                const WeightAdam& wa) {
   __shared__ float s_part[RD_Y][RD_IDX];
   const int t = threadIdx.x % RD_IDX, y = threadIdx.x / RD_IDX;
-  const int idx = blockIdx.x * RD_IDX + t;
+  const int idx = block * RD_IDX + t;
   constexpr int TOT = Cfg::W_TOTAL + Cfg::B_TOTAL;
   float s = 0.0f;
   if (idx < TOT) {
@@ -669,6 +669,12 @@ __global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __rest
       else *dst += s;
     }
   }
+}
+
+template <class Cfg, bool ADAM>
+__global__ __launch_bounds__(RD_IDX * RD_Y) void k_reduce_dw(const float* __restrict__ partials, int nblocks, FieldPtrs grads,
+                                                             WeightAdam wa) {
+  reduce_dw_block<Cfg, ADAM>((int)blockIdx.x, partials, nblocks, grads, wa);
 }
 
 // Per-ray finish of mlp_head layer 0 (see the colour branch above).  For every ray: g = sum of its tiles' G1 row
@@ -758,11 +764,11 @@ static_assert(RAYG_RB * COLOR_CONST_K % 256 == 0, "staging loop covers the batch
 // No atomics: direct adds into the [n_images, 32] table serialise at ~12 ns per same-address add (393k adds on
 // 90 rows made the colour branch 4x slower than its MFMA time).
 template <class Cfg, bool ADAM>
-__global__ __launch_bounds__(1024) void k_embedding_grad(RaysDev rays, const float* __restrict__ g_ray,
-                                                         const float* __restrict__ packed,
-                                                         float* __restrict__ g_embedding, WeightAdam wa) {
+__device__ __forceinline__ void embedding_grad_block(int c, const RaysDev& rays, const float* __restrict__ g_ray,
+                                                     const float* __restrict__ packed, float* __restrict__ g_embedding,
+                                                     const WeightAdam& wa) {
   __shared__ float red[16][64];
-  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.0f;
   for (long long base = 64 * wave; base < rays.n_rays; base += 1024) {
     const long long r = base + lane;
@@ -793,6 +799,28 @@ __global__ __launch_bounds__(1024) void k_embedding_grad(RaysDev rays, const flo
   } else {
     if (oo == 0 && s != 0.0f) g_embedding[(size_t)c * 32 + k] += s;
   }
+}
+
+template <class Cfg, bool ADAM>
+__global__ __launch_bounds__(1024) void k_embedding_grad(RaysDev rays, const float* __restrict__ g_ray,
+                                                         const float* __restrict__ packed,
+                                                         float* __restrict__ g_embedding, WeightAdam wa) {
+  embedding_grad_block<Cfg, ADAM>((int)blockIdx.x, rays, g_ray, packed, g_embedding, wa);
+}
+
+// The two finishing launches of the MLP backward as ONE (round 6): workgroups [0, n_images) take the appearance embedding's
+// rows (k_embedding_grad), the rest the weight-gradient images (k_reduce_dw) — both only need the colour kernel's per-ray
+// sums (k_color_ray_grads) and every branch's partial images, neither reads what the other writes, both are 1024 threads.
+// One launch ramp less on the launch stream's chain and the two roles next to each other instead of one after the other
+// (7.4 + 9.7 us -> ~10); the same sums in the same order by the same single writers.
+static_assert(RD_IDX * RD_Y == 1024, "k_finish_weights: both roles are 1024-thread workgroups");
+template <class Cfg, bool ADAM>
+__global__ __launch_bounds__(1024) void k_finish_weights(int n_images, RaysDev rays, const float* __restrict__ g_ray,
+                                                         const float* __restrict__ packed, float* __restrict__ g_embedding,
+                                                         const float* __restrict__ partials, int nblocks, FieldPtrs grads,
+                                                         WeightAdam wa) {
+  if ((int)blockIdx.x < n_images) embedding_grad_block<Cfg, ADAM>((int)blockIdx.x, rays, g_ray, packed, g_embedding, wa);
+  else reduce_dw_block<Cfg, ADAM>((int)blockIdx.x - n_images, partials, nblocks, grads, wa);
 }
 
 int field_ptrs(const fnr_field_net* net, FieldPtrs& p, int* cfg_id);  // field_mlp.hip
@@ -908,13 +936,7 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     hipLaunchKernelGGL((k_color_ray_grads<Cfg>), dim3((unsigned)rb), dim3(256), 0, st, rd, S, N, net->embedding,
                        ws.gsum_tile, gsum_extra, ws.g_ray, partials);
     FNR_LAUNCH_CHECK();
-    if (wadam)
-      hipLaunchKernelGGL((k_embedding_grad<Cfg, true>), dim3((unsigned)net->n_images), dim3(1024), 0, st, rd, ws.g_ray,
-                         packed, grads->embedding, *wadam);
-    else
-      hipLaunchKernelGGL((k_embedding_grad<Cfg, false>), dim3((unsigned)net->n_images), dim3(1024), 0, st, rd, ws.g_ray,
-                         packed, grads->embedding, WeightAdam{});
-    FNR_LAUNCH_CHECK();
+    // (the appearance embedding's rows, which only need g_ray, are taken by the LAST launch: k_finish_weights)
   }
   if (bf_sem_big) {
     int rc = field_mlp_bwd_sem_big_bf16(mode, p, bf16_image, packed, N, h_saved, d_logit, partials, blocks, st);
@@ -946,12 +968,13 @@ int field_mlp_bwd_launch(const FieldPtrs& p, const FieldPtrs& gp, const fnr_fiel
     FNR_LAUNCH_CHECK();
   }
   constexpr int TOT = Cfg::W_TOTAL + Cfg::B_TOTAL;
+  const unsigned finish_blocks = (unsigned)net->n_images + (unsigned)((TOT + RD_IDX - 1) / RD_IDX);
   if (wadam)
-    hipLaunchKernelGGL((k_reduce_dw<Cfg, true>), dim3((TOT + RD_IDX - 1) / RD_IDX), dim3(RD_IDX * RD_Y), 0, st, partials,
-                       (int)blocks, gp, *wadam);
+    hipLaunchKernelGGL((k_finish_weights<Cfg, true>), dim3(finish_blocks), dim3(1024), 0, st, (int)net->n_images, rd, ws.g_ray,
+                       packed, grads->embedding, partials, (int)blocks, gp, *wadam);
   else
-    hipLaunchKernelGGL((k_reduce_dw<Cfg, false>), dim3((TOT + RD_IDX - 1) / RD_IDX), dim3(RD_IDX * RD_Y), 0, st, partials,
-                       (int)blocks, gp, WeightAdam{});
+    hipLaunchKernelGGL((k_finish_weights<Cfg, false>), dim3(finish_blocks), dim3(1024), 0, st, (int)net->n_images, rd,
+                       ws.g_ray, packed, grads->embedding, partials, (int)blocks, gp, WeightAdam{});
   FNR_LAUNCH_CHECK();
   // fp32 chains: their base-branch kernel does not carry the contraction with the encode's Jacobian
   if (jac && d_pos && !bf_all) return position_contract(N, net->grid.n_levels, jac, df2, d_pos, st);
