@@ -1317,9 +1317,11 @@ SAMPLE_AHEAD = os.environ.get("FNR_SAMPLE_AHEAD", "1") != "0"
 # entry points, same arguments, same streams, same order: bit-identical training (tests/test_gpu_sequencer.py).
 # FNR_NATIVE_SEQUENCER=0: every step is interpreted (A/B, debugging).
 NATIVE_SEQUENCER = os.environ.get("FNR_NATIVE_SEQUENCER", "1") != "0"
-# a step shape is recorded on its n-th interpreted occurrence (the first ones create lazily-built state — second stream,
-# events, touched bitmaps, persistent workspaces — through launches a recording must not contain)
-RECORD_ON_OCCURRENCE = 2
+# a step shape is recorded on its n-th interpreted occurrence, never before the loop's third step: the first two create
+# lazily-built state — second stream, events, touched bitmaps, collider planes, persistent workspaces — through launches a
+# recording must not contain (a scatter workspace's first use is also caught per step: K.fresh_workspaces)
+RECORD_ON_OCCURRENCE = 1
+RECORD_FROM_STEP = 2
 
 
 class _StepProgram:
@@ -1492,7 +1494,7 @@ class TrainingSteps:
             if prog is not None:
                 return self._replay(prog, step, want_metrics, updated)
             n = self._seen[key] = self._seen.get(key, 0) + 1
-            if n >= RECORD_ON_OCCURRENCE and key not in self._unrecordable:
+            if n >= RECORD_ON_OCCURRENCE and step >= RECORD_FROM_STEP and key not in self._unrecordable:
                 return self._step_interpreted(want_metrics, arena, record_key=key)
         return self._step_interpreted(want_metrics, arena)
 

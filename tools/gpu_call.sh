@@ -10,6 +10,7 @@
 #                             set to a, then b, on the quick settings (--no-cpu-baseline --no-quality), alternating 2x
 #   kt[=<bench.py args>]      rocprofv3 --kernel-trace --stats of a short serialised-streams bench run -> per-kernel table
 #   kt2[=<bench.py args>]     the same with the default two streams (timeline)
+#   ktbig                     kernel trace of the fruit_nerf_big method (serialised streams) -> prof_kernel_trace_big.txt
 #   pmc[=<bench.py args>]     the three counter passes (FETCH_SIZE | WRITE_SIZE | SQ_*), each its own run with --kernel-trace only
 #   py=<script and args>      python <script and args>
 #   sh=<command>              bash -c <command>
@@ -55,6 +56,12 @@ for leg in "$@"; do
       python tools/kt_step.py /tmp/pf_$name/p_kernel_trace.csv > $O/prof_step_timeline$sfx.txt 2>&1
       head -60 /tmp/pf_$name/p_kernel_stats.csv > $O/prof_kernel_stats_head$sfx.csv 2>/dev/null
       echo "[$name] $(wc -l < $O/prof_kernel_trace$sfx.txt) kernel rows";;
+    ktbig)
+      export FNR_SERIALIZE_STREAMS=1
+      (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/pf_big -o p -- python /root/repo/bench.py --method fruit_nerf_big --steps 40 --warmup 10 $QUICK > $O/prof_bench_big.json 2>/dev/null)
+      unset FNR_SERIALIZE_STREAMS
+      python tools/kt_agg.py /tmp/pf_big/p_kernel_trace.csv fnr > $O/prof_kernel_trace_big.txt 2>&1
+      echo "[ktbig] $(wc -l < $O/prof_kernel_trace_big.txt) kernel rows";;
     pmc)
       [ -z "$arg" ] && arg="--steps 60 --warmup 10 $QUICK"
       export FNR_SERIALIZE_STREAMS=1
