@@ -12,6 +12,7 @@
 #   kt2[=<bench.py args>]     the same with the default two streams (timeline)
 #   ktbig                     kernel trace of the fruit_nerf_big method (serialised streams) -> prof_kernel_trace_big.txt
 #   pmc[=<bench.py args>]     the three counter passes (FETCH_SIZE | WRITE_SIZE | SQ_*), each its own run with --kernel-trace only
+#   ktpy=<script and args>    rocprofv3 --kernel-trace of python <script and args> -> per-kernel table
 #   py=<script and args>      python <script and args>
 #   sh=<command>              bash -c <command>
 TAG=$1; shift
@@ -73,6 +74,11 @@ for leg in "$@"; do
       python tools/pmc_agg.py /tmp/pf_s/p_counter_collection.csv fnr > $O/prof_sq.txt 2>&1
       unset FNR_SERIALIZE_STREAMS
       echo "[pmc] fetch $(wc -l < $O/prof_fetch.txt) write $(wc -l < $O/prof_write.txt) sq $(wc -l < $O/prof_sq.txt) rows";;
+    ktpy)   # rocprofv3 kernel trace of a python script -> per-kernel table ktpy<n>.txt
+      n=ktpy$nb; nb=$((nb+1))
+      (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/pf_$n -o p -- python /root/repo/$arg > $O/$n.out 2>/tmp/pf_$n.err)
+      python tools/kt_agg.py /tmp/pf_$n/p_kernel_trace.csv fnr > $O/$n.txt 2>&1
+      echo "[ktpy $arg] $(wc -l < $O/$n.txt) kernel rows -> $n.txt";;
     py)
       n=$(basename ${arg%% *} .py)
       python $arg > $O/$n.log 2>&1; echo "[py $arg] rc $?: $(tail -2 $O/$n.log | tr '\n' ' ' | cut -c1-300)";;
