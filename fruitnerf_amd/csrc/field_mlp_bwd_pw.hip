@@ -27,6 +27,8 @@
 // pass's signs), NS = 2 for dX / dW in the bf16x3 mode; 1 / 1 in the plain bf16 mode.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "field_bf16.hpp"
 
 namespace fnr {
@@ -158,12 +160,22 @@ __device__ __forceinline__ void layer(const bf16x8* __restrict__ seg, const floa
 }
 
 // ---- dW: operands through the wave's private transposition region ---------------------------------------------------------
-// [block][piece][tile][sample][feature]: lane (j, g) holds features 4g .. 4g+3 of sample j.  The first NS of the NSH pieces the
+// A 512-byte tile holds [16 samples][16 features] bf16 as 64 chunks of 8 bytes: chunk (s, c) = features 4c .. 4c+3 of sample s.
+// The transposing read lets every lane name its own chunk (lane t of a 16-lane group must point at chunk (row t/4, column group
+// t%4) of the 4-sample block it wants), so the chunk order is free, and it is chosen for the banks:
+//     chunk (s, c) sits at 8 * (16 c + (s ^ 8 (c >> 1))) bytes.
+// Writes (ds_write_b64, banks of 16 contiguous lanes mod 32 dwords): lane (j, g) holds chunk (s = j, c = g): a 16-lane group
+// covers 128 contiguous bytes (permuted by the XOR) — every bank once.  Reads (ds_read_b64_tr_b16, two 32-lane groups, mod 64
+// dwords): lanes 0..31 read samples 0..7 of all four column groups: dwords 2s, 32 + 2s, 80 + 2s, 112 + 2s — every bank once; lanes
+// 32..63 likewise.  (The row-major order [s][c] is 4-way conflicted on the writes: half of this kernel's LDS cycles, round 6
+// counters.)
+__device__ __forceinline__ int chunk_offset(int s, int c) { return 8 * (16 * c + (s ^ ((c >> 1) << 3))); }
+// [block][piece][tile] x 512-byte tile; lane (j, g) holds features 4g .. 4g+3 of sample j.  The first NS of the NSH pieces the
 // operand holds are written (the forward recompute splits into three, dW uses two).
 template <int NT, int NS, int NB, int NSH>
 __device__ __forceinline__ void tr_write(unsigned char* __restrict__ scr, const Ops<NT, NB, NSH>& x, int lane) {
   static_assert(NS <= NSH, "pieces");
-  unsigned char* dst = scr + (lane & 15) * 32 + (lane >> 4) * 8;
+  unsigned char* dst = scr + chunk_offset(lane & 15, lane >> 4);
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
@@ -175,11 +187,16 @@ __device__ __forceinline__ void tr_write(unsigned char* __restrict__ scr, const 
         *reinterpret_cast<s16x4*>(dst + ((blk * NS + pc) * NT + t) * TILE_BYTES) = h;
       }
 }
+// this lane's chunk for the transposing read of samples 4g .. 4g+3 (g = lane >> 4): row t/4, column group t%4
+__device__ __forceinline__ int frag_offset(int lane) {
+  const int t = lane & 15, g = lane >> 4;
+  return chunk_offset(4 * g + (t >> 2), t & 3);
+}
 // MFMA operand of block blk, piece pc over the tile pair kp: lane (t, g) gets feature t of samples 4g .. 4g+3 of tile 2 kp
-// (K-slots 0..3) and of tile 2 kp + 1 (4..7).  Address: row 4g + t/4, column 4 (t%4) of the block = byte 8 * lane.
+// (K-slots 0..3) and of tile 2 kp + 1 (4..7)
 template <int NT, int NS>
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* __restrict__ scr, int blk, int pc, int kp, int lane) {
-  const unsigned char* p = scr + ((blk * NS + pc) * NT + 2 * kp) * TILE_BYTES + lane * 8;
+  const unsigned char* p = scr + ((blk * NS + pc) * NT + 2 * kp) * TILE_BYTES + frag_offset(lane);
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + TILE_BYTES));
   const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -188,16 +205,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* __restrict__ scr,
 // one tile per wave: the K = 16 operand of v_mfma_f32_16x16x16_bf16 is exactly one transposing read
 template <int NS>
 __device__ __forceinline__ s16x4 tr_frag1(const unsigned char* __restrict__ scr, int blk, int pc, int lane) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(scr + (blk * NS + pc) * TILE_BYTES + lane * 8));
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(scr + (blk * NS + pc) * TILE_BYTES + frag_offset(lane)));
 }
 // acc[ob][ib] += (G block ob)^T (X block ib) over the wave's 16 NT samples.  The region is used twice (X, then G): the wave's
 // LDS operations execute in order.
-template <int NT, int NS, int NOB, int NIB, int NSG, int NSX>
+// ROWSUM: additionally rs[ob] += (G block ob)^T SEL, SEL [sample][16 columns] a 0/1 selector operand (see the colour branch):
+// column c of rs[ob] = the sum of the block's rows over the samples column c selects — on the matrix pipe, from the fragments
+// that are in registers anyway, instead of 64 dependent DPP additions (+ their hazard no-ops) per tile.
+template <int NT>
+struct SelOperand {
+  typename std::conditional<NT == 1, s16x4, bf16x8>::type v[NT == 1 ? 1 : NT / 2];
+};
+template <int NT, int NS, int NOB, int NIB, int NSG, int NSX, bool ROWSUM = false>
 __device__ __forceinline__ void dw_round(unsigned char* __restrict__ scr, const Ops<NT, NOB, NSG>& G, const Ops<NT, NIB, NSX>& X,
-                                         f32x4 (&acc)[NOB * NIB], int lane) {
-#ifdef PW_EXP_NODW
-  return;
-#endif
+                                         f32x4 (&acc)[NOB * NIB], int lane, const SelOperand<NT>* sel = nullptr,
+                                         f32x4 (*rs)[NOB] = nullptr) {
   tr_write<NT, NS, NIB, NSX>(scr, X, lane);
   if constexpr (NT == 1) {
     s16x4 xf[NIB][NS];
@@ -222,6 +244,11 @@ __device__ __forceinline__ void dw_round(unsigned char* __restrict__ scr, const 
 #pragma unroll
           for (int pg = 0; pg <= s; ++pg)
             acc[ob * NIB + ib] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gf[ob & 1][pg], xf[ib][s - pg], acc[ob * NIB + ib], 0, 0, 0);
+      if constexpr (ROWSUM) {
+#pragma unroll
+        for (int pc = NS - 1; pc >= 0; --pc)
+          (*rs)[ob] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gf[ob & 1][pc], sel->v[0], (*rs)[ob], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -255,6 +282,13 @@ __device__ __forceinline__ void dw_round(unsigned char* __restrict__ scr, const 
             for (int pg = 0; pg <= s; ++pg)
               acc[ob * NIB + ib] =
                   __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ob & 1][kp][pg], xf[ib][kp][s - pg], acc[ob * NIB + ib], 0, 0, 0);
+      if constexpr (ROWSUM) {
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+          for (int pc = NS - 1; pc >= 0; --pc)
+            (*rs)[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ob & 1][kp][pc], sel->v[kp], (*rs)[ob], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -426,11 +460,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
   zero_vec(bC);
   zero_vec(bB);
 
-#ifdef PW_EXP_NOLOOP
-  const int n_groups = 0, n_tiles = 0;
-#else
   const int n_groups = (N + 16 * NT - 1) / (16 * NT), n_tiles = (N + 15) / 16;
-#endif
   for (int gr = blockIdx.x * WAVES + wave; gr < n_groups; gr += gridDim.x * WAVES) {
     asm volatile("" ::: "memory");  // keep the LDS fragment reads inside the loop
     // (the dW accumulators are MFMA-only: pinned in the accumulation half of the register file, which the vector ALU cannot address)
@@ -504,42 +534,75 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
     }
     // col1: G = G2, X = c1
     dw_round<NT, NS, 4, 4>(scr, g2, x1, accB, lane);
-    Acts<NT, 4> G1;
-    layer<NT, NS, 4, 4>(T::template seg<LC1, true>(wt), nullptr, g2, G1, lane);
-    gate(G1, x1);
     Ops<NT, 4, NS> g1;
-    to_ops(g1, G1);
-    // col0: G = G1, X = h -> its h block; the 48 ray-constant inputs and the bias are finished per ray by k_color_ray_grads
-    // from the tiles' 64 row sums of G1 (exact fp32 DPP sums)
+    {
+      Acts<NT, 4> G1;
+      layer<NT, NS, 4, 4>(T::template seg<LC1, true>(wt), nullptr, g2, G1, lane);
+      gate(G1, x1);
+      to_ops(g1, G1);
+    }
+    // col0: G = G1, X = h -> its h block.  The 48 ray-constant inputs and the bias are finished per ray by k_color_ray_grads
+    // from per-ray row sums of G1: a tile inside one ray stores its 64 sums to gsum_tile; a tile that straddles two rays
+    // (S % 16 != 0) adds its two parts to gsum_extra.  The sums ride on the round's MFMAs: selector column 2 t' = the samples of
+    // tile t' (of a K-block's two) that belong to the tile's first ray, column 2 t' + 1 = the rest.
+    int first_ray[NT], boundary[NT];
+    SelOperand<NT> sel;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int s0 = (gr * NT + t) * 16;
+      first_ray[t] = (s0 < N ? s0 : N - 1) / S;
+      boundary[t] = (first_ray[t] + 1) * S;  // first sample of the next ray
+    }
+    {
+      const unsigned short one = 0x3F80;  // bf16 1.0
+      if constexpr (NT == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool lo = 16 * gr + 4 * g + e < boundary[0];
+          sel.v[0][e] = (short)(((j == 0 && lo) || (j == 1 && !lo)) ? one : 0);
+        }
+      } else {
+#pragma unroll
+        for (int kp = 0; kp < NT / 2; ++kp) {
+          s16x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int t = 2 * kp + (e >> 2);
+            const bool lo = (gr * NT + t) * 16 + 4 * g + (e & 3) < boundary[t];
+            v[e] = (short)(((j == 2 * (e >> 2) && lo) || (j == 2 * (e >> 2) + 1 && !lo)) ? one : 0);
+          }
+          sel.v[kp] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+    }
+    f32x4 rs[NT == 1 ? 1 : NT / 2][4];
     {
       Acts<NT, 1> h;  // (re-read, L2-resident, instead of its pieces living through the whole recompute)
       Ops<NT, 1, NS> hx;
 #pragma unroll
       for (int t = 0; t < NT; ++t) h.v[t][0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)sm.n[t] * 16 + 4 * g);
       to_ops(hx, h);
-      dw_round<NT, NS, 4, 1>(scr, g1, hx, accA, lane);
+      static_assert(NT <= 2, "one K-block of row sums per round");
+      zero_vec(rs[0]);
+      dw_round<NT, NS, 4, 1, NS, NS, true>(scr, g1, hx, accA, lane, &sel, &rs[0]);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int tile = gr * NT + t;
       if (tile < n_tiles) {
-        const int ray0 = __shfl(ray[t], lane & 48, 64);
-        const bool uniform = __all(ray[t] == ray0);  // invalid lanes were clamped to the last sample's ray
-        if (uniform) {
-          float mine = 0.0f;  // lane (g, j) keeps feature 16 (j >> 2) + 4 g + (j & 3)
+        const int last = (16 * tile + 15 < N) ? 16 * tile + 15 : N - 1;
+        const int col = (NT == 1) ? 0 : 2 * (t & 1);
+        if (last < boundary[t]) {  // inside one ray
+          if (j == col) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) *reinterpret_cast<f32x4*>(gsum_tile + (size_t)tile * 64 + 16 * ob + 4 * g) = rs[0][ob];
+          }
+        } else if (j == col || j == col + 1) {
+          const int ray = first_ray[t] + (j - col);
 #pragma unroll
           for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float tot = row16_sum(G1.v[t][ob][r]);
-              mine = (j == 4 * ob + r) ? tot : mine;
-            }
-          gsum_tile[(size_t)tile * 64 + 16 * (j >> 2) + 4 * g + (j & 3)] = mine;
-        } else if (sm.ok[t]) {  // tile straddles rays (S % 16 != 0): per-sample contributions
-#pragma unroll
-          for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&gsum_extra[(size_t)ray[t] * 64 + 16 * ob + 4 * g + r], G1.v[t][ob][r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(&gsum_extra[(size_t)ray * 64 + 16 * ob + 4 * g + r], rs[0][ob][r]);
         }
       }
     }
@@ -611,11 +674,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_sem_pw(
   zero_vec(bH);
   zero_vec(bB);
   zero_vec(bA);
-#ifdef PW_EXP_NOLOOP
-  const int n_groups = 0;
-#else
   const int n_groups = (N + 16 * NT - 1) / (16 * NT);
-#endif
   for (int gr = blockIdx.x * WAVES + wave; gr < n_groups; gr += gridDim.x * WAVES) {
     asm volatile("" ::: "memory");
     // (the dW accumulators are MFMA-only: pinned in the accumulation half of the register file, which the vector ALU cannot address)
@@ -742,11 +801,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
   zero_vec(accA);
   zero_vec(bB);
   zero_vec(bA);
-#ifdef PW_EXP_NOLOOP
-  const int n_groups = 0;
-#else
   const int n_groups = (N + 16 * NT - 1) / (16 * NT);
-#endif
   for (int gr = blockIdx.x * WAVES + wave; gr < n_groups; gr += gridDim.x * WAVES) {
     asm volatile("" ::: "memory");
     // (the dW accumulators are MFMA-only: pinned in the accumulation half of the register file, which the vector ALU cannot address)
@@ -873,11 +928,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
   reduce_and_store<17, WAVES, Table>(smem, part, all, wave, lane);
 }
 
-#ifndef FNR_PW_NT
-#define FNR_PW_NT 1      // tiles per wave ...
+// tiles per wave, by branch (the colour branch's 116 accumulator registers leave room for one tile's activations: two spill),
+// and waves per workgroup (8 = two waves per SIMD, 256 registers each)
+#ifndef FNR_PW_NT_COLOR
+#define FNR_PW_NT_COLOR 1
+#endif
+#ifndef FNR_PW_NT_SEM
+#define FNR_PW_NT_SEM 2
+#endif
+#ifndef FNR_PW_NT_BASE
+#define FNR_PW_NT_BASE 2
 #endif
 #ifndef FNR_PW_WAVES
-#define FNR_PW_WAVES 8   // ... and waves per workgroup (4 = one wave per SIMD with the whole register file)
+#define FNR_PW_WAVES 8
 #endif
 
 template <int NSF, int NS>
@@ -886,12 +949,13 @@ static int launch(int branch, const float* packed, const __bf16* image, const fl
                   const float* d_logit, float2* d_feats, float* d_h, float* gsum_tile, float* gsum_extra, float* partials,
                   long long blocks, hipStream_t st, const float2* jac, float4* d_pos) {
   using Cfg = FieldCfgBase;
-  constexpr int NT = FNR_PW_NT, WAVES = FNR_PW_WAVES, THREADS = 64 * WAVES;
+  constexpr int WAVES = FNR_PW_WAVES, THREADS = 64 * WAVES;
   FNR_CHECK_ARG(N < (1ll << 31) - 64, "field_mlp_bwd: %lld samples exceed the 32-bit sample index of the backward kernels", N);
   const int n = (int)N;
   // exactly `blocks` workgroups: every one of the caller's partial images receives this branch's blocks (a workgroup
   // without samples stores zeros)
   if (branch == 0) {
+    constexpr int NT = FNR_PW_NT_COLOR;
     using L = Lds<Cfg, SegsColF<Cfg>, SegsColT<Cfg>, NSF, NS, NT, WAVES, 80>;
     static_assert(L::BYTES <= 160 * 1024, "colour branch exceeds the LDS");
     auto kern = k_field_mlp_bwd_color_pw<Cfg, NSF, NS, NT, WAVES>;
@@ -900,6 +964,7 @@ static int launch(int branch, const float* packed, const __bf16* image, const fl
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), L::BYTES, st, packed, image, ray_bias, rd, S, n, h_saved,
                        d_rgb, d_h, gsum_tile, gsum_extra, partials);
   } else if (branch == 1) {
+    constexpr int NT = FNR_PW_NT_SEM;
     using L = Lds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS, NT, WAVES, 128>;
     static_assert(L::BYTES <= 160 * 1024, "semantic branch exceeds the LDS");
     auto kern = k_field_mlp_bwd_sem_pw<Cfg, NSF, NS, NT, WAVES>;
@@ -907,6 +972,7 @@ static int launch(int branch, const float* packed, const __bf16* image, const fl
     if (once) return once;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), L::BYTES, st, packed, image, n, h_saved, d_logit, partials);
   } else {
+    constexpr int NT = FNR_PW_NT_BASE;
     using L = Lds<Cfg, SegsBaseF<Cfg>, SegsBaseT<Cfg>, NSF, NS, NT, WAVES, 64>;
     static_assert(L::BYTES <= 160 * 1024, "base branch exceeds the LDS");
     if (jac && d_pos) {

@@ -13,6 +13,7 @@
 #   ktbig                     kernel trace of the fruit_nerf_big method (serialised streams) -> prof_kernel_trace_big.txt
 #   pmc[=<bench.py args>]     the three counter passes (FETCH_SIZE | WRITE_SIZE | SQ_*), each its own run with --kernel-trace only
 #   ktpy=<script and args>    rocprofv3 --kernel-trace of python <script and args> -> per-kernel table
+#   pmcpy=<script and args>   SQ counter passes over python <script and args> -> per-kernel counter means
 #   py=<script and args>      python <script and args>
 #   sh=<command>              bash -c <command>
 TAG=$1; shift
@@ -79,6 +80,13 @@ for leg in "$@"; do
       (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/pf_$n -o p -- python /root/repo/$arg > $O/$n.out 2>/tmp/pf_$n.err)
       python tools/kt_agg.py /tmp/pf_$n/p_kernel_trace.csv fnr > $O/$n.txt 2>&1
       echo "[ktpy $arg] $(wc -l < $O/$n.txt) kernel rows -> $n.txt";;
+    pmcpy)  # two SQ counter passes over a python script (each its own run, --kernel-trace only) -> pmcpy<n>.txt
+      n=pmcpy$nb; nb=$((nb+1))
+      (cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/pf_${n}a -o p -- python /root/repo/$arg > /dev/null 2>&1)
+      python tools/pmc_agg.py /tmp/pf_${n}a/p_counter_collection.csv fnr > $O/$n.txt 2>&1
+      (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM --kernel-trace --output-format csv -d /tmp/pf_${n}b -o p -- python /root/repo/$arg > /dev/null 2>&1)
+      python tools/pmc_agg.py /tmp/pf_${n}b/p_counter_collection.csv fnr >> $O/$n.txt 2>&1
+      echo "[pmcpy $arg] $(wc -l < $O/$n.txt) rows -> $n.txt";;
     py)
       n=$(basename ${arg%% *} .py)
       python $arg > $O/$n.log 2>&1; echo "[py $arg] rc $?: $(tail -2 $O/$n.log | tr '\n' ' ' | cut -c1-300)";;
