@@ -539,11 +539,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
       Acts<NT, 4> G1;
       layer<NT, NS, 4, 4>(T::template seg<LC1, true>(wt), nullptr, g2, G1, lane);
       gate(G1, x1);
+      if (S < 16) {  // a tile holds more than two rays (the plugin API's per-sample queries: S = 1): per-sample contributions
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (sm.ok[t]) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) atomicAdd(&gsum_extra[(size_t)ray[t] * 64 + 16 * ob + 4 * g + r], G1.v[t][ob][r]);
+          }
+      }
       to_ops(g1, G1);
     }
     // col0: G = G1, X = h -> its h block.  The 48 ray-constant inputs and the bias are finished per ray by k_color_ray_grads
     // from per-ray row sums of G1: a tile inside one ray stores its 64 sums to gsum_tile; a tile that straddles two rays
-    // (S % 16 != 0) adds its two parts to gsum_extra.  The sums ride on the round's MFMAs: selector column 2 t' = the samples of
+    // (S % 16 != 0, S >= 16) adds its two parts to gsum_extra.  The sums ride on the round's MFMAs: selector column 2 t' = the samples of
     // tile t' (of a K-block's two) that belong to the tile's first ray, column 2 t' + 1 = the rest.
     int first_ray[NT], boundary[NT];
     SelOperand<NT> sel;
@@ -592,12 +602,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
       if (tile < n_tiles) {
         const int last = (16 * tile + 15 < N) ? 16 * tile + 15 : N - 1;
         const int col = (NT == 1) ? 0 : 2 * (t & 1);
-        if (last < boundary[t]) {  // inside one ray
+        if (last < boundary[t]) {  // inside one ray (S < 16: only the last, partial tile can be; its samples went to gsum_extra)
           if (j == col) {
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) *reinterpret_cast<f32x4*>(gsum_tile + (size_t)tile * 64 + 16 * ob + 4 * g) = rs[0][ob];
+            for (int ob = 0; ob < 4; ++ob)
+              *reinterpret_cast<f32x4*>(gsum_tile + (size_t)tile * 64 + 16 * ob + 4 * g) = (S < 16) ? f32x4{0.f, 0.f, 0.f, 0.f} : rs[0][ob];
           }
-        } else if (j == col || j == col + 1) {
+        } else if (S >= 16 && (j == col || j == col + 1)) {
           const int ray = first_ray[t] + (j - col);
 #pragma unroll
           for (int ob = 0; ob < 4; ++ob)

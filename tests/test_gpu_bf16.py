@@ -118,10 +118,11 @@ def test_bf16_modes_vs_the_fp32_kernels_forward(dev, precision, tol_rgb, tol_log
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-4), ("bf16", 0.2)])
-@pytest.mark.parametrize("S,shape", [(48, "fruit_nerf"), (40, "fruit_nerf"), (48, "fruit_nerf_big"), (37, "fruit_nerf_big")])
+@pytest.mark.parametrize("S,shape", [(48, "fruit_nerf"), (40, "fruit_nerf"), (24, "fruit_nerf"), (8, "fruit_nerf"), (1, "fruit_nerf"),
+                                     (48, "fruit_nerf_big"), (37, "fruit_nerf_big")])
 def test_bf16_modes_vs_the_fp32_kernels_backward(dev, precision, tol, S, shape):
     """d_feats and every MLP / embedding gradient of fnr_field_mlp_bwd in the bf16-pipe modes vs the fp32 kernels
-    (S = 40: tiles straddle rays).  bf16x3 (three piece products in the backward pass): max error relative to each
+    (S = 40, 24: tiles straddle two rays; S = 8, 1 — the plugin API's per-sample queries — a tile holds many).  bf16x3 (three piece products in the backward pass): max error relative to each
     tensor's max |g| within the 5e-4 bar of the oracle tests (measured 5e-6 .. 2e-4).  Plain bf16: L2-relative error —
     the random zero-mean upstream gradients of this test make the weight gradients sums with ~100x cancellation and
     bf16-sized pre-activation errors flip ReLU gates, so max-norm errors of single elements reach 10-25 %."""

@@ -99,6 +99,43 @@ def test_position_gradient_reduction_is_free_of_packed_math(tmp_path, mask):
             assert any(l.startswith("global_load_dwordx2") and l.endswith(" nt") for l in body), "the variant under test streams the Jacobian"
 
 
+# ---- round 6: the per-wave MLP backward (field_mlp_bwd_pw.hip) ---------------------------------------------------------------
+# Its kernels sit at the register limit of two waves per SIMD by design (116 dW accumulator registers in the colour branch): a
+# spill would put accumulators into scratch memory inside the loop.  And its base branch carries the same position-gradient
+# reduction as k_field_mlp_bwd_base_coop, once per tile.
+
+@pytest.fixture(scope="module")
+def per_wave_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    return _compile("field_mlp_bwd_pw.hip", tmp_path_factory.mktemp("isa_pw") / "field_mlp_bwd_pw.s")
+
+
+def test_per_wave_backward_kernels_do_not_spill(per_wave_asm):
+    text = "\n".join(per_wave_asm)
+    meta = re.findall(r"\.name:\s*(\S+)\s*\n(?:.*\n)*?\s*\.private_segment_fixed_size:\s*(\d+)(?:.*\n)*?\s*\.vgpr_count:\s*(\d+)"
+                      r"(?:.*\n)*?\s*\.vgpr_spill_count:\s*(\d+)", text)
+    kernels = {name: (int(scratch), int(vgpr), int(spill)) for name, scratch, vgpr, spill in meta if name.startswith("_ZN3fnr2pw")}
+    assert len(kernels) == 8, sorted(kernels)        # (colour | semantic | base | base + position gradient) x (bf16 | bf16x3)
+    for name, (scratch, vgpr, spill) in kernels.items():
+        assert scratch == 0 and spill == 0 and vgpr <= 256, (name, scratch, vgpr, spill)
+
+
+def test_per_wave_position_gradient_reduction_is_free_of_packed_math(per_wave_asm):
+    lines = per_wave_asm
+    kernels = [m.group(1) for m in (re.match(r"^(_ZN3fnr2pw23k_field_mlp_bwd_base_pw\w+):", l) for l in lines) if m]
+    posgrad = [k for k in kernels if "Lb1EEE" in k]
+    assert len(posgrad) == 2, kernels                     # bf16 | bf16x3
+    for name in posgrad:
+        body = [l for l in _kernel(lines, name) if l and not l.startswith((";", "."))]
+        shuffles = [i for i, l in enumerate(body) if l.startswith("ds_bpermute_b32")]
+        assert len(shuffles) in (6, 12, 24), (name, len(shuffles))   # x, y, z by 16 lanes, then by 32 — per tile of the wave
+        for k in range(0, len(shuffles), 6):
+            window = body[shuffles[k] - 24:shuffles[k + 5] + 8]
+            packed = [l for l in window if l.startswith("v_pk_")]
+            assert not packed, f"{name}: packed math in the position-gradient reduction: {packed[:3]}"
+
+
 def test_streaming_accesses_share_partial_waits_only_in_known_kernels():
     """tools/isa_nt_scan.py: partial `s_waitcnt vmcnt(n)` with `nt` and plain accesses both in flight are fine (measured:
     tools/microbench/nt_load_order.hip) — this pins WHICH kernel families have them, so that a new one gets looked at."""
@@ -109,7 +146,7 @@ def test_streaming_accesses_share_partial_waits_only_in_known_kernels():
     import isa_nt_scan
     known = ("k_scatter_accumulate", "k_prop_bwd", "k_scatter_emit", "k_hash_encode", "k_prop_density", "k_adam", "k_radam")
     seen = set()
-    for src in ("hash_scatter.hip", "hashgrid.hip", "field_mlp_bf16.hip", "position_grad.hip", "train.hip"):
+    for src in ("hash_scatter.hip", "hashgrid.hip", "field_mlp_bf16.hip", "field_mlp_bwd_pw.hip", "position_grad.hip", "train.hip"):
         for k, r in isa_nt_scan.scan_source(os.path.join(CSRC, src)).items():
             if r["mixed"]:
                 fam = [f for f in known if f in k]
