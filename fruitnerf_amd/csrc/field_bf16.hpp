@@ -226,16 +226,60 @@ struct BfLds {
 };
 
 // ---- operands ---------------------------------------------------------------------------------------------------
+// Two floats -> one dword of two bf16 (round to nearest even), ONE instruction: the TWO-wide vector conversion is what hipcc
+// turns into a single v_cvt_pk_bf16_f32 with both sources.  The eight-wide __builtin_convertvector(f32x8 -> bf16x8) becomes one
+// v_cvt_pk_bf16_f32 per VALUE (second source unused) plus a v_perm_b32 per pair to pack: 3.5 instructions per value and piece
+// where 2.5 do (round 6: the MLP kernels are vector-ALU bound, not MFMA bound — 14.7 M vector against 2.5 M matrix
+// wave-instructions in the forward kernel; profiles/r06_raw/per_wave_mlp_bwd.md).  No inline assembly: the compiler keeps
+// seeing the instruction (hazards, constant folding).
+using bf_f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  const bf_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf_bf16x2));
+}
+using bf_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+// the exact split x = x1 + x2 + x3 of eight values, pairwise: same roundings (same bits) as the scalar form bf_piece
 template <int NS>
 __device__ __forceinline__ void bf_split(const f32x8 v, bf16x8 (&p)[NS]) {
-  p[0] = __builtin_convertvector(v, bf16x8);
-  if constexpr (NS > 1) {
-    const f32x8 r1 = v - __builtin_convertvector(p[0], f32x8);
-    p[1] = __builtin_convertvector(r1, bf16x8);
-    if constexpr (NS > 2) {
-      const f32x8 r2 = r1 - __builtin_convertvector(p[1], f32x8);
-      p[2] = __builtin_convertvector(r2, bf16x8);
+  bf_u32x4 out[NS];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float a = v[2 * d], b = v[2 * d + 1];
+#pragma unroll
+    for (int pc = 0; pc < NS; ++pc) {
+      const unsigned w = cvt_pk_bf16(a, b);
+      out[pc][d] = w;
+      if (pc + 1 < NS) {
+        a -= __builtin_bit_cast(float, w << 16);
+        b -= __builtin_bit_cast(float, w & 0xffff0000u);
+      }
     }
+  }
+#pragma unroll
+  for (int pc = 0; pc < NS; ++pc) p[pc] = __builtin_bit_cast(bf16x8, out[pc]);
+}
+// ... of four values (the upper half of the K-block is structurally zero)
+template <int NS>
+__device__ __forceinline__ void bf_split_half(const f32x4 v, bf16x8 (&p)[NS]) {
+  bf_u32x4 out[NS];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    float a = v[2 * d], b = v[2 * d + 1];
+#pragma unroll
+    for (int pc = 0; pc < NS; ++pc) {
+      const unsigned w = cvt_pk_bf16(a, b);
+      out[pc][d] = w;
+      if (pc + 1 < NS) {
+        a -= __builtin_bit_cast(float, w << 16);
+        b -= __builtin_bit_cast(float, w & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int pc = 0; pc < NS; ++pc) {
+    out[pc][2] = out[pc][3] = 0u;
+    p[pc] = __builtin_bit_cast(bf16x8, out[pc]);
   }
 }
 
@@ -244,13 +288,17 @@ template <int NS, int NB>
 __device__ __forceinline__ void bf_operand(const f32x4 (&act)[NB], bf16x8 (&x)[(NB + 1) / 2][NS]) {
 #pragma unroll
   for (int kb = 0; kb < (NB + 1) / 2; ++kb) {
-    f32x8 v;
+    if (2 * kb + 1 < NB) {
+      f32x8 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = act[2 * kb][e];
-      v[4 + e] = (2 * kb + 1 < NB) ? act[(2 * kb + 1 < NB) ? 2 * kb + 1 : 0][e] : 0.0f;
+      for (int e = 0; e < 4; ++e) {
+        v[e] = act[2 * kb][e];
+        v[4 + e] = act[(2 * kb + 1 < NB) ? 2 * kb + 1 : 0][e];
+      }
+      bf_split<NS>(v, x[kb]);
+    } else {
+      bf_split_half<NS>(act[2 * kb], x[kb]);
     }
-    bf_split<NS>(v, x[kb]);
   }
 }
 

@@ -54,47 +54,10 @@ template <int NT, int NB, int NS>
 struct Ops {
   bf16x8 v[NT][(NB + 1) / 2][NS];
 };
-// The exact bf16 split of field_bf16.hpp (bf_split: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); same roundings, same
-// bits) with the conversions PAIRED: hipcc lowers the vector conversion to one v_cvt_pk_bf16_f32 per VALUE (second source
-// unused) plus a v_perm_b32 per pair to pack — 3.5 instructions per value and piece where 2.5 do.
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-template <int NS>
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&p)[NS]) {
-  u32x4 out[NS];
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    float a = v[2 * d], b = v[2 * d + 1];
-#pragma unroll
-    for (int pc = 0; pc < NS; ++pc) {
-      const unsigned w = cvt_pk_bf16(a, b);
-      out[pc][d] = w;
-      if (pc + 1 < NS) {
-        a -= __builtin_bit_cast(float, w << 16);
-        b -= __builtin_bit_cast(float, w & 0xffff0000u);
-      }
-    }
-  }
-#pragma unroll
-  for (int pc = 0; pc < NS; ++pc) p[pc] = __builtin_bit_cast(bf16x8, out[pc]);
-}
 template <int NT, int NB, int NS>
 __device__ __forceinline__ void to_ops(Ops<NT, NB, NS>& x, const Acts<NT, NB>& a) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int kb = 0; kb < (NB + 1) / 2; ++kb) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = a.v[t][2 * kb][e];
-        v[4 + e] = (2 * kb + 1 < NB) ? a.v[t][(2 * kb + 1 < NB) ? 2 * kb + 1 : 0][e] : 0.0f;
-      }
-      split8<NS>(v, x.v[t][kb]);
-    }
+  for (int t = 0; t < NT; ++t) bf_operand<NS, NB>(a.v[t], x.v[t]);
 }
 template <int NT, int NB>
 __device__ __forceinline__ void relu(Acts<NT, NB>& a) {
@@ -702,10 +665,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_sem_pw(
     asm volatile("" : "+v"(lane));
     const int j = lane & 15, g = lane >> 4;
     const Samples<NT> sm(gr, j, N);
-    Ops<NT, 1, NSF> hx;
     Ops<NT, 4, NSF> x1;
     Ops<NT, 4, NS> x2;
     {
+      Ops<NT, 1, NSF> hx;
       Acts<NT, 1> h;
       Acts<NT, 4> s1;
 #pragma unroll
@@ -751,7 +714,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_sem_pw(
       to_ops(g1, Gs1);
     }
     // sem0: G = Gs1, X = h (input = detached geo: no dX)
-    dw_round<NT, NS, 4, 1>(scr, g1, hx, accA, lane);
+    {
+      Acts<NT, 1> h;  // (re-read, L2-resident, instead of its pieces living through the whole recompute)
+      Ops<NT, 1, NS> hx;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) h.v[t][0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)sm.n[t] * 16 + 4 * g);
+      to_ops(hx, h);
+      dw_round<NT, NS, 4, 1>(scr, g1, hx, accA, lane);
+    }
   }
   const int lane = lane0;
   float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
@@ -975,7 +945,7 @@ static int launch(int branch, const float* packed, const __bf16* image, const fl
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), L::BYTES, st, packed, image, ray_bias, rd, S, n, h_saved,
                        d_rgb, d_h, gsum_tile, gsum_extra, partials);
   } else if (branch == 1) {
-    constexpr int NT = FNR_PW_NT_SEM;
+    constexpr int NT = NSF == 1 ? 1 : FNR_PW_NT_SEM;  // (plain bf16: hipcc's schedule of the two-tile form spills 8 registers)
     using L = Lds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS, NT, WAVES, 128>;
     static_assert(L::BYTES <= 160 * 1024, "semantic branch exceeds the LDS");
     auto kern = k_field_mlp_bwd_sem_pw<Cfg, NSF, NS, NT, WAVES>;
