@@ -46,8 +46,8 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("FNR_BENCH_FORCE
 from fruitnerf_amd.hostinfo import usable_cpus  # noqa: E402  (the container's CPU quota, see its docstring)
 
 # Arithmetic generation of the training kernels: bumped whenever a kernel change legitimately changes a rounding (the
-# pinned checksums below are per generation).  r05: unchanged since round 5 (round 6's sequencer replays the same launches).
-NUMERICS = "r05"
+# pinned checksums below are per generation).
+NUMERICS = "r06"
 CHECKSUMS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "parameter_checksums.json")
 N_CAMERAS = 100
 TRAIN_SPLIT = 0.9              # fruitnerf_dataparser.py:62
