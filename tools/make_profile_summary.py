@@ -36,7 +36,7 @@ def pmc(path):
 
 def short(n):
     n = n.replace('fnr::', '')
-    m = re.match(r'_ZN3fnr\d+(k_[a-z_0-9]+?)INS', n)
+    m = re.match(r'_ZN3fnr(?:2pw)?\d+(k_[a-z_0-9]+?)INS', n)
     if m:
         n = m.group(1) + '<...> (mangled)'
     return n[:72]
@@ -90,10 +90,11 @@ tot = 0.0
 
 
 def pmc_for(name, grid_x, d):
-    """counter record of a kernel-trace row: same kernel; the emit's main-field call is the one after k_reduce_dw"""
+    """counter record of a kernel-trace row: same kernel; the emit's main-field call is the one after the MLP backward's last
+    launch (k_finish_weights; k_reduce_dw before round 6; k_position_contract in the fp32 window)"""
     cands = [k for k in d if k.split(' grid ')[0].split(' after ')[0][:50] == name[:50]]
     if 'k_scatter_emit' in name:
-        main = [k for k in cands if 'after k_reduce_dw' in k]
+        main = [k for k in cands if 'after k_reduce_dw' in k or 'after k_finish_weights' in k]
         prop = [k for k in cands if 'after k_prop_reduce' in k]
         if grid_x == '196608' and main:
             return d[main[0]]
@@ -127,8 +128,8 @@ out.append('\nSum of kernel time: %.0f us per step (the un-profiled step time is
 ENTRY = {
     'hash_encode_bwd[196608]': [('k_scatter_emit', '196608'), ('k_scatter_accumulate<true>', None)],
     'hash_encode_fwd[196608]': [('k_hash_encode', None)],
-    'field_mlp_bwd[196608]': [('k_field_mlp_bwd_color_coop', None), ('k_color_ray_grads', None), ('k_embedding_grad', None),
-                              ('k_field_mlp_bwd_sem_coop', None), ('k_field_mlp_bwd_base_coop', None), ('k_reduce_dw', None)],
+    'field_mlp_bwd[196608]': [('k_field_mlp_bwd_color_pw', None), ('k_color_ray_grads', None), ('k_field_mlp_bwd_sem_pw', None),
+                              ('k_field_mlp_bwd_base_pw', None), ('k_finish_weights', None)],
     'field_mlp_fwd[196608]': [('k_prepare_field', None), ('k_field_mlp_fwd_bf16', None)],
 }
 traffic = {}
@@ -169,6 +170,9 @@ out.append('| command | rays/s | ms/step | `roofline` | `roofline_other_bound` |
 out.append('|---|---|---|---|---|')
 for fn, cmd in (('bench_fruit_nerf.log', 'python bench.py'), ('bench_fruit_nerf_fp32.log', 'python bench.py --mlp-precision fp32'),
                 ('bench_fruit_nerf_big.log', 'python bench.py --method fruit_nerf_big')):
+    import os
+    if not os.path.exists(base + fn):
+        continue
     d = line(fn)
     out.append('| `%s` | %.0f | %s | %s | %s |' % (cmd, d['value'], d['ms_per_step'], rf(d['roofline']), rf(d['roofline_other_bound'])))
 d = bench
@@ -178,8 +182,12 @@ out.append('\nDefault line, other fields: cpu_baseline ' + json.dumps(d['cpu_bas
            + '; eval %.3g rays/s; export 256^3 %.3g samples/s (passes %s ms); export points %s; fruit_nerf_big window %s rays/s (%s ms/step).\n'
            % (sec['eval_rays_per_s'], sec['export_samples_per_s'], sec['export_pass_ms'], json.dumps(sec['export_points']),
               sec.get('fruit_nerf_big', {}).get('value'), sec.get('fruit_nerf_big', {}).get('ms_per_step')))
-dbig = line('bench_fruit_nerf_big.log')
-out.append('`fruit_nerf_big` line: quality ' + json.dumps(dbig['quality']) + '.\n')
+import os
+if os.path.exists(base + 'bench_fruit_nerf_big.log'):
+    dbig = line('bench_fruit_nerf_big.log')
+    out.append('`fruit_nerf_big` line: quality ' + json.dumps(dbig['quality']) + '.\n')
+else:   # the default line's own 20 000-step look at the big method
+    out.append('`fruit_nerf_big` (the default line\'s secondary run): quality ' + json.dumps(sec.get('fruit_nerf_big', {}).get('quality')) + '.\n')
 big = kt(base + 'prof_kernel_trace_big.txt')
 sb = max(n for name, g, n, *_ in big if 'k_train_losses' in name)
 out.append(f'## `fruit_nerf_big` (8192 rays, samples 512/256/128, T = 2^21): kernel trace of `bench.py --method fruit_nerf_big --steps 40 --warmup 10`, {sb} steps\n')
