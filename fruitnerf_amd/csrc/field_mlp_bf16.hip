@@ -1021,7 +1021,7 @@ static int bwd_launch_coop(const float* packed, const __bf16* image, const float
 }
 
 // ---- launch helpers (called from field_mlp.hip / field_mlp_bwd.hip when fnr_field_net.mlp_mode != 0) --------------
-int field_mlp_bwd_pw(int mode, int branch, const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd,
+int field_mlp_bwd_pw(int cfg, int mode, int branch, const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd,
                      int S, long long N, const float2* feats, const float* h_saved, const uint8_t* selector,
                      const float* d_density, const float* d_rgb, const float* d_logit, float2* d_feats, float* d_h,
                      float* gsum_tile, float* gsum_extra, float* partials, long long blocks, hipStream_t st, const float2* jac,
@@ -1078,6 +1078,15 @@ int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool p
       launch_pack_field_weights_bf16<FieldCfgBig>(p, mode == MLP_BF16 ? 1 : 3, image, st);
     FNR_LAUNCH_CHECK();
   }
+  // the per-wave kernels (field_mlp_bwd_pw.hip): every branch of `fruit_nerf`, colour and base of `fruit_nerf_big`.
+  // FNR_MLP_BWD_PW=0: the cooperative ones below (A/B).
+  static const bool per_wave = [] {
+    const char* e = getenv("FNR_MLP_BWD_PW");
+    return !(e && atoi(e) == 0);
+  }();
+  if (per_wave)
+    return field_mlp_bwd_pw(cfg, mode, branch, packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit,
+                            d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, st, jac, d_pos);
   if (cfg == 1) {
     if (mode == MLP_BF16)
       return bwd_launch_coop<FieldCfgBig, 1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
@@ -1085,14 +1094,6 @@ int field_mlp_bwd_bf16(int cfg, int mode, int branch, const FieldPtrs& p, bool p
     return bwd_launch_coop<FieldCfgBig, 3, 2>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
                                               d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st, jac, d_pos);
   }
-  // `fruit_nerf` shape: the per-wave kernels (field_mlp_bwd_pw.hip).  FNR_MLP_BWD_PW=0: the cooperative ones below (A/B).
-  static const bool per_wave = [] {
-    const char* e = getenv("FNR_MLP_BWD_PW");
-    return !(e && atoi(e) == 0);
-  }();
-  if (per_wave)
-    return field_mlp_bwd_pw(mode, branch, packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit,
-                            d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, st, jac, d_pos);
   if (mode == MLP_BF16)
     return bwd_launch_coop<FieldCfgBase, 1, 1>(packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb,
                                                d_logit, d_feats, d_h, gsum_tile, gsum_extra, partials, blocks, branch, st, jac, d_pos);

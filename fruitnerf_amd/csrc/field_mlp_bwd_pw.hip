@@ -1,4 +1,5 @@
-// field_mlp_bwd_pw.hip — backward pass of FruitField's MLP stack, `fruit_nerf` shape, PER-WAVE form (round 6).
+// field_mlp_bwd_pw.hip — backward pass of FruitField's MLP stack, PER-WAVE form (round 6): every branch of the `fruit_nerf`
+// shape, the colour and base branches of `fruit_nerf_big` (whose 128-wide semantic branch keeps its weight-streaming kernel).
 // Replaces the same reference code as field_mlp_bf16.hip: fruit_field.py:132-166,187-281 and its autograd.
 //
 // The cooperative kernels (field_mlp_bf16.hip) give every 16 x 16 block of a layer's weight gradient to ONE wave over a
@@ -398,7 +399,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
     const float* __restrict__ packed, const __bf16* __restrict__ image, const float* __restrict__ ray_bias, RaysDev rays,
     int S, int N, const float* __restrict__ h_saved, const float* __restrict__ d_rgb, float* __restrict__ d_h,
     float* __restrict__ gsum_tile, float* __restrict__ gsum_extra, float* __restrict__ partials) {
-  static_assert(Cfg::HB == 1, "`fruit_nerf` shape");
+  constexpr int HB = Cfg::HB;  // 16-wide blocks of h: 1 (`fruit_nerf`) or 2 (`fruit_nerf_big`)
+  static_assert(HB == 1 || HB == 2, "built shapes");
   constexpr int THREADS = 64 * WAVES;
   constexpr int LC0 = Cfg::L_COL0, LC1 = Cfg::L_COL1, LC2 = Cfg::L_COL2;
   using L = Lds<Cfg, SegsColF<Cfg>, SegsColT<Cfg>, NSF, NS, NT, WAVES, 80>;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* scr = smem + L::SCR_OFF + wave * scratch_bytes<NS, NT>();
-  f32x4 accC[4], accB[16], accA[4];  // col2 [ob 0][ib], col1 [ob][ib], col0's h block [ob][0]
+  f32x4 accC[4], accB[16], accA[4 * HB];  // col2 [ob 0][ib], col1 [ob][ib], col0's h blocks [ob][ib < HB]
   f32x4 bC[1], bB[4];                // (the bias of col0 belongs to k_color_ray_grads)
   zero_vec(accC);
   zero_vec(accB);
@@ -447,17 +449,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
     Ops<NT, 4, NSF> x1, x2;
     Acts<NT, 1> c3;
     {
-      Acts<NT, 1> h;
+      Acts<NT, HB> h;
       Acts<NT, 4> c1;
-      Ops<NT, 1, NSF> hx;
+      Ops<NT, HB, NSF> hx;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        h.v[t][0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)sm.n[t] * 16 + 4 * g);
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) h.v[t][hb] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)sm.n[t] * (16 * HB) + 16 * hb + 4 * g);
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) c1.v[t][ob] = *reinterpret_cast<const f32x4*>(ray_bias + (size_t)ray[t] * 64 + 16 * ob + 4 * g);
       }
       to_ops(hx, h);
-      layer_acc<NT, NSF, 4, 1>(F::template seg<LC0, false>(wf), hx, c1, lane);
+      layer_acc<NT, NSF, 4, HB>(F::template seg<LC0, false>(wf), hx, c1, lane);
       relu(c1);
       to_ops(x1, c1);
     }
@@ -550,14 +553,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
     }
     f32x4 rs[NT == 1 ? 1 : NT / 2][4];
     {
-      Acts<NT, 1> h;  // (re-read, L2-resident, instead of its pieces living through the whole recompute)
-      Ops<NT, 1, NS> hx;
+      Acts<NT, HB> h;  // (re-read, L2-resident, instead of its pieces living through the whole recompute)
+      Ops<NT, HB, NS> hx;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) h.v[t][0] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)sm.n[t] * 16 + 4 * g);
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) h.v[t][hb] = *reinterpret_cast<const f32x4*>(h_saved + (size_t)sm.n[t] * (16 * HB) + 16 * hb + 4 * g);
       to_ops(hx, h);
       static_assert(NT <= 2, "one K-block of row sums per round");
       zero_vec(rs[0]);
-      dw_round<NT, NS, 4, 1, NS, NS, true>(scr, g1, hx, accA, lane, &sel, &rs[0]);
+      dw_round<NT, NS, 4, HB, NS, NS, true>(scr, g1, hx, accA, lane, &sel, &rs[0]);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -580,34 +585,40 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
         }
       }
     }
-    Acts<NT, 1> Gh;
-    layer<NT, NS, 1, 4>(T::template seg<LC0, true>(wt), nullptr, g1, Gh, lane);
+    Acts<NT, HB> Gh;
+    layer<NT, NS, HB, 4>(T::template seg<LC0, true>(wt), nullptr, g1, Gh, lane);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-      if (sm.ok[t]) *reinterpret_cast<f32x4*>(d_h + (size_t)sm.n[t] * 16 + 4 * g) = Gh.v[t][0];
+      if (sm.ok[t]) {
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) *reinterpret_cast<f32x4*>(d_h + (size_t)sm.n[t] * (16 * HB) + 16 * hb + 4 * g) = Gh.v[t][hb];
+      }
   }
   const int lane = lane0;
   float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
-  struct Table {  // accA [ob] | accB [ob][ib] | accC [ib] | bias col1 [ob] | bias col2
+  constexpr int NA = 4 * HB, NALL = NA + 25;
+  struct Table {  // accA [ob][ib < HB] | accB [ob][ib] | accC [ib] | bias col1 [ob] | bias col2
     __device__ static __forceinline__ Dest get(int b) {
-      if (b < 4) return Dest{Cfg::woff(LC0), b, 0, Cfg::HB + 3, 0};
-      if (b < 20) return Dest{Cfg::woff(LC1), (b - 4) >> 2, (b - 4) & 3, 4, 0};
-      if (b < 24) return Dest{Cfg::woff(LC2), 0, b - 20, 4, 0};
-      if (b < 28) return Dest{Cfg::W_TOTAL + Cfg::boff(LC1), b - 24, 0, 0, 1};
+      constexpr int NA = 4 * Cfg::HB;
+      if (b < NA) return Dest{Cfg::woff(LC0), b / Cfg::HB, b % Cfg::HB, Cfg::HB + 3, 0};
+      b -= NA;
+      if (b < 16) return Dest{Cfg::woff(LC1), b >> 2, b & 3, 4, 0};
+      if (b < 20) return Dest{Cfg::woff(LC2), 0, b - 16, 4, 0};
+      if (b < 24) return Dest{Cfg::W_TOTAL + Cfg::boff(LC1), b - 20, 0, 0, 1};
       return Dest{Cfg::W_TOTAL + Cfg::boff(LC2), 0, 0, 0, 1};
     }
   };
-  f32x4 all[29];
+  f32x4 all[NALL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) all[i] = accA[i];
+  for (int i = 0; i < NA; ++i) all[i] = accA[i];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) all[4 + i] = accB[i];
+  for (int i = 0; i < 16; ++i) all[NA + i] = accB[i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) all[20 + i] = accC[i];
+  for (int i = 0; i < 4; ++i) all[NA + 16 + i] = accC[i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) all[24 + i] = bias_total(bB[i]);
-  all[28] = bias_total(bC[0]);
-  reduce_and_store<29, WAVES, Table>(smem, part, all, wave, lane);
+  for (int i = 0; i < 4; ++i) all[NA + 20 + i] = bias_total(bB[i]);
+  all[NA + 24] = bias_total(bC[0]);
+  reduce_and_store<NALL, WAVES, Table>(smem, part, all, wave, lane);
   // col0: this kernel owns the h input block; the three blocks of ray-constant inputs and the bias belong to
   // k_color_ray_grads, which only overwrites SOME workgroups' images: zero them here
   constexpr int NIB0 = Cfg::HB + 3;
@@ -759,7 +770,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
     const float* __restrict__ h_saved, const uint8_t* __restrict__ selector, const float* __restrict__ d_density,
     const float* __restrict__ d_h, float2* __restrict__ d_feats, float* __restrict__ partials,
     const float2* __restrict__ jac, float4* __restrict__ d_pos) {
-  static_assert(Cfg::HB == 1, "`fruit_nerf` shape");
+  constexpr int HB = Cfg::HB;
+  static_assert(HB == 1 || HB == 2, "built shapes");
   constexpr int THREADS = 64 * WAVES;
   constexpr int LB0 = Cfg::L_BASE0, LB1 = Cfg::L_BASE1;
   static_assert(LB1 == LB0 + 1, "the branch's layers are adjacent in the fp32 image");
@@ -776,8 +788,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
   __syncthreads();
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned char* scr = smem + L::SCR_OFF + wave * scratch_bytes<NS, NT>();
-  f32x4 accB[4], accA[8];  // base1 [0][ib], base0 [ob][ib]
-  f32x4 bB[1], bA[4];
+  f32x4 accB[4 * HB], accA[8];  // base1 [ob < HB][ib], base0 [ob][ib]
+  f32x4 bB[HB], bA[4];
   zero_vec(accB);
   zero_vec(accA);
   zero_vec(bB);
@@ -813,17 +825,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
       relu(a1);
       to_ops(x1, a1);
     }
-    Ops<NT, 1, NS> gh;
+    Ops<NT, HB, NS> gh;
     {
-      Acts<NT, 1> Gh;
+      Acts<NT, HB> Gh;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        Gh.v[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) Gh.v[t][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (sm.ok[t]) {
-          Gh.v[t][0] = *reinterpret_cast<const f32x4*>(d_h + (size_t)sm.n[t] * 16 + 4 * g);
+#pragma unroll
+          for (int hb = 0; hb < HB; ++hb) Gh.v[t][hb] = *reinterpret_cast<const f32x4*>(d_h + (size_t)sm.n[t] * (16 * HB) + 16 * hb + 4 * g);
           if (g == 0) {  // trunc_exp backward (fruit_field.py:191) on the saved density logit; the colour block has a zero row 0
             const bool sel = selector ? (selector[sm.n[t]] != 0) : true;
-            const float te = expf(fminf(fmaxf(h_saved[(size_t)sm.n[t] * 16], -15.0f), 15.0f));
+            const float te = expf(fminf(fmaxf(h_saved[(size_t)sm.n[t] * (16 * HB)], -15.0f), 15.0f));
             Gh.v[t][0][0] = sel ? d_density[sm.n[t]] * te : 0.0f;
           }
         }
@@ -832,11 +846,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
       to_ops(gh, Gh);
     }
     // base1: G = Gh, X = a1
-    dw_round<NT, NS, 1, 4>(scr, gh, x1, accB, lane);
+    dw_round<NT, NS, HB, 4>(scr, gh, x1, accB, lane);
     Ops<NT, 4, NS> ga;
     {
       Acts<NT, 4> Ga;
-      layer<NT, NS, 4, 1>(T::template seg<LB1, true>(wt), nullptr, gh, Ga, lane);
+      layer<NT, NS, 4, HB>(T::template seg<LB1, true>(wt), nullptr, gh, Ga, lane);
       gate(Ga, x1);
       bias_add(bA, Ga);
       to_ops(ga, Ga);
@@ -890,23 +904,28 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
   }
   const int lane = lane0;
   float* part = partials + (size_t)blockIdx.x * (Cfg::W_TOTAL + Cfg::B_TOTAL);
-  struct Table {  // accA [ob][ib] | accB [ib] | bias base0 [ob] | bias base1
+  constexpr int NB1 = 4 * HB, NALL = 8 + NB1 + 4 + HB;
+  struct Table {  // accA [ob][ib] | accB [ob < HB][ib] | bias base0 [ob] | bias base1 [ob < HB]
     __device__ static __forceinline__ Dest get(int b) {
+      constexpr int NB1 = 4 * Cfg::HB;
       if (b < 8) return Dest{Cfg::woff(LB0), b >> 1, b & 1, 2, 0};
-      if (b < 12) return Dest{Cfg::woff(LB1), 0, b - 8, 4, 0};
-      if (b < 16) return Dest{Cfg::W_TOTAL + Cfg::boff(LB0), b - 12, 0, 0, 1};
-      return Dest{Cfg::W_TOTAL + Cfg::boff(LB1), 0, 0, 0, 1};
+      b -= 8;
+      if (b < NB1) return Dest{Cfg::woff(LB1), b >> 2, b & 3, 4, 0};
+      b -= NB1;
+      if (b < 4) return Dest{Cfg::W_TOTAL + Cfg::boff(LB0), b, 0, 0, 1};
+      return Dest{Cfg::W_TOTAL + Cfg::boff(LB1), b - 4, 0, 0, 1};
     }
   };
-  f32x4 all[17];
+  f32x4 all[NALL];
 #pragma unroll
   for (int i = 0; i < 8; ++i) all[i] = accA[i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) all[8 + i] = accB[i];
+  for (int i = 0; i < NB1; ++i) all[8 + i] = accB[i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) all[12 + i] = bias_total(bA[i]);
-  all[16] = bias_total(bB[0]);
-  reduce_and_store<17, WAVES, Table>(smem, part, all, wave, lane);
+  for (int i = 0; i < 4; ++i) all[8 + NB1 + i] = bias_total(bA[i]);
+#pragma unroll
+  for (int i = 0; i < HB; ++i) all[12 + NB1 + i] = bias_total(bB[i]);
+  reduce_and_store<NALL, WAVES, Table>(smem, part, all, wave, lane);
 }
 
 // tiles per wave, by branch (the colour branch's 116 accumulator registers leave room for one tile's activations: two spill),
@@ -920,16 +939,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
 #ifndef FNR_PW_NT_BASE
 #define FNR_PW_NT_BASE 2
 #endif
+#ifndef FNR_PW_NT_BASE_BIG
+#define FNR_PW_NT_BASE_BIG 1
+#endif
 #ifndef FNR_PW_WAVES
 #define FNR_PW_WAVES 8
 #endif
 
-template <int NSF, int NS>
+template <class Cfg, int NSF, int NS>
 static int launch(int branch, const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd, int S, long long N,
                   const float2* feats, const float* h_saved, const uint8_t* selector, const float* d_density, const float* d_rgb,
                   const float* d_logit, float2* d_feats, float* d_h, float* gsum_tile, float* gsum_extra, float* partials,
                   long long blocks, hipStream_t st, const float2* jac, float4* d_pos) {
-  using Cfg = FieldCfgBase;
   constexpr int WAVES = FNR_PW_WAVES, THREADS = 64 * WAVES;
   FNR_CHECK_ARG(N < (1ll << 31) - 64, "field_mlp_bwd: %lld samples exceed the 32-bit sample index of the backward kernels", N);
   const int n = (int)N;
@@ -945,15 +966,19 @@ static int launch(int branch, const float* packed, const __bf16* image, const fl
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), L::BYTES, st, packed, image, ray_bias, rd, S, n, h_saved,
                        d_rgb, d_h, gsum_tile, gsum_extra, partials);
   } else if (branch == 1) {
-    constexpr int NT = NSF == 1 ? 1 : FNR_PW_NT_SEM;  // (plain bf16: hipcc's schedule of the two-tile form spills 8 registers)
-    using L = Lds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS, NT, WAVES, 128>;
-    static_assert(L::BYTES <= 160 * 1024, "semantic branch exceeds the LDS");
-    auto kern = k_field_mlp_bwd_sem_pw<Cfg, NSF, NS, NT, WAVES>;
-    const int once = ensure_dyn_lds(kern, L::BYTES);
-    if (once) return once;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), L::BYTES, st, packed, image, n, h_saved, d_logit, partials);
+    if constexpr (Cfg::NSEM == 2) {
+      constexpr int NT = NSF == 1 ? 1 : FNR_PW_NT_SEM;  // (plain bf16: hipcc's schedule of the two-tile form spills 8 registers)
+      using L = Lds<Cfg, SegsSemF<Cfg>, SegsSemT<Cfg>, NSF, NS, NT, WAVES, 128>;
+      static_assert(L::BYTES <= 160 * 1024, "semantic branch exceeds the LDS");
+      auto kern = k_field_mlp_bwd_sem_pw<Cfg, NSF, NS, NT, WAVES>;
+      const int once = ensure_dyn_lds(kern, L::BYTES);
+      if (once) return once;
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), L::BYTES, st, packed, image, n, h_saved, d_logit, partials);
+    } else {
+      FNR_CHECK_ARG(false, "the fruit_nerf_big semantic branch has its own kernel (field_mlp_bwd_sem_big_bf16)");
+    }
   } else {
-    constexpr int NT = FNR_PW_NT_BASE;
+    constexpr int NT = Cfg::HB == 1 ? FNR_PW_NT_BASE : FNR_PW_NT_BASE_BIG;
     using L = Lds<Cfg, SegsBaseF<Cfg>, SegsBaseT<Cfg>, NSF, NS, NT, WAVES, 64>;
     static_assert(L::BYTES <= 160 * 1024, "base branch exceeds the LDS");
     if (jac && d_pos) {
@@ -976,18 +1001,20 @@ static int launch(int branch, const float* packed, const __bf16* image, const fl
 
 }  // namespace pw
 
-// branch: 0 colour, 1 semantic, 2 base — the `fruit_nerf` shape's backward in the bf16-pipe modes (called by
-// field_mlp_bwd_bf16, which has packed the fragment image)
-int field_mlp_bwd_pw(int mode, int branch, const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd,
+// cfg: 0 `fruit_nerf` (branch: 0 colour, 1 semantic, 2 base), 1 `fruit_nerf_big` (colour and base; its 128-wide semantic branch
+// is field_mlp_bwd_sem_big_bf16) — the backward in the bf16-pipe modes (called by field_mlp_bwd_bf16, which has packed the
+// fragment image)
+int field_mlp_bwd_pw(int cfg, int mode, int branch, const float* packed, const __bf16* image, const float* ray_bias, const RaysDev& rd,
                      int S, long long N, const float2* feats, const float* h_saved, const uint8_t* selector,
                      const float* d_density, const float* d_rgb, const float* d_logit, float2* d_feats, float* d_h,
                      float* gsum_tile, float* gsum_extra, float* partials, long long blocks, hipStream_t st, const float2* jac,
                      float4* d_pos) {
-  if (mode == MLP_BF16)
-    return pw::launch<1, 1>(branch, packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit, d_feats,
-                            d_h, gsum_tile, gsum_extra, partials, blocks, st, jac, d_pos);
-  return pw::launch<3, 2>(branch, packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit, d_feats,
-                          d_h, gsum_tile, gsum_extra, partials, blocks, st, jac, d_pos);
+#define FNR_PW_LAUNCH(C, A, B)                                                                                                      \
+  pw::launch<C, A, B>(branch, packed, image, ray_bias, rd, S, N, feats, h_saved, selector, d_density, d_rgb, d_logit, d_feats, d_h, \
+                      gsum_tile, gsum_extra, partials, blocks, st, jac, d_pos)
+  if (cfg == 0) return mode == MLP_BF16 ? FNR_PW_LAUNCH(FieldCfgBase, 1, 1) : FNR_PW_LAUNCH(FieldCfgBase, 3, 2);
+  return mode == MLP_BF16 ? FNR_PW_LAUNCH(FieldCfgBig, 1, 1) : FNR_PW_LAUNCH(FieldCfgBig, 3, 2);
+#undef FNR_PW_LAUNCH
 }
 
 }  // namespace fnr

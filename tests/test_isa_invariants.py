@@ -116,7 +116,8 @@ def test_per_wave_backward_kernels_do_not_spill(per_wave_asm):
     meta = re.findall(r"\.name:\s*(\S+)\s*\n(?:.*\n)*?\s*\.private_segment_fixed_size:\s*(\d+)(?:.*\n)*?\s*\.vgpr_count:\s*(\d+)"
                       r"(?:.*\n)*?\s*\.vgpr_spill_count:\s*(\d+)", text)
     kernels = {name: (int(scratch), int(vgpr), int(spill)) for name, scratch, vgpr, spill in meta if name.startswith("_ZN3fnr2pw")}
-    assert len(kernels) == 8, sorted(kernels)        # (colour | semantic | base | base + position gradient) x (bf16 | bf16x3)
+    # fruit_nerf: (colour | semantic | base | base + position gradient) x (bf16 | bf16x3); fruit_nerf_big: the same without semantic
+    assert len(kernels) == 14, sorted(kernels)
     for name, (scratch, vgpr, spill) in kernels.items():
         assert scratch == 0 and spill == 0 and vgpr <= 256, (name, scratch, vgpr, spill)
 
@@ -125,7 +126,7 @@ def test_per_wave_position_gradient_reduction_is_free_of_packed_math(per_wave_as
     lines = per_wave_asm
     kernels = [m.group(1) for m in (re.match(r"^(_ZN3fnr2pw23k_field_mlp_bwd_base_pw\w+):", l) for l in lines) if m]
     posgrad = [k for k in kernels if "Lb1EEE" in k]
-    assert len(posgrad) == 2, kernels                     # bf16 | bf16x3
+    assert len(posgrad) == 4, kernels                     # (fruit_nerf | fruit_nerf_big) x (bf16 | bf16x3)
     for name in posgrad:
         body = [l for l in _kernel(lines, name) if l and not l.startswith((";", "."))]
         shuffles = [i for i, l in enumerate(body) if l.startswith("ds_bpermute_b32")]
