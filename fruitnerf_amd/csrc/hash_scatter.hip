@@ -853,14 +853,19 @@ __global__ __launch_bounds__(256) void k_prop_bwd(GridDev grid, float4* __restri
 // slice 0 adds them up in slice order.
 // ADAM (fnr_prop_density_bwd_adam): the owning thread also takes the parameter's optimiser step (weight_adam_entry).
 constexpr int PRD_E = 16, PRD_Y = 64;
+struct PropReduceArgs {
+  const float* partials;
+  int nblocks, K;
+  float *g_w0, *g_b0, *g_w1, *g_b1;
+  WeightAdam wa;
+};
 template <bool ADAM>
-__global__ __launch_bounds__(PRD_E * PRD_Y) void k_prop_reduce(const float* __restrict__ partials, int nblocks, int K,
-                                                               float* __restrict__ g_w0, float* __restrict__ g_b0,
-                                                               float* __restrict__ g_w1, float* __restrict__ g_b1,
-                                                               WeightAdam wa) {
+__device__ __forceinline__ void prop_reduce_block(int block, const PropReduceArgs& a) {
   __shared__ float s_part[PRD_Y][PRD_E];
+  const float* __restrict__ partials = a.partials;
+  const int nblocks = a.nblocks, K = a.K;
   const int t = threadIdx.x % PRD_E, y = threadIdx.x / PRD_E;
-  const int e = blockIdx.x * PRD_E + t;
+  const int e = block * PRD_E + t;
   float s = 0.0f;
   if (e <= 288) {
     int b = y;
@@ -882,17 +887,29 @@ __global__ __launch_bounds__(PRD_E * PRD_Y) void k_prop_reduce(const float* __re
   float* dst = nullptr;
   if (e < 256) {
     const int o = e >> 4, k = e & 15;
-    if (k < K) dst = &g_w0[o * K + k];
+    if (k < K) dst = &a.g_w0[o * K + k];
   } else if (e < 272) {
-    dst = &g_w1[e - 256];
+    dst = &a.g_w1[e - 256];
   } else if (e < 288) {
-    dst = &g_b0[e - 272];
+    dst = &a.g_b0[e - 272];
   } else {
-    dst = &g_b1[0];
+    dst = &a.g_b1[0];
   }
   if (!dst) return;
-  if constexpr (ADAM) weight_adam_entry(wa, dst, s);
+  if constexpr (ADAM) weight_adam_entry(a.wa, dst, s);
   else *dst += s;
+}
+template <bool ADAM>
+__global__ __launch_bounds__(PRD_E * PRD_Y) void k_prop_reduce(PropReduceArgs a) {
+  prop_reduce_block<ADAM>((int)blockIdx.x, a);
+}
+// both proposal levels' weight reductions as one launch (fnr_prop_density_bwd_pair_split: level 1's MLP backward no longer
+// waits for level 0's reduction to start and drain; same sums in the same order by the same single writers)
+template <bool ADAM>
+__global__ __launch_bounds__(PRD_E * PRD_Y) void k_prop_reduce2(PropReduceArgs a, PropReduceArgs b) {
+  constexpr int NB = PROP_PART / PRD_E;
+  if ((int)blockIdx.x < NB) prop_reduce_block<ADAM>((int)blockIdx.x, a);
+  else prop_reduce_block<ADAM>((int)blockIdx.x - NB, b);
 }
 
 }  // namespace fnr
@@ -991,7 +1008,7 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
                                     size_t workspace_bytes, int workspace_clean, void* stream,
                                     const fnr_table_adam* table_adam, const fnr_table_adam* weight_adam,
                                     const float* grad_arena, AccArgs* defer_acc = nullptr, int phase = 0,
-                                    bool own_scope = true) {
+                                    bool own_scope = true, PropReduceArgs* defer_reduce = nullptr) {
   // own_scope false: the caller's ProfScope spans this call (the paired entry points open ONE scope over both levels and
   // their joint accumulate launch, which runs outside any per-level call)
   // phase 0: the whole backward; 1: MLP backward + weight reduction only (d_feats stay in the workspace, d_position is
@@ -1066,13 +1083,14 @@ static int prop_density_bwd_entry(const fnr_prop_net* net, const fnr_prop_net* g
   }
 #undef FNR_PROPB_CASE
   FNR_LAUNCH_CHECK();
-  if (table_adam)
-    hipLaunchKernelGGL(k_prop_reduce<true>, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), partials,
-                       (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1, wa);
-  else
-    hipLaunchKernelGGL(k_prop_reduce<false>, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), partials,
-                       (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1, WeightAdam{});
-  FNR_LAUNCH_CHECK();
+  const PropReduceArgs ra{partials, (int)blocks, 2 * L, grads->w0, grads->b0, grads->w1, grads->b1, table_adam ? wa : WeightAdam{}};
+  if (defer_reduce) {   // the caller launches the reduction (together with the other level's)
+    *defer_reduce = ra;
+  } else {
+    if (table_adam) hipLaunchKernelGGL(k_prop_reduce<true>, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), ra);
+    else hipLaunchKernelGGL(k_prop_reduce<false>, dim3(PROP_PART / PRD_E), dim3(PRD_E * PRD_Y), 0, as_stream(stream), ra);
+    FNR_LAUNCH_CHECK();
+  }
   }
   if (phase == 1) return FNR_OK;
   AccArgs acc;
@@ -1235,16 +1253,23 @@ extern "C" int fnr_prop_density_bwd_pair_split(const fnr_prop_net* const* nets, 
   }
   FNR_PROF(OP_PROP_BWD, rays->n_rays * ((long long)S[0] + (long long)S[1]));   // one scope: both phases + the joint accumulate
   AccArgs acc[2];
+  PropReduceArgs red[2];
   for (int phase = 1; phase <= 2; ++phase) {
     for (int q = 0; q < 2; ++q) {
       const int rc = prop_density_bwd_entry(nets[q], grads[q], warps[q], rays, euclid_bins[q], S[q], feat_save[q], d_density[q],
                                             d_position[q], workspace[q], workspace_bytes[q], workspace_clean[q], stream,
                                             adam ? table_adam[q] : nullptr, adam ? weight_adam : nullptr,
-                                            adam ? grad_arena : nullptr, &acc[q], phase, false);
+                                            adam ? grad_arena : nullptr, &acc[q], phase, false, phase == 1 ? &red[q] : nullptr);
       if (rc) return rc;
     }
-    if (phase == 1 && position_ready_event)
-      FNR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(position_ready_event), as_stream(stream)));
+    if (phase == 1) {
+      // d_position is final behind the two MLP backward launches; their weight reductions (+ optimiser steps) are ONE launch
+      if (position_ready_event) FNR_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(position_ready_event), as_stream(stream)));
+      constexpr unsigned NB = PROP_PART / PRD_E;
+      if (adam) hipLaunchKernelGGL(k_prop_reduce2<true>, dim3(2 * NB), dim3(PRD_E * PRD_Y), 0, as_stream(stream), red[0], red[1]);
+      else hipLaunchKernelGGL(k_prop_reduce2<false>, dim3(2 * NB), dim3(PRD_E * PRD_Y), 0, as_stream(stream), red[0], red[1]);
+      FNR_LAUNCH_CHECK();
+    }
   }
   const bool first_longer = (long long)S[0] >= (long long)S[1];
   return scatter_accumulate2(first_longer ? acc[0] : acc[1], first_longer ? acc[1] : acc[0], adam, as_stream(stream));

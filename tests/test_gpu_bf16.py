@@ -167,3 +167,19 @@ def test_bf16_modes_vs_the_fp32_kernels_backward(dev, precision, tol, S, shape):
         print(f"[{precision} S={S}] {n}: max|g| {scale:.3e} err {rel:.3e}")
         worst = max(worst, rel)
     assert worst <= tol
+
+
+def test_transposing_lds_read_returns_what_the_per_wave_backward_assumes(dev, tmp_path):
+    """tools/microbench/lds_tr16_transpose.hip on this box: ds_read_b64_tr_b16 over the shipped chunk order hands lane t of
+    16-lane group g feature t of samples 4g .. 4g+3 (the dW operands of field_mlp_bwd_pw.hip are built on it)."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "microbench", "lds_tr16_transpose.hip")
+    exe = tmp_path / "lds_tr16_transpose"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", src, "-o", str(exe)], check=True, capture_output=True, timeout=600)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "OK: 0 mismatches of 512" in out.stdout, out.stdout[-400:]
