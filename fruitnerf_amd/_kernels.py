@@ -357,6 +357,30 @@ def composite_fwd(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: T
     return weights, out_rgb, acc, depth, sem, label
 
 
+def composite_fwd_bwd_targets(rays: RaysArg, S: int, euclid: Tensor, density: Tensor, rgb: Tensor, logit: Tensor, image: Tensor,
+                              mask: Tensor, sem_weight: float):
+    """composite_fwd (training) and composite_bwd_targets as one launch (fnr_composite_fwd_bwd_targets): the same outputs and
+    gradients, bit for bit.  -> (weights, out_rgb, acc, depth, sem, label), (d_density, d_rgb, d_logit)."""
+    lib = L.load()
+    dev = rays.device
+    N = rays.n * S
+    weights = _empty(rays.n, S, device=dev)
+    out_rgb = _empty(rays.n, 3, device=dev)
+    acc = _empty(rays.n, device=dev)
+    depth = _empty(rays.n, device=dev)
+    sem = _empty(rays.n, device=dev)
+    label = _empty(rays.n, dtype=torch.int64, device=dev)
+    d_density = _empty(N, device=dev)
+    d_rgb = _empty(N, 3, device=dev)
+    d_logit = _empty(N, device=dev)
+    L.check(lib.fnr_composite_fwd_bwd_targets(rays.ref, S, L.ptr(euclid), L.ptr(density), L.ptr(rgb), L.ptr(logit),
+                                              L.ptr(_f32c(image)), L.ptr(_f32c(mask.reshape(-1))), float(sem_weight),
+                                              L.ptr(weights), L.ptr(out_rgb), L.ptr(acc), L.ptr(depth), L.ptr(sem), L.ptr(label),
+                                              L.ptr(d_density), L.ptr(d_rgb), L.ptr(d_logit), L.stream_ptr(dev)),
+            "composite_fwd_bwd_targets")
+    return (weights, out_rgb, acc, depth, sem, label), (d_density, d_rgb, d_logit)
+
+
 # ---- export -------------------------------------------------------------------------------------------
 
 

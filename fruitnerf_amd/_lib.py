@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("FNR_LIB_PATH") or os.path.join(_HERE, "lib", "libfrui
 FNR_MAX_LEVELS = 16
 FNR_MAX_SEM_LAYERS = 4
 FNR_LOSS_SLOTS = 1024
-ABI_VERSION = 12     # include/fruitnerf_hip.h: FNR_ABI_VERSION
+ABI_VERSION = 13     # include/fruitnerf_hip.h: FNR_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -138,6 +138,8 @@ SIGNATURES = {
     "fnr_interlevel_fwd": (_i, [_i64, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "fnr_distortion": (_i, [_i64, _i, _vp, _vp, _vp, _vp]),
     "fnr_composite_bwd": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fnr_composite_fwd_bwd_targets": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _vp, _vp, _vp]),
     "fnr_composite_bwd_targets": (_i, [P(fnr_rays), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp,
                                        _vp]),
     "fnr_weights_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -530,6 +530,137 @@ __global__ __launch_bounds__(256) void k_weights_bwd(long long R, int S, const f
   }
 }
 
+// k_composite_fwd (render.hip, training mode) followed by k_weights_bwd<true, true> for the same ray, in one wave: everything the
+// backward read back from memory (weights, composited colour and logit) stays in registers.
+__global__ __launch_bounds__(256) void k_composite_fwd_bwd(RaysDev rays, int S, const float* __restrict__ euclid,
+                                                           const float* __restrict__ density, const float* __restrict__ rgb,
+                                                           const float* __restrict__ logit, const float* __restrict__ image,
+                                                           const float* __restrict__ mask, float sem_weight,
+                                                           float* __restrict__ weights, float* __restrict__ out_rgb,
+                                                           float* __restrict__ out_acc, float* __restrict__ out_depth,
+                                                           float* __restrict__ out_sem, long long* __restrict__ out_label,
+                                                           float* __restrict__ d_density, float* __restrict__ d_rgb,
+                                                           float* __restrict__ d_logit) {
+  static_assert(WB_MAXE == 8, "the forward and the backward chunk a ray the same way");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long R = rays.n_rays;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int E = (S + 63) >> 6;
+  const float* eb = euclid + r * (S + 1);
+  const float* dn = density + r * S;
+  const float* cs = rgb + r * S * 3;
+  const float* lg = logit + r * S;
+  // ---- forward: k_composite_fwd with training = 1 -----------------------------------------------------------------------
+  float dd[WB_MAXE];
+  float local = 0.0f;
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    dd[e] = 0.0f;
+    if (e < E && k < S) dd[e] = fmul(fsub(eb[k + 1], eb[k]), dn[k]);
+    local += dd[e];
+  }
+  float excl = wave_excl_scan(local, lane);
+  float w[WB_MAXE];
+  float acc_l = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, sm = 0.0f;
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    const float T = expf(-excl);
+    const float alpha = 1.0f - expf(-dd[e]);
+    w[e] = nan_to_num(alpha * T);
+    excl += dd[e];
+    if (e < E && k < S) {
+      weights[r * S + k] = w[e];
+      const float c0 = cs[3 * k], c1 = cs[3 * k + 1], c2 = cs[3 * k + 2];
+      acc_l += w[e];
+      cr = fmaf(w[e], c0, cr);
+      cg = fmaf(w[e], c1, cg);
+      cb = fmaf(w[e], c2, cb);
+      sm = fmaf(w[e], lg[k], sm);
+    } else {
+      w[e] = 0.0f;
+    }
+  }
+  float cw = wave_excl_scan(acc_l, lane);
+  int first = 0x7fffffff;
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    cw += w[e];
+    if (e < E && k < S && cw >= 0.5f && first == 0x7fffffff) first = k;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) first = min(first, __shfl_xor(first, d, 64));
+  if (first > S - 1) first = S - 1;
+  const float acc = wave_sum(acc_l);
+  cr = wave_sum(cr);
+  cg = wave_sum(cg);
+  cb = wave_sum(cb);
+  sm = wave_sum(sm);
+  // (every lane: the backward wants the composited colour; wave_sum leaves the same total in all of them)
+  const float l0 = cs[3 * (S - 1)], l1 = cs[3 * (S - 1) + 1], l2 = cs[3 * (S - 1) + 2];
+  const float o0 = cr + l0 * (1.0f - acc), o1 = cg + l1 * (1.0f - acc), o2 = cb + l2 * (1.0f - acc);
+  if (lane == 0) {
+    out_rgb[3 * r] = o0;
+    out_rgb[3 * r + 1] = o1;
+    out_rgb[3 * r + 2] = o2;
+    out_acc[r] = acc;
+    out_sem[r] = sm;
+    if (out_label) out_label[r] = (fsub(1.0f / (1.0f + expf(-sm)), 0.9f) > 0.0f) ? 1 : 0;
+    out_depth[r] = fdiv(fadd(eb[first], eb[first + 1]), 2.0f);
+  }
+  // ---- backward: k_weights_bwd<true, true> --------------------------------------------------------------------------------
+  const float inv3r = 1.0f / (float)(3 * R), invr = 1.0f / (float)R;
+  const float gr = mse_grad(o0 - image[3 * r], inv3r), gg = mse_grad(o1 - image[3 * r + 1], inv3r),
+              gb = mse_grad(o2 - image[3 * r + 2], inv3r);
+  const float gs = bce_logit_grad(sm, mask[r], sem_weight, invr);
+  float delta[WB_MAXE], gw[WB_MAXE], wk[WB_MAXE];
+  float dd_local = 0.0f, gww_local = 0.0f, wsum_local = 0.0f;
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    delta[e] = 0.0f;
+    gw[e] = 0.0f;
+    wk[e] = 0.0f;
+    if (e < E && k < S) {
+      delta[e] = eb[k + 1] - eb[k];
+      wk[e] = w[e];
+      const float* c = cs + 3 * k;
+      gw[e] = gr * (c[0] - l0) + gg * (c[1] - l1) + gb * (c[2] - l2);  // semantic weights are detached
+      dd_local += delta[e] * dn[k];
+      gww_local += gw[e] * wk[e];
+      wsum_local += wk[e];
+    }
+  }
+  float cum_dd = wave_excl_scan(dd_local, lane);
+  float suffix = wave_bcast_lane(wave_excl_scan(wave_bcast_lane(gww_local, 63 - lane), lane), 63 - lane);
+  const float bgw = 1.0f - wave_sum(wsum_local);
+  float suf[WB_MAXE];
+#pragma unroll
+  for (int e = WB_MAXE - 1; e >= 0; --e) {
+    suf[e] = suffix;
+    suffix += gw[e] * wk[e];
+  }
+#pragma unroll
+  for (int e = 0; e < WB_MAXE; ++e) {
+    const int k = lane * E + e;
+    if (e < E && k < S) {
+      cum_dd += delta[e] * dn[k];
+      const float T_next = expf(-cum_dd);
+      d_density[r * S + k] = delta[e] * (gw[e] * T_next - suf[e]);
+      float f = wk[e];
+      if (k == S - 1) f += bgw;
+      float* o = d_rgb + (r * S + k) * 3;
+      o[0] = gr * f;
+      o[1] = gg * f;
+      o[2] = gb * f;
+      d_logit[r * S + k] = gs * wk[e];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam incl. its L2 weight_decay, no amsgrad), whole arena in one launch; optionally zeroes grads
 // ---------------------------------------------------------------------------------------------------
@@ -735,6 +866,38 @@ extern "C" int fnr_composite_bwd_targets(const fnr_rays* rays, int S, const floa
   hipLaunchKernelGGL((k_weights_bwd<true, true>), dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
                      (long long)rays->n_rays, S, euclid_bins, density, weights, (const float*)nullptr,
                      (const float*)nullptr, rgb, (const float*)nullptr, (const float*)nullptr, d_density, d_rgb, d_logit, tg);
+  FNR_LAUNCH_CHECK();
+  return FNR_OK;
+}
+
+// fnr_composite_fwd (training) and fnr_composite_bwd_targets as ONE launch (ABI 13): a wave composites its ray and, with the
+// outputs still in registers, forms the per-ray loss gradients and runs the backward — the same operations on the same values in
+// the same order as the two kernels (tests/test_gpu_training_parity.py: bit-identical), one launch ramp less on the chain
+// forward -> MLP backward of every training step.
+extern "C" int fnr_composite_fwd_bwd_targets(const fnr_rays* rays, int S, const float* euclid_bins, const float* density,
+                                             const float* rgb, const float* logit, const float* image, const float* mask,
+                                             float semantic_loss_weight, float* weights, float* out_rgb,
+                                             float* out_accumulation, float* out_depth, float* out_semantics,
+                                             int64_t* out_label, float* d_density, float* d_rgb, float* d_logit,
+                                             void* stream) {
+  if (seq::recording() && rays) {
+    const fnr_rays rays_ = *rays;
+    seq::push("fnr_composite_fwd_bwd_targets", [=](const fnr_step_scalars*) {
+      return fnr_composite_fwd_bwd_targets(&rays_, S, euclid_bins, density, rgb, logit, image, mask, semantic_loss_weight, weights,
+                                           out_rgb, out_accumulation, out_depth, out_semantics, out_label, d_density, d_rgb,
+                                           d_logit, stream);
+    });
+  }
+  FNR_CHECK_ARG(rays && euclid_bins && density && rgb && logit && image && mask && weights && out_rgb && out_accumulation &&
+                    out_depth && out_semantics && d_density && d_rgb && d_logit,
+                "composite_fwd_bwd_targets: null argument");
+  FNR_CHECK_ARG(S > 0 && S <= 64 * WB_MAXE, "composite_fwd_bwd_targets: S %d out of range", S);
+  if (rays->n_rays == 0) return FNR_OK;
+  FNR_PROF(OP_COMPOSITE_FWD, rays->n_rays * (long long)S);
+  hipLaunchKernelGGL(k_composite_fwd_bwd, dim3((unsigned)((rays->n_rays + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     make_rays(rays), S, euclid_bins, density, rgb, logit, image, mask, semantic_loss_weight, weights, out_rgb,
+                     out_accumulation, out_depth, out_semantics, reinterpret_cast<long long*>(out_label), d_density, d_rgb,
+                     d_logit);
   FNR_LAUNCH_CHECK();
   return FNR_OK;
 }

@@ -175,6 +175,7 @@ class RenderContext:
     weights: Optional[Tensor] = None
     field_jacobian: Optional[Tensor] = None  # d feats / d(unit-cube position) [L,3,N,2] when the rays want gradients
     ray_bundle: Optional[object] = None   # the caller's RayBundle (its origins / directions may carry autograd history)
+    composite_grads: Optional[tuple] = None   # (d_density, d_rgb, d_logit) when the compositing launch ran its own backward
 
 
 class FruitModel(nn.Module):
@@ -372,8 +373,11 @@ class FruitModel(nn.Module):
 
     # ---- the hot path ----------------------------------------------------------------------------------------
     def _render(self, ray_bundle: RayBundle, jitter: Optional[List[Tensor]] = None,
-                save_input_jacobian: bool = False) -> Tuple[Dict, RenderContext]:
-        """ProposalNetworkSampler.generate_ray_samples + field + weights + renderers (fruit_nerf.py:316-357)."""
+                save_input_jacobian: bool = False, loss_targets=None) -> Tuple[Dict, RenderContext]:
+        """ProposalNetworkSampler.generate_ray_samples + field + weights + renderers (fruit_nerf.py:316-357).
+        loss_targets = (image [R,3], fruit_mask [R,1], semantic loss weight), training steps that do not train the proposal networks:
+        the compositing launch also runs its own backward under the rgb / semantic losses of get_loss_dict (fnr_composite_fwd_bwd_targets) and the context carries
+        `composite_grads` = (d_density, d_rgb, d_logit) per sample."""
         self.arena()
         cfg = self.config
         sampler = self.proposal_sampler
@@ -426,7 +430,14 @@ class FruitModel(nn.Module):
         if mean_emb is None and rays.cam is None:
             raise AttributeError("Camera indices are not provided.")
         density, rgb, logit, _, h_saved = K.field_mlp_fwd(net, rays, S, feats, selector, mean_emb, want_h=True)
-        weights, out_rgb, acc, depth, sem, label = K.composite_fwd(rays, S, euclid, density, rgb, logit, training)
+        composite_grads = None
+        # (not on the steps that train the proposal networks: there the second stream's chain — losses launch, proposal
+        #  backward, their scatter — is the longer one, and it starts behind this launch)
+        if loss_targets is not None and training and not updated:
+            (weights, out_rgb, acc, depth, sem, label), composite_grads = K.composite_fwd_bwd_targets(
+                rays, S, euclid, density, rgb, logit, loss_targets[0], loss_targets[1], loss_targets[2])
+        else:
+            weights, out_rgb, acc, depth, sem, label = K.composite_fwd(rays, S, euclid, density, rgb, logit, training)
         levels.append(dict(S=S, spacing=spacing, euclid=euclid, density=density.view(rays.n, S), weights=weights,
                            depth=depth, feats=None))
         ctx = RenderContext(rays=rays, levels=levels, updated=updated, training=training, field_feats=feats,
@@ -435,6 +446,7 @@ class FruitModel(nn.Module):
         ctx.labels = label[:, None]
         ctx.ray_bundle = ray_bundle
         ctx.field_jacobian = jac
+        ctx.composite_grads = composite_grads
         outputs = {"rgb": out_rgb, "accumulation": acc[:, None], "depth": depth[:, None],
                    "semantics": sem[:, None]}
         for i in range(n_prop):

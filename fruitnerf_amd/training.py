@@ -925,10 +925,17 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
     dev = model.device
     with torch.no_grad():
         ray_bundle = model._collide(ray_bundle)
-        outputs, rctx = model._render(ray_bundle, jitter, save_input_jacobian=ray_grads is not None)
+        image, mask = batch["image"].to(dev), batch["fruit_mask"].to(dev)
+        # (single process only: on the exchange path — one-rank RCCL A/B, profiles/r05_raw/exchange_losses_ab.log — it is
+        #  neutral to slightly negative, 0.860 - 0.870 against 0.857 ms/step: the second stream has the collectives' tail there)
+        losses_on_side = bool(LOSSES_ON_SIDE and overlap_proposal_backward and not serialize_streams and exchange is None)
+        # ... and then the compositing launch runs its own backward too (FUSE_COMPOSITE_BACKWARD): nothing between the field's
+        # forward and backward pass depends on another launch
+        fuse_composite = bool(FUSE_COMPOSITE_BACKWARD and losses_on_side)
+        outputs, rctx = model._render(ray_bundle, jitter, save_input_jacobian=ray_grads is not None,
+                                      loss_targets=(image, mask, cfg.semantic_loss_weight) if fuse_composite else None)
         rays, fin = rctx.rays, rctx.levels[-1]
         S = fin["S"]
-        image, mask = batch["image"].to(dev), batch["fruit_mask"].to(dev)
         # one fill for everything this step accumulates into: the loss slots (+ completion counter) and, with a camera
         # optimiser, the ray gradients d(loss)/d(origins | directions); one launch for every loss and metric
         # the loss / metric accumulator is persistent: fnr_train_losses leaves it zeroed (its last workgroup cleans up),
@@ -950,9 +957,6 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
         main = torch.cuda.current_stream(dev)
         fj = _ForkJoin(main)
         side = None
-        # (single process only: on the exchange path — one-rank RCCL A/B, profiles/r05_raw/exchange_losses_ab.log — it is
-        #  neutral to slightly negative, 0.860 - 0.870 against 0.857 ms/step: the second stream has the collectives' tail there)
-        losses_on_side = bool(LOSSES_ON_SIDE and overlap_proposal_backward and not serialize_streams and exchange is None)
         if losses_on_side:
             side = _second_stream(model, dev)
             fj.fork(side)                       # behind the forward pass
@@ -1006,7 +1010,9 @@ def fused_forward_backward(model, ray_bundle, batch, jitter: Optional[List[Tenso
                 crosses_to(main, ray_sources)
                 if serialize_streams:
                     K.stream_wait_stream(main, side)
-        if losses_on_side:
+        if getattr(rctx, "composite_grads", None) is not None:
+            d_density, d_rgb_s, d_logit = rctx.composite_grads
+        elif losses_on_side:
             d_density, d_rgb_s, d_logit = K.composite_bwd_targets(rays, S, fin["euclid"], rctx.sample_density,
                                                                   rctx.sample_rgb, rctx.weights, outputs["rgb"], image,
                                                                   outputs["semantics"], mask, cfg.semantic_loss_weight)
@@ -1179,6 +1185,9 @@ PAIR_PROPOSAL_LEVELS = os.environ.get("FNR_PAIR_PROPOSAL_LEVELS", "1") != "0"   
 # The losses launch on the second stream, the composite backward forming its own per-ray loss gradients (see
 # fused_forward_backward).  FNR_LOSSES_ON_SIDE=0: losses on the launch stream ahead of the backward, as before (A/B).
 LOSSES_ON_SIDE = os.environ.get("FNR_LOSSES_ON_SIDE", "1") != "0"
+# The compositing launch of a training step runs its own backward (fnr_composite_fwd_bwd_targets) when the losses launch is on
+# the second stream.  FNR_FUSE_COMPOSITE_BACKWARD=0: two launches (A/B); same bits either way.
+FUSE_COMPOSITE_BACKWARD = os.environ.get("FNR_FUSE_COMPOSITE_BACKWARD", "1") != "0"
 FUSE_CAMERA_OPTIMIZER = True  # single process: the pose table's optimiser step runs inside the pose-gradient kernel
 FUSE_WEIGHT_OPTIMIZER = True  # ... and the field's MLP weights + embedding step inside k_reduce_dw / k_embedding_grad
 FUSE_TABLE_OPTIMIZER = True   # single process: the main hash table's Adam / RAdam step runs inside the scatter
@@ -1451,7 +1460,7 @@ class TrainingSteps:
                 getattr(fld, "mlp_precision", None), model.arena().params.data_ptr(), id(self.optimizer),
                 L.stream_ptr(dev), None if side is None else side.cuda_stream,
                 OVERLAP_PROPOSAL_BACKWARD, SERIALIZE_STREAMS, LOSSES_ON_SIDE, PAIR_PROPOSAL_LEVELS, FUSE_CAMERA_OPTIMIZER,
-                FUSE_WEIGHT_OPTIMIZER, FUSE_TABLE_OPTIMIZER, SPARSE_TOUCH_SKIPPING, STREAM_SAFE,
+                FUSE_WEIGHT_OPTIMIZER, FUSE_TABLE_OPTIMIZER, SPARSE_TOUCH_SKIPPING, STREAM_SAFE, FUSE_COMPOSITE_BACKWARD,
                 cfg.semantic_loss_weight, cfg.interlevel_loss_mult, cfg.near_plane, cfg.far_plane)
 
     # ---- one step ------------------------------------------------------------------------------------------------

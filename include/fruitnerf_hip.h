@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNR_ABI_VERSION 12
+#define FNR_ABI_VERSION 13
 #define FNR_MAX_LEVELS 16
 #define FNR_MAX_SEM_LAYERS 4
 /* floats in a loss accumulator buffer: per-ray partials are spread over 32 accumulators that sit in 32 different
@@ -319,6 +319,14 @@ int fnr_composite_bwd_targets(const fnr_rays* rays, int S, const float* euclid_b
                               const float* rgb, const float* weights, const float* out_rgb, const float* image,
                               const float* out_semantics, const float* mask, float semantic_loss_weight,
                               float* d_density, float* d_rgb, float* d_logit, void* stream);
+/* fnr_composite_fwd (training = 1) + fnr_composite_bwd_targets as one launch (ABI 13): the same outputs and the same gradients,
+ * bit for bit, one kernel boundary less between the field's forward and backward pass of a training step
+ * (fruit_nerf.py:325-348 + the autograd of its renderers and of get_loss_dict's rgb / semantic terms, :365-391). */
+int fnr_composite_fwd_bwd_targets(const fnr_rays* rays, int S, const float* euclid_bins, const float* density,
+                                  const float* rgb, const float* logit, const float* image, const float* mask,
+                                  float semantic_loss_weight, float* weights, float* out_rgb, float* out_accumulation,
+                                  float* out_depth, float* out_semantics, int64_t* out_label, float* d_density,
+                                  float* d_rgb, float* d_logit, void* stream);
 
 /* Backward of RaySamples.get_weights for a proposal level: d_weights [R,S] (x *upstream if non-NULL, a
  * device scalar) -> d_density [R,S]. */

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/fruitnerf_hip.h but not exported"
         assert name in L.SIGNATURES, f"{name} has no ctypes signature in fruitnerf_amd/_lib.py"
     assert set(L.SIGNATURES) == set(declared)
-    assert lib.fnr_abi_version() == L.ABI_VERSION == 12
+    assert lib.fnr_abi_version() == L.ABI_VERSION == 13
 
 
 def test_struct_layouts_match_header_sizes():

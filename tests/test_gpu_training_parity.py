@@ -1232,6 +1232,33 @@ def test_composite_bwd_targets_is_losses_then_composite_bwd(dev, R, S):
         assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} entries differ"
 
 
+@pytest.mark.parametrize("R,S", [(4096, 48), (1001, 48), (64, 96), (7, 129), (33, 256)])
+def test_fused_composite_forward_backward_is_the_two_launches(dev, R, S):
+    """fnr_composite_fwd_bwd_targets (round 6: the compositing launch of a training step runs its own backward) against
+    fnr_composite_fwd -> fnr_composite_bwd_targets: weights, every composited output and the three gradients bit-identical."""
+    from fruitnerf_amd import _kernels as K
+    g0 = torch.Generator().manual_seed(R * 17 + S)
+    o, d, pa, cam = util.random_rays(R, 7, seed=4)
+    rays = K.RaysArg(o.to(dev), d.to(dev), torch.full((R, 1), 0.05, device=dev), torch.full((R, 1), 1000.0, device=dev),
+                     cam.to(dev))
+    euclid = torch.cumsum(torch.rand(R, S + 1, generator=g0) * 0.07 + 1e-3, dim=-1).to(dev)
+    density = (torch.rand(R, S, generator=g0) ** 6 * 1e3).to(dev)
+    rgb_s = torch.rand(R, S, 3, generator=g0).to(dev)
+    logit_s = (torch.randn(R, S, generator=g0) * 6.0).to(dev)
+    image = torch.rand(R, 3, generator=g0).to(dev)
+    mask = (torch.rand(R, 1, generator=g0) > 0.5).float().to(dev)
+    sem_w = 2.0
+    fwd = K.composite_fwd(rays, S, euclid, density, rgb_s, logit_s, training=True)
+    weights, out_rgb, acc, depth, out_sem, labels = fwd
+    bwd = K.composite_bwd_targets(rays, S, euclid, density, rgb_s, weights, out_rgb, image, out_sem, mask, sem_w)
+    fwd2, bwd2 = K.composite_fwd_bwd_targets(rays, S, euclid, density, rgb_s, logit_s, image, mask, sem_w)
+    for name, a, b in zip(("weights", "rgb", "accumulation", "depth", "semantics", "labels"), fwd2, fwd):
+        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} entries differ"
+    for name, a, b in zip(("d_density", "d_rgb", "d_logit"), bwd2, bwd):
+        assert float(b.abs().max()) > 0, name
+        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} entries differ"
+
+
 def test_proposal_backward_on_a_second_stream_changes_nothing(dev):
     """training.OVERLAP_PROPOSAL_BACKWARD (FNR_OVERLAP_PROPOSAL_BACKWARD=1): the proposal-network backward runs on a
     second HIP stream underneath the field backward.  One full step (camera optimiser included, ray gradients from both
