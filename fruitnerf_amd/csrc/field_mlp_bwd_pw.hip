@@ -428,16 +428,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_color_p
   const int n_groups = (N + 16 * NT - 1) / (16 * NT), n_tiles = (N + 15) / 16;
   for (int gr = blockIdx.x * WAVES + wave; gr < n_groups; gr += gridDim.x * WAVES) {
     asm volatile("" ::: "memory");  // keep the LDS fragment reads inside the loop
-    // (the dW accumulators are MFMA-only: pinned in the accumulation half of the register file, which the vector ALU cannot address)
-    if constexpr (WAVES == 4)
-#pragma unroll
-      for (auto& a_ : accC) asm volatile("" : "+a"(a_));
-    if constexpr (WAVES == 4)
-#pragma unroll
-      for (auto& a_ : accB) asm volatile("" : "+a"(a_));
-    if constexpr (WAVES == 4)
-#pragma unroll
-      for (auto& a_ : accA) asm volatile("" : "+a"(a_));
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int j = lane & 15, g = lane >> 4;
@@ -662,16 +652,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_sem_pw(
   const int n_groups = (N + 16 * NT - 1) / (16 * NT);
   for (int gr = blockIdx.x * WAVES + wave; gr < n_groups; gr += gridDim.x * WAVES) {
     asm volatile("" ::: "memory");
-    // (the dW accumulators are MFMA-only: pinned in the accumulation half of the register file, which the vector ALU cannot address)
-    if constexpr (WAVES == 4)
-#pragma unroll
-      for (auto& a_ : accH) asm volatile("" : "+a"(a_));
-    if constexpr (WAVES == 4)
-#pragma unroll
-      for (auto& a_ : accB) asm volatile("" : "+a"(a_));
-    if constexpr (WAVES == 4)
-#pragma unroll
-      for (auto& a_ : accA) asm volatile("" : "+a"(a_));
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int j = lane & 15, g = lane >> 4;
@@ -797,13 +777,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_field_mlp_bwd_base_pw
   const int n_groups = (N + 16 * NT - 1) / (16 * NT);
   for (int gr = blockIdx.x * WAVES + wave; gr < n_groups; gr += gridDim.x * WAVES) {
     asm volatile("" ::: "memory");
-    // (the dW accumulators are MFMA-only: pinned in the accumulation half of the register file, which the vector ALU cannot address)
-    if constexpr (WAVES == 4)
-#pragma unroll
-      for (auto& a_ : accB) asm volatile("" : "+a"(a_));
-    if constexpr (WAVES == 4)
-#pragma unroll
-      for (auto& a_ : accA) asm volatile("" : "+a"(a_));
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int j = lane & 15, g = lane >> 4;
