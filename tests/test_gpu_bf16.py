@@ -183,3 +183,50 @@ def test_transposing_lds_read_returns_what_the_per_wave_backward_assumes(dev, tm
     subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", src, "-o", str(exe)], check=True, capture_output=True, timeout=600)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "OK: 0 mismatches of 512" in out.stdout, out.stdout[-400:]
+
+
+@pytest.mark.parametrize("shape", ["fruit_nerf", "fruit_nerf_big"])
+def test_per_wave_backward_is_reproducible_and_its_position_gradient_is_its_own_contraction(dev, shape):
+    """The MLP backward with the hash grid's input gradient (fnr_field_mlp_bwd_rays -> k_field_mlp_bwd_base_pw<.., POSGRAD>) at the
+    training size, called repeatedly on identical inputs: d_feats and d_position bit-identical call to call (round 5's
+    irreproducibility sat in exactly this reduction of the cooperative kernel), and every d_position equal to the contraction
+    of the kernel's own d_feats with the encode's Jacobian recomputed in float64."""
+    from fruitnerf_amd import _kernels as K
+    from fruitnerf_amd.data.semantics import apple_metadata
+    from fruitnerf_amd.fruit_nerf import FruitModel
+    from fruitnerf_amd.fruit_nerf_config import model_config
+    from fruitnerf_amd.rays import RayBundle
+    cfg = model_config(shape, mlp_precision="bf16x3")
+    torch.manual_seed(0)
+    hm = FruitModel(cfg, apple_metadata(), num_train_data=40, device=dev)
+    hm.train()
+    with torch.no_grad():
+        hm.field.mlp_base_grid.hash_table.mul_(300.0)          # features of O(0.3): gradients of a visible size
+    R = 4096 if shape == "fruit_nerf" else 1024
+    o, d, _, cam = util.random_rays(R, 40, seed=3)
+    rb = hm._collide(RayBundle(o.to(dev), d.to(dev), None, cam.to(dev)))
+    with torch.no_grad():
+        outputs, rctx = hm._render(rb, None, save_input_jacobian=True)
+    rays, fin = rctx.rays, rctx.levels[-1]
+    S = fin["S"]
+    N = rays.n * S
+    g = torch.Generator(device=dev).manual_seed(1)
+    d_density = torch.randn(N, device=dev, generator=g) * 1e-3
+    d_rgb = torch.randn(N, 3, device=dev, generator=g) * 1e-3
+    d_logit = torch.randn(N, device=dev, generator=g) * 1e-3
+    fld = hm.field
+    hm.arena()
+    net, gnet = fld.net_struct(), fld.net_struct(grads=True)
+    ref = None
+    for r in range(6):
+        d_feats, d_pos = K.field_mlp_bwd(net, gnet, rays, S, rctx.field_feats, rctx.field_h, rctx.field_selector, d_density,
+                                         d_rgb, d_logit, jacobian=rctx.field_jacobian)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (d_feats.clone(), d_pos.clone())
+            want = (d_feats[:, None, :, :] * rctx.field_jacobian).sum(dim=-1).double().sum(dim=0).t()      # [N, 3]
+            err = (d_pos[:, :3].double() - want).abs().max()
+            assert float(want.abs().max()) > 0 and float(err) <= 1e-4 * float(want.abs().max()), (float(err), float(want.abs().max()))
+        else:
+            assert torch.equal(d_feats, ref[0]), f"call {r}: {int((d_feats != ref[0]).sum())} d_feats entries differ"
+            assert torch.equal(d_pos, ref[1]), f"call {r}: {int((d_pos != ref[1]).any(dim=1).sum())} d_position rows differ"
