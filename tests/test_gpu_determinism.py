@@ -197,6 +197,36 @@ def test_stream_safe_mode_changes_nothing(dev):
         assert torch.equal(x, y), f"{name} differ with FNR_STREAM_SAFE"
 
 
+def test_fused_composite_backward_changes_nothing(dev):
+    """training.FUSE_COMPOSITE_BACKWARD (round 6): on the steps without a proposal backward the compositing launch runs its own
+    backward (fnr_composite_fwd_bwd_targets).  150 steps (every-step and every-other-step proposal updates, so both kinds of
+    step occur), eval passes in between: parameters, moments, poses and the logged losses bit-identical with the switch off,
+    and the fused entry point is what ran."""
+    import fruitnerf_amd.training as T
+    from fruitnerf_amd import _kernels as K
+    calls = []
+    orig = K.composite_fwd_bwd_targets
+
+    def counting(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+
+    K.composite_fwd_bwd_targets = counting
+    try:
+        ref = _run(dev, 150, "bf16x3", eval_after=(12, 41))
+        n_fused = len(calls)
+        saved, T.FUSE_COMPOSITE_BACKWARD = T.FUSE_COMPOSITE_BACKWARD, False
+        try:
+            got = _run(dev, 150, "bf16x3", eval_after=(12, 41))
+        finally:
+            T.FUSE_COMPOSITE_BACKWARD = saved
+    finally:
+        K.composite_fwd_bwd_targets = orig
+    assert n_fused > 0 and len(calls) == n_fused, (n_fused, len(calls))   # interpreted steps of the first run only (replays bypass Python)
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "camera poses", "losses + metrics"), ref, got):
+        assert torch.equal(x, y), f"{name} differ with FNR_FUSE_COMPOSITE_BACKWARD=0"
+
+
 def test_lookahead_is_dropped_when_parameters_change_between_steps(dev):
     """a cached look-ahead carries the next step's proposal samples and saved proposal features; it is tied to
     torch's version counters of the proposal networks' parameters and of the camera poses, so a load_state_dict or a pose
